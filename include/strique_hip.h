@@ -1,0 +1,96 @@
+/*
+ * libstrique_hip -- C ABI of the MI355X (gfx950) implementation of STRique's per-read hot path.
+ *
+ * Plain C, caller-owned buffers, no torch / pybind types.  Every function returns 0 on success
+ * or a STRQ_ERR_* code; strq_last_error(ctx) gives the message.  One ctx per process per GPU;
+ * calls on one ctx are not re-entrant (the reference holds the GIL for the whole native call,
+ * src/pyalign.cpp:59-61, and each worker process owns its own aligner, scripts/STRique.py:743-745).
+ *
+ * What each entry point replaces in giesselmann/STRique (file:line in the reference tree):
+ *   strq_ctx_create / strq_ctx_destroy   pyseqan.align_raw()            src/pyalign.cpp:50
+ *   strq_set_align_params / get          the 8 float properties         src/pyalign.cpp:51-58,
+ *                                                                       src/align_raw.h:84-103
+ *   strq_align_overlap                   align_raw.align_overlap(a, b)  src/pyalign.cpp:59-61,
+ *                                                                       src/align_raw.h:106-158
+ *   strq_model_create / strq_viterbi     pomegranate HiddenMarkovModel.bake()/.viterbi() as used
+ *                                        at scripts/STRique.py:431,434,490,493
+ *   strq_target_add / strq_detect_batch  repeatCounter.add_target / detect
+ *                                                                       scripts/STRique.py:553-618
+ */
+#ifndef STRIQUE_HIP_H
+#define STRIQUE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STRQ_OK 0
+#define STRQ_ERR_ARG 1          /* bad argument */
+#define STRQ_ERR_DEVICE 2       /* HIP runtime / no GPU */
+#define STRQ_ERR_UNSUPPORTED 3  /* input outside what the kernels cover (documented per call) */
+#define STRQ_ERR_NOMEM 4
+
+typedef struct strq_ctx strq_ctx;
+
+/* Version of this ABI (bumped on any signature change). */
+int strq_abi_version(void);
+
+/* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
+ * there is no CPU fallback in this library. */
+int strq_ctx_create(int device_id, strq_ctx** out);
+void strq_ctx_destroy(strq_ctx* ctx);
+const char* strq_last_error(const strq_ctx* ctx);
+
+/* Alignment parameters, order: open_h, ext_h, open_v, ext_v, dist_offset, dist_min.
+ * Defaults after create are align_raw's own (src/align_raw.h:51-60): -2,-8,-2,-8, 8,-16;
+ * STRique overrides them from its config (scripts/STRique.py:507-523). */
+int strq_set_align_params(strq_ctx* ctx, const float params[6]);
+int strq_get_align_params(const strq_ctx* ctx, float params[6]);
+
+/*
+ * Semi-global alignment of flank `b` (m samples, end to end) inside read `a` (n samples, free
+ * ends) -- align_raw.align_overlap(a, b).
+ *   score      best score (float32, as the reference returns it)
+ *   a_idx[n]   view position of every element of a   (nullable)
+ *   b_idx[m]   view position of every element of b   (nullable)
+ *   rec[m]     compact per-flank-row record (nullable): (j << 1) | is_vertical, where for a
+ *              diagonal step b[k] is aligned to a[j-1] and for a vertical step j samples of `a`
+ *              precede b[k]
+ *   j_end,j0   DP columns where the path ends / leaves the free top row (nullable)
+ * Supported here: `a` with at most 256 distinct float32 values and `b` made of runs of 6 equal
+ * samples (what repeatCounter.detect always passes: an 8-bit morphology signal and
+ * generate_signal(..., samples=6), scripts/STRique.py:592-601,562-565), m <= 1536.
+ * Anything else returns STRQ_ERR_UNSUPPORTED.
+ */
+int strq_align_overlap(strq_ctx* ctx, const float* a, int64_t n, const float* b, int64_t m,
+                       float* score, uint64_t* a_idx, uint64_t* b_idx,
+                       int32_t* rec, int64_t* j_end, int64_t* j0);
+
+/*
+ * Batched form of the same alignment for 8-bit level signals (the throughput path).
+ *   n_align            number of alignments
+ *   levels             concatenated level streams (uint8), one per *read*
+ *   read_off[n_reads+1]offsets of each read in `levels`
+ *   level_val          n_reads x 256 float32: value of each level of each read
+ *   align_read[n_align]read index of each alignment
+ *   flank              concatenated flank templates (float32, runs of `samples` equal values)
+ *   flank_off[n_align+1]
+ *   samples            run length of the flank templates (6)
+ * Outputs per alignment: score, j_end, j0 and rec (concatenated like `flank`).
+ */
+int strq_align_batch(strq_ctx* ctx, int64_t n_align, int64_t n_reads,
+                     const uint8_t* levels, const int64_t* read_off, const float* level_val,
+                     const int32_t* align_read, const float* flank, const int64_t* flank_off,
+                     int32_t samples,
+                     float* score, int64_t* j_end, int64_t* j0, int32_t* rec);
+
+/* Kernel timing of the last batched call, milliseconds (HIP events on the library's stream):
+ * [0] table build  [1] forward DP  [2] trace pass  [3] total.  */
+int strq_last_timing(const strq_ctx* ctx, float ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,61 @@
+"""Build the HIP shared library (gfx950) in-tree: strique_amd/lib/libstrique_hip.so.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container too.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libstrique_hip.so")
+
+# -ffp-contract=off: every float op of the DP / Viterbi must round exactly like the CPU oracle
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "strique_hip.h"))
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode(errors="replace")))
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,46 @@
+// Internal device-side structures of the flank-alignment kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define STRQ_CKPT_STEPS 512                  // wavefront checkpoint spacing in steps (multiple of 64)
+#define STRQ_COLS_PER_STEP 2                 // a lane computes two DP columns per step (ILP 2)
+#define STRQ_CKPT_FIELDS(R) (2 * (R) + 6)    // S[R], H[R], SbotA, VbotA, VbotB, upS, pad, pad
+#define STRQ_TRACE_WORDS(R) (((R) + 15) / 16)
+
+namespace strq {
+
+struct AlignParams {   // reference: scripts/STRique.py:507-523 -> src/align_raw.h:84-103
+    float open_h, ext_h, open_v, ext_v, dist_offset, dist_min;
+};
+
+// read-only description of one alignment (flank x read)
+struct AlignTask {
+    const uint8_t* levels;   // n levels of the read (column j <-> levels[j-1]); 2-byte aligned
+    const float* table;      // k x (tw+1) banded scores; index 0 and tw-1 of each row hold dist_min
+    const int32_t* band_lo;  // k: level that maps to table index 0
+    const float* col0;       // m+1: S[i][0] (column 0 is not free)
+    float* ckpt;             // wavefront checkpoints of the forward pass
+    int32_t* rec;            // m: per flank row (j << 1) | is_vertical   (trace pass output)
+    int32_t n, m, k, tw;
+};
+
+struct AlignResult {
+    float best;              // forward: max_j S[m][j]
+    int32_t j_end;           // forward: leftmost column of that maximum
+    int32_t j0;              // trace: column where the path leaves row 0
+    int32_t status;
+};
+
+static inline int align_num_steps(int n) { return (n + 1) / 2 + 63; }
+static inline int align_num_ckpts(int n) { return (align_num_steps(n) - 1) / STRQ_CKPT_STEPS; }
+
+int align_pick_rows_per_lane(int m, int samples);   // 0 if no compiled shape fits
+// phase 0 = forward, 1 = trace.  `queue`: one zero-initialised int per launch.
+int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* results,
+                 int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
+                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase);
+size_t align_trace_scratch_words_per_wave(int R);
+int align_set_debug_buffer(int* host_pinned);   // debug only
+
+}  // namespace strq

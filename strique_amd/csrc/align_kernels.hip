@@ -1,0 +1,608 @@
+// Flank alignment on gfx950 (MI355X): semi-global affine-gap DP of a short flank template
+// (vertical, M rows) against a whole raw-signal read (horizontal, N columns).
+//
+// Replaces: align_raw<float,float>::semiglobal  (reference src/align_raw.h:106-158),
+//           Score<float,Distance>::score + gap accessors (src/score_distance.h:115-122,140-226),
+//           i.e. the SeqAn2 globalAlignment(AlignConfig<true,false,false,true>, AffineGaps) call.
+//
+// Mapping (one wave64 per alignment, persistent waves, one per SIMD):
+//   * lane l owns rows [l*R, l*R+R) of the flank in registers (R rows per lane);
+//   * the wave marches an anti-diagonal wavefront, two DP columns per lane per step (two
+//     independent dependency chains -> ILP 2 inside one wave): at step t lane l computes
+//     columns 2(t-l)-1 and 2(t-l).  Cross-lane traffic per step is the bottom cells of lane
+//     l-1 and the packed levels of the two columns, each one DPP wave_shr:1;
+//   * per-cell scores come from a per-alignment banded table staged in LDS
+//     (row = k-mer class of the flank, column = 8-bit level of the read sample): the
+//     pow(|h-v|,1.2) of the reference never runs in the DP loop;
+//   * no per-cell trace is written by the forward pass.  It stores the wavefront registers
+//     every STRQ_CKPT_STEPS steps; the trace pass re-runs only the blocks of steps the optimal
+//     path crosses, with the full affine tie-break semantics, and walks a 4-bit trace back.
+//     Re-computation is deterministic IEEE f32 add/max in the same order => identical path.
+//
+// All arithmetic is float32 add / max exactly in the order of the CPU oracle
+// (oracle/align_oracle.c); compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "align_kernels.h"
+
+namespace strq {
+
+#define STRQ_NINF (-3.4028234663852886e38f / 2)
+
+// debug progress markers (host-pinned buffer; null in production)
+__device__ int* g_strq_dbg = nullptr;
+#define STRQ_MARK(slot, val) do { int* d_ = g_strq_dbg; if (d_) { __hip_atomic_store(d_ + (slot), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
+
+// tie rules -- keep identical to oracle/align_oracle.c
+#define STRQ_TIE_EXT(ext, opn)  ((ext) >= (opn))
+#define STRQ_TIE_H_OVER_V(h, v) ((h) >= (v))
+#define STRQ_TIE_D_OVER_G(d, g) ((d) >= (g))
+
+static __device__ __forceinline__ float dpp_shr1_f(float v, float fill)
+{
+    // wave_shr:1 -- lane l receives lane l-1; lane 0 keeps `fill` (bound_ctrl = 0 keeps old)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
+                              __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+static __device__ __forceinline__ int dpp_shr1_i(int v, int fill)
+{
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false);
+}
+static __device__ __forceinline__ int med3i(int a, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(lo), "v"(hi));
+    return r;
+}
+// per-lane select with a wave-uniform 64-bit lane mask held in an SGPR pair
+static __device__ __forceinline__ float sel_mask(float if0, float if1, uint64_t mask)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+    return r;
+}
+
+// Next task of a persistent wave.  The wave barriers keep the compiler from threading the
+// `lane == 0` branch into neighbouring code (which would run readfirstlane with lane 0 masked off).
+static __device__ __forceinline__ int next_task(int* queue, int lane)
+{
+    __builtin_amdgcn_wave_barrier();
+    int ti = 0;
+    if (lane == 0) ti = atomicAdd(queue, 1);
+    __builtin_amdgcn_wave_barrier();
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    __builtin_amdgcn_wave_barrier();
+    return ti;
+}
+
+template <int R, int S> struct Shape {
+    static constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+    static constexpr int G = gcd_(R, S);                 // lane phases are multiples of G
+    static constexpr int C = (S - G + R - 1) / S + 1;    // k-mer classes a lane can touch
+    static constexpr int NMASK = S / G;                  // phase thresholds (index 0 unused)
+    static_assert(C <= 6, "too many classes per lane");
+};
+
+// Wavefront state of one lane after a step (columns jA = 2(t-l)-1, jB = 2(t-l)).
+template <int R> struct Lane {
+    float S[R];      // S[row][jB]
+    float H[R];      // H[row][jB]
+    float SbotA;     // S[bottom row][jA]
+    float VbotA;     // V[bottom row][jA]
+    float VbotB;     // V[bottom row][jB]
+    float upS;       // S[top row - 1][jB]   (diagonal input of the next step's column A)
+};
+
+struct LaneConst {
+    int off[6];   // LDS byte offset of the class row minus lo4
+    int lo4[6];   // band_lo * 4
+    int hi4[6];   // (band_lo + tw - 1) * 4
+};
+
+template <int R, int S>
+static __device__ __forceinline__ void fetch_scores(const char* lds, const LaneConst& lc, int q4,
+                                                    float (&sc)[Shape<R, S>::C])
+{
+#pragma unroll
+    for (int c = 0; c < Shape<R, S>::C; ++c) {
+        const int t = med3i(q4, lc.lo4[c], lc.hi4[c]) + lc.off[c];
+        sc[c] = *reinterpret_cast<const float*>(lds + t);
+    }
+}
+
+// expand the <=C class scores of a column to the R rows of the lane.
+// row r of a lane with phase p belongs to class slot (p + r) / S; p is a multiple of G, so rows
+// split into groups of G with at most one lane-mask select per group (none when R % S == 0).
+template <int R, int S>
+static __device__ __forceinline__ void expand_scores(const float (&sc)[Shape<R, S>::C],
+                                                     const uint64_t (&pm)[Shape<R, S>::NMASK],
+                                                     float (&rs)[R])
+{
+    constexpr int G = Shape<R, S>::G, C = Shape<R, S>::C;
+#pragma unroll
+    for (int r = 0; r < R; r += G) {
+        const int base = r / S, x = (r % S) / G;
+        float v;
+        if (x == 0 || base + 1 >= C) v = sc[base < C ? base : C - 1];
+        else v = sel_mask(sc[base], sc[base + 1], pm[x]);
+#pragma unroll
+        for (int g = 0; g < G && r + g < R; ++g) rs[r + g] = v;
+    }
+}
+
+struct TraceWords { uint64_t a[2], b[2]; };
+
+// Two DP columns (jA, jB) for this lane.
+// LH / LV: open == extend in that direction, where the affine recurrence collapses exactly
+// (H[i][j-1] <= S[i][j-1] always and x -> x+e is monotone in IEEE arithmetic, so
+// max(H+e, S+e) == S+e bit for bit).  KEEP additionally materialises the H / V values the
+// collapsed form does not carry (needed when the state is checkpointed).  TRACE computes the
+// full recurrence with the oracle's tie rules and returns the 4-bit trace codes.
+template <int R, bool LH, bool LV, bool KEEP, bool TRACE>
+static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[R], const float (&rsB)[R],
+                                                float upA, float upB, float upVA, float upVB,
+                                                const AlignParams& p, TraceWords* tw)
+{
+    float SA[R], SB[R];
+    float HA[R], HB[R];
+    float vA = upVA, vB = upVB;
+    if constexpr (TRACE) { tw->a[0] = tw->a[1] = tw->b[0] = tw->b[1] = 0; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        // ---- column A, row r
+        {
+            const float diag = r == 0 ? st.upS : st.S[r - 1];
+            const float up = r == 0 ? upA : SA[r > 0 ? r - 1 : 0];
+            const float D = diag + rsA[r];
+            if constexpr (TRACE) {
+                const float hext = st.H[r] + p.ext_h, hopn = st.S[r] + p.open_h;
+                const bool he = STRQ_TIE_EXT(hext, hopn);
+                const float Hn = he ? hext : hopn;
+                const float vext = vA + p.ext_v, vopn = up + p.open_v;
+                const bool ve = STRQ_TIE_EXT(vext, vopn);
+                const float Vn = ve ? vext : vopn;
+                const bool gh = STRQ_TIE_H_OVER_V(Hn, Vn);
+                const float Gm = gh ? Hn : Vn;
+                const bool dd = STRQ_TIE_D_OVER_G(D, Gm);
+                SA[r] = dd ? D : Gm; HA[r] = Hn; vA = Vn;
+                const uint64_t code = (dd ? 0u : (gh ? 1u : 2u)) | (he ? 4u : 0u) | (ve ? 8u : 0u);
+                tw->a[r / 16] |= code << (4 * (r % 16));
+            } else {
+                float Hn, Vn;
+                if constexpr (LH) Hn = st.S[r] + p.ext_h;
+                else Hn = __builtin_fmaxf(st.H[r] + p.ext_h, st.S[r] + p.open_h);
+                if constexpr (LV) Vn = up + p.ext_v;
+                else Vn = __builtin_fmaxf(vA + p.ext_v, up + p.open_v);
+                SA[r] = __builtin_fmaxf(__builtin_fmaxf(D, Hn), Vn);
+                HA[r] = Hn; vA = Vn;
+            }
+        }
+        // ---- column B, row r
+        {
+            const float diag = r == 0 ? upA : SA[r > 0 ? r - 1 : 0];
+            const float up = r == 0 ? upB : SB[r > 0 ? r - 1 : 0];
+            const float D = diag + rsB[r];
+            if constexpr (TRACE) {
+                const float hext = HA[r] + p.ext_h, hopn = SA[r] + p.open_h;
+                const bool he = STRQ_TIE_EXT(hext, hopn);
+                const float Hn = he ? hext : hopn;
+                const float vext = vB + p.ext_v, vopn = up + p.open_v;
+                const bool ve = STRQ_TIE_EXT(vext, vopn);
+                const float Vn = ve ? vext : vopn;
+                const bool gh = STRQ_TIE_H_OVER_V(Hn, Vn);
+                const float Gm = gh ? Hn : Vn;
+                const bool dd = STRQ_TIE_D_OVER_G(D, Gm);
+                SB[r] = dd ? D : Gm; HB[r] = Hn; vB = Vn;
+                const uint64_t code = (dd ? 0u : (gh ? 1u : 2u)) | (he ? 4u : 0u) | (ve ? 8u : 0u);
+                tw->b[r / 16] |= code << (4 * (r % 16));
+            } else {
+                float Hn, Vn;
+                if constexpr (LH) Hn = SA[r] + p.ext_h;
+                else Hn = __builtin_fmaxf(HA[r] + p.ext_h, SA[r] + p.open_h);
+                if constexpr (LV) Vn = up + p.ext_v;
+                else Vn = __builtin_fmaxf(vB + p.ext_v, up + p.open_v);
+                SB[r] = __builtin_fmaxf(__builtin_fmaxf(D, Hn), Vn);
+                HB[r] = Hn; vB = Vn;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) st.S[r] = SB[r];
+    if constexpr (TRACE || !LH || KEEP) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) st.H[r] = HB[r];
+    }
+    st.SbotA = SA[R - 1];
+    if constexpr (TRACE || !LV || KEEP) { st.VbotA = vA; st.VbotB = vB; }
+    st.upS = upB;
+}
+
+template <int R, int S>
+static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int lane, int lds_base,
+                                                        LaneConst& lc, uint64_t (&pm)[Shape<R, S>::NMASK])
+{
+    const int row0 = lane * R;
+    const int kbase = row0 / S, phase = row0 % S;
+    const int tstride = tk.tw + 1;
+#pragma unroll
+    for (int c = 0; c < Shape<R, S>::C; ++c) {
+        int k = kbase + c; if (k > tk.k - 1) k = tk.k - 1;
+        const int lo = tk.band_lo[k];
+        lc.lo4[c] = lo * 4;
+        lc.hi4[c] = (lo + tk.tw - 1) * 4;
+        lc.off[c] = lds_base + k * tstride * 4 - lo * 4;
+    }
+#pragma unroll
+    for (int x = 0; x < Shape<R, S>::NMASK; ++x) pm[x] = __ballot(phase >= S - x * Shape<R, S>::G);
+}
+
+// stage the banded score table of one alignment into this wave's LDS slice
+static __device__ __forceinline__ void stage_table(const AlignTask& tk, float* lds, int lane)
+{
+    const int nfl = tk.k * (tk.tw + 1);
+    for (int i = lane; i < nfl; i += 64) lds[i] = tk.table[i];
+}
+
+template <int R>
+static __device__ __forceinline__ void init_lane(const AlignTask& tk, int lane, Lane<R>& st)
+{
+    const int row0 = lane * R;   // DP row of register r is row0 + r + 1
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int i = row0 + r + 1; if (i > tk.m) i = tk.m;
+        st.S[r] = tk.col0[i];
+        st.H[r] = STRQ_NINF;
+    }
+    { int i = row0 + R; if (i > tk.m) i = tk.m; st.SbotA = st.VbotA = st.VbotB = tk.col0[i]; }  // V[i][0] == S[i][0]
+    { int i = row0;     if (i > tk.m) i = tk.m; st.upS = tk.col0[i]; }    // S[row0][0]; col0[0] == 0
+}
+
+// packed levels (x4) of columns 2*(64*chunk+lane)+1 and +2
+static __device__ __forceinline__ int load_chunk(const AlignTask& tk, int chunk, int lane)
+{
+    const int idx = (chunk * 64 + lane) * 2;
+    int a = 0, b = 0;
+    if (idx < tk.n) a = tk.levels[idx];
+    if (idx + 1 < tk.n) b = tk.levels[idx + 1];
+    return (a << 2) | (b << 18);
+}
+
+template <int R>
+static __device__ __forceinline__ void save_ckpt(float* c, int lane, const Lane<R>& st)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) c[r * 64 + lane] = st.S[r];
+#pragma unroll
+    for (int r = 0; r < R; ++r) c[(R + r) * 64 + lane] = st.H[r];
+    c[(2 * R + 0) * 64 + lane] = st.SbotA;
+    c[(2 * R + 1) * 64 + lane] = st.VbotA;
+    c[(2 * R + 2) * 64 + lane] = st.VbotB;
+    c[(2 * R + 3) * 64 + lane] = st.upS;
+}
+template <int R>
+static __device__ __forceinline__ void load_ckpt(const float* c, int lane, Lane<R>& st)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) st.S[r] = c[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < R; ++r) st.H[r] = c[(R + r) * 64 + lane];
+    st.SbotA = c[(2 * R + 0) * 64 + lane];
+    st.VbotA = c[(2 * R + 1) * 64 + lane];
+    st.VbotB = c[(2 * R + 2) * 64 + lane];
+    st.upS = c[(2 * R + 3) * 64 + lane];
+}
+
+// runtime-indexed read of x[rM] (rM wave-uniform, in an SGPR)
+template <int R>
+static __device__ __forceinline__ float pick_row(const float (&x)[R], int rM)
+{
+    typedef float vec_t __attribute__((ext_vector_type(R <= 16 ? 16 : 32)));
+    vec_t v;
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = x[r];
+    return v[rM];
+}
+
+// ------------------------------------------------------------------------------------------
+// forward pass: best score of the last flank row, its column, and wavefront checkpoints
+// ------------------------------------------------------------------------------------------
+template <int R, int S, bool LH, bool LV, bool RM_LAST>
+struct Forward {
+    const AlignTask& tk;
+    const AlignParams& p;
+    const char* ldsb;
+    const LaneConst& lc;
+    const uint64_t (&pm)[Shape<R, S>::NMASK];
+    const int lane, rM;
+    Lane<R> st;
+    float best; int bestj;
+    int qq;
+
+    // PRED: lanes may be idle (before their first / after their last column)
+    template <bool PRED, bool KEEP>
+    __device__ __forceinline__ void step(int t, int qin)
+    {
+        qq = dpp_shr1_i(qq, qin);
+        const float upA = dpp_shr1_f(st.SbotA, 0.0f);
+        const float upB = dpp_shr1_f(st.S[R - 1], 0.0f);
+        float upVA = STRQ_NINF, upVB = STRQ_NINF;
+        if constexpr (!LV) { upVA = dpp_shr1_f(st.VbotA, STRQ_NINF); upVB = dpp_shr1_f(st.VbotB, STRQ_NINF); }
+        const int jB = 2 * (t - lane), jA = jB - 1;
+        bool act = true;
+        if constexpr (PRED) act = (jA >= 1) && (jA <= tk.n);
+        if (act) {
+            float scA[Shape<R, S>::C], scB[Shape<R, S>::C], rsA[R], rsB[R];
+            fetch_scores<R, S>(ldsb, lc, qq & 0xffff, scA);
+            fetch_scores<R, S>(ldsb, lc, (int)((unsigned)qq >> 16), scB);
+            expand_scores<R, S>(scA, pm, rsA);
+            expand_scores<R, S>(scB, pm, rsB);
+            float candA, candB;
+            if constexpr (RM_LAST) {
+                dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr);
+                candA = st.SbotA;
+                candB = st.S[R - 1];
+            } else {
+                // the last flank row sits in an interior register: column A is not retained by the
+                // state, so redo column A alone from a copy (rare shapes only)
+                const Lane<R> before = st;
+                dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr);
+                float SAonly[R];
+                float up = upA, vA = upVA;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float diag = r == 0 ? before.upS : before.S[r > 0 ? r - 1 : 0];
+                    const float D = diag + rsA[r];
+                    float Hn, Vn;
+                    if constexpr (LH) Hn = before.S[r] + p.ext_h;
+                    else Hn = __builtin_fmaxf(before.H[r] + p.ext_h, before.S[r] + p.open_h);
+                    if constexpr (LV) Vn = up + p.ext_v;
+                    else Vn = __builtin_fmaxf(vA + p.ext_v, up + p.open_v);
+                    SAonly[r] = __builtin_fmaxf(__builtin_fmaxf(D, Hn), Vn);
+                    up = SAonly[r]; vA = Vn;
+                }
+                candA = pick_row<R>(SAonly, rM);
+                candB = pick_row<R>(st.S, rM);
+            }
+            if (candA > best) { best = candA; bestj = jA; }
+            bool okB = true;
+            if constexpr (PRED) okB = jB <= tk.n;
+            if (okB && candB > best) { best = candB; bestj = jB; }
+        }
+    }
+};
+
+template <int R, int S, bool LH, bool LV, bool RM_LAST>
+static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignResult* res, const AlignParams& p,
+                                                   float* lds, int lds_base, const char* ldsb, int lane)
+{
+    stage_table(tk, lds, lane);
+    LaneConst lc; uint64_t pm[Shape<R, S>::NMASK];
+    load_lane_consts<R, S>(tk, lane, lds_base, lc, pm);
+    const int lM = (tk.m - 1) / R, rM = (tk.m - 1) % R;
+    Forward<R, S, LH, LV, RM_LAST> f{tk, p, ldsb, lc, pm, lane, rM};
+    init_lane<R>(tk, lane, f.st);
+    f.best = tk.col0[tk.m]; f.bestj = 0; f.qq = 0;
+    __builtin_amdgcn_s_waitcnt(0);   // LDS table written by this wave is visible to it
+
+    const int nsteps = (tk.n + 1) / 2 + 63;
+    int qcur = load_chunk(tk, 0, lane);
+    for (int t0 = 0; t0 < nsteps; t0 += 64) {
+        STRQ_MARK(3, t0 + 1);
+        const int qnext = load_chunk(tk, t0 / 64 + 1, lane);   // prefetch next 128 columns
+        // every lane busy with two valid columns for all 64 steps?
+        const bool full = (t0 >= 63) && (2 * (t0 + 64) <= tk.n);
+        const bool ckpt_here = ((t0 + 64) % STRQ_CKPT_STEPS) == 0 && (t0 + 64) < nsteps;
+        const int send = nsteps - t0 < 64 ? nsteps - t0 : 64;
+        if (full) {
+            for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, __builtin_amdgcn_readlane(qcur, s));
+            if (ckpt_here) f.template step<false, true>(t0 + 64, __builtin_amdgcn_readlane(qcur, 63));
+            else f.template step<false, false>(t0 + 64, __builtin_amdgcn_readlane(qcur, 63));
+        } else {
+            for (int s = 0; s < send; ++s) {
+                if (ckpt_here && s == 63) f.template step<true, true>(t0 + s + 1, __builtin_amdgcn_readlane(qcur, s));
+                else f.template step<true, false>(t0 + s + 1, __builtin_amdgcn_readlane(qcur, s));
+            }
+        }
+        if (ckpt_here)
+            save_ckpt<R>(tk.ckpt + (size_t)((t0 + 64) / STRQ_CKPT_STEPS - 1) * (STRQ_CKPT_FIELDS(R) * 64), lane, f.st);
+        qcur = qnext;
+    }
+    STRQ_MARK(4, 1);
+    const float b = __shfl(f.best, lM, 64);
+    const int bj = __shfl(f.bestj, lM, 64);
+    res->best = b; res->j_end = bj;   // every lane stores the same value
+}
+
+template <int R, int S, bool LH, bool LV>
+__global__ void __launch_bounds__(256, 1)
+align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
+                     int* __restrict__ queue, AlignParams p, int lds_floats_per_wave)
+{
+    extern __shared__ float lds_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* lds = lds_all + (size_t)wave * lds_floats_per_wave;
+    const int lds_base = wave * lds_floats_per_wave * 4;
+    const char* ldsb = reinterpret_cast<const char*>(lds_all);
+    for (;;) {
+        const int ti = next_task(queue, lane);
+        if (ti >= n_tasks) break;
+        const AlignTask& tk = tasks[ti];
+        STRQ_MARK(0, ti + 1); STRQ_MARK(1, tk.n); STRQ_MARK(2, tk.m);
+        if ((tk.m - 1) % R == R - 1) forward_one<R, S, LH, LV, true>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+        else forward_one<R, S, LH, LV, false>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// trace pass: re-run the blocks of steps the optimal path crosses, keep 4 bits per cell,
+// walk back, and emit one record per flank row.
+// ------------------------------------------------------------------------------------------
+template <int R, int S>
+__global__ void __launch_bounds__(256, 1)
+align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
+                   int* __restrict__ queue, AlignParams p, int lds_floats_per_wave,
+                   uint64_t* __restrict__ scratch_all)
+{
+    extern __shared__ float lds_all[];
+    constexpr int W = STRQ_TRACE_WORDS(R);
+    constexpr size_t STEP_WORDS = 2 * W * 64;   // [col A/B][word][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* lds = lds_all + (size_t)wave * lds_floats_per_wave;
+    const int lds_base = wave * lds_floats_per_wave * 4;
+    const char* ldsb = reinterpret_cast<const char*>(lds_all);
+    uint64_t* scratch = scratch_all + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * (STRQ_CKPT_STEPS * STEP_WORDS);
+
+    for (;;) {
+        const int ti = next_task(queue, lane);
+        if (ti >= n_tasks) break;
+        const AlignTask& tk = tasks[ti];
+        int32_t* rec = tk.rec;
+
+        stage_table(tk, lds, lane);
+        LaneConst lc; uint64_t pm[Shape<R, S>::NMASK];
+        load_lane_consts<R, S>(tk, lane, lds_base, lc, pm);
+        __builtin_amdgcn_s_waitcnt(0);
+
+        int ci = tk.m, cj = results[ti].j_end, state = 0;     // walker position (wave-uniform)
+        while (ci > 0 && cj > 0) {
+            // step at which the walker's current cell was computed
+            const int tcur = (ci - 1) / R + (cj + 1) / 2;
+            const int blk = (tcur - 1) / STRQ_CKPT_STEPS;
+            const int tb = blk * STRQ_CKPT_STEPS;          // state after step tb is the restart point
+            Lane<R> st;
+            if (blk == 0) init_lane<R>(tk, lane, st);
+            else load_ckpt<R>(tk.ckpt + (size_t)(blk - 1) * (STRQ_CKPT_FIELDS(R) * 64), lane, st);
+            // packed levels of the two columns this lane finished at step tb
+            int qq = 0;
+            {
+                const int jB = 2 * (tb - lane), jA = jB - 1;
+                int a = 0, b = 0;
+                if (jA >= 1 && jA <= tk.n) a = tk.levels[jA - 1];
+                if (jB >= 1 && jB <= tk.n) b = tk.levels[jB - 1];
+                qq = (a << 2) | (b << 18);
+            }
+            int qcur = load_chunk(tk, tb / 64, lane);
+            for (int t0 = tb; t0 < tcur; t0 += 64) {
+                const int qnext = load_chunk(tk, t0 / 64 + 1, lane);
+                const int send = tcur - t0 < 64 ? tcur - t0 : 64;
+                for (int s = 0; s < send; ++s) {
+                    const int t = t0 + s + 1;
+                    qq = dpp_shr1_i(qq, __builtin_amdgcn_readlane(qcur, s));
+                    const float upA = dpp_shr1_f(st.SbotA, 0.0f);
+                    const float upB = dpp_shr1_f(st.S[R - 1], 0.0f);
+                    const float upVA = dpp_shr1_f(st.VbotA, STRQ_NINF);
+                    const float upVB = dpp_shr1_f(st.VbotB, STRQ_NINF);
+                    const int jB = 2 * (t - lane), jA = jB - 1;
+                    TraceWords w; w.a[0] = w.a[1] = w.b[0] = w.b[1] = 0;
+                    if (jA >= 1 && jA <= tk.n) {
+                        float scA[Shape<R, S>::C], scB[Shape<R, S>::C], rsA[R], rsB[R];
+                        fetch_scores<R, S>(ldsb, lc, qq & 0xffff, scA);
+                        fetch_scores<R, S>(ldsb, lc, (int)((unsigned)qq >> 16), scB);
+                        expand_scores<R, S>(scA, pm, rsA);
+                        expand_scores<R, S>(scB, pm, rsB);
+                        dp_step2<R, false, false, true, true>(st, rsA, rsB, upA, upB, upVA, upVB, p, &w);
+                    }
+                    uint64_t* dst = scratch + (size_t)(t - tb - 1) * STEP_WORDS;
+#pragma unroll
+                    for (int x = 0; x < W; ++x) {
+                        dst[(0 * W + x) * 64 + lane] = w.a[x];
+                        dst[(1 * W + x) * 64 + lane] = w.b[x];
+                    }
+                }
+                qcur = qnext;
+            }
+            __threadfence();   // the walker below reads words written by other lanes of this wave
+            // walk back while the current cell lies inside this block
+            while (ci > 0 && cj > 0) {
+                const int l = (ci - 1) / R, r = (ci - 1) % R;
+                const int t = l + (cj + 1) / 2;
+                if (t <= tb) break;
+                const int colsel = (cj & 1) ? 0 : 1;
+                const uint64_t w = scratch[(size_t)(t - tb - 1) * STEP_WORDS + (colsel * W + r / 16) * 64 + l];
+                const uint32_t code = (uint32_t)(w >> (4 * (r % 16))) & 15u;
+                if (state == 0) {
+                    const uint32_t d = code & 3u;
+                    if (d == 0) { rec[ci - 1] = cj << 1; --ci; --cj; }
+                    else state = (int)d;
+                } else if (state == 1) {
+                    --cj; if (!(code & 4u)) state = 0;
+                } else {
+                    rec[ci - 1] = (cj << 1) | 1;
+                    --ci; if (!(code & 8u)) state = 0;
+                }
+            }
+        }
+        // column 0 is not free: whatever is left of the flank is a vertical run before a[0]
+        for (int i = ci - lane; i > 0; i -= 64) rec[i - 1] = 1;
+        results[ti].j0 = cj;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <int R, int S>
+static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult* results, int n_tasks,
+                        int* queue, const AlignParams& p, int lds_floats_per_wave, int waves_per_block,
+                        int n_blocks, uint64_t* scratch, int phase)
+{
+    const size_t lds_bytes = (size_t)lds_floats_per_wave * 4 * waves_per_block;
+    const dim3 grid(n_blocks), block(64 * waves_per_block);
+    const bool lh = p.open_h == p.ext_h, lv = p.open_v == p.ext_v;
+#define STRQ_FWD(LH_, LV_)                                                                              \
+    do {                                                                                                \
+        (void)hipFuncSetAttribute((const void*)align_forward_kernel<R, S, LH_, LV_>,                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);          \
+        hipLaunchKernelGGL((align_forward_kernel<R, S, LH_, LV_>), grid, block, lds_bytes, stream,       \
+                           tasks, results, n_tasks, queue, p, lds_floats_per_wave);                     \
+    } while (0)
+    if (phase == 0) {
+        if (lh && lv) STRQ_FWD(true, true);
+        else if (lh) STRQ_FWD(true, false);
+        else if (lv) STRQ_FWD(false, true);
+        else STRQ_FWD(false, false);
+    } else {
+        (void)hipFuncSetAttribute((const void*)align_trace_kernel<R, S>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((align_trace_kernel<R, S>), grid, block, lds_bytes, stream, tasks, results,
+                           n_tasks, queue, p, lds_floats_per_wave, scratch);
+    }
+#undef STRQ_FWD
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+#define STRQ_SHAPES(X) X(6, 6) X(12, 6) X(15, 6) X(18, 6) X(24, 6)
+
+int align_set_debug_buffer(int* p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_strq_dbg), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+
+int align_pick_rows_per_lane(int m, int samples)
+{
+    if (samples != 6 || m < 1) return 0;
+    // 870 = 58 lanes x 15 rows: last flank row lands in the last register of its lane
+    const int cand[] = {6, 12, 15, 18, 24};
+    for (int r : cand) if (64 * r >= m) return r;
+    return 0;
+}
+
+size_t align_trace_scratch_words_per_wave(int R)
+{
+    return (size_t)STRQ_CKPT_STEPS * 2 * STRQ_TRACE_WORDS(R) * 64;
+}
+
+int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* results,
+                 int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
+                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase)
+{
+#define STRQ_CASE(R_, S_)                                                                               \
+    if (R == R_ && S == S_)                                                                             \
+        return launch_shape<R_, S_>(stream, tasks, results, n_tasks, queue, p, lds_floats_per_wave,     \
+                                    waves_per_block, n_blocks, scratch, phase);
+    STRQ_SHAPES(STRQ_CASE)
+#undef STRQ_CASE
+    return 2;
+}
+
+}  // namespace strq

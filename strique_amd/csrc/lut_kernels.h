@@ -1,0 +1,27 @@
+// Internal: score-table build kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "align_kernels.h"
+
+#define STRQ_LUT_MAX_K 160          // classes per flank that fit the 160 KB LDS build buffer
+#define STRQ_LUT_LOCAL_HARD 64
+#define STRQ_TABLE_SLOT_FLOATS(k) ((size_t)(k) * 259)
+
+namespace strq {
+
+struct LutJob {
+    const float* level_val;   // 256 level values of the read
+    const float* cls_val;     // k class values of the flank
+    float* table;             // slot of STRQ_TABLE_SLOT_FLOATS(k) floats
+    int32_t* band_lo;         // k
+    int32_t k, pad_;
+};
+struct LutInfo { int32_t tw, n_hard; };
+struct HardEntry { int32_t job, k, level, index; };
+
+int launch_lut_build(hipStream_t stream, const LutJob* jobs, LutInfo* info, int n_jobs, int max_k,
+                     HardEntry* hard, int* hard_count, int hard_cap, const AlignParams& p);
+int launch_lut_patch(hipStream_t stream, const LutJob* jobs, const HardEntry* hard, const float* vals, int n);
+
+}  // namespace strq
