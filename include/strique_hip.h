@@ -86,6 +86,34 @@ int strq_align_batch(strq_ctx* ctx, int64_t n_align, int64_t n_reads,
                      int32_t samples,
                      float* score, int64_t* j_end, int64_t* j0, int32_t* rec);
 
+/*
+ * Upload a "baked" profile HMM (what pomegranate's HiddenMarkovModel.bake(merge='All') leaves,
+ * scripts/STRique.py:431,490): emitting states first, silent states after them in topological
+ * order, in-edges in CSR form sorted by source.
+ *   emis_kind  1 = Normal(mu, sigma):  a = mu, b = 1/(2 sigma^2), c = -log(sigma sqrt(2 pi))
+ *              2 = Uniform(lo, hi):    a = lo, b = hi,            c = -log(hi - lo)
+ *   count_inc  n_states ints (nullable): states whose visits along the best path are counted
+ *              (the two dummy states of repeatHMM, scripts/STRique.py:374-378)
+ * Limits: <= 512 emitting and <= 256 silent states.
+ */
+int strq_model_create(strq_ctx* ctx, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
+                      const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
+                      const int32_t* emis_kind, const double* emis_a, const double* emis_b,
+                      const double* emis_c, const int32_t* count_inc, int32_t* model_id);
+
+/*
+ * HiddenMarkovModel.viterbi(x) (scripts/STRique.py:434,493).
+ *   logp     log-probability of the best path (-inf and status 1 when there is none)
+ *   counted  visits of count_inc states on that path
+ *   path[T]  emitting state (index in the baked order) of every observation (nullable; asking
+ *            for it makes the kernel write back-pointers)
+ */
+int strq_viterbi(strq_ctx* ctx, int32_t model_id, const double* x, int64_t T,
+                 double* logp, int64_t* counted, int32_t* status, int32_t* path);
+int strq_viterbi_batch(strq_ctx* ctx, int32_t model_id, int64_t n_seq, const double* x,
+                       const int64_t* x_off, double* logp, int64_t* counted, int32_t* status,
+                       int32_t* paths);
+
 /* Kernel timing of the last batched call, milliseconds (HIP events on the library's stream):
  * [0] table build  [1] forward DP  [2] trace pass  [3] total.  */
 int strq_last_timing(const strq_ctx* ctx, float ms[8]);

@@ -1,0 +1,269 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+CPU restatement of STRique's per-read hot path `repeatCounter.detect`
+(reference scripts/STRique.py:581-618) and of what it calls:
+
+    signal conditioning              STRique.py:590-597, pore_model.normalize2model :150-180, MAD :142-143
+    flank alignment (native)         src/align_raw.h:106-158, src/score_distance.h:115-122  -> align_oracle.c
+    __detect_range__                 STRique.py:538-548
+    flanked-repeat HMM Viterbi       STRique.py:433-441 (+ pomegranate 0.10.0 bake/viterbi)   -> viterbi_oracle.c
+    base-modification pass           STRique.py:492-500, 605-609
+
+numpy / scipy calls are the same ones the reference makes (np.median, np.percentile, scipy medfilt
+semantics); grey opening/closing follow scikit-image 0.14 (`requirements.txt:9`), which is not
+installed here -- see `grey_open_close_1x8`.
+
+PARITY STATUS
+  pinned by tests/golden (generated from the reference's own code, tests/golden/make_golden.py):
+      pore-model statistics, minmax / median normalisation, flank templates, HMM topology.
+  pinned by the reference's docs/tests: integer geometry of the bundled read (offset 1633,
+      ticks 40758; docs/installation/test.md:15-16) and repeat counts of scripts/STRique_test.py.
+  "parity unpinned": float outputs at the SeqAn and pomegranate boundaries (neither library is
+      in /root/reference nor installable here) -- see the headers of align_oracle.c / viterbi_oracle.c.
+"""
+import ctypes
+import itertools
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    """Compile liboracle.so from the C restatements (gcc, no other dependency)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return os.path.join(_HERE, "liboracle.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+        if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.strq_oracle_cell_score.restype = ctypes.c_float
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+DEFAULT_ALIGN = {'dist_offset': 16.0, 'dist_min': 0.0, 'gap_open_h': -1.0, 'gap_open_v': -16.0,
+                 'gap_extension_h': -1.0, 'gap_extension_v': -16.0, 'samples': 6}     # STRique.py:507-513
+
+
+def align_params(cfg=None):
+    c = dict(DEFAULT_ALIGN)
+    if cfg:
+        c.update(cfg)
+    return np.array([c['gap_open_h'], c['gap_extension_h'], c['gap_open_v'], c['gap_extension_v'],
+                     c['dist_offset'], c['dist_min']], dtype=np.float32)
+
+
+def align_overlap(a, b, params, use_lut=True, want_idx=True):
+    """(score, a_idx, b_idx, rec, j_end, j0) of the semi-global alignment; a, b are rounded to
+    float32 on entry like the pybind11 list caster does (src/pyalign.cpp:59-61)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    n, m = len(a), len(b)
+    score = ctypes.c_float(); j_end = ctypes.c_int64(); j0 = ctypes.c_int64()
+    rec = np.zeros(m, np.int32)
+    a_idx = np.zeros(n, np.uint64) if want_idx else None
+    b_idx = np.zeros(m, np.uint64) if want_idx else None
+    rc = lib().strq_oracle_align(_p(a), ctypes.c_int64(n), _p(b), ctypes.c_int64(m),
+                                 _p(np.ascontiguousarray(params, np.float32)),
+                                 ctypes.byref(score), ctypes.byref(j_end), ctypes.byref(j0),
+                                 _p(rec), _p(a_idx), _p(b_idx), ctypes.c_int(1 if use_lut else 0))
+    if rc != 0:
+        raise RuntimeError("oracle align failed: %d" % rc)
+    return score.value, a_idx, b_idx, rec, j_end.value, j0.value
+
+
+def viterbi(baked, x, want_path=True):
+    """(logp, emitting-state path or None, counted visits) on a baked model (strique_amd.hmm.bake)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    T = len(x)
+    logp = ctypes.c_double(); counted = ctypes.c_int64(0)
+    path = np.zeros(T, np.int32) if want_path else None
+    i32 = lambda v: np.ascontiguousarray(v, np.int32)
+    f64 = lambda v: np.ascontiguousarray(v, np.float64)
+    arrs = [i32(baked.in_ptr), i32(baked.in_src), f64(baked.in_logp), i32(baked.emis_kind),
+            f64(baked.emis_a), f64(baked.emis_b), f64(baked.emis_c), i32(baked.count_inc)]
+    rc = lib().strq_oracle_viterbi(ctypes.c_int32(baked.n_states), ctypes.c_int32(baked.silent_start),
+                                   ctypes.c_int32(baked.start), ctypes.c_int32(baked.end),
+                                   *[_p(a) for a in arrs], _p(x), ctypes.c_int64(T),
+                                   ctypes.byref(logp), _p(path), ctypes.byref(counted))
+    if rc == 2:
+        raise RuntimeError("oracle viterbi failed")
+    if rc == 1:
+        return logp.value, None, 0
+    return logp.value, path, counted.value
+
+
+# ---------------------------------------------------------------------------------------------
+# signal conditioning
+# ---------------------------------------------------------------------------------------------
+def medfilt3(x):
+    """scipy.signal.medfilt(x, kernel_size=3): zero padding, dtype preserved (STRique.py:590)."""
+    x = np.asarray(x)
+    p = np.concatenate([np.zeros(1, x.dtype), x, np.zeros(1, x.dtype)])
+    w = np.stack([p[:-2], p[1:-1], p[2:]])
+    return np.sort(w, axis=0)[1].astype(x.dtype)
+
+
+def _window_reduce(x, lo, hi, fn):
+    """fn over x[i+lo .. i+hi] with scipy.ndimage 'reflect' borders (d c b a | a b c d | d c b a)."""
+    n = len(x)
+    pad = max(-lo, hi)
+    idx = np.arange(-pad, n + pad)
+    period = 2 * n
+    idx = np.mod(idx, period)
+    idx = np.where(idx >= n, period - 1 - idx, idx)
+    xp = x[idx]
+    out = None
+    for off in range(lo, hi + 1):
+        seg = xp[pad + off: pad + off + n]
+        out = seg.copy() if out is None else fn(out, seg)
+    return out
+
+
+def grey_open_close_1x8(u8):
+    """closing(opening(img, rectangle(1, 8)), rectangle(1, 8)) of scikit-image 0.14 on a 1 x N
+    uint8 image (STRique.py:593-595).  Even footprints are padded to 9 with one zero column:
+    on the left in the first stage of opening/closing, on the right in the second; dilation
+    inverts the footprint before scipy.ndimage inverts it again.  Net 1-D windows:
+        opening = max_{-4..+3}( min_{-3..+4} ),   closing = min_{-4..+3}( max_{-3..+4} )."""
+    x = np.asarray(u8, dtype=np.uint8)
+    opened = _window_reduce(_window_reduce(x, -3, 4, np.minimum), -4, 3, np.maximum)
+    return _window_reduce(_window_reduce(opened, -3, 4, np.maximum), -4, 3, np.minimum)
+
+
+class PoreModel(object):
+    """Statistics of a k-mer table the normalisation needs (STRique.py:114-127,154-158)."""
+
+    def __init__(self, model_file):
+        table = {}
+        with open(model_file) as fp:
+            for line in fp:
+                c = line.strip().split('\t')
+                if len(c) >= 3:
+                    table[c[0]] = (float(c[1]), float(c[2]))
+        self.table = table
+        self.kmer = len(next(iter(table)))
+        means = np.array([v[0] for v in table.values()])
+        self.means = means
+        lo = min(table.values(), key=lambda v: v[0]); hi = max(table.values(), key=lambda v: v[0])
+        self.model_min = lo[0] - 6 * lo[1]
+        self.model_max = hi[0] + 6 * hi[1]
+
+    def normalize_minmax(self, signal):
+        signal = np.asarray(signal, dtype=np.float64)
+        mv = self.means
+        q5_sig, q95_sig = np.percentile(signal, [1, 99])
+        q5_mod, q95_mod = np.percentile(mv, [1, 99])
+        m5_sig = np.median(signal[signal < q5_sig]); m95_sig = np.median(signal[signal > q95_sig])
+        m5_mod = np.median(mv[mv < q5_mod]); m95_mod = np.median(mv[mv > q95_mod])
+        out = (signal - (m5_sig + (m95_sig - m5_sig) / 2)) / ((m95_sig - m5_sig) / 2)
+        out = out * ((m95_mod - m5_mod) / 2) + (m5_mod + (m95_mod - m5_mod) / 2)
+        np.clip(out, self.model_min + .5, self.model_max - .5, out=out)
+        return out
+
+
+def mad(signal):
+    return np.mean(np.absolute(np.subtract(signal, np.median(signal))))
+
+
+def condition(raw_signal, pm):
+    """Steps 1-6 of detect (STRique.py:590-597): returns (flt, u8 morphology levels, morph, fltn)."""
+    flt = medfilt3(raw_signal)
+    z = (flt - np.median(flt)) / mad(flt)
+    u8 = np.clip(z * 24 + 127, 0, 255).astype(np.uint8)
+    u8 = grey_open_close_1x8(u8)
+    morph = pm.normalize_minmax(u8.astype(np.float64))
+    fltn = pm.normalize_minmax(flt.astype(np.float64))
+    return flt, u8, morph, fltn
+
+
+def detect_range(signal, segment, params, pre_trim=0, post_trim=0, use_lut=True):
+    """__detect_range__ (STRique.py:538-548), computed from the full view-position lists exactly
+    as the reference does."""
+    score, idx_signal, idx_segment, _, _, _ = align_overlap(signal, segment, params, use_lut=use_lut)
+    idx_signal = idx_signal.astype(np.int64); idx_segment = idx_segment.astype(np.int64)
+    begin = int(np.abs(idx_signal - idx_segment[0]).argmin())
+    end = int(np.abs(idx_signal - idx_segment[-1]).argmin())
+    score = float(score) / (end - begin) if end > begin else 0.0
+    begin = int(np.abs(idx_signal - idx_segment[0 + pre_trim]).argmin())
+    end = int(np.abs(idx_signal - idx_segment[-1 - post_trim]).argmin())
+    return score, begin, end
+
+
+def positions_from_rec(rec, j0, j_end, n, rows):
+    """Same four positions derived from the compact per-row record (cross-checks the GPU rule)."""
+    m = len(rec)
+    out = []
+    for k in rows:
+        j = int(rec[k]) >> 1
+        if not (rec[k] & 1):
+            out.append(j - 1); continue
+        k1 = k
+        while k1 > 0 and (rec[k1 - 1] & 1) and (int(rec[k1 - 1]) >> 1) == j:
+            k1 -= 1
+        k2 = k
+        while k2 < m - 1 and (rec[k2 + 1] & 1) and (int(rec[k2 + 1]) >> 1) == j:
+            k2 += 1
+        d_prev, d_next = k - k1 + 1, k2 - k + 1
+        has_prev, has_next = j >= 1, j < n
+        if has_prev and (not has_next or d_prev <= d_next):
+            out.append(j - 1)
+        else:
+            out.append(j)
+    return out
+
+
+def detect(raw_signal, tc, pm, params, pm_mod=None, use_lut=True):
+    """repeatCounter.detect for one strand-specific classifier `tc` with fields prefix, suffix,
+    prefix_ext, suffix_ext (float64 templates), hmm (baked flanked model + count_bias) and
+    optionally mod (baked mod model, hub indices, model_min/max).
+    Returns (n, score_prefix, score_suffix, log_p, offset, ticks, mod_pattern) plus a dict with
+    the intermediate geometry."""
+    raw_signal = np.asarray(raw_signal)
+    flt, u8, morph, fltn = condition(raw_signal, pm)
+    trim_prefix = len(tc['prefix_ext']) - len(tc['prefix'])
+    trim_suffix = len(tc['suffix_ext']) - len(tc['suffix'])
+    score_prefix, prefix_begin, prefix_end = detect_range(morph, tc['prefix_ext'], params, pre_trim=trim_prefix, use_lut=use_lut)
+    score_suffix, suffix_begin, suffix_end = detect_range(morph, tc['suffix_ext'], params, post_trim=trim_suffix, use_lut=use_lut)
+    n = 0; p = 0; mod_pattern = '-'
+    if prefix_begin < suffix_end and score_prefix > 0.0 and score_suffix > 0.0:
+        baked = tc['hmm'].baked
+        logp, path, counted = viterbi(baked, fltn[prefix_begin:suffix_end])
+        if path is not None:
+            n = int(counted) + tc['hmm'].count_bias
+            p = logp
+            if pm_mod is not None and tc.get('mod') is not None:
+                nrm = pm.normalize_minmax(raw_signal.astype(np.float64))
+                mask = baked.tag[path].astype(bool)
+                rep = nrm[prefix_begin:suffix_end][mask]
+                mod_pattern = mod_repeats(tc['mod'], rep)
+        else:
+            n, p = 0, 0
+    info = dict(prefix_begin=prefix_begin, prefix_end=prefix_end, suffix_begin=suffix_begin, suffix_end=suffix_end, u8=u8)
+    return (n, score_prefix, score_suffix, p, prefix_end, max(suffix_begin - prefix_end, 0), mod_pattern), info
+
+
+def mod_repeats(mod, signal):
+    """repeatModHMM.mod_repeats (STRique.py:492-500)."""
+    baked = mod.baked
+    logp, path, _ = viterbi(baked, np.clip(signal, mod.model_min, mod.model_max))
+    if path is None:
+        return '-'
+    names = [baked.names[s] for s in path]
+    first = [next(g) for k, g in itertools.groupby(names, key=lambda x: x not in ('s0', 'e0')) if k]
+    return ''.join('1' if 'mod' in x else '0' for x in first)

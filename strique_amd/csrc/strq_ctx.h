@@ -6,6 +6,7 @@
 #include <vector>
 #include <cstdio>
 #include "align_kernels.h"
+#include "viterbi_kernels.h"
 
 namespace strq {
 
@@ -26,6 +27,12 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+struct HostModel {
+    VitModel h;              // host copy (pointers are device pointers)
+    const VitModel* dev = nullptr;
+    DevBuf blob;
+};
+
 }  // namespace strq
 
 struct strq_ctx {
@@ -38,7 +45,8 @@ struct strq_ctx {
     float timing[8] = {};
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, band_lo, col0, ckpt, rec, tasks, results,
-        queue, scratch, lutinfo, hard, misc;
+        queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path;
+    std::vector<strq::HostModel*> models;
     size_t max_ws_bytes = (size_t)48 << 30;   // cap for checkpoint workspace per sub-batch
 };
 

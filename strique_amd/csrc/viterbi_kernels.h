@@ -1,0 +1,49 @@
+// Internal: profile-HMM Viterbi kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace strq {
+
+// Device image of a baked model (strique_amd/hmm.py: bake), laid out for one wave64:
+// emitting state e lives in (slot e / 64, lane e % 64); silent state silent_start + q likewise.
+// Every slot has a lane-major padded in-edge list: entry (j, lane) at edge_base[slot] + j*64 + lane.
+// Padding edges point at the extra cell v[n_states] == -inf.
+struct VitModel {
+    int32_t n_states, n_emit, n_silent, start, end;
+    int32_t epl, spl;                 // slots per lane (emitting / silent)
+    int32_t e_deg[8], e_base[8];      // padded in-degree and edge offset (in units of 64 entries) per emitting slot
+    int32_t s_deg[8], s_base[8];
+    int32_t n_edge_rows;              // total rows of 64 entries
+    const int32_t* edge_src;          // n_edge_rows * 64
+    const double* edge_logp;          // n_edge_rows * 64
+    const int32_t* emis_kind;         // epl * 64  (0 = padding)
+    const double* emis_a;             // mu | lo
+    const double* emis_b;             // 1/(2 sigma^2) | hi
+    const double* emis_c;             // -log(sigma sqrt(2pi)) | -log(hi - lo)
+    const int32_t* count_inc;         // n_states + 1
+};
+
+enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };
+
+struct VitTask {
+    const void* sig;         // first observation
+    int64_t T;
+    int32_t src_kind, pad_;
+    double c1, h1, h2, c2, lo, hi;    // x = clip((s - c1) / h1 * h2 + c2, lo, hi)  (STRique.py:159-160,178-179)
+    uint16_t* bp;            // (T + 1) x (n_states) predecessor states, nullable (count-only mode)
+};
+
+struct VitResult {
+    double logp;
+    int64_t counted;
+    int32_t status;          // 0 ok, 1 no path
+    int32_t pad_;
+};
+
+int launch_viterbi(hipStream_t stream, const VitModel& model_host, const VitModel* model_dev,
+                   const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp);
+int launch_vit_traceback(hipStream_t stream, const VitModel* model_dev, const VitTask* tasks, const VitResult* results,
+                         int32_t* const* paths, int n_tasks);
+
+}  // namespace strq

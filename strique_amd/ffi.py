@@ -1,0 +1,144 @@
+"""ctypes binding of libstrique_hip.so (include/strique_hip.h).
+
+This is the only place the package touches the native library.  There is no CPU fallback:
+if the library is missing or no GPU is present, creating a `Context` raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstrique_hip.so")
+
+STRQ_OK, STRQ_ERR_ARG, STRQ_ERR_DEVICE, STRQ_ERR_UNSUPPORTED, STRQ_ERR_NOMEM = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+class StriqueHipError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libstrique_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+def load_library(path=None):
+    """Load the shared library (building nothing: see strique_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError("%s not found: run `python -m strique_amd.build` (hipcc, gfx950) first" % path)
+        lib = ctypes.CDLL(path)
+        lib.strq_last_error.restype = ctypes.c_char_p
+        lib.strq_last_error.argtypes = [ctypes.c_void_p]
+        lib.strq_ctx_destroy.restype = None
+        lib.strq_ctx_destroy.argtypes = [ctypes.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Context(object):
+    """One HIP context / stream / workspace on one GPU (strq_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.strq_ctx_create(ctypes.c_int(device), ctypes.byref(self._h))
+        if rc != STRQ_OK:
+            self._h = None
+            raise StriqueHipError(rc, "cannot create a context on HIP device %d (no GPU?)" % device)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.strq_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != STRQ_OK:
+            raise StriqueHipError(rc, self._lib.strq_last_error(self._h).decode())
+
+    # ---- alignment ------------------------------------------------------------------------
+    def set_align_params(self, open_h, ext_h, open_v, ext_v, dist_offset, dist_min):
+        p = np.array([open_h, ext_h, open_v, ext_v, dist_offset, dist_min], dtype=np.float32)
+        self._check(self._lib.strq_set_align_params(self._h, _ptr(p)))
+
+    def get_align_params(self):
+        p = np.zeros(6, np.float32)
+        self._check(self._lib.strq_get_align_params(self._h, _ptr(p)))
+        return p
+
+    def align_overlap(self, a, b, want_idx=True):
+        """(score, a_idx, b_idx, rec, j_end, j0); inputs are rounded to float32 like the reference's
+        pybind11 caster does (src/pyalign.cpp:59-61)."""
+        a = _c(a, np.float32); b = _c(b, np.float32)
+        n, m = len(a), len(b)
+        score = ctypes.c_float(); j_end = ctypes.c_int64(); j0 = ctypes.c_int64()
+        rec = np.zeros(m, np.int32)
+        a_idx = np.zeros(n, np.uint64) if want_idx else None
+        b_idx = np.zeros(m, np.uint64) if want_idx else None
+        self._check(self._lib.strq_align_overlap(self._h, _ptr(a), ctypes.c_int64(n), _ptr(b), ctypes.c_int64(m),
+                                                 ctypes.byref(score), _ptr(a_idx), _ptr(b_idx), _ptr(rec),
+                                                 ctypes.byref(j_end), ctypes.byref(j0)))
+        return score.value, a_idx, b_idx, rec, j_end.value, j0.value
+
+    def align_batch(self, levels, read_off, level_val, align_read, flank, flank_off, samples=6, want_rec=True):
+        levels = _c(levels, np.uint8); read_off = _c(read_off, np.int64); level_val = _c(level_val, np.float32)
+        align_read = _c(align_read, np.int32); flank = _c(flank, np.float32); flank_off = _c(flank_off, np.int64)
+        na, nr = len(align_read), len(read_off) - 1
+        score = np.zeros(na, np.float32); j_end = np.zeros(na, np.int64); j0 = np.zeros(na, np.int64)
+        rec = np.zeros(len(flank), np.int32) if want_rec else None
+        self._check(self._lib.strq_align_batch(self._h, ctypes.c_int64(na), ctypes.c_int64(nr), _ptr(levels), _ptr(read_off),
+                                               _ptr(level_val), _ptr(align_read), _ptr(flank), _ptr(flank_off),
+                                               ctypes.c_int32(samples), _ptr(score), _ptr(j_end), _ptr(j0), _ptr(rec)))
+        return score, j_end, j0, rec
+
+    def last_timing(self):
+        t = np.zeros(8, np.float32)
+        self._check(self._lib.strq_last_timing(self._h, _ptr(t)))
+        return t
+
+    # ---- HMM ------------------------------------------------------------------------------
+    def model_create(self, baked):
+        mid = ctypes.c_int32(-1)
+        arrs = [_c(baked.in_ptr, np.int32), _c(baked.in_src, np.int32), _c(baked.in_logp, np.float64),
+                _c(baked.emis_kind, np.int32), _c(baked.emis_a, np.float64), _c(baked.emis_b, np.float64),
+                _c(baked.emis_c, np.float64), _c(baked.count_inc, np.int32)]
+        self._check(self._lib.strq_model_create(self._h, ctypes.c_int32(baked.n_states), ctypes.c_int32(baked.silent_start),
+                                                ctypes.c_int32(baked.start), ctypes.c_int32(baked.end),
+                                                *[_ptr(a) for a in arrs], ctypes.byref(mid)))
+        return mid.value
+
+    def viterbi_batch(self, model_id, seqs, want_path=False):
+        """seqs: list of float64 arrays.  Returns (logp[], counted[], status[], paths or None)."""
+        off = np.zeros(len(seqs) + 1, np.int64)
+        for i, s in enumerate(seqs):
+            off[i + 1] = off[i] + len(s)
+        x = np.concatenate([_c(s, np.float64) for s in seqs]) if len(seqs) else np.zeros(0)
+        n = len(seqs)
+        logp = np.zeros(n); counted = np.zeros(n, np.int64); status = np.zeros(n, np.int32)
+        paths = np.zeros(len(x), np.int32) if want_path else None
+        self._check(self._lib.strq_viterbi_batch(self._h, ctypes.c_int32(model_id), ctypes.c_int64(n), _ptr(x), _ptr(off),
+                                                 _ptr(logp), _ptr(counted), _ptr(status), _ptr(paths)))
+        if want_path:
+            paths = [paths[off[i]:off[i + 1]] for i in range(n)]
+        return logp, counted, status, paths
+
+    def viterbi(self, model_id, x, want_path=True):
+        logp, counted, status, paths = self.viterbi_batch(model_id, [x], want_path)
+        return logp[0], int(counted[0]), int(status[0]), (paths[0] if want_path else None)

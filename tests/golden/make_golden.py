@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container, where /root/reference exists.  It imports the reference's
+scripts/STRique.py with stub modules for the third-party packages that are not installed
+(pomegranate, scikit-image, h5py, ont_fast5_api, the compiled pyseqan) and records what the
+reference's own pure-numpy / pure-python code computes.  Nothing of the reference is copied:
+the fixtures are inputs and outputs (data), the reference text stays where it is.
+
+    python tests/golden/make_golden.py
+
+Fixtures written (all small):
+    pore_model.json        statistics of both bundled k-mer models        (STRique.py:113-127,142-148)
+    pore_tables.npz        the two k-mer tables (models/*.model) as arrays
+    flank_signals.npz      generate_signal() templates for both loci       (STRique.py:182-195,553-575)
+    normalize.npz          normalize2model('minmax') input/output pairs    (STRique.py:150-180)
+    config.json            parse_config() of the bundled tsv + json        (STRique.py:836-868)
+    sam.json               SAM decode + target intersection of data/*.sam  (STRique.py:648-679)
+    hmm_topology.json      states / edges emitted by the reference's HMM classes run against a
+                           recording stand-in for pomegranate              (STRique.py:201-500)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------------------------------------
+# recording stand-in for pomegranate: stores what the reference hands to it, computes nothing
+# ---------------------------------------------------------------------------------------------
+class _Dist:
+    def __init__(self, kind, *params):
+        self.kind, self.params = kind, tuple(float(p) for p in params)
+
+
+class _State:
+    def __init__(self, distribution, name=None):
+        self.distribution, self.name = distribution, name
+
+
+class _HMM:
+    _count = 0
+
+    def __init__(self, name=None):
+        _HMM._count += 1
+        self.name = name or "model%d" % _HMM._count
+        self.states, self.edges = [], []
+        self.start = _State(None, name=self.name + "-start")
+        self.end = _State(None, name=self.name + "-end")
+        self.states += [self.start, self.end]
+        self.baked_with = None
+
+    def add_state(self, s):
+        self.states.append(s)
+
+    def add_states(self, *states):
+        for s in states:
+            if isinstance(s, (list, tuple)):
+                self.states.extend(s)
+            else:
+                self.states.append(s)
+
+    def add_transition(self, a, b, probability, pseudocount=None, group=None):
+        # like networkx add_edge underneath pomegranate: unknown end points join the graph
+        known = {id(s) for s in self.states}
+        for s in (a, b):
+            if id(s) not in known:
+                self.states.append(s)
+                known.add(id(s))
+        self.edges.append((a, b, float(probability), group))
+
+    def add_model(self, other):
+        self.states.extend(other.states)
+        self.edges.extend(other.edges)
+
+    def bake(self, *args, **kwargs):
+        self.baked_with = kwargs
+
+
+def _install_stubs():
+    pg = types.ModuleType("pomegranate")
+    pg.HiddenMarkovModel = _HMM
+    pg.State = _State
+    pg.NormalDistribution = lambda mu, sd: _Dist("normal", mu, sd)
+    pg.UniformDistribution = lambda lo, hi: _Dist("uniform", lo, hi)
+    sys.modules["pomegranate"] = pg
+    sk = types.ModuleType("skimage")
+    skm = types.ModuleType("skimage.morphology")
+    for n in ("opening", "closing", "dilation", "erosion", "rectangle"):
+        setattr(skm, n, None)
+    sk.morphology = skm
+    sys.modules["skimage"] = sk
+    sys.modules["skimage.morphology"] = skm
+    lib = types.ModuleType("STRique_lib")
+    lib.fast5Index = types.ModuleType("STRique_lib.fast5Index")
+    lib.fast5Index.fast5Index = lambda *a, **k: None
+    lib.pyseqan = types.ModuleType("STRique_lib.pyseqan")
+
+    class _Aligner:   # attribute bag; align_overlap is never called here
+        pass
+    lib.pyseqan.align_raw = _Aligner
+    sys.modules["STRique_lib"] = lib
+    sys.modules["STRique_lib.fast5Index"] = lib.fast5Index
+    sys.modules["STRique_lib.pyseqan"] = lib.pyseqan
+
+
+def _graph(model):
+    """States and edges of a recorded model, by name, in insertion order (names may repeat)."""
+    ids = {id(s): i for i, s in enumerate(model.states)}
+    states = []
+    for s in model.states:
+        d = s.distribution
+        states.append({"name": s.name, "kind": d.kind if d else "silent",
+                       "params": list(d.params) if d else []})
+    edges = [[ids[id(a)], ids[id(b)], p, g] for a, b, p, g in model.edges]
+    return {"start": ids[id(model.start)], "end": ids[id(model.end)], "states": states, "edges": edges}
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present: fixtures can only be regenerated in the build container")
+    _install_stubs()
+    sys.path.insert(0, os.path.join(REF, "scripts"))
+    import STRique as ref
+    ref.logger.log = staticmethod(lambda *a, **k: None)
+
+    base = os.path.join(REF, "models", "r9_4_450bps.model")
+    mod = os.path.join(REF, "models", "r9_4_450bps_mCpG.model")
+    pm, pmm = ref.pore_model(base), ref.pore_model(mod)
+
+    # ---- pore model statistics
+    def stats(p):
+        return {"kmer": p.kmer, "median": float(p.model_median), "MAD": float(p.model_MAD),
+                "min": float(p.model_min), "max": float(p.model_max)}
+    json.dump({"base": stats(pm), "mod": stats(pmm), "mod_scale2stdv_base": float(pmm.scale2stdv(pm)),
+               "base_scale2stdv_mod": float(pm.scale2stdv(pmm))},
+              open(os.path.join(OUT, "pore_model.json"), "w"), indent=1)
+
+    # ---- the two k-mer tables as arrays (inputs of every synthetic test / benchmark signal)
+    def table(p):
+        kmers = np.array(list(p.model_dict.keys()), dtype="S%d" % p.kmer)
+        vals = np.array(list(p.model_dict.values()))
+        return kmers, vals[:, 0], vals[:, 1]
+    kb, mb, sb = table(pm); km, mm, sm = table(pmm)
+    np.savez_compressed(os.path.join(OUT, "pore_tables.npz"), base_kmer=kb, base_mean=mb, base_stdv=sb,
+                        mod_kmer=km, mod_mean=mm, mod_stdv=sm)
+
+    # ---- config
+    cfg = ref.parse_config(os.path.join(REF, "configs", "repeat_config.tsv"),
+                           os.path.join(REF, "configs", "STRique.json"))
+    json.dump(cfg, open(os.path.join(OUT, "config.json"), "w"), indent=1)
+
+    # ---- flank templates as repeatCounter.add_target builds them (both strands)
+    rc = ref.repeatCounter(base, mod_model_file=mod, align_config=cfg["align"], HMM_config=cfg["HMM"])
+    arrays, topo = {}, {}
+    for name, (chrom, begin, end, repeat, prefix, suffix) in cfg["repeat"].items():
+        rc.add_target(name, repeat, prefix, suffix)
+        for strand, tc in zip("+-", rc.targets[name]):
+            for field in ("prefix", "suffix", "prefix_ext", "suffix_ext"):
+                arrays["%s|%s|%s" % (name, strand, field)] = np.asarray(getattr(tc, field), dtype=np.float64)
+            topo["%s|%s|flanked" % (name, strand)] = dict(
+                _graph(tc.repeatHMM), flanking_count=int(tc.repeatHMM.flanking_count),
+                repeat_offset=int(tc.repeatHMM.repeat_model.repeat_offset),
+                d1=tc.repeatHMM.repeat_model.d1.name, d2=tc.repeatHMM.repeat_model.d2.name,
+                bake=tc.repeatHMM.baked_with)
+            topo["%s|%s|mod" % (name, strand)] = dict(
+                _graph(tc.modHMM), model_min=float(tc.modHMM.model_min), model_max=float(tc.modHMM.model_max),
+                bake=tc.modHMM.baked_with)
+    arrays["revcomp_in"] = np.frombuffer(b"ACGTNacgtGGCCCC", dtype=np.uint8)
+    arrays["revcomp_out"] = np.frombuffer(rc.__reverse_complement__("ACGTNacgtGGCCCC").encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "flank_signals.npz"), **arrays)
+    json.dump(topo, open(os.path.join(OUT, "hmm_topology.json"), "w"))
+
+    # ---- a short-repeat (interpolated) target like the reference's own unit test (STRique_test.py:67-82)
+    rc2 = ref.repeatCounter(base)
+    prefix = cfg["repeat"]["fmr1"][4]; suffix = cfg["repeat"]["fmr1"][5]
+    rc2.add_target("gcg", "GCG", prefix, suffix)
+    topo2 = {"gcg|+|flanked": dict(_graph(rc2.targets["gcg"][0].repeatHMM),
+                                   flanking_count=int(rc2.targets["gcg"][0].repeatHMM.flanking_count),
+                                   repeat_offset=int(rc2.targets["gcg"][0].repeatHMM.repeat_model.repeat_offset))}
+    json.dump(topo2, open(os.path.join(OUT, "hmm_topology_gcg.json"), "w"))
+
+    # ---- normalize2model: integer-valued (uint8-like, int16-like) and float-valued inputs
+    rng = np.random.Generator(np.random.PCG64(20260001))
+    seq = "".join(rng.choice(list("ACGT"), 400))
+    level = np.array([pm.model_dict[seq[i:i + 6]][0] for i in range(len(seq) - 5)])
+    sig_f = np.repeat(level, rng.integers(6, 10, len(level))) + rng.normal(0, 1.5, None)
+    sig_f = sig_f + rng.normal(0, 1.5, len(sig_f))
+    sig_i16 = np.round(sig_f * (8192 / 1400.0) - 10).astype(np.int16)
+    sig_u8 = np.clip((sig_i16 - np.median(sig_i16)) / pm.MAD(sig_i16) * 24 + 127, 0, 255).astype(np.uint8)
+    norm = {}
+    for key, sig in (("f64", sig_f), ("i16", sig_i16.astype(float)), ("u8", sig_u8.astype(float))):
+        norm[key + "_in"] = sig
+        norm[key + "_minmax"] = pm.normalize2model(sig.copy(), mode="minmax")
+        norm[key + "_median"] = pm.normalize2model(sig.copy(), mode="median")
+        norm[key + "_minmax_mod"] = pmm.normalize2model(sig.copy(), mode="minmax")
+        norm[key + "_MAD"] = np.array(pm.MAD(sig))
+    norm["generate_fixed"] = pm.generate_signal(seq[:60], samples=8)
+    np.savez_compressed(os.path.join(OUT, "normalize.npz"), **norm)
+
+    # ---- SAM decode of the bundled record
+    rd = ref.repeatDetector(cfg["repeat"], base, None)
+    rd._repeatDetector__init_hmm = None
+    for tname, (chrom, begin, end, repeat, prefix, suffix) in cfg["repeat"].items():
+        rd.repeatLoci[chrom].append((tname, begin, end))
+    recs = []
+    with open(os.path.join(REF, "data", "c9orf72.sam")) as fp:
+        for line in fp:
+            if line.startswith("@"):
+                continue
+            sr = rd.__decode_sam__(line)
+            recs.append({"QNAME": sr.QNAME, "FLAG": sr.FLAG, "RNAME": sr.RNAME, "POS": sr.POS, "TLEN": sr.TLEN,
+                         "CLIP_BEGIN": sr.CLIP_BEGIN, "CLIP_END": sr.CLIP_END,
+                         "targets": rd.__intersect_target__(sr), "cigar_head": line.split("\t")[5][:40]})
+    cig = "5S10M2I3D7N4=1X6H"
+    ops = rd.__decode_cigar__(cig)
+    json.dump({"records": recs, "cigar": cig, "ops": ops,
+               "len_MIS=X": rd.__ops_length__(ops), "len_MDN=X": rd.__ops_length__(ops, recOps="MDN=X")},
+              open(os.path.join(OUT, "sam.json"), "w"), indent=1)
+    print("fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
