@@ -114,8 +114,58 @@ int strq_viterbi_batch(strq_ctx* ctx, int32_t model_id, int64_t n_seq, const dou
                        const int64_t* x_off, double* logp, int64_t* counted, int32_t* status,
                        int32_t* paths);
 
+/*
+ * ---- repeatCounter.add_target / detect (scripts/STRique.py:553-618) as one device pipeline ----
+ *
+ * strq_set_pore_stats   the four model-side constants of pore_model.normalize2model('minmax')
+ *                       (STRique.py:154,157-158,123-126): medians of the k-mer means below the 1st /
+ *                       above the 99th percentile, model_min, model_max.
+ * strq_target_add       one strand of one target (the reference's target_classifier tuple,
+ *                       STRique.py:560-576): the two full flank templates generate_signal(*_ext,
+ *                       samples) as float32, trim_prefix = len(prefix_ext) - len(prefix) and
+ *                       trim_suffix likewise (STRique.py:598-599), the flanked-repeat HMM uploaded
+ *                       with strq_model_create and count_bias = flanking_count - repeat_offset
+ *                       (STRique.py:374-378,412,437).
+ * strq_detect_batch     detect() for n_reads reads.  signals: concatenated raw samples,
+ *                       dtype 0 = int16 (fast5 DAC values), 1 = float64 (pA, as the reference's
+ *                       unit tests feed them).  For float64 the caller passes host_stats, six
+ *                       doubles per read that numpy gives in O(N log N): median and MAD of the
+ *                       median-filtered signal, (c1, h1) of its minmax map and of the raw signal's;
+ *                       for int16 everything is computed on the GPU from exact histograms and
+ *                       host_stats is ignored (may be NULL).
+ * A read whose normalisation is undefined (constant signal, empty tails) gets status 1 and the
+ * n = 0 row the reference writes for a failed gate; it never aborts the batch.
+ */
+typedef struct strq_result {
+    int32_t count;          /* repeat count n (0 if the gate failed, STRique.py:602-603) */
+    int32_t status;         /* 0 ok, 1 signal could not be normalised */
+    double score_prefix, score_suffix, log_p;
+    int64_t offset, ticks;  /* prefix_end, max(suffix_begin - prefix_end, 0) (STRique.py:616) */
+    int64_t prefix_begin, prefix_end, suffix_begin, suffix_end;
+} strq_result;
+
+int strq_set_pore_stats(strq_ctx* ctx, double tail_lo, double tail_hi, double model_min, double model_max);
+int strq_target_add(strq_ctx* ctx, const float* prefix_ext, int64_t m_prefix, const float* suffix_ext,
+                    int64_t m_suffix, int32_t trim_prefix, int32_t trim_suffix, int32_t samples,
+                    int32_t hmm_model_id, int32_t count_bias, int32_t* target_id);
+int strq_detect_batch(strq_ctx* ctx, int64_t n_reads, const void* signals, int32_t dtype,
+                      const int64_t* offsets, const int32_t* target_id, const double* host_stats,
+                      strq_result* out);
+/* The same in three steps, so that a caller can keep the signals resident in HBM and time (or
+ * repeat) the device work alone: upload = host -> HBM copy, run = all kernels, fetch = results. */
+int strq_batch_upload(strq_ctx* ctx, int64_t n_reads, const void* signals, int32_t dtype,
+                      const int64_t* offsets, const int32_t* target_id, const double* host_stats);
+int strq_batch_run(strq_ctx* ctx);
+int strq_batch_fetch(strq_ctx* ctx, strq_result* out);
+/* Test hook: conditioning outputs (8-bit morphology levels, their 256 float32 values, and
+ * {median, MAD, c1/h1 of the filtered, morphology and raw signal, h2, c2}) of read `read` of the
+ * last sub-batch processed by strq_batch_run. */
+int strq_debug_conditioning(strq_ctx* ctx, int64_t read, uint8_t* levels, int64_t n, float* level_val,
+                            double* scalars10);
+
 /* Kernel timing of the last batched call, milliseconds (HIP events on the library's stream):
- * [0] table build  [1] forward DP  [2] trace pass  [3] total.  */
+ * [0] table build  [1] forward DP  [2] trace pass  [3] total  [4] table entries re-evaluated on
+ * the host  [5] conditioning  [6] Viterbi.  */
 int strq_last_timing(const strq_ctx* ctx, float ms[8]);
 
 #ifdef __cplusplus

@@ -1,0 +1,288 @@
+// Signal conditioning of repeatCounter.detect on gfx950 -- reference scripts/STRique.py:590-597:
+//   flt   = scipy.signal.medfilt(raw, 3)                       zero padded, dtype preserved
+//   z     = (flt - median(flt)) / MAD(flt)                     MAD = mean |x - median|      (:142-143)
+//   u8    = clip(z*24 + 127, 0, 255).astype(uint8)
+//   u8    = closing(opening(u8, rectangle(1,8)), rectangle(1,8))            scikit-image 0.14
+//   morph = normalize2model(u8, 'minmax');  fltn = normalize2model(flt, 'minmax')            (:150-180)
+//
+// Everything numpy computes with order statistics (median, percentile, medians of the tails) is
+// taken from exact histograms: 65536 bins for int16 samples, 256 bins for the 8-bit signal.  The
+// sums involved are sums of multiples of 0.5 and therefore exact in float64 in any order, and the
+// remaining scalar arithmetic repeats numpy's operations one rounding at a time
+// (-ffp-contract=off), so the results are bit-identical to the CPU oracle (oracle/strique_oracle.py).
+//
+// These kernels are HBM-bound byte/short streaming: coalesced 2-byte loads, LDS tiles for the
+// four sliding min/max passes, LDS-free global atomics for the histograms.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cond_kernels.h"
+
+namespace strq {
+
+#define COND_TILE 2048      // samples per workgroup (256 threads x 8)
+#define COND_HALO 16        // >= 14 = 3+4+4+3 samples of context on each side of a tile
+
+template <class T> static __device__ __forceinline__ T med3(T a, T b, T c)
+{
+    const T lo = a < b ? a : b, hi = a < b ? b : a;
+    const T m = hi < c ? hi : c;
+    return lo > m ? lo : m;
+}
+
+// scipy.ndimage 'reflect' (d c b a | a b c d | d c b a), valid for any offset
+static __device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    const int period = 2 * n;
+    int r = i % period; if (r < 0) r += period;
+    return r >= n ? period - 1 - r : r;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+medfilt_kernel(const T* __restrict__ raw_all, T* __restrict__ flt_all, const ReadCond* __restrict__ rc_all,
+               uint32_t* __restrict__ hist_flt, uint32_t* __restrict__ hist_raw)
+{
+    const ReadCond rc = rc_all[blockIdx.y];
+    const int n = rc.n;
+    const int base = blockIdx.x * COND_TILE;
+    if (base >= n) return;
+    const T* raw = raw_all + rc.off;
+    T* flt = flt_all + rc.off;
+    for (int k = 0; k < COND_TILE / 256; ++k) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i >= n) break;
+        const T c = raw[i];
+        const T a = i > 0 ? raw[i - 1] : (T)0;           // zero padding (scipy medfilt)
+        const T b = i + 1 < n ? raw[i + 1] : (T)0;
+        const T m = med3<T>(a, c, b);
+        flt[i] = m;
+        if constexpr (sizeof(T) == 2) {
+            if (hist_flt) atomicAdd(&hist_flt[(size_t)blockIdx.y * 65536 + (int)m + 32768], 1u);
+            if (hist_raw) atomicAdd(&hist_raw[(size_t)blockIdx.y * 65536 + (int)c + 32768], 1u);
+        }
+    }
+}
+
+// numpy's _lerp (np.percentile, method 'linear')
+static __device__ __forceinline__ double np_lerp(double a, double b, double t)
+{
+    const double d = b - a;
+    return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+
+// One workgroup per read: order statistics of a histogram, then the constants of the 'minmax'
+// normalisation (STRique.py:152-160) and, for the filtered signal, median and MAD.
+__global__ void __launch_bounds__(256)
+hist_stats_kernel(const uint32_t* __restrict__ hist_all, int nbins, int bias, ReadCond* __restrict__ rc_all,
+                  PoreStats ps, int which, float* __restrict__ level_val_all)
+{
+    __shared__ uint32_t excl[257];
+    __shared__ long long ranks[8];
+    __shared__ int vals[8];
+    __shared__ double red[256];
+    __shared__ unsigned long long cnt_lo, cnt_hi;
+    const int t = threadIdx.x;
+    ReadCond& rc = rc_all[blockIdx.x];
+    const uint32_t* hist = hist_all + (size_t)blockIdx.x * nbins;
+    const int n = rc.n;
+    const int bpt = nbins / 256, b0 = t * bpt;
+    if (n <= 0) { if (t == 0) rc.status = COND_DEGENERATE; return; }
+    uint32_t mysum = 0;
+    for (int b = 0; b < bpt; ++b) mysum += hist[b0 + b];
+    excl[t + 1] = mysum;
+    if (t == 0) excl[0] = 0;
+    __syncthreads();
+    if (t == 0) for (int i = 1; i <= 256; ++i) excl[i] += excl[i - 1];
+    __syncthreads();
+    const uint32_t mybase = excl[t];
+
+    auto select_ranks = [&](int k) {     // ranks[0..k) -> vals[0..k)  (value = bin + bias)
+        __syncthreads();
+        if (mysum) {
+            uint32_t c = mybase;
+            for (int b = 0; b < bpt; ++b) {
+                const uint32_t h = hist[b0 + b];
+                if (h) for (int i = 0; i < k; ++i) if (ranks[i] >= (long long)c && ranks[i] < (long long)c + h) vals[i] = b0 + b + bias;
+                c += h;
+            }
+        }
+        __syncthreads();
+    };
+    // --- median ranks and the two percentiles' neighbours
+    double g_lo = 0, g_hi = 0;
+    {
+        const double vi_lo = (double)(n - 1) * 0.01, vi_hi = (double)(n - 1) * 0.99;
+        long long p_lo = (long long)floor(vi_lo), p_hi = (long long)floor(vi_hi);
+        long long n_lo = p_lo + 1, n_hi = p_hi + 1;
+        if (vi_lo >= (double)(n - 1)) { p_lo = n_lo = -1; }
+        if (vi_hi >= (double)(n - 1)) { p_hi = n_hi = -1; }
+        g_lo = vi_lo - (double)p_lo; g_hi = vi_hi - (double)p_hi;
+        if (t == 0) {
+            ranks[0] = (n - 1) / 2; ranks[1] = n / 2;
+            ranks[2] = p_lo < 0 ? n - 1 : p_lo; ranks[3] = n_lo < 0 ? n - 1 : n_lo;
+            ranks[4] = p_hi < 0 ? n - 1 : p_hi; ranks[5] = n_hi < 0 ? n - 1 : n_hi;
+        }
+    }
+    select_ranks(6);
+    const double med = ((double)vals[0] + (double)vals[1]) / 2;
+    const double q_lo = np_lerp((double)vals[2], (double)vals[3], g_lo);
+    const double q_hi = np_lerp((double)vals[4], (double)vals[5], g_hi);
+    // --- sizes of the two tails (strict comparisons, STRique.py:155-156)
+    if (t == 0) { cnt_lo = 0; cnt_hi = 0; }
+    __syncthreads();
+    {
+        unsigned long long cl = 0, ch = 0;
+        for (int b = 0; b < bpt; ++b) {
+            const double v = (double)(b0 + b + bias);
+            const uint32_t h = hist[b0 + b];
+            if (v < q_lo) cl += h;
+            if (v > q_hi) ch += h;
+        }
+        if (cl) atomicAdd(&cnt_lo, cl);
+        if (ch) atomicAdd(&cnt_hi, ch);
+    }
+    __syncthreads();
+    const long long c_lo = (long long)cnt_lo, c_hi = (long long)cnt_hi;
+    bool degenerate = (c_lo == 0 || c_hi == 0);
+    double c1 = 0, h1 = 0;
+    if (!degenerate) {
+        if (t == 0) {
+            ranks[0] = (c_lo - 1) / 2; ranks[1] = c_lo / 2;
+            ranks[2] = n - c_hi + (c_hi - 1) / 2; ranks[3] = n - c_hi + c_hi / 2;
+        }
+        select_ranks(4);
+        const double m_lo = ((double)vals[0] + (double)vals[1]) / 2;
+        const double m_hi = ((double)vals[2] + (double)vals[3]) / 2;
+        c1 = m_lo + (m_hi - m_lo) / 2;
+        h1 = (m_hi - m_lo) / 2;
+        if (!(h1 > 0.0)) degenerate = true;
+    }
+    const double h2 = (ps.M_hi - ps.M_lo) / 2, c2 = ps.M_lo + (ps.M_hi - ps.M_lo) / 2;
+    if (which == 0) {
+        // MAD = mean |x - median|: every term is a multiple of 0.5, the sum is exact in any order
+        double s = 0;
+        for (int b = 0; b < bpt; ++b) {
+            const uint32_t h = hist[b0 + b];
+            if (h) s += (double)h * fabs((double)(b0 + b + bias) - med);
+        }
+        red[t] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+        const double mad = red[0] / (double)n;
+        if (!(mad > 0.0)) degenerate = true;
+        if (t == 0) { rc.med = med; rc.mad = mad; rc.f_c1 = c1; rc.f_h1 = h1; rc.h2 = h2; rc.c2 = c2; rc.status = degenerate ? COND_DEGENERATE : COND_OK; }
+    } else if (which == 1) {
+        if (t == 0) { rc.m_c1 = c1; rc.m_h1 = h1; if (degenerate) rc.status = COND_DEGENERATE; }
+        // value of every 8-bit level after normalize2model + clip, rounded to float32 like the
+        // pybind11 list caster does on the way into align_overlap (src/pyalign.cpp:59-61)
+        double v = ((double)t - c1) / h1;
+        v = v * h2 + c2;
+        v = v < ps.clip_lo ? ps.clip_lo : v;
+        v = v > ps.clip_hi ? ps.clip_hi : v;
+        level_val_all[(size_t)blockIdx.x * 256 + t] = degenerate ? 0.0f : (float)v;
+    } else {
+        if (t == 0) { rc.r_c1 = c1; rc.r_h1 = h1; if (degenerate) rc.status = COND_DEGENERATE; }
+    }
+}
+
+// z-score -> 8 bit -> grey opening and closing with a 1x8 footprint, one LDS tile per workgroup.
+// scikit-image 0.14 pads the even footprint to 9 with a zero on the left in the first stage of
+// opening/closing and on the right in the second, so the 1-D windows are
+//   opening = max_{-4..+3}( min_{-3..+4} ),  closing = min_{-4..+3}( max_{-3..+4} ),
+// each stage reading its input with scipy.ndimage 'reflect' borders.
+template <class T>
+__global__ void __launch_bounds__(256)
+quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_all, const ReadCond* __restrict__ rc_all,
+                   uint32_t* __restrict__ hist8)
+{
+    __shared__ uint8_t bufA[COND_TILE + 2 * COND_HALO], bufB[COND_TILE + 2 * COND_HALO];
+    __shared__ uint32_t h8[256];
+    const ReadCond rc = rc_all[blockIdx.y];
+    const int n = rc.n;
+    const int t0 = blockIdx.x * COND_TILE;
+    if (t0 >= n || rc.status != COND_OK) return;
+    const T* flt = flt_all + rc.off;
+    const int lo = t0 - COND_HALO, span = COND_TILE + 2 * COND_HALO;
+    h8[threadIdx.x] = 0;
+    // stage 0: quantised signal at the real positions of the extended tile
+    for (int x = threadIdx.x; x < span; x += 256) {
+        const int i = lo + x;
+        uint8_t q = 0;
+        if (i >= 0 && i < n) {
+            double z = ((double)flt[i] - rc.med) / rc.mad;
+            z = z * 24.0 + 127.0;
+            z = z < 0.0 ? 0.0 : z;
+            z = z > 255.0 ? 255.0 : z;
+            q = (uint8_t)z;                       // astype(uint8): truncation
+        }
+        bufA[x] = q;
+    }
+    __syncthreads();
+    // a stage reads position p of the previous stage; positions outside [0, n) are reflections of it
+    auto at = [&](const uint8_t* buf, int p) -> int {
+        if (p < 0 || p >= n) p = reflect_idx(p, n);
+        int x = p - lo;
+        x = x < 0 ? 0 : (x >= span ? span - 1 : x);     // only reached for positions no result depends on
+        return buf[x];
+    };
+    auto stage = [&](const uint8_t* src, uint8_t* dst, int k0, int k1, bool take_min) {
+        for (int x = threadIdx.x; x < span; x += 256) {
+            const int i = lo + x;
+            int v = 0;
+            if (i >= 0 && i < n) {
+                v = at(src, i + k0);
+                for (int k = k0 + 1; k <= k1; ++k) { const int w = at(src, i + k); v = take_min ? (w < v ? w : v) : (w > v ? w : v); }
+            }
+            dst[x] = (uint8_t)v;
+        }
+        __syncthreads();
+    };
+    stage(bufA, bufB, -3, 4, true);      // erosion   (opening, first stage)
+    stage(bufB, bufA, -4, 3, false);     // dilation  (opening, second stage)
+    stage(bufA, bufB, -3, 4, false);     // dilation  (closing, first stage)
+    stage(bufB, bufA, -4, 3, true);      // erosion   (closing, second stage)
+    uint8_t* levels = levels_all + rc.off;
+    for (int x = threadIdx.x; x < COND_TILE; x += 256) {
+        const int i = t0 + x;
+        if (i < n) { const uint8_t v = bufA[x + COND_HALO]; levels[i] = v; atomicAdd(&h8[v], 1u); }
+    }
+    __syncthreads();
+    if (h8[threadIdx.x]) atomicAdd(&hist8[(size_t)blockIdx.y * 256 + threadIdx.x], h8[threadIdx.x]);
+}
+
+static inline dim3 tile_grid(int max_n, int n_reads) { return dim3((max_n + COND_TILE - 1) / COND_TILE, n_reads); }
+
+int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, const ReadCond* rc, int n_reads, int max_n,
+                            uint32_t* hist_flt, uint32_t* hist_raw)
+{
+    if (n_reads <= 0 || max_n <= 0) return 0;
+    hipLaunchKernelGGL((medfilt_kernel<int16_t>), tile_grid(max_n, n_reads), dim3(256), 0, s, raw, flt, rc, hist_flt, hist_raw);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int launch_medfilt_f64(hipStream_t s, const double* raw, double* flt, const ReadCond* rc, int n_reads, int max_n)
+{
+    if (n_reads <= 0 || max_n <= 0) return 0;
+    hipLaunchKernelGGL((medfilt_kernel<double>), tile_grid(max_n, n_reads), dim3(256), 0, s, raw, flt, rc, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int launch_hist_stats(hipStream_t s, const uint32_t* hist, int nbins, int bias, ReadCond* rc, int n_reads, PoreStats ps,
+                      int which, float* level_val)
+{
+    if (n_reads <= 0) return 0;
+    hipLaunchKernelGGL(hist_stats_kernel, dim3(n_reads), dim3(256), 0, s, hist, nbins, bias, rc, ps, which, level_val);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int launch_quant_morph_i16(hipStream_t s, const int16_t* flt, uint8_t* levels, const ReadCond* rc, int n_reads, int max_n, uint32_t* hist8)
+{
+    if (n_reads <= 0 || max_n <= 0) return 0;
+    hipLaunchKernelGGL((quant_morph_kernel<int16_t>), tile_grid(max_n, n_reads), dim3(256), 0, s, flt, levels, rc, hist8);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int launch_quant_morph_f64(hipStream_t s, const double* flt, uint8_t* levels, const ReadCond* rc, int n_reads, int max_n, uint32_t* hist8)
+{
+    if (n_reads <= 0 || max_n <= 0) return 0;
+    hipLaunchKernelGGL((quant_morph_kernel<double>), tile_grid(max_n, n_reads), dim3(256), 0, s, flt, levels, rc, hist8);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+}  // namespace strq

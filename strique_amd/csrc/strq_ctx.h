@@ -27,6 +27,24 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// one sub-batch of alignments for align_core (strq_align_api.hip)
+struct AlignCoreIn {
+    int nb = 0, samples = 6;
+    const uint8_t* d_levels = nullptr;     // device: concatenated level streams
+    const int64_t* read_off = nullptr;     // host: offsets of the reads in d_levels
+    const float* d_level_val = nullptr;    // device: 256 level values per read
+    const int32_t* read = nullptr;         // host, per alignment
+    const int* n = nullptr; const int* m = nullptr; const int* k = nullptr; const int* R = nullptr;
+    const float* const* flank = nullptr;   // host: flank template of each alignment
+};
+struct AlignCoreOut {
+    std::vector<int> order;                // task position -> alignment index
+    std::vector<size_t> rec_off;           // per alignment: offset of its record in d_rec
+    size_t rec_total = 0;
+    AlignTask* d_tasks = nullptr; AlignResult* d_results = nullptr; int32_t* d_rec = nullptr;
+    int n_hard = 0;
+};
+
 struct HostModel {
     VitModel h;              // host copy (pointers are device pointers)
     const VitModel* dev = nullptr;
@@ -47,8 +65,17 @@ struct strq_ctx {
     strq::DevBuf levels, level_val, flank_cls, tables, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path;
     std::vector<strq::HostModel*> models;
+    void* detect = nullptr;                   // DetectState (strq_detect_api.hip)
     size_t max_ws_bytes = (size_t)48 << 30;   // cap for checkpoint workspace per sub-batch
 };
+
+namespace strq {
+int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out);
+int align_core_times(strq_ctx* c, float* t_lut, float* t_fwd, float* t_tr);
+int align_validate_flank(strq_ctx* c, const float* f, int64_t m, int samples, int* k_out, int* R_out);
+float host_cell_score(const AlignParams& p, float h, float v);
+void detect_state_free(strq_ctx* c);
+}
 
 #define STRQ_HIP(ctx, call)                                                                    \
     do {                                                                                       \

@@ -1,0 +1,385 @@
+// C ABI: repeatCounter.add_target / detect as a batched device pipeline
+// (reference scripts/STRique.py:553-618):
+//   conditioning -> score tables -> 2 flank alignments per read -> positions / gate -> HMM Viterbi
+// Everything between upload and fetch stays in HBM; the host only sequences kernels, reads back the
+// table-width class of each alignment and assembles the result records.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+#include "../../include/strique_hip.h"
+#include "strq_ctx.h"
+#include "cond_kernels.h"
+#include "viterbi_kernels.h"
+
+using namespace strq;
+
+namespace strq {
+
+struct ReadGeom {           // per read, written by finalize_kernel
+    double score_prefix, score_suffix;
+    int64_t prefix_begin, prefix_end, suffix_begin, suffix_end;
+    int32_t gate, pad_;
+};
+
+// position of flank row k in the read: argmin_i |a_idx[i] - b_idx[k]| of __detect_range__
+// (STRique.py:540-547) evaluated on the compact record: a diagonal row sits on its sample; a row
+// inside a vertical run sits between two samples and takes the nearer one, the lower index on a tie.
+static __device__ int64_t row_position(const int32_t* rec, int m, int k, int n)
+{
+    const int32_t r = rec[k];
+    const int64_t j = r >> 1;
+    if (!(r & 1)) return j - 1;
+    int k1 = k; while (k1 > 0 && rec[k1 - 1] == r) --k1;
+    int k2 = k; while (k2 < m - 1 && rec[k2 + 1] == r) ++k2;
+    const int d_prev = k - k1 + 1, d_next = k2 - k + 1;
+    const bool has_prev = j >= 1, has_next = j < n;
+    if (has_prev && (!has_next || d_prev <= d_next)) return j - 1;
+    return j;
+}
+
+struct FinalizeArgs {
+    const AlignTask* tasks; const AlignResult* results;
+    const int32_t* task_of;        // 2 per read: task position of the prefix / suffix alignment
+    const int32_t* trim;           // 2 per read: pre_trim of the prefix flank, post_trim of the suffix flank
+    const int32_t* vit_slot;       // per read: index of its VitTask
+    const ReadCond* rc;
+    const void* flt;               // filtered signal (int16 or double), concatenated
+    int is_f64;
+    PoreStats ps;
+    ReadGeom* geom; VitTask* vit;
+    int n_reads;
+};
+
+__global__ void finalize_kernel(FinalizeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const ReadCond rc = a.rc[r];
+    ReadGeom g = {};
+    VitTask vt = {};
+    if (rc.status == COND_OK) {
+        const AlignTask& tp = a.tasks[a.task_of[2 * r]]; const AlignResult& rp = a.results[a.task_of[2 * r]];
+        const AlignTask& ts = a.tasks[a.task_of[2 * r + 1]]; const AlignResult& rs = a.results[a.task_of[2 * r + 1]];
+        {
+            const int64_t b = row_position(tp.rec, tp.m, 0, tp.n), e = row_position(tp.rec, tp.m, tp.m - 1, tp.n);
+            g.score_prefix = e > b ? (double)rp.best / (double)(e - b) : 0.0;
+            g.prefix_begin = row_position(tp.rec, tp.m, a.trim[2 * r], tp.n);
+            g.prefix_end = e;
+        }
+        {
+            const int64_t b = row_position(ts.rec, ts.m, 0, ts.n), e = row_position(ts.rec, ts.m, ts.m - 1, ts.n);
+            g.score_suffix = e > b ? (double)rs.best / (double)(e - b) : 0.0;
+            g.suffix_begin = b;
+            g.suffix_end = row_position(ts.rec, ts.m, ts.m - 1 - a.trim[2 * r + 1], ts.n);
+        }
+        g.gate = (g.prefix_begin < g.suffix_end && g.score_prefix > 0.0 && g.score_suffix > 0.0) ? 1 : 0;
+    }
+    if (g.gate) {
+        vt.T = g.suffix_end - g.prefix_begin;
+        if (a.is_f64) { vt.sig = reinterpret_cast<const double*>(a.flt) + rc.off + g.prefix_begin; vt.src_kind = VIT_SRC_F64_AFFINE; }
+        else { vt.sig = reinterpret_cast<const int16_t*>(a.flt) + rc.off + g.prefix_begin; vt.src_kind = VIT_SRC_I16_AFFINE; }
+        vt.c1 = rc.f_c1; vt.h1 = rc.f_h1; vt.h2 = rc.h2; vt.c2 = rc.c2; vt.lo = a.ps.clip_lo; vt.hi = a.ps.clip_hi;
+    }
+    a.geom[r] = g;
+    a.vit[a.vit_slot[r]] = vt;
+}
+
+struct Target {
+    std::vector<float> prefix_ext, suffix_ext;
+    int trim_prefix = 0, trim_suffix = 0, samples = 6;
+    int kp = 0, Rp = 0, ks = 0, Rs = 0;
+    int model_id = -1, count_bias = 0;
+};
+
+struct Batch {
+    int64_t n_reads = 0;
+    int dtype = 0;                       // 0 int16, 1 float64
+    std::vector<int64_t> off;            // n_reads + 1
+    std::vector<int32_t> target;
+    std::vector<double> host_stats;      // 6 per read (float64 input only)
+    DevBuf raw;                          // all reads, resident
+    std::vector<strq_result> results;
+    float t_cond = 0, t_lut = 0, t_fwd = 0, t_trace = 0, t_vit = 0, t_total = 0;
+    double n_hard = 0;
+};
+
+struct DetectState {
+    PoreStats ps{0, 0, 0, 0};
+    bool have_ps = false;
+    std::vector<Target> targets;
+    Batch batch;
+    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx;
+    hipEvent_t ev[4] = {};
+    bool ev_ok = false;
+};
+
+static DetectState* dstate(strq_ctx* c)
+{
+    if (!c->detect) c->detect = new DetectState();
+    return static_cast<DetectState*>(c->detect);
+}
+
+void detect_state_free(strq_ctx* c)
+{
+    if (!c->detect) return;
+    DetectState* d = static_cast<DetectState*>(c->detect);
+    for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx}) b->release();
+    if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
+    delete d;
+    c->detect = nullptr;
+}
+
+static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
+{
+    Batch& B = d->batch;
+    hipStream_t st = c->stream;
+    const int nr = (int)(r1 - r0);
+    const int esz = B.dtype == 0 ? 2 : 8;
+    const int64_t s0 = B.off[r0], tot = B.off[r1] - s0;
+    int max_n = 0;
+    std::vector<ReadCond> rc(nr);
+    std::vector<int64_t> loff(nr + 1);
+    for (int i = 0; i < nr; ++i) {
+        std::memset(&rc[i], 0, sizeof(ReadCond));
+        rc[i].off = B.off[r0 + i] - s0; rc[i].n = (int)(B.off[r0 + i + 1] - B.off[r0 + i]);
+        loff[i] = rc[i].off;
+        max_n = std::max(max_n, rc[i].n);
+        if (B.dtype == 1) {
+            const double* hs = &B.host_stats[(size_t)(r0 + i) * 6];
+            rc[i].med = hs[0]; rc[i].mad = hs[1]; rc[i].f_c1 = hs[2]; rc[i].f_h1 = hs[3]; rc[i].r_c1 = hs[4]; rc[i].r_h1 = hs[5];
+            rc[i].h2 = (d->ps.M_hi - d->ps.M_lo) / 2; rc[i].c2 = d->ps.M_lo + (d->ps.M_hi - d->ps.M_lo) / 2;
+            const bool okv = std::isfinite(hs[0]) && hs[1] > 0.0 && std::isfinite(hs[2]) && hs[3] > 0.0 && std::isfinite(hs[3]);
+            rc[i].status = okv ? COND_OK : COND_DEGENERATE;
+        }
+    }
+    loff[nr] = tot;
+    STRQ_HIP(c, d->flt.reserve((size_t)tot * esz + 64));
+    STRQ_HIP(c, c->levels.reserve((size_t)tot + 64));
+    STRQ_HIP(c, c->level_val.reserve((size_t)nr * 256 * 4));
+    STRQ_HIP(c, d->rc.reserve((size_t)nr * sizeof(ReadCond)));
+    STRQ_HIP(c, d->hist8.reserve((size_t)nr * 256 * 4));
+    if (B.dtype == 0) STRQ_HIP(c, d->hist16.reserve((size_t)nr * 65536 * 4));
+    ReadCond* d_rc = d->rc.as<ReadCond>();
+    STRQ_HIP(c, hipMemcpyAsync(d_rc, rc.data(), (size_t)nr * sizeof(ReadCond), hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemsetAsync(d->hist8.p, 0, (size_t)nr * 256 * 4, st));
+    STRQ_HIP(c, hipEventRecord(d->ev[0], st));
+    // ---- conditioning (STRique.py:590-597)
+    const char* raw = d->batch.raw.as<char>() + (size_t)s0 * esz;
+    int bad = 0;
+    if (B.dtype == 0) {
+        STRQ_HIP(c, hipMemsetAsync(d->hist16.p, 0, (size_t)nr * 65536 * 4, st));
+        bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), d->flt.as<int16_t>(), d_rc, nr, max_n, d->hist16.as<uint32_t>(), nullptr);
+        bad |= launch_hist_stats(st, d->hist16.as<uint32_t>(), 65536, -32768, d_rc, nr, d->ps, 0, nullptr);
+        bad |= launch_quant_morph_i16(st, d->flt.as<int16_t>(), c->levels.as<uint8_t>(), d_rc, nr, max_n, d->hist8.as<uint32_t>());
+    } else {
+        bad |= launch_medfilt_f64(st, reinterpret_cast<const double*>(raw), d->flt.as<double>(), d_rc, nr, max_n);
+        bad |= launch_quant_morph_f64(st, d->flt.as<double>(), c->levels.as<uint8_t>(), d_rc, nr, max_n, d->hist8.as<uint32_t>());
+    }
+    bad |= launch_hist_stats(st, d->hist8.as<uint32_t>(), 256, 0, d_rc, nr, d->ps, 1, c->level_val.as<float>());
+    if (bad) { c->err = "conditioning launch failed"; return STRQ_ERR_DEVICE; }
+    STRQ_HIP(c, hipEventRecord(d->ev[1], st));
+
+    // ---- the two flank alignments of every read
+    const int na = 2 * nr;
+    std::vector<int32_t> a_read(na); std::vector<int> n(na), m(na), k(na), R(na); std::vector<const float*> fl(na);
+    std::vector<int32_t> trim(na);
+    int S = 6;
+    for (int i = 0; i < nr; ++i) {
+        const Target& t = d->targets[B.target[r0 + i]];
+        S = t.samples;
+        a_read[2 * i] = a_read[2 * i + 1] = i;
+        n[2 * i] = n[2 * i + 1] = rc[i].n;
+        m[2 * i] = (int)t.prefix_ext.size(); k[2 * i] = t.kp; R[2 * i] = t.Rp; fl[2 * i] = t.prefix_ext.data(); trim[2 * i] = t.trim_prefix;
+        m[2 * i + 1] = (int)t.suffix_ext.size(); k[2 * i + 1] = t.ks; R[2 * i + 1] = t.Rs; fl[2 * i + 1] = t.suffix_ext.data(); trim[2 * i + 1] = t.trim_suffix;
+    }
+    AlignCoreIn ci; AlignCoreOut co;
+    ci.nb = na; ci.samples = S; ci.d_levels = c->levels.as<uint8_t>(); ci.read_off = loff.data(); ci.d_level_val = c->level_val.as<float>();
+    ci.read = a_read.data(); ci.n = n.data(); ci.m = m.data(); ci.k = k.data(); ci.R = R.data(); ci.flank = fl.data();
+    int rcode = align_core(c, ci, co);
+    if (rcode) return rcode;
+    B.n_hard += co.n_hard;
+
+    // ---- positions, gate, Viterbi tasks (grouped by HMM)
+    std::vector<int32_t> task_of(na);
+    for (int pos = 0; pos < na; ++pos) task_of[co.order[pos]] = pos;
+    std::map<int, std::vector<int>> by_model;
+    for (int i = 0; i < nr; ++i) by_model[d->targets[B.target[r0 + i]].model_id].push_back(i);
+    std::vector<int32_t> vit_slot(nr); std::vector<int> slot_read(nr);
+    struct VL { int model, first, count; };
+    std::vector<VL> vls;
+    { int s = 0; for (auto& g : by_model) { vls.push_back({g.first, s, (int)g.second.size()}); for (int i : g.second) { vit_slot[i] = s; slot_read[s] = i; ++s; } } }
+    STRQ_HIP(c, d->idx.reserve((size_t)(na * 2 + nr) * 4 + 64));
+    int32_t* d_task_of = d->idx.as<int32_t>(); int32_t* d_trim = d_task_of + na; int32_t* d_slot = d_trim + na;
+    STRQ_HIP(c, hipMemcpyAsync(d_task_of, task_of.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemcpyAsync(d_trim, trim.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemcpyAsync(d_slot, vit_slot.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, d->geom.reserve((size_t)nr * sizeof(ReadGeom)));
+    STRQ_HIP(c, d->vit.reserve((size_t)nr * sizeof(VitTask)));
+    STRQ_HIP(c, d->vres.reserve((size_t)nr * sizeof(VitResult)));
+    FinalizeArgs fa;
+    fa.tasks = co.d_tasks; fa.results = co.d_results; fa.task_of = d_task_of; fa.trim = d_trim; fa.vit_slot = d_slot;
+    fa.rc = d_rc; fa.flt = d->flt.p; fa.is_f64 = B.dtype; fa.ps = d->ps; fa.geom = d->geom.as<ReadGeom>(); fa.vit = d->vit.as<VitTask>(); fa.n_reads = nr;
+    hipLaunchKernelGGL(finalize_kernel, dim3((nr + 127) / 128), dim3(128), 0, st, fa);
+    STRQ_HIP(c, hipGetLastError());
+    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
+    STRQ_HIP(c, hipEventRecord(d->ev[2], st));
+    { int qi = 0;
+      for (auto& v : vls) {
+        HostModel* hm = c->models[v.model];
+        const int rc2 = launch_viterbi(st, hm->h, hm->dev, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
+                                       c->queue.as<int>() + qi, c->n_cu, 0);
+        if (rc2) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
+        ++qi;
+      } }
+    STRQ_HIP(c, hipEventRecord(d->ev[3], st));
+    // ---- results
+    std::vector<ReadGeom> geom(nr); std::vector<VitResult> vres(nr); std::vector<ReadCond> rc_out(nr);
+    STRQ_HIP(c, hipMemcpyAsync(geom.data(), d->geom.p, (size_t)nr * sizeof(ReadGeom), hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipMemcpyAsync(vres.data(), d->vres.p, (size_t)nr * sizeof(VitResult), hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipMemcpyAsync(rc_out.data(), d_rc, (size_t)nr * sizeof(ReadCond), hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipStreamSynchronize(st));
+    for (int i = 0; i < nr; ++i) {
+        strq_result& o = B.results[r0 + i];
+        std::memset(&o, 0, sizeof(o));
+        const ReadGeom& g = geom[i];
+        const VitResult& v = vres[vit_slot[i]];
+        o.status = rc_out[i].status == COND_OK ? 0 : 1;
+        o.score_prefix = g.score_prefix; o.score_suffix = g.score_suffix;
+        o.prefix_begin = g.prefix_begin; o.prefix_end = g.prefix_end; o.suffix_begin = g.suffix_begin; o.suffix_end = g.suffix_end;
+        o.offset = g.prefix_end; o.ticks = std::max<int64_t>(g.suffix_begin - g.prefix_end, 0);
+        if (g.gate && v.status == 0) {
+            o.count = (int32_t)v.counted + d->targets[B.target[r0 + i]].count_bias;
+            o.log_p = v.logp;
+        }
+    }
+    float ms;
+    STRQ_HIP(c, hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); B.t_cond += ms;
+    STRQ_HIP(c, hipEventElapsedTime(&ms, d->ev[2], d->ev[3])); B.t_vit += ms;
+    rcode = align_core_times(c, &B.t_lut, &B.t_fwd, &B.t_trace);
+    return rcode;
+}
+
+}  // namespace strq
+
+extern "C" {
+
+int strq_set_pore_stats(strq_ctx* c, double tail_lo, double tail_hi, double model_min, double model_max)
+{
+    if (!c) return STRQ_ERR_ARG;
+    DetectState* d = dstate(c);
+    d->ps.M_lo = tail_lo; d->ps.M_hi = tail_hi; d->ps.clip_lo = model_min + .5; d->ps.clip_hi = model_max - .5;
+    d->have_ps = true;
+    return STRQ_OK;
+}
+
+int strq_target_add(strq_ctx* c, const float* prefix_ext, int64_t m_prefix, const float* suffix_ext, int64_t m_suffix,
+                    int32_t trim_prefix, int32_t trim_suffix, int32_t samples, int32_t hmm_model_id, int32_t count_bias,
+                    int32_t* target_id)
+{
+    if (!c) return STRQ_ERR_ARG;
+    if (!prefix_ext || !suffix_ext || !target_id || hmm_model_id < 0 || hmm_model_id >= (int32_t)c->models.size() ||
+        trim_prefix < 0 || trim_suffix < 0 || trim_prefix >= m_prefix || trim_suffix >= m_suffix) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+    DetectState* d = dstate(c);
+    Target t;
+    int rc = align_validate_flank(c, prefix_ext, m_prefix, samples, &t.kp, &t.Rp); if (rc) return rc;
+    rc = align_validate_flank(c, suffix_ext, m_suffix, samples, &t.ks, &t.Rs); if (rc) return rc;
+    t.prefix_ext.assign(prefix_ext, prefix_ext + m_prefix); t.suffix_ext.assign(suffix_ext, suffix_ext + m_suffix);
+    t.trim_prefix = trim_prefix; t.trim_suffix = trim_suffix; t.samples = samples; t.model_id = hmm_model_id; t.count_bias = count_bias;
+    d->targets.push_back(t);
+    *target_id = (int32_t)d->targets.size() - 1;
+    return STRQ_OK;
+}
+
+int strq_batch_upload(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
+                      const int32_t* target_id, const double* host_stats)
+{
+    if (!c) return STRQ_ERR_ARG;
+    DetectState* d = dstate(c);
+    if (n_reads < 0 || (n_reads > 0 && (!signals || !offsets || !target_id)) || (dtype != 0 && dtype != 1) || (dtype == 1 && n_reads > 0 && !host_stats)) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+    if (!d->have_ps) { c->err = "strq_set_pore_stats has not been called"; return STRQ_ERR_ARG; }
+    STRQ_HIP(c, hipSetDevice(c->device));
+    Batch& B = d->batch;
+    B.n_reads = n_reads; B.dtype = dtype;
+    B.off.assign(offsets, offsets + n_reads + 1);
+    B.target.assign(target_id, target_id + n_reads);
+    for (int64_t i = 0; i < n_reads; ++i) {
+        if (B.target[i] < 0 || B.target[i] >= (int32_t)d->targets.size()) { c->err = "unknown target id"; return STRQ_ERR_ARG; }
+        if (B.off[i + 1] < B.off[i] || B.off[i + 1] - B.off[i] > ((int64_t)1 << 30)) { c->err = "bad offsets"; return STRQ_ERR_ARG; }
+    }
+    B.host_stats.clear();
+    if (dtype == 1) B.host_stats.assign(host_stats, host_stats + n_reads * 6);
+    const size_t bytes = (size_t)(n_reads ? B.off[n_reads] : 0) * (dtype == 0 ? 2 : 8);
+    STRQ_HIP(c, B.raw.reserve(bytes + 64));
+    if (bytes) STRQ_HIP(c, hipMemcpyAsync(B.raw.p, signals, bytes, hipMemcpyHostToDevice, c->stream));
+    STRQ_HIP(c, hipStreamSynchronize(c->stream));
+    B.results.assign((size_t)n_reads, strq_result());
+    if (!d->ev_ok) { for (auto& e : d->ev) STRQ_HIP(c, hipEventCreate(&e)); d->ev_ok = true; }
+    return STRQ_OK;
+}
+
+int strq_batch_run(strq_ctx* c)
+{
+    if (!c) return STRQ_ERR_ARG;
+    DetectState* d = dstate(c);
+    Batch& B = d->batch;
+    STRQ_HIP(c, hipSetDevice(c->device));
+    B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0;
+    int64_t r0 = 0;
+    while (r0 < B.n_reads) {
+        int64_t r1 = r0; size_t ck = 0; int64_t samples = 0;
+        while (r1 < B.n_reads && r1 - r0 < 4096) {
+            const Target& t = d->targets[B.target[r1]];
+            const int n = (int)(B.off[r1 + 1] - B.off[r1]);
+            const size_t need = (size_t)align_num_ckpts(n) * 64 * 4 * (STRQ_CKPT_FIELDS(t.Rp) + STRQ_CKPT_FIELDS(t.Rs));
+            if (r1 > r0 && (ck + need > c->max_ws_bytes || samples + n > ((int64_t)3 << 30))) break;
+            ck += need; samples += n; ++r1;
+        }
+        const int rc = run_sub_batch(c, d, r0, r1);
+        if (rc) return rc;
+        r0 = r1;
+    }
+    std::fill(c->timing, c->timing + 8, 0.0f);
+    c->timing[0] = B.t_lut; c->timing[1] = B.t_fwd; c->timing[2] = B.t_trace; c->timing[5] = B.t_cond; c->timing[6] = B.t_vit;
+    c->timing[3] = B.t_lut + B.t_fwd + B.t_trace + B.t_cond + B.t_vit; c->timing[4] = (float)B.n_hard;
+    return STRQ_OK;
+}
+
+int strq_batch_fetch(strq_ctx* c, strq_result* out)
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    DetectState* d = dstate(c);
+    std::memcpy(out, d->batch.results.data(), d->batch.results.size() * sizeof(strq_result));
+    return STRQ_OK;
+}
+
+int strq_detect_batch(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
+                      const int32_t* target_id, const double* host_stats, strq_result* out)
+{
+    int rc = strq_batch_upload(c, n_reads, signals, dtype, offsets, target_id, host_stats);
+    if (rc) return rc;
+    rc = strq_batch_run(c);
+    if (rc) return rc;
+    return strq_batch_fetch(c, out);
+}
+
+// conditioning outputs of the last sub-batch (parity tests of STRique.py:590-597): levels of read
+// `read` (index inside the last sub-batch), its 256 level values and the scalars.
+int strq_debug_conditioning(strq_ctx* c, int64_t read, uint8_t* levels, int64_t n, float* level_val, double* scalars10)
+{
+    if (!c) return STRQ_ERR_ARG;
+    DetectState* d = dstate(c);
+    ReadCond rc;
+    STRQ_HIP(c, hipMemcpy(&rc, d->rc.as<ReadCond>() + read, sizeof(rc), hipMemcpyDeviceToHost));
+    if (levels) STRQ_HIP(c, hipMemcpy(levels, c->levels.as<uint8_t>() + rc.off, (size_t)std::min<int64_t>(n, rc.n), hipMemcpyDeviceToHost));
+    if (level_val) STRQ_HIP(c, hipMemcpy(level_val, c->level_val.as<float>() + read * 256, 1024, hipMemcpyDeviceToHost));
+    if (scalars10) {
+        const double v[10] = {rc.med, rc.mad, rc.f_c1, rc.f_h1, rc.m_c1, rc.m_h1, rc.r_c1, rc.r_h1, rc.h2, rc.c2};
+        std::memcpy(scalars10, v, sizeof(v));
+    }
+    return STRQ_OK;
+}
+
+}  // extern "C"

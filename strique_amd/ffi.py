@@ -142,3 +142,55 @@ class Context(object):
     def viterbi(self, model_id, x, want_path=True):
         logp, counted, status, paths = self.viterbi_batch(model_id, [x], want_path)
         return logp[0], int(counted[0]), int(status[0]), (paths[0] if want_path else None)
+
+    # ---- detect pipeline ------------------------------------------------------------------
+    def set_pore_stats(self, tail_lo, tail_hi, model_min, model_max):
+        self._check(self._lib.strq_set_pore_stats(self._h, ctypes.c_double(tail_lo), ctypes.c_double(tail_hi),
+                                                  ctypes.c_double(model_min), ctypes.c_double(model_max)))
+
+    def target_add(self, prefix_ext, suffix_ext, trim_prefix, trim_suffix, samples, model_id, count_bias):
+        pe = _c(prefix_ext, np.float32); se = _c(suffix_ext, np.float32)
+        tid = ctypes.c_int32(-1)
+        self._check(self._lib.strq_target_add(self._h, _ptr(pe), ctypes.c_int64(len(pe)), _ptr(se), ctypes.c_int64(len(se)),
+                                              ctypes.c_int32(trim_prefix), ctypes.c_int32(trim_suffix), ctypes.c_int32(samples),
+                                              ctypes.c_int32(model_id), ctypes.c_int32(count_bias), ctypes.byref(tid)))
+        return tid.value
+
+    def batch_upload(self, signals, offsets, target_ids, host_stats=None):
+        """signals: one concatenated int16 or float64 array; offsets: n_reads + 1."""
+        signals = np.ascontiguousarray(signals)
+        if signals.dtype == np.int16:
+            dtype = 0
+        elif signals.dtype == np.float64:
+            dtype = 1
+        else:
+            raise ValueError("signals must be int16 or float64")
+        offsets = _c(offsets, np.int64); target_ids = _c(target_ids, np.int32)
+        hs = None if host_stats is None else _c(host_stats, np.float64)
+        self._n_batch = len(target_ids)
+        self._check(self._lib.strq_batch_upload(self._h, ctypes.c_int64(len(target_ids)), _ptr(signals), ctypes.c_int32(dtype),
+                                                _ptr(offsets), _ptr(target_ids), _ptr(hs)))
+
+    def batch_run(self):
+        self._check(self._lib.strq_batch_run(self._h))
+
+    def batch_fetch(self):
+        out = np.zeros(self._n_batch, dtype=RESULT_DTYPE)
+        self._check(self._lib.strq_batch_fetch(self._h, _ptr(out)))
+        return out
+
+    def detect_batch(self, signals, offsets, target_ids, host_stats=None):
+        self.batch_upload(signals, offsets, target_ids, host_stats)
+        self.batch_run()
+        return self.batch_fetch()
+
+    def debug_conditioning(self, read, n):
+        levels = np.zeros(n, np.uint8); lval = np.zeros(256, np.float32); sc = np.zeros(10)
+        self._check(self._lib.strq_debug_conditioning(self._h, ctypes.c_int64(read), _ptr(levels), ctypes.c_int64(n), _ptr(lval), _ptr(sc)))
+        return levels, lval, sc
+
+
+RESULT_DTYPE = np.dtype([("count", np.int32), ("status", np.int32), ("score_prefix", np.float64),
+                         ("score_suffix", np.float64), ("log_p", np.float64), ("offset", np.int64),
+                         ("ticks", np.int64), ("prefix_begin", np.int64), ("prefix_end", np.int64),
+                         ("suffix_begin", np.int64), ("suffix_end", np.int64)], align=True)
