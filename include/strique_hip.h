@@ -42,6 +42,8 @@ int strq_abi_version(void);
 int strq_ctx_create(int device_id, strq_ctx** out);
 void strq_ctx_destroy(strq_ctx* ctx);
 const char* strq_last_error(const strq_ctx* ctx);
+/* hipDeviceSynchronize on the context's device (benchmark brackets). */
+int strq_device_synchronize(strq_ctx* ctx);
 
 /* Alignment parameters, order: open_h, ext_h, open_v, ext_v, dist_offset, dist_min.
  * Defaults after create are align_raw's own (src/align_raw.h:51-60): -2,-8,-2,-8, 8,-16;
@@ -165,7 +167,7 @@ int strq_debug_conditioning(strq_ctx* ctx, int64_t read, uint8_t* levels, int64_
 
 /* Kernel timing of the last batched call, milliseconds (HIP events on the library's stream):
  * [0] table build  [1] forward DP  [2] trace pass  [3] total  [4] table entries re-evaluated on
- * the host  [5] conditioning  [6] Viterbi.  */
+ * the host  [5] conditioning  [6] Viterbi  [7] number of forward-DP kernel launches.  */
 int strq_last_timing(const strq_ctx* ctx, float ms[8]);
 
 #ifdef __cplusplus

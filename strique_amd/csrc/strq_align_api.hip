@@ -203,6 +203,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         STRQ_HIP(c, hipEventRecord(c->ev[3 + phase], st));
     }
     out.d_tasks = d_tasks; out.d_results = d_res; out.d_rec = c->rec.as<int32_t>();
+    out.n_launches = (int)launches.size();
     return STRQ_OK;
 }
 
@@ -250,7 +251,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
     STRQ_HIP(c, hipMemcpyAsync(c->levels.p, in.levels, (size_t)tot_levels, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(c->level_val.p, in.level_val, (size_t)in.n_reads * 256 * 4, hipMemcpyHostToDevice, st));
     int64_t a0 = 0;
-    float t_lut = 0, t_fwd = 0, t_tr = 0, n_hard = 0;
+    float t_lut = 0, t_fwd = 0, t_tr = 0, n_hard = 0, n_launch = 0;
     while (a0 < NA) {
         int64_t a1 = a0; size_t ck_bytes = 0;
         while (a1 < NA) {
@@ -281,10 +282,10 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
         }
         rc = align_core_times(c, &t_lut, &t_fwd, &t_tr);
         if (rc) return rc;
-        n_hard += co.n_hard;
+        n_hard += co.n_hard; n_launch += co.n_launches;
         a0 = a1;
     }
-    c->timing[0] = t_lut; c->timing[1] = t_fwd; c->timing[2] = t_tr; c->timing[3] = t_lut + t_fwd + t_tr; c->timing[4] = n_hard;
+    c->timing[0] = t_lut; c->timing[1] = t_fwd; c->timing[2] = t_tr; c->timing[3] = t_lut + t_fwd + t_tr; c->timing[4] = n_hard; c->timing[7] = n_launch;
     return STRQ_OK;
 }
 
@@ -341,6 +342,14 @@ int strq_get_align_params(const strq_ctx* c, float p[6])
     if (!c || !p) return STRQ_ERR_ARG;
     p[0] = c->ap.open_h; p[1] = c->ap.ext_h; p[2] = c->ap.open_v; p[3] = c->ap.ext_v;
     p[4] = c->ap.dist_offset; p[5] = c->ap.dist_min;
+    return STRQ_OK;
+}
+
+int strq_device_synchronize(strq_ctx* c)
+{
+    if (!c) return STRQ_ERR_ARG;
+    STRQ_HIP(c, hipSetDevice(c->device));
+    STRQ_HIP(c, hipDeviceSynchronize());
     return STRQ_OK;
 }
 

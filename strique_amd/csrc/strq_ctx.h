@@ -43,6 +43,7 @@ struct AlignCoreOut {
     size_t rec_total = 0;
     AlignTask* d_tasks = nullptr; AlignResult* d_results = nullptr; int32_t* d_rec = nullptr;
     int n_hard = 0;
+    int n_launches = 0;                    // forward-kernel launches
 };
 
 struct HostModel {

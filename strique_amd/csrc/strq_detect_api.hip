@@ -104,6 +104,7 @@ struct Batch {
     std::vector<strq_result> results;
     float t_cond = 0, t_lut = 0, t_fwd = 0, t_trace = 0, t_vit = 0, t_total = 0;
     double n_hard = 0;
+    int n_fwd_launches = 0;
 };
 
 struct DetectState {
@@ -200,7 +201,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     ci.read = a_read.data(); ci.n = n.data(); ci.m = m.data(); ci.k = k.data(); ci.R = R.data(); ci.flank = fl.data();
     int rcode = align_core(c, ci, co);
     if (rcode) return rcode;
-    B.n_hard += co.n_hard;
+    B.n_hard += co.n_hard; B.n_fwd_launches += co.n_launches;
 
     // ---- positions, gate, Viterbi tasks (grouped by HMM)
     std::vector<int32_t> task_of(na);
@@ -326,7 +327,7 @@ int strq_batch_run(strq_ctx* c)
     DetectState* d = dstate(c);
     Batch& B = d->batch;
     STRQ_HIP(c, hipSetDevice(c->device));
-    B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0;
+    B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
     int64_t r0 = 0;
     while (r0 < B.n_reads) {
         int64_t r1 = r0; size_t ck = 0; int64_t samples = 0;
@@ -343,7 +344,7 @@ int strq_batch_run(strq_ctx* c)
     }
     std::fill(c->timing, c->timing + 8, 0.0f);
     c->timing[0] = B.t_lut; c->timing[1] = B.t_fwd; c->timing[2] = B.t_trace; c->timing[5] = B.t_cond; c->timing[6] = B.t_vit;
-    c->timing[3] = B.t_lut + B.t_fwd + B.t_trace + B.t_cond + B.t_vit; c->timing[4] = (float)B.n_hard;
+    c->timing[3] = B.t_lut + B.t_fwd + B.t_trace + B.t_cond + B.t_vit; c->timing[4] = (float)B.n_hard; c->timing[7] = (float)B.n_fwd_launches;
     return STRQ_OK;
 }
 

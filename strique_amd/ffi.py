@@ -73,6 +73,9 @@ class Context(object):
         if rc != STRQ_OK:
             raise StriqueHipError(rc, self._lib.strq_last_error(self._h).decode())
 
+    def device_synchronize(self):
+        self._check(self._lib.strq_device_synchronize(self._h))
+
     # ---- alignment ------------------------------------------------------------------------
     def set_align_params(self, open_h, ext_h, open_v, ext_v, dist_offset, dist_min):
         p = np.array([open_h, ext_h, open_v, ext_v, dist_offset, dist_min], dtype=np.float32)

@@ -263,6 +263,21 @@ def bake(g, count_states=(), tag_substring=None):
                 break
         if not merged:
             break
+    # parallel edges (two spliced paths between the same pair of states, e.g. insert -> e1 -> e0
+    # and insert -> e2 -> e0 in the modification model): Viterbi takes the better one, so keep a
+    # single edge with the larger probability.  (pomegranate's networkx DiGraph would keep
+    # whichever of the two it happened to re-insert last -- an order that depends on id() hashes
+    # and differs between runs of the reference; see DESIGN.md "unpinned semantics".)
+    best = {}
+    for a, b, lp in edges:
+        if (a, b) not in best or lp > best[(a, b)]:
+            best[(a, b)] = lp
+    seen = set()
+    dedup = []
+    for a, b, lp in edges:
+        if (a, b) not in seen:
+            seen.add((a, b)); dedup.append((a, b, best[(a, b)]))
+    edges = dedup
     # 4. ordering
     emitting = sorted((i for i in range(n) if alive[i] and g.kinds[i] != SILENT), key=lambda i: (g.names[i], i))
     silent = [i for i in range(n) if alive[i] and g.kinds[i] == SILENT]

@@ -1,0 +1,67 @@
+"""C-ABI surface (no GPU needed to load the library) and host-side logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _lib():
+    from strique_amd import build, ffi
+    if not os.path.exists(ffi.LIB_PATH):
+        build.build_lib()
+    return ctypes.CDLL(ffi.LIB_PATH)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "strique_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(strq_[a-z_0-9]+)\s*\(", header)))
+    assert len(names) >= 15
+    lib = _lib()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.strq_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the context cannot be created -- and nothing else is tried."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from strique_amd import ffi
+    with pytest.raises(ffi.StriqueHipError):
+        ffi.Context(0)
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package never imports, includes, links or loads anything under oracle/."""
+    bad = re.compile(r"(^\s*(import|from)\s+oracle\b)|(#include\s+[\"<][^\">]*oracle)|(liboracle)|(oracle[/\\][a-z_]+\.(so|c|py)\b.*(CDLL|dlopen|open))", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "strique_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(text), (dirpath, f)
+
+
+def test_shard_indices_cover_everything():
+    from strique_amd.dist import shard_indices
+    cost = np.random.default_rng(0).integers(1, 100, 37)
+    parts = [shard_indices(37, r, 4, cost) for r in range(4)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(37))
+    loads = [cost[p].sum() for p in parts]
+    assert max(loads) - min(loads) <= cost.max()
+
+
+def test_synth_is_seeded_and_has_the_repeat(pm, cfg):
+    from strique_amd import synth
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    t = synth.KmerTable(pm)
+    a, sa = synth.make_read(t, 2, 5, 6000, (repeat, prefix, suffix), 30)
+    b2, sb = synth.make_read(t, 2, 5, 6000, (repeat, prefix, suffix), 30)
+    assert sa == sb and np.array_equal(a, b2) and a.dtype == np.int16
+    assert 6 * 5995 <= len(a) <= 9 * 5995
+    idx = t.indices(b"ACGTACGTAC")
+    assert np.allclose(t.mean[idx], pm.level_means("ACGTACGTAC"))

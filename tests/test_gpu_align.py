@@ -1,0 +1,119 @@
+"""HIP flank alignment vs the CPU oracle through the C ABI: bit-exact score, identical path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from strique_amd import ffi
+    return ffi.Context(0)
+
+
+def _toy(rng, n, k=145, s=6, scale=0.45):
+    cls = rng.uniform(60, 120, k).astype(np.float32)
+    flank = np.repeat(cls, s)
+    lval = (40 + scale * np.arange(256)).astype(np.float32)
+    lv = np.repeat(rng.integers(30, 200, n // 5 + 1), rng.integers(3, 10, n // 5 + 1))[:n].astype(np.uint8)
+    emb = np.repeat(np.clip(np.round((cls - 40) / scale), 0, 255).astype(np.uint8), rng.integers(6, 10, k))
+    pos = int(rng.integers(0, max(1, n - len(emb))))
+    emb = emb[:max(0, n - pos)]
+    lv[pos:pos + len(emb)] = emb
+    return lv, lval, flank
+
+
+def _same(o, g):
+    assert np.float32(o[0]).tobytes() == np.float32(g[0]).tobytes()
+    assert o[4] == g[4] and o[5] == g[5]
+    assert np.array_equal(o[3], g[3])
+    if o[1] is not None and g[1] is not None:
+        assert np.array_equal(o[1], g[1]) and np.array_equal(o[2], g[2])
+
+
+@pytest.mark.parametrize("n", [1, 2, 10, 63, 127, 128, 129, 1000, 1023, 1024, 1025, 2049, 20001])
+def test_align_overlap_lengths(ctx, orc, n):
+    """Includes reads shorter than the flank (vertical run at column 0), the 64-step wavefront
+    boundaries and the 1024-column checkpoint boundaries."""
+    rng = np.random.default_rng(100 + n)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    lv, lval, flank = _toy(rng, n)
+    a = lval[lv]
+    _same(orc.align_overlap(a, flank, params), ctx.align_overlap(a, flank))
+
+
+@pytest.mark.parametrize("params", [[-2, -8, -2, -8, 8, -16], [-3, -1, -20, -4, 16, 0], [-1, -1, -12, -16, 16, -2],
+                                    [-2, -1, -16, -16, 16, 0]])
+def test_general_affine_parameters(ctx, orc, params):
+    """open != extend in one or both directions runs the non-collapsed kernels; the first row is
+    align_raw's own defaults (src/align_raw.h:51-60)."""
+    rng = np.random.default_rng(7)
+    p = np.array(params, np.float32)
+    ctx.set_align_params(*[float(v) for v in p])
+    for n in (300, 5000):
+        lv, lval, flank = _toy(rng, n)
+        a = lval[lv]
+        _same(orc.align_overlap(a, flank, p), ctx.align_overlap(a, flank))
+    ctx.set_align_params(*[float(v) for v in orc.align_params(None)])
+
+
+@pytest.mark.parametrize("k", [1, 40, 64, 100, 128, 150, 158])
+def test_flank_shapes(ctx, orc, k):
+    """6 / 12 / 15 / 18 rows per lane, last flank row in an interior register or not."""
+    rng = np.random.default_rng(k)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    lv, lval, flank = _toy(rng, 4000, k=k)
+    a = lval[lv]
+    _same(orc.align_overlap(a, flank, params), ctx.align_overlap(a, flank))
+
+
+def test_wide_bands_and_table_classes(ctx, orc):
+    """Level spacing decides the band width: 64-, 128- and full-width table classes."""
+    rng = np.random.default_rng(11)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    for scale in (0.45, 0.2, 0.05):
+        lv, lval, flank = _toy(rng, 3000, scale=scale)
+        a = lval[lv]
+        _same(orc.align_overlap(a, flank, params, want_idx=False), ctx.align_overlap(a, flank, want_idx=False))
+
+
+def test_batch_ragged(ctx, orc):
+    rng = np.random.default_rng(5)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    reads, lvals, flanks = [], [], []
+    for n in (50, 700, 1300, 9000, 2500, 64, 4097):
+        lv, lval, flank = _toy(rng, n)
+        reads.append(lv); lvals.append(lval); flanks.append(flank)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    foff = np.concatenate([[0], np.cumsum([len(f) for f in flanks])])
+    sc, je, j0, rec = ctx.align_batch(np.concatenate(reads), off, np.stack(lvals), np.arange(len(reads)), np.concatenate(flanks), foff)
+    for i in range(len(reads)):
+        o = orc.align_overlap(lvals[i][reads[i]], flanks[i], params, want_idx=False)
+        assert np.float32(o[0]).tobytes() == sc[i].tobytes() and o[4] == je[i] and o[5] == j0[i]
+        assert np.array_equal(o[3], rec[foff[i]:foff[i + 1]])
+    assert ctx.align_batch(np.zeros(0, np.uint8), [0], np.zeros((0, 256), np.float32), [], np.zeros(0, np.float32), [0])[0].size == 0
+
+
+def test_full_size_read(ctx, orc):
+    """BASELINE config 3 size: N = 375 000 columns."""
+    rng = np.random.default_rng(9)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    lv, lval, flank = _toy(rng, 375000)
+    a = lval[lv]
+    _same(orc.align_overlap(a, flank, params, want_idx=False), ctx.align_overlap(a, flank, want_idx=False))
+
+
+def test_unsupported_inputs(ctx):
+    from strique_amd import ffi
+    rng = np.random.default_rng(1)
+    with pytest.raises(ffi.StriqueHipError) as e:
+        ctx.align_overlap(rng.normal(90, 10, 5000), np.repeat(rng.uniform(60, 120, 10), 6))      # > 256 levels
+    assert e.value.code == ffi.STRQ_ERR_UNSUPPORTED
+    with pytest.raises(ffi.StriqueHipError):
+        ctx.align_overlap(np.ones(100), rng.uniform(60, 120, 60))                                 # no runs of 6
+    assert np.array_equal(ctx.get_align_params(), ctx.get_align_params())

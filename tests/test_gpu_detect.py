@@ -1,0 +1,97 @@
+"""repeatCounter.detect on the GPU vs the CPU oracle: every output field identical."""
+import numpy as np
+import pytest
+
+from conftest import oracle_tc
+
+pytestmark = pytest.mark.gpu
+
+
+def _read(pm, cfg, name, strand, total_nt, nrep, idx, as_int16=True):
+    from strique_amd import synth
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"][name]
+    return synth.make_read(synth.KmerTable(pm), 9, idx, total_nt, (repeat, prefix, suffix), nrep, strand=strand, as_int16=as_int16)[0]
+
+
+def _check(gpu_counter, orc, opm, cfg, items):
+    got = gpu_counter.detect_batch([(n, s, st) for n, s, st in items])
+    params = orc.align_params(cfg["align"])
+    for (name, sig, strand), g in zip(items, got):
+        want, _ = orc.detect(sig, oracle_tc(gpu_counter, name, strand), opm, params)
+        assert tuple(g[:6]) == tuple(want[:6]), (name, strand, g, want)
+    return got
+
+
+def test_int16_and_float64_reads(gpu_counter, orc, opm, pm, cfg):
+    rng = np.random.default_rng(2)
+    items = []
+    for k in range(10):
+        name = ["c9orf72", "fmr1"][k % 2]; strand = "+-"[(k // 2) % 2]
+        items.append((name, _read(pm, cfg, name, strand, int(rng.integers(3000, 8000)), int(rng.integers(4, 90)), k, as_int16=(k % 3 != 0)), strand))
+    ints = [it for it in items if it[1].dtype == np.int16]
+    flts = [it for it in items if it[1].dtype != np.int16]
+    _check(gpu_counter, orc, opm, cfg, ints)
+    _check(gpu_counter, orc, opm, cfg, flts)
+
+
+def test_reference_scenarios(gpu_counter, pm, cfg):
+    """scripts/STRique_test.py:47-62,86-100: noise-free float signals, n must equal i."""
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    rng = np.random.default_rng(5)
+    backbone = "".join(rng.choice(list("ACTG"), 2000))
+    for i in (100, 300):
+        seq = backbone[:1000] + prefix + repeat * i + suffix + backbone[-1000:]
+        assert gpu_counter.detect("c9orf72", pm.generate_signal(seq, samples=8), "+")[0] == i
+    for i in (10, 60):
+        assert gpu_counter.detect("c9orf72", pm.generate_signal(prefix + repeat * i + suffix, samples=8), "+")[0] == i
+
+
+def test_bad_reads_do_not_kill_the_batch(gpu_counter, orc, opm, pm, cfg):
+    rng = np.random.default_rng(6)
+    good = _read(pm, cfg, "c9orf72", "+", 4000, 12, 77)
+    const = np.full(3000, 500, np.int16)                       # normalisation undefined
+    noise = rng.integers(300, 900, 5000).astype(np.int16)      # no locus inside
+    got = gpu_counter.detect_batch([("c9orf72", const, "+"), ("c9orf72", good, "+"), ("fmr1", noise, "-")])
+    assert got[0][0] == 0 and got[0][6] == "-"
+    want, _ = orc.detect(good, oracle_tc(gpu_counter, "c9orf72", "+"), opm, orc.align_params(cfg["align"]))
+    assert tuple(got[1][:6]) == tuple(want[:6]) and got[1][0] == 12
+    want, _ = orc.detect(noise, oracle_tc(gpu_counter, "fmr1", "-"), opm, orc.align_params(cfg["align"]))
+    assert tuple(got[2][:6]) == tuple(want[:6])
+
+
+def test_errors_match_the_reference(gpu_counter):
+    with pytest.raises(ValueError):
+        gpu_counter.detect("nope", np.zeros(100, np.int16), "+")           # STRique.py:618
+    with pytest.raises(ValueError):
+        gpu_counter.detect("c9orf72", np.zeros(100, np.int16), "x")        # STRique.py:589
+    with pytest.raises(ValueError):
+        gpu_counter.add_target("c9orf72", "GGCCCC", "A" * 150, "C" * 150)  # STRique.py:579
+
+
+def test_conditioning_stage(gpu_counter, orc, opm, pm, cfg):
+    """Steps 1-6 of detect (STRique.py:590-597): 8-bit morphology levels and their values."""
+    sigs = [_read(pm, cfg, "c9orf72", "+", 3000 + 500 * i, 10 + i, 200 + i) for i in range(3)]
+    gpu_counter.detect_batch([("c9orf72", s, "+") for s in sigs])
+    for i, s in enumerate(sigs):
+        lv, lval, sc = gpu_counter.ctx.debug_conditioning(i, len(s))
+        flt, u8, morph, fltn = orc.condition(s, opm)
+        assert np.array_equal(lv, u8)
+        uq, first = np.unique(u8, return_index=True)
+        assert np.array_equal(lval[uq], morph[first].astype(np.float32))
+        assert sc[0] == np.median(flt) and sc[1] == orc.mad(flt)
+
+
+def test_full_size_reads_properties(gpu_counter, orc, opm, pm, cfg):
+    """BASELINE config 3 size (50 kb reads).  One read is compared field by field with the oracle;
+    for the rest: determinism, planted count recovered, geometry consistent with the planted locus."""
+    plan = [(200, "+"), (1000, "-"), (2000, "+"), (500, "-")]
+    sigs = [_read(pm, cfg, "c9orf72", st, 50000, n, 300 + i) for i, (n, st) in enumerate(plan)]
+    items = [("c9orf72", s, st) for s, (n, st) in zip(sigs, plan)]
+    a = gpu_counter.detect_batch(items)
+    b = gpu_counter.detect_batch(items)
+    assert a == b
+    for (n, st), r, s in zip(plan, a, sigs):
+        assert abs(r[0] - n) <= 2
+        assert 0 < r[4] < len(s) and 6 * 6 * n * 0.9 < r[5] < 9 * 6 * n * 1.1      # ticks ~ 6 nt x n x dwell
+    want, _ = orc.detect(sigs[0], oracle_tc(gpu_counter, "c9orf72", "+"), opm, orc.align_params(cfg["align"]))
+    assert tuple(a[0][:6]) == tuple(want[:6])

@@ -1,0 +1,78 @@
+"""HMM topologies against what the reference's own classes hand to pomegranate."""
+import json
+import os
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+KIND = {0: "silent", 1: "normal", 2: "uniform"}
+
+
+def _golden(t):
+    names = [s["name"] for s in t["states"]]
+    names[t["start"]] = "start"; names[t["end"]] = "end"
+    used = set()
+    for a, b, p, g in t["edges"]:
+        used.add(a); used.add(b)
+    st = Counter((names[i], t["states"][i]["kind"], tuple(t["states"][i]["params"])) for i in used)
+    ed = Counter((names[a], names[b], p) for a, b, p, g in t["edges"])
+    return st, ed
+
+
+def _mine(g):
+    used = set()
+    for a, b, p in g.edges:
+        used.add(a); used.add(b)
+    st = Counter((g.names[i], KIND[g.kinds[i]], g.params[i]) for i in used)
+    ed = Counter((g.names[a], g.names[b], p) for a, b, p in g.edges)
+    return st, ed
+
+
+@pytest.mark.parametrize("name", ["c9orf72", "fmr1"])
+@pytest.mark.parametrize("strand", ["+", "-"])
+def test_topology_matches_reference(pm, pm_mod, cfg, name, strand):
+    from strique_amd import hmm
+    from strique_amd.counter import reverse_complement as rc
+    topo = json.load(open(os.path.join(GOLDEN, "hmm_topology.json")))
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"][name]
+    p, s, r = prefix[-50:].upper(), suffix[:50].upper(), repeat.upper()
+    if strand == "-":
+        r, p, s = rc(r), rc(s), rc(p)
+    fm = hmm.FlankedRepeatModel(r, p, s, pm, cfg["HMM"])
+    t = topo["%s|%s|flanked" % (name, strand)]
+    assert _golden(t) == _mine(fm.graph)
+    assert fm.flanking_count == t["flanking_count"] and fm.repeat_offset == t["repeat_offset"]
+    mm = hmm.RepeatModModel(r, pm, pm_mod, cfg["HMM"])
+    t = topo["%s|%s|mod" % (name, strand)]
+    assert _golden(t) == _mine(mm.graph)
+    assert mm.model_min == t["model_min"] and mm.model_max == t["model_max"]
+
+
+def test_interpolated_repeat(pm, cfg):
+    from strique_amd import hmm
+    t = json.load(open(os.path.join(GOLDEN, "hmm_topology_gcg.json")))["gcg|+|flanked"]
+    fm = hmm.FlankedRepeatModel("GCG", cfg["repeat"]["fmr1"][4][-50:].upper(), cfg["repeat"]["fmr1"][5][:50].upper(), pm, None)
+    assert _golden(t) == _mine(fm.graph)
+    assert (fm.flanking_count, fm.repeat_offset) == (t["flanking_count"], t["repeat_offset"]) == (3, 1)
+
+
+def test_bake_invariants(pm, cfg):
+    from strique_amd import hmm
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    fm = hmm.FlankedRepeatModel(repeat, prefix[-50:], suffix[:50], pm, cfg["HMM"])
+    bk = fm.baked
+    assert bk.silent_start == 216                       # 216 emitting states
+    assert sorted(bk.names[:bk.silent_start]) == bk.names[:bk.silent_start]
+    # out-edge probabilities of every state but `end` sum to 1 after bake
+    out = np.zeros(bk.n_states)
+    for l in range(bk.n_states):
+        for e_ in range(bk.in_ptr[l], bk.in_ptr[l + 1]):
+            out[bk.in_src[e_]] += np.exp(bk.in_logp[e_])
+            if l >= bk.silent_start and bk.in_src[e_] >= bk.silent_start:
+                assert bk.in_src[e_] < l                 # topological order of silent states
+    mask = np.ones(bk.n_states, bool); mask[bk.end] = False
+    assert np.allclose(out[mask], 1.0, atol=1e-8)
+    assert bk.count_inc.sum() == 2 and all("dummy" in bk.names[i] for i in np.nonzero(bk.count_inc)[0])
