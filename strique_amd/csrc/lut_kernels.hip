@@ -4,9 +4,11 @@
 // src/score_distance.h:115-122):  s = max(dist_offset - (float)pow((double)|h - v|, 1.2), dist_min)
 // by one evaluation per (k-mer class of the flank, 8-bit level of the read) pair.
 //
-// The table is banded: for class k only the contiguous level range [lo_k, hi_k] that contains
-// every level scoring above dist_min is stored, framed by two guard entries equal to dist_min,
-// so the DP kernel clamps the level into the band with one v_med3_i32.
+// The table is banded: for class k only a contiguous level range [e_l, e_r] is stored and the DP
+// kernel clamps the level into it with one v_med3_i32.  The range is chosen so that clamping
+// cannot change a score: left of e_l (right of e_r) every level scores like e_l (e_r) -- either
+// because they all clip to dist_min, or because they all sit on the plateau that
+// normalize2model's np.clip (scripts/STRique.py:178-179) makes of the lowest / highest levels.
 //
 // Bit-exactness versus the host libm: the reference casts a double pow to float.  Two pow
 // implementations that are both accurate to a few ulp(double) give the same float unless the
@@ -27,8 +29,19 @@ static __device__ __forceinline__ float cell_score_dev(const AlignParams& p, flo
     const double y = pow((double)d, 1.2);
     const uint64_t bits = __builtin_bit_cast(uint64_t, y);
     const int64_t low = (int64_t)(bits & 0x1FFFFFFFull) - 0x10000000ll;   // distance to the float midpoint
-    *hard = (low >= -STRQ_HARD_ULPS && low <= STRQ_HARD_ULPS);
-    const float s = p.dist_offset - (float)y;
+    bool hd = (low >= -STRQ_HARD_ULPS && low <= STRQ_HARD_ULPS);
+    const float x = (float)y;
+    const float s = p.dist_offset - x;
+    if (hd) {
+        // the other float the host could have rounded to; if both give a clipped score the entry is
+        // dist_min on the host as well and needs no second opinion
+        // x = (float)y >= 0 here (a power of a non-negative number): neighbours by bit pattern
+        const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+        const float x2 = __builtin_bit_cast(float, (double)x < y ? xb + 1u : (xb ? xb - 1u : 0u));
+        const float s2 = p.dist_offset - x2;
+        if (!(s > p.dist_min) && !(s2 > p.dist_min)) hd = false;
+    }
+    *hard = hd;
     return s > p.dist_min ? s : p.dist_min;
 }
 
@@ -38,38 +51,47 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
 {
     extern __shared__ float sc_all[];          // k x 256 scores
     __shared__ int lo[STRQ_LUT_MAX_K], hi[STRQ_LUT_MAX_K];
-    __shared__ int width, n_local;
+    __shared__ int width, n_local, plat_lo, plat_hi;
     __shared__ unsigned short local_hard[STRQ_LUT_LOCAL_HARD][2];
     const LutJob jb = jobs[blockIdx.x];
     const int q = threadIdx.x;
     for (int k = q; k < jb.k; k += 256) { lo[k] = 256; hi[k] = -1; }
-    if (q == 0) { width = 0; n_local = 0; }
+    if (q == 0) { width = 0; n_local = 0; plat_lo = 255; plat_hi = 0; }
     __syncthreads();
     const float v = jb.level_val[q];
+    // plateaus: levels 0..plat_lo share the value of level 0, levels plat_hi..255 that of level 255
+    {
+        const float v0 = jb.level_val[0], v255 = jb.level_val[255];
+        if (__builtin_bit_cast(uint32_t, v) != __builtin_bit_cast(uint32_t, v0)) atomicMin(&plat_lo, q - 1);
+        if (__builtin_bit_cast(uint32_t, v) != __builtin_bit_cast(uint32_t, v255)) atomicMax(&plat_hi, q + 1);
+    }
+    __syncthreads();
+    const int plat_lo_r = plat_lo, plat_hi_r = plat_hi;
     for (int k = 0; k < jb.k; ++k) {
         bool hd;
         const float s = cell_score_dev(p, v, jb.cls_val[k], &hd);
         sc_all[k * 256 + q] = s;
         if (s > p.dist_min) { atomicMin(&lo[k], q); atomicMax(&hi[k], q); }
-        if (hd) {
+        if (hd && q >= plat_lo_r && q <= plat_hi_r) {     // levels inside a plateau duplicate its end level
             const int slot = atomicAdd(&n_local, 1);
             if (slot < STRQ_LUT_LOCAL_HARD) { local_hard[slot][0] = (unsigned short)k; local_hard[slot][1] = (unsigned short)q; }
         }
     }
     __syncthreads();
-    for (int k = q; k < jb.k; k += 256) if (hi[k] >= lo[k]) atomicMax(&width, hi[k] - lo[k] + 1);
+    // stored range of class k: [e_l, e_r]
+    auto edge_l = [&](int k) { return hi[k] < lo[k] ? 0 : (lo[k] <= plat_lo ? plat_lo : lo[k] - 1); };
+    auto edge_r = [&](int k) { return hi[k] < lo[k] ? 0 : (hi[k] >= plat_hi ? plat_hi : hi[k] + 1); };
+    for (int k = q; k < jb.k; k += 256) atomicMax(&width, edge_r(k) - edge_l(k) + 1);
     __syncthreads();
-    const int need = width + 2;
+    const int need = width;
     const int tw = need <= 64 ? 64 : (need <= 128 ? 128 : 258);
     const int stride = tw + 1;
     for (int idx = q; idx < jb.k * stride; idx += 256) {
         const int k = idx / stride, w = idx - k * stride;
-        const int blo = (hi[k] >= lo[k] ? lo[k] : 1) - 1;
-        const int lv = blo + w;
-        float s = p.dist_min;
-        if (w < tw && lv >= lo[k] && lv <= hi[k]) s = sc_all[k * 256 + lv];
-        jb.table[idx] = s;
-        if (w == 0) jb.band_lo[k] = blo;
+        const int el = edge_l(k), er = edge_r(k);
+        int lv = el + w; if (lv > er) lv = er;
+        jb.table[idx] = sc_all[k * 256 + lv];
+        if (w == 0) jb.band_lo[k] = el;
     }
     if (q == 0) {
         int nh = n_local;
@@ -78,7 +100,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
         // the band itself would be wrong, so let the host rebuild this table
         for (int i = 0; i < nh; ++i) {
             const int k = local_hard[i][0], lv = local_hard[i][1];
-            if (lv < lo[k] || lv > hi[k]) { nh = -1; break; }
+            if (lv < edge_l(k) || lv > edge_r(k)) { nh = -1; break; }
         }
         info[blockIdx.x].tw = tw;
         info[blockIdx.x].n_hard = nh;
@@ -88,7 +110,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
             if (slot < hard_cap) {
                 HardEntry e;
                 e.job = blockIdx.x; e.k = k; e.level = lv;
-                e.index = k * stride + (lv - (lo[k] - 1));
+                e.index = k * stride + (lv - edge_l(k));
                 hard[slot] = e;
             }
         }

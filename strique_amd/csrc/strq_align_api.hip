@@ -167,6 +167,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         launches.push_back({g.first.first, g.first.second, (int)out.order.size(), (int)v.size()});
         out.order.insert(out.order.end(), v.begin(), v.end());
     }
+    for (auto& L : launches) STRQ_DBG("launch group R=%d tw=%d count=%d", L.R, L.tw, L.count);
     for (int pos = 0; pos < nb; ++pos) {
         const int i = out.order[pos];
         AlignTask& t = tasks[pos];

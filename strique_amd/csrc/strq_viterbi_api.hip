@@ -34,61 +34,110 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     VitModel& m = hm->h;
     std::memset(&m, 0, sizeof(m));
     m.n_states = n_states; m.n_emit = ne; m.n_silent = ns; m.start = start; m.end = end; m.epl = epl; m.spl = spl;
+    // emitting states: dealt to slots by descending in-degree (slot 0 takes the 64 busiest, ...)
+    auto deg_of = [&](int st) { return in_ptr[st + 1] - in_ptr[st]; };
+    std::vector<int> eord(ne);
+    for (int i = 0; i < ne; ++i) eord[i] = i;
+    std::stable_sort(eord.begin(), eord.end(), [&](int a, int b) { return deg_of(a) > deg_of(b); });
+    std::vector<int32_t> own_e((size_t)epl * 64, -1);
+    for (int i = 0; i < ne; ++i) own_e[i] = eord[i];
+    // silent states: chains.  The chain predecessor of b is its highest-numbered silent predecessor
+    // (the last in-edge in evaluation order, so a strict '>' reproduces the tie rule) if that state
+    // does not already lead another chain.
+    std::vector<int> chain_pred(n_states, -1), chain_succ(n_states, -1); std::vector<double> chain_lp(n_states, 0.0);
+    for (int b = ne; b < n_states; ++b) {
+        int a = -1; double lpv = 0;
+        for (int e = in_ptr[b]; e < in_ptr[b + 1]; ++e) if (in_src[e] >= ne) { a = in_src[e]; lpv = in_logp[e]; }
+        if (a >= 0 && chain_succ[a] < 0) { chain_pred[b] = a; chain_succ[a] = b; chain_lp[b] = lpv; }
+    }
+    std::vector<std::vector<int>> chains;
+    for (int b = ne; b < n_states; ++b) if (chain_pred[b] < 0) { std::vector<int> ch; for (int x = b; x >= 0; x = chain_succ[x]) ch.push_back(x); chains.push_back(ch); }
+    std::stable_sort(chains.begin(), chains.end(), [](const std::vector<int>& x, const std::vector<int>& y) { return x.size() > y.size(); });
+    std::vector<int32_t> own_s, chain_src_v; std::vector<double> chain_lp_v;
+    {   // first-fit: a chain never straddles two slots (a straddling edge falls back to the edge list)
+        std::vector<int> fill;   // lanes used per slot
+        for (auto& ch : chains) {
+            size_t pos = 0;
+            while (pos < ch.size()) {
+                const int want = (int)std::min<size_t>(ch.size() - pos, 64);
+                int slot = -1;
+                for (size_t sl = 0; sl < fill.size(); ++sl) if (fill[sl] + want <= 64) { slot = (int)sl; break; }
+                if (slot < 0) { fill.push_back(0); slot = (int)fill.size() - 1; own_s.resize(fill.size() * 64, -1); chain_src_v.resize(fill.size() * 64, -1); chain_lp_v.resize(fill.size() * 64, 0.0); }
+                for (int q = 0; q < want; ++q) {
+                    const int lane = fill[slot] + q, st = ch[pos + q];
+                    own_s[slot * 64 + lane] = st;
+                    if (q > 0) { chain_src_v[slot * 64 + lane] = ch[pos + q - 1]; chain_lp_v[slot * 64 + lane] = chain_lp[st]; }
+                }
+                fill[slot] += want; pos += want;
+            }
+        }
+        if ((int)fill.size() > 4) { delete hm; c->err = "too many silent states for the compiled Viterbi kernels"; return STRQ_ERR_UNSUPPORTED; }
+        m.spl = (int)fill.size();
+    }
+    const int spl2 = m.spl;
+    auto is_chain_edge = [&](int dst, int srcst) {
+        for (int i = 0; i < spl2 * 64; ++i) if (own_s[i] == dst) return chain_src_v[i] == srcst;
+        return false;
+    };
     int rows = 0;
     for (int s = 0; s < epl; ++s) {
         int deg = 0;
-        for (int lane = 0; lane < 64; ++lane) { const int e = s * 64 + lane; if (e < ne) deg = std::max(deg, in_ptr[e + 1] - in_ptr[e]); }
+        for (int lane = 0; lane < 64; ++lane) if (own_e[s * 64 + lane] >= 0) deg = std::max(deg, deg_of(own_e[s * 64 + lane]));
         m.e_deg[s] = deg; m.e_base[s] = rows; rows += deg;
     }
-    for (int s = 0; s < spl; ++s) {
+    std::vector<int> sdeg_state(n_states, 0);
+    for (int b = ne; b < n_states; ++b) { int dg = 0; for (int e = in_ptr[b]; e < in_ptr[b + 1]; ++e) if (!is_chain_edge(b, in_src[e])) ++dg; sdeg_state[b] = dg; }
+    for (int s = 0; s < spl2; ++s) {
         int deg = 0;
-        for (int lane = 0; lane < 64; ++lane) { const int q = s * 64 + lane; if (q < ns) deg = std::max(deg, in_ptr[ne + q + 1] - in_ptr[ne + q]); }
+        for (int lane = 0; lane < 64; ++lane) if (own_s[s * 64 + lane] >= 0) deg = std::max(deg, sdeg_state[own_s[s * 64 + lane]]);
         m.s_deg[s] = deg; m.s_base[s] = rows; rows += deg;
     }
+    for (int s = 0; s < 8; ++s) if (m.e_deg[s] > 8 || m.s_deg[s] > 8) { delete hm; c->err = "a state has more than 8 in-edges"; return STRQ_ERR_UNSUPPORTED; }
     m.n_edge_rows = rows;
-    std::vector<int32_t> src((size_t)rows * 64, n_states);   // padding -> the -inf cell
-    std::vector<double> lp((size_t)rows * 64, 0.0);
+    std::vector<int32_t> src((size_t)std::max(rows, 1) * 64, n_states);   // padding -> the -inf cell
+    std::vector<double> lp((size_t)std::max(rows, 1) * 64, 0.0);
     auto fill = [&](int state, int base, int lane) {
-        for (int e = in_ptr[state], j = 0; e < in_ptr[state + 1]; ++e, ++j) {
+        for (int e = in_ptr[state], j = 0; e < in_ptr[state + 1]; ++e) {
+            if (state >= ne && is_chain_edge(state, in_src[e])) continue;
             src[(size_t)(base + j) * 64 + lane] = in_src[e];
             lp[(size_t)(base + j) * 64 + lane] = in_logp[e];
+            ++j;
         }
     };
-    for (int s = 0; s < epl; ++s) for (int lane = 0; lane < 64; ++lane) { const int e = s * 64 + lane; if (e < ne) fill(e, m.e_base[s], lane); }
-    for (int s = 0; s < spl; ++s) for (int lane = 0; lane < 64; ++lane) { const int q = s * 64 + lane; if (q < ns) fill(ne + q, m.s_base[s], lane); }
+    for (int s = 0; s < epl; ++s) for (int lane = 0; lane < 64; ++lane) if (own_e[s * 64 + lane] >= 0) fill(own_e[s * 64 + lane], m.e_base[s], lane);
+    for (int s = 0; s < spl2; ++s) for (int lane = 0; lane < 64; ++lane) if (own_s[s * 64 + lane] >= 0) fill(own_s[s * 64 + lane], m.s_base[s], lane);
     std::vector<int32_t> kind((size_t)epl * 64, 0); std::vector<double> a((size_t)epl * 64, 0.0), b(a), cc(a);
-    for (int e = 0; e < ne; ++e) { kind[e] = emis_kind[e]; a[e] = emis_a[e]; b[e] = emis_b[e]; cc[e] = emis_c[e]; }
+    for (int i = 0; i < epl * 64; ++i) if (own_e[i] >= 0) { const int e = own_e[i]; kind[i] = emis_kind[e]; a[i] = emis_a[e]; b[i] = emis_b[e]; cc[i] = emis_c[e]; }
     std::vector<int32_t> inc((size_t)n_states + 1, 0);
     if (count_inc) std::copy(count_inc, count_inc + n_states, inc.begin());
     // one device blob
-    const size_t o_src = 0, o_lp = o_src + src.size() * 4, o_kind = o_lp + lp.size() * 8, o_a = o_kind + kind.size() * 4 + 4,
-                 o_b = o_a + a.size() * 8, o_c = o_b + b.size() * 8, o_inc = o_c + cc.size() * 8, o_m = (o_inc + inc.size() * 4 + 15) & ~(size_t)15,
-                 total = o_m + sizeof(VitModel);
-    const size_t o_a8 = (o_a + 7) & ~(size_t)7;
-    const size_t o_b8 = o_a8 + a.size() * 8, o_c8 = o_b8 + b.size() * 8, o_inc8 = o_c8 + cc.size() * 8;
-    const size_t o_m8 = (o_inc8 + inc.size() * 4 + 15) & ~(size_t)15;
-    (void)o_b; (void)o_c; (void)o_inc; (void)o_m; (void)total;
-    const size_t total8 = o_m8 + sizeof(VitModel);
-    if (hm->blob.reserve(total8) != hipSuccess) { delete hm; c->err = "out of device memory"; return STRQ_ERR_NOMEM; }
+    struct Part { const void* p; size_t bytes; size_t off; };
+    std::vector<Part> parts = {
+        {lp.data(), lp.size() * 8, 0}, {a.data(), a.size() * 8, 0}, {b.data(), b.size() * 8, 0}, {cc.data(), cc.size() * 8, 0},
+        {src.data(), src.size() * 4, 0}, {kind.data(), kind.size() * 4, 0}, {inc.data(), inc.size() * 4, 0},
+        {own_e.data(), own_e.size() * 4, 0}, {own_s.data(), own_s.size() * 4, 0},
+        {chain_src_v.data(), chain_src_v.size() * 4, 0}, {chain_lp_v.data(), chain_lp_v.size() * 8, 0}};
+    size_t total = 0;
+    for (auto& pt : parts) { pt.off = total; total += (pt.bytes + 15) & ~(size_t)15; }
+    const size_t o_m = total; total += sizeof(VitModel);
+    if (hm->blob.reserve(total) != hipSuccess) { delete hm; c->err = "out of device memory"; return STRQ_ERR_NOMEM; }
     char* d = hm->blob.as<char>();
-    m.edge_src = reinterpret_cast<const int32_t*>(d + o_src);
-    m.edge_logp = reinterpret_cast<const double*>(d + o_lp);
-    m.emis_kind = reinterpret_cast<const int32_t*>(d + o_kind);
-    m.emis_a = reinterpret_cast<const double*>(d + o_a8);
-    m.emis_b = reinterpret_cast<const double*>(d + o_b8);
-    m.emis_c = reinterpret_cast<const double*>(d + o_c8);
-    m.count_inc = reinterpret_cast<const int32_t*>(d + o_inc8);
-    hm->dev = reinterpret_cast<const VitModel*>(d + o_m8);
-    std::vector<char> host(total8, 0);
-    std::memcpy(&host[o_src], src.data(), src.size() * 4);
-    std::memcpy(&host[o_lp], lp.data(), lp.size() * 8);
-    std::memcpy(&host[o_kind], kind.data(), kind.size() * 4);
-    std::memcpy(&host[o_a8], a.data(), a.size() * 8);
-    std::memcpy(&host[o_b8], b.data(), b.size() * 8);
-    std::memcpy(&host[o_c8], cc.data(), cc.size() * 8);
-    std::memcpy(&host[o_inc8], inc.data(), inc.size() * 4);
-    std::memcpy(&host[o_m8], &m, sizeof(VitModel));
-    if (hipMemcpy(d, host.data(), total8, hipMemcpyHostToDevice) != hipSuccess) { delete hm; c->err = "model upload failed"; return STRQ_ERR_DEVICE; }
+    m.edge_logp = reinterpret_cast<const double*>(d + parts[0].off);
+    m.emis_a = reinterpret_cast<const double*>(d + parts[1].off);
+    m.emis_b = reinterpret_cast<const double*>(d + parts[2].off);
+    m.emis_c = reinterpret_cast<const double*>(d + parts[3].off);
+    m.edge_src = reinterpret_cast<const int32_t*>(d + parts[4].off);
+    m.emis_kind = reinterpret_cast<const int32_t*>(d + parts[5].off);
+    m.count_inc = reinterpret_cast<const int32_t*>(d + parts[6].off);
+    m.own_e = reinterpret_cast<const int32_t*>(d + parts[7].off);
+    m.own_s = reinterpret_cast<const int32_t*>(d + parts[8].off);
+    m.chain_src = reinterpret_cast<const int32_t*>(d + parts[9].off);
+    m.chain_logp = reinterpret_cast<const double*>(d + parts[10].off);
+    hm->dev = reinterpret_cast<const VitModel*>(d + o_m);
+    std::vector<char> host(total, 0);
+    for (auto& pt : parts) std::memcpy(&host[pt.off], pt.p, pt.bytes);
+    std::memcpy(&host[o_m], &m, sizeof(VitModel));
+    if (hipMemcpy(d, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) { delete hm; c->err = "model upload failed"; return STRQ_ERR_DEVICE; }
     *out = hm;
     return STRQ_OK;
 }

@@ -5,23 +5,31 @@
 
 namespace strq {
 
-// Device image of a baked model (strique_amd/hmm.py: bake), laid out for one wave64:
-// emitting state e lives in (slot e / 64, lane e % 64); silent state silent_start + q likewise.
-// Every slot has a lane-major padded in-edge list: entry (j, lane) at edge_base[slot] + j*64 + lane.
-// Padding edges point at the extra cell v[n_states] == -inf.
+// Device image of a baked model (strique_amd/hmm.py: bake), laid out for one wave64.
+// Every lane owns up to `epl` emitting and `spl` silent states (slot-major: entry slot*64 + lane);
+// states are dealt to slots by descending in-degree so that the padded in-edge lists are short.
+// Silent states are laid out in chains: when the highest-numbered silent predecessor of a silent
+// state is free, the pair becomes lane neighbours (lane-1 -> lane) of one slot and that edge leaves
+// the edge list (chain_src / chain_logp).
+// In-edge j of the state owned by (slot, lane) is entry (base[slot] + j) * 64 + lane of
+// edge_src / edge_logp; padding edges point at the extra cell v[n_states] == -inf.
 struct VitModel {
     int32_t n_states, n_emit, n_silent, start, end;
     int32_t epl, spl;                 // slots per lane (emitting / silent)
-    int32_t e_deg[8], e_base[8];      // padded in-degree and edge offset (in units of 64 entries) per emitting slot
+    int32_t e_deg[8], e_base[8];      // padded in-degree and first edge row of every emitting slot
     int32_t s_deg[8], s_base[8];
-    int32_t n_edge_rows;              // total rows of 64 entries
+    int32_t n_edge_rows;
     const int32_t* edge_src;          // n_edge_rows * 64
     const double* edge_logp;          // n_edge_rows * 64
-    const int32_t* emis_kind;         // epl * 64  (0 = padding)
+    const int32_t* own_e;             // epl * 64: state owned by (slot, lane) or -1
+    const int32_t* own_s;             // spl * 64
+    const int32_t* chain_src;         // spl * 64: state in (slot, lane-1) when it is the chain predecessor, else -1
+    const double* chain_logp;         // spl * 64: log-probability of that chain edge
+    const int32_t* emis_kind;         // epl * 64, by owner slot  (0 = padding)
     const double* emis_a;             // mu | lo
     const double* emis_b;             // 1/(2 sigma^2) | hi
     const double* emis_c;             // -log(sigma sqrt(2pi)) | -log(hi - lo)
-    const int32_t* count_inc;         // n_states + 1
+    const int32_t* count_inc;         // n_states + 1, by state
 };
 
 enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };

@@ -8,12 +8,18 @@
 //   silent   l:  v[t][l] = max_k( v[t][k]   + A[k][l] )                  emitting k, then earlier silent k
 //
 // Mapping: states are spread over the 64 lanes (EPL emitting + SPL silent slots per lane), the
-// value vector of the previous/current time step lives in this wave's LDS slice and every lane
-// gathers its predecessors from it.  The silent states form a DAG (delete chains ~50 long); instead
-// of walking it serially, all silent states are relaxed together until nothing changes.  Max-plus on
-// a DAG has a unique fixed point and every relaxation evaluates the same `v[k] + A` sums, so the
-// fixed point is bit-identical to the serial topological pass, including the argmax of the final
-// sweep; a typical time step needs 2-3 sweeps because long delete chains are improbable.
+// value vector of the previous/current time step lives in this wave's LDS slice, and every lane
+// gathers the predecessors of the states it owns from it (in-edges and their log-probabilities
+// stay in registers).  The silent states form a DAG dominated by the delete chains of the two
+// flank profiles (~50 states each), and those chains are live on every time step: ahead of the
+// decoding front a state is best reached by skipping, so the value of d[i] really is
+// d[i-1] + log(delete_delete).  The chains are therefore laid along the lanes -- the chain
+// predecessor of the state in lane l sits in lane l-1 -- and relaxed systolically in registers:
+//     y[l] = max(y[l], y[l-1] + a[l])          one DPP wave_shr:1 per sweep, no LDS
+// until no lane changes.  Each sweep performs exactly the additions of the serial topological pass
+// (max commutes with the monotone map y -> fl(y + a)), so the fixed point is bit-identical to the
+// oracle's, including the argmax.  The few silent edges that are not chain edges (profile exits,
+// model end) go through LDS like the emitting states, in an outer fixed-point loop.
 //
 // Repeat counting does not need a traceback: the number of visits of the counted states
 // (the two `dummy` states of repeatHMM, STRique.py:374-378) is carried along the best path.
@@ -45,97 +51,169 @@ static __device__ __forceinline__ double readlane_f64(double v, int l)
 
 #define VIT_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
-template <int EPL, int SPL, bool BP>
-__global__ void __launch_bounds__(1024)
+// wave_shr:1 -- lane l receives lane l-1 (lane 0 receives -inf / 0)
+static __device__ __forceinline__ double dpp_shr1_f64(double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint64_t ninf = 0xFFF0000000000000ull;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)ninf, (int)(uint32_t)u, 0x138, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(ninf >> 32), (int)(uint32_t)(u >> 32), 0x138, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+static __device__ __forceinline__ int dpp_shr1_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
+}
+
+// In-edges per state held in registers: compile-time bounds so that the gather loops are branch free
+// and all LDS reads of a time step are issued back to back.  Emitting slots are sorted by in-degree:
+// the first half of the slots gets DE_HI edge registers, the second half DE_LO; silent slots get DS
+// (without their chain edge).  Padding edges read the -inf cell.
+template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP>
+__global__ void __launch_bounds__(512)
 viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
                int n_tasks, int* __restrict__ queue)
 {
     extern __shared__ double lds_d[];
     const VitModel& M = *mp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int n = M.n_states, ne = M.n_emit, ns = M.n_silent;
+    const int n = M.n_states;
     const int NP = (n + 2) & ~1;                    // value cells per buffer incl. the -inf cell v[n]
-    const int nrows = M.n_edge_rows;
-    double* e_lp = lds_d;                                                   // nrows*64
-    double* vbase = e_lp + (size_t)nrows * 64 + (size_t)wave * 2 * NP;       // two value buffers per wave
-    int* e_src = reinterpret_cast<int*>(e_lp + (size_t)nrows * 64 + (size_t)nw * 2 * NP);
-    int* cbase = e_src + (size_t)nrows * 64 + (size_t)wave * 2 * NP;
-    for (int i = threadIdx.x; i < nrows * 64; i += blockDim.x) { e_lp[i] = M.edge_logp[i]; e_src[i] = M.edge_src[i]; }
-    __syncthreads();
+    char* vbase = reinterpret_cast<char*>(lds_d + (size_t)wave * 2 * NP);                       // two f64 buffers per wave
+    char* cbase = reinterpret_cast<char*>(lds_d + (size_t)nw * 2 * NP) + (size_t)wave * 2 * NP * 4;   // two i32 buffers per wave
 
-    // per-lane emission parameters and count increments
-    int ekind[EPL]; double ea[EPL], eb[EPL], ec[EPL]; int einc[EPL], sinc[SPL];
+    // ---- everything a lane needs about the states it owns lives in registers
+    constexpr int DEMAX = DE_HI > DE_LO ? DE_HI : DE_LO;
+    auto de_of = [](int s) constexpr { return s < (EPL + 1) / 2 ? DE_HI : DE_LO; };
+    int own_e[EPL], ekind[EPL], einc[EPL], eoff[EPL][DEMAX];
+    double ea[EPL], eb[EPL], ec[EPL], elp[EPL][DEMAX];
+    int own_s[SPL], sinc[SPL], soff[SPL][DS], chain_src[SPL];
+    double slp[SPL][DS], clp[SPL];
+    bool has_chain[SPL];
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const int e = s * 64 + lane;
-        ekind[s] = (s < M.epl) ? M.emis_kind[e] : 0;
-        ea[s] = (s < M.epl) ? M.emis_a[e] : 0.0; eb[s] = (s < M.epl) ? M.emis_b[e] : 0.0; ec[s] = (s < M.epl) ? M.emis_c[e] : 0.0;
-        einc[s] = (e < ne) ? M.count_inc[e] : 0;
+        const bool on = s < M.epl;
+        own_e[s] = on ? M.own_e[s * 64 + lane] : -1;
+        ekind[s] = on ? M.emis_kind[s * 64 + lane] : 0;
+        ea[s] = on ? M.emis_a[s * 64 + lane] : 0.0; eb[s] = on ? M.emis_b[s * 64 + lane] : 0.0; ec[s] = on ? M.emis_c[s * 64 + lane] : 0.0;
+        einc[s] = own_e[s] >= 0 ? M.count_inc[own_e[s]] : 0;
+#pragma unroll
+        for (int j = 0; j < DEMAX; ++j) {
+            const bool ej = on && j < M.e_deg[s];
+            eoff[s][j] = (ej ? M.edge_src[(M.e_base[s] + j) * 64 + lane] : n) * 8;
+            elp[s][j] = ej ? M.edge_logp[(M.e_base[s] + j) * 64 + lane] : 0.0;
+        }
     }
 #pragma unroll
-    for (int s = 0; s < SPL; ++s) { const int q = s * 64 + lane; sinc[s] = (q < ns) ? M.count_inc[ne + q] : 0; }
+    for (int s = 0; s < SPL; ++s) {
+        const bool on = s < M.spl;
+        own_s[s] = on ? M.own_s[s * 64 + lane] : -1;
+        sinc[s] = own_s[s] >= 0 ? M.count_inc[own_s[s]] : 0;
+        chain_src[s] = on ? M.chain_src[s * 64 + lane] : -1;
+        has_chain[s] = chain_src[s] >= 0;
+        clp[s] = has_chain[s] ? M.chain_logp[s * 64 + lane] : 0.0;
+#pragma unroll
+        for (int j = 0; j < DS; ++j) {
+            const bool ej = on && j < M.s_deg[s];
+            soff[s][j] = (ej ? M.edge_src[(M.s_base[s] + j) * 64 + lane] : n) * 8;
+            slp[s][j] = ej ? M.edge_logp[(M.s_base[s] + j) * 64 + lane] : 0.0;
+        }
+    }
+    // header fields used inside the time loop: copy out of global memory once
+    const int m_epl = M.epl, m_spl = M.spl, m_start = M.start, m_end = M.end;
+    (void)m_epl; (void)m_spl;
     const double NEGINF = -__builtin_inf();
+    auto ldv = [](const char* b, int off8) { return *reinterpret_cast<const double*>(b + off8); };
+    auto ldc = [](const char* b, int off8) { return *reinterpret_cast<const int*>(b + (off8 >> 1)); };
 
     for (;;) {
         const int ti = vit_next_task(queue, lane);
         if (ti >= n_tasks) break;
-        const VitTask& tk = tasks[ti];
+        const VitTask tk = tasks[ti];
         const int64_t T = tk.T;
-        double* vcur = vbase; double* vnxt = vbase + NP;
-        int* ccur = cbase; int* cnxt = cbase + NP;
-        for (int i = lane; i < NP; i += 64) { vcur[i] = NEGINF; vnxt[i] = NEGINF; ccur[i] = 0; cnxt[i] = 0; }
+        char* vcur = vbase; char* vnxt = vbase + (size_t)NP * 8;
+        char* ccur = cbase; char* cnxt = cbase + (size_t)NP * 4;
+        for (int i = lane; i < NP; i += 64) {
+            reinterpret_cast<double*>(vcur)[i] = NEGINF; reinterpret_cast<double*>(vnxt)[i] = NEGINF;
+            reinterpret_cast<int*>(ccur)[i] = 0; reinterpret_cast<int*>(cnxt)[i] = 0;
+        }
         VIT_FENCE();
-        if (lane == 0) vcur[M.start] = 0.0;
+        if (lane == 0) reinterpret_cast<double*>(vcur)[m_start] = 0.0;
         VIT_FENCE();
 
-        // relax all silent states of buffer `vb` (values) / `cb` (carried counts) to their fixed
-        // point; `pin`: keep start at 0 (t = 0).  Counts ride along: a state's count is final one
-        // sweep after its predecessor's, exactly like its value.
-        auto relax_silent = [&](double* vb, int* cb, bool pin, int64_t trow) {
-            double oldv[SPL]; int oldc[SPL]; int arg[SPL];
+        // Silent states of buffer `vb` (values) / `cb` (carried counts) to their fixed point.
+        // `pin`: keep start at 0 (t = 0).
+        auto relax_silent = [&](char* vb, char* cb, bool pin, int64_t trow) {
+            double y[SPL], base_prev[SPL]; int yc[SPL], arg[SPL];
 #pragma unroll
-            for (int s = 0; s < SPL; ++s) {
-                const int q = s * 64 + lane;
-                oldv[s] = (s < M.spl && q < ns) ? vb[ne + q] : NEGINF;
-                oldc[s] = (s < M.spl && q < ns) ? cb[ne + q] : 0;
-                arg[s] = n;
-            }
-            for (;;) {
-                bool changed = false;
-                double newv[SPL]; int newc[SPL];
+            for (int s = 0; s < SPL; ++s) { y[s] = NEGINF; yc[s] = 0; arg[s] = n; base_prev[s] = __builtin_nan(""); }
+            for (int outer = 0;; ++outer) {
+                // (A) best non-chain in-edge of every silent state: emitting predecessors (final for
+                //     this time step) and silent predecessors that are not chain neighbours
+                bool base_changed = false;
+                double base[SPL]; int basec[SPL], basea[SPL];
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    newv[s] = NEGINF; newc[s] = 0;
-                    if (s >= M.spl) continue;
-                    const int q = s * 64 + lane, l = ne + q;
-                    double best = NEGINF; int a = n;
-                    const int base = M.s_base[s], deg = M.s_deg[s];
-                    for (int j = 0; j < deg; ++j) {
-                        const int src = e_src[(base + j) * 64 + lane];
-                        const double c = vb[src] + e_lp[(base + j) * 64 + lane];
-                        if (c > best) { best = c; a = src; }
+                    double best = NEGINF; int bc = 0, a = n;
+#pragma unroll
+                    for (int j = 0; j < DS; ++j) {
+                        const double c = ldv(vb, soff[s][j]) + slp[s][j];
+                        const int cc = ldc(cb, soff[s][j]);
+                        if (c > best) { best = c; bc = cc; a = soff[s][j] >> 3; }
                     }
-                    if (pin && l == M.start) { best = 0.0; a = n; }
-                    if (q >= ns) { best = NEGINF; a = n; }
-                    newv[s] = best; arg[s] = a; newc[s] = cb[a] + sinc[s];
-                    if (q < ns && (!(best == oldv[s]) || newc[s] != oldc[s])) changed = true;
+                    if (pin && own_s[s] == m_start) { best = 0.0; bc = -sinc[s]; a = n; }
+                    if (own_s[s] < 0) { best = NEGINF; bc = 0; a = n; }
+                    base[s] = best; basec[s] = bc + sinc[s]; basea[s] = a;
+                    if (!(best == base_prev[s]) && !(best != best)) base_changed = true;
+                    if (outer == 0) base_changed = true;
+                }
+                bool changed = false;
+                if (__any(base_changed)) {
+                    // (B) chains.  Within a time step every quantity only grows, so the sweep continues
+                    //     from the current values; a local candidate that ties with a chain token wins
+                    //     (it precedes the chain edge in evaluation order).
+#pragma unroll
+                    for (int s = 0; s < SPL; ++s) {
+                        if (base[s] >= y[s]) { y[s] = base[s]; yc[s] = basec[s]; arg[s] = basea[s]; }
+                        base_prev[s] = base[s];
+                    }
+                    for (;;) {
+                        bool win_any = false;
+#pragma unroll
+                        for (int s = 0; s < SPL; ++s) {
+                            const double tin = dpp_shr1_f64(y[s]) + clp[s];
+                            const int cin = dpp_shr1_i32(yc[s]) + sinc[s];
+                            const bool win = has_chain[s] && tin > y[s];     // the chain edge is the last in-edge: strict
+                            y[s] = win ? tin : y[s];
+                            yc[s] = win ? cin : yc[s];
+                            arg[s] = win ? chain_src[s] : arg[s];
+                            win_any |= win;
+                        }
+                        if (!__any(win_any)) break;
+                    }
+#pragma unroll
+                    for (int s = 0; s < SPL; ++s) {
+                        if (own_s[s] >= 0) {
+                            const double ov = ldv(vb, own_s[s] * 8); const int oc = ldc(cb, own_s[s] * 8);
+                            if (!(ov == y[s]) || oc != yc[s]) changed = true;
+                        }
+                    }
                 }
                 if (!__any(changed)) break;
                 VIT_FENCE();
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    const int q = s * 64 + lane;
-                    if (s < M.spl && q < ns) { vb[ne + q] = newv[s]; cb[ne + q] = newc[s]; }
-                    oldv[s] = newv[s]; oldc[s] = newc[s];
+                    if (own_s[s] >= 0) {
+                        *reinterpret_cast<double*>(vb + own_s[s] * 8) = y[s];
+                        *reinterpret_cast<int*>(cb + own_s[s] * 4) = yc[s];
+                    }
                 }
                 VIT_FENCE();
             }
             if (BP) {
 #pragma unroll
-                for (int s = 0; s < SPL; ++s) {
-                    const int q = s * 64 + lane;
-                    if (s < M.spl && q < ns) tk.bp[(size_t)trow * n + ne + q] = (uint16_t)arg[s];
-                }
+                for (int s = 0; s < SPL; ++s)
+                    if (own_s[s] >= 0) tk.bp[(size_t)trow * n + own_s[s]] = (uint16_t)arg[s];
             }
         };
 
@@ -165,37 +243,43 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
             for (int s0 = 0; s0 < send; ++s0) {
                 const double x = readlane_f64(xchunk, s0);
                 const int64_t t = t0 + s0;
+                double nv[EPL]; int nc[EPL], na[EPL];
 #pragma unroll
                 for (int s = 0; s < EPL; ++s) {
-                    if (s >= M.epl) continue;
-                    const int e = s * 64 + lane;
-                    double best = NEGINF; int a = n;
-                    const int base = M.e_base[s], deg = M.e_deg[s];
-                    for (int j = 0; j < deg; ++j) {
-                        const int src = e_src[(base + j) * 64 + lane];
-                        const double c = vcur[src] + e_lp[(base + j) * 64 + lane];
-                        if (c > best) { best = c; a = src; }
+                    double best = NEGINF; int bc = 0, a = n;
+#pragma unroll
+                    for (int j = 0; j < DEMAX; ++j) {
+                        if (j < de_of(s)) {     // compile-time
+                            const double c = ldv(vcur, eoff[s][j]) + elp[s][j];
+                            const int cc = ldc(ccur, eoff[s][j]);
+                            if (c > best) { best = c; bc = cc; a = eoff[s][j] >> 3; }
+                        }
                     }
                     double em;
                     if (ekind[s] == 1) { const double d = x - ea[s]; em = ec[s] - (d * d) * eb[s]; }
                     else if (ekind[s] == 2) em = (x >= ea[s] && x <= eb[s]) ? ec[s] : NEGINF;
                     else em = NEGINF;
-                    if (e < ne) {
-                        vnxt[e] = best + em;
-                        cnxt[e] = ccur[a] + einc[s];
-                        if (BP) tk.bp[(size_t)(t + 1) * n + e] = (uint16_t)a;
+                    nv[s] = best + em; nc[s] = bc + einc[s]; na[s] = a;
+                }
+#pragma unroll
+                for (int s = 0; s < EPL; ++s) {
+                    if (own_e[s] >= 0) {
+                        *reinterpret_cast<double*>(vnxt + own_e[s] * 8) = nv[s];
+                        *reinterpret_cast<int*>(cnxt + own_e[s] * 4) = nc[s];
+                        if (BP) tk.bp[(size_t)(t + 1) * n + own_e[s]] = (uint16_t)na[s];
                     }
                 }
 #pragma unroll
-                for (int s = 0; s < SPL; ++s) { const int q = s * 64 + lane; if (s < M.spl && q < ns) { vnxt[ne + q] = NEGINF; cnxt[ne + q] = 0; } }
+                for (int s = 0; s < SPL; ++s)
+                    if (own_s[s] >= 0) { *reinterpret_cast<double*>(vnxt + own_s[s] * 8) = NEGINF; *reinterpret_cast<int*>(cnxt + own_s[s] * 4) = 0; }
                 VIT_FENCE();
                 relax_silent(vnxt, cnxt, false, t + 1);
-                double* tv = vcur; vcur = vnxt; vnxt = tv;
-                int* tc = ccur; ccur = cnxt; cnxt = tc;
+                char* tv = vcur; vcur = vnxt; vnxt = tv;
+                char* tc = ccur; ccur = cnxt; cnxt = tc;
             }
         }
-        const double lp = vcur[M.end];
-        const int cnt = ccur[M.end];
+        const double lp = *reinterpret_cast<const double*>(vcur + m_end * 8);
+        const int cnt = *reinterpret_cast<const int*>(ccur + m_end * 4);
         VitResult r; r.logp = lp; r.counted = cnt; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
         results[ti] = r;     // every lane stores the same value
         VIT_FENCE();
@@ -228,28 +312,34 @@ int launch_viterbi(hipStream_t stream, const VitModel& mh, const VitModel* model
                    VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp)
 {
     const int NP = (mh.n_states + 2) & ~1;
-    // one block per CU: the edge lists are shared, every wave adds two value/count buffers
-    int nw = 16;
-    while (nw > 1 && ((size_t)mh.n_edge_rows * 64 + (size_t)nw * 2 * NP) * 12 > 160 * 1024) nw >>= 1;
-    const size_t lds = ((size_t)mh.n_edge_rows * 64 + (size_t)nw * 2 * NP) * (8 + 4);
+    // per wave: two f64 value buffers and two i32 count buffers; waves of a block are independent
+    int nw = 8;
+    while (nw > 1 && (size_t)nw * 2 * NP * 12 > 64 * 1024) nw >>= 1;
+    const size_t lds = (size_t)nw * 2 * NP * 12;
     if (lds > 160 * 1024) return 3;
-    const dim3 grid(n_cu), block(64 * nw);
-#define VIT_LAUNCH(E_, S_)                                                                                  \
+    int blocks_per_cu = (int)((160 * 1024) / lds);
+    if (blocks_per_cu * nw > 16) blocks_per_cu = 16 / nw;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const dim3 grid(n_cu * blocks_per_cu), block(64 * nw);
+#define VIT_LAUNCH(E_, S_, H_, L_, D_)                                                                      \
     do {                                                                                                    \
         if (want_bp) {                                                                                      \
-            (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((viterbi_kernel<E_, S_, true>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue); \
+            (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, true>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue); \
         } else {                                                                                            \
-            (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((viterbi_kernel<E_, S_, false>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue); \
+            (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, false>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue); \
         }                                                                                                   \
     } while (0)
     const int e = mh.epl, s = mh.spl;
-    if (e <= 1 && s <= 1) VIT_LAUNCH(1, 1);
-    else if (e <= 2 && s <= 2) VIT_LAUNCH(2, 2);
-    else if (e <= 4 && s <= 2) VIT_LAUNCH(4, 2);
-    else if (e <= 4 && s <= 4) VIT_LAUNCH(4, 4);
-    else if (e <= 8 && s <= 4) VIT_LAUNCH(8, 4);
+    int hi = 0, lo = 0, ds = 0;
+    for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
+    for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
+    if (e <= 4 && s <= 2 && e > 2 && hi <= 6 && lo <= 3 && ds <= 3) VIT_LAUNCH(4, 2, 6, 3, 3);      // flanked-repeat models
+    else if (e <= 1 && s <= 1 && hi <= 8 && ds <= 4) VIT_LAUNCH(1, 1, 8, 8, 4);                       // modification models
+    else if (e <= 2 && s <= 2 && hi <= 8 && lo <= 8 && ds <= 4) VIT_LAUNCH(2, 2, 8, 8, 4);
+    else if (e <= 4 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) VIT_LAUNCH(4, 4, 8, 8, 8);
+    else if (e <= 8 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) VIT_LAUNCH(8, 4, 8, 8, 8);
     else return 2;
 #undef VIT_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : 1;
