@@ -112,7 +112,7 @@ struct DetectState {
     bool have_ps = false;
     std::vector<Target> targets;
     Batch batch;
-    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx;
+    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
 };
@@ -127,7 +127,7 @@ void detect_state_free(strq_ctx* c)
 {
     if (!c->detect) return;
     DetectState* d = static_cast<DetectState*>(c->detect);
-    for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx}) b->release();
+    for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx, &d->order}) b->release();
     if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
     delete d;
     c->detect = nullptr;
@@ -220,6 +220,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     STRQ_HIP(c, d->geom.reserve((size_t)nr * sizeof(ReadGeom)));
     STRQ_HIP(c, d->vit.reserve((size_t)nr * sizeof(VitTask)));
     STRQ_HIP(c, d->vres.reserve((size_t)nr * sizeof(VitResult)));
+    STRQ_HIP(c, d->order.reserve((size_t)nr * 4 + 64));
     FinalizeArgs fa;
     fa.tasks = co.d_tasks; fa.results = co.d_results; fa.task_of = d_task_of; fa.trim = d_trim; fa.vit_slot = d_slot;
     fa.rc = d_rc; fa.flt = d->flt.p; fa.is_f64 = B.dtype; fa.ps = d->ps; fa.geom = d->geom.as<ReadGeom>(); fa.vit = d->vit.as<VitTask>(); fa.n_reads = nr;
@@ -230,8 +231,13 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     { int qi = 0;
       for (auto& v : vls) {
         HostModel* hm = c->models[v.model];
+        int* d_order = nullptr;
+        if (v.count <= 8192) {
+            d_order = d->order.as<int>() + v.first;
+            if (launch_vit_sort(st, d->vit.as<VitTask>() + v.first, v.count, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
+        }
         const int rc2 = launch_viterbi(st, hm->h, hm->dev, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
-                                       c->queue.as<int>() + qi, c->n_cu, 0);
+                                       c->queue.as<int>() + qi, c->n_cu, 0, d_order);
         if (rc2) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
       } }

@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <cstdio>
 #include <vector>
 #include "../../include/strique_hip.h"
 #include "strq_ctx.h"
@@ -92,6 +94,8 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
         for (int lane = 0; lane < 64; ++lane) if (own_s[s * 64 + lane] >= 0) deg = std::max(deg, sdeg_state[own_s[s * 64 + lane]]);
         m.s_deg[s] = deg; m.s_base[s] = rows; rows += deg;
     }
+    m.single_stage = 1;
+    for (int b = ne; b < n_states; ++b) for (int e = in_ptr[b]; e < in_ptr[b + 1]; ++e) if (in_src[e] >= ne && !is_chain_edge(b, in_src[e])) m.single_stage = 0;
     for (int s = 0; s < 8; ++s) if (m.e_deg[s] > 8 || m.s_deg[s] > 8) { delete hm; c->err = "a state has more than 8 in-edges"; return STRQ_ERR_UNSUPPORTED; }
     m.n_edge_rows = rows;
     std::vector<int32_t> src((size_t)std::max(rows, 1) * 64, n_states);   // padding -> the -inf cell
@@ -211,6 +215,8 @@ int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const doubl
     STRQ_HIP(c, hipMemcpyAsync(res.data(), d_res, (size_t)n_seq * sizeof(VitResult), hipMemcpyDeviceToHost, st));
     if (paths) STRQ_HIP(c, hipMemcpyAsync(paths, c->vit_path.p, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
+    if (getenv("STRQ_DEBUG")) for (int64_t pos = 0; pos < std::min<int64_t>(n_seq, 4); ++pos)
+        fprintf(stderr, "[strq] viterbi T=%lld outer=%u sweeps=%u emit_kcyc=%u silent_kcyc=%u\n", (long long)(x_off[order[pos] + 1] - x_off[order[pos]]), res[pos].dbg[0], res[pos].dbg[1], res[pos].dbg[2], res[pos].dbg[3]);
     for (int64_t pos = 0; pos < n_seq; ++pos) {
         const int64_t i = order[pos];
         if (logp) logp[i] = res[pos].logp;

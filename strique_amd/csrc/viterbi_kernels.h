@@ -19,6 +19,7 @@ struct VitModel {
     int32_t e_deg[8], e_base[8];      // padded in-degree and first edge row of every emitting slot
     int32_t s_deg[8], s_base[8];
     int32_t n_edge_rows;
+    int32_t single_stage;             // 1: no silent state has a silent predecessor outside its chain
     const int32_t* edge_src;          // n_edge_rows * 64
     const double* edge_logp;          // n_edge_rows * 64
     const int32_t* own_e;             // epl * 64: state owned by (slot, lane) or -1
@@ -47,10 +48,13 @@ struct VitResult {
     int64_t counted;
     int32_t status;          // 0 ok, 1 no path
     int32_t pad_;
+    uint32_t dbg[4];         // profiling aid: outer iterations, chain sweeps, emitting / silent kilo-cycles
 };
 
 int launch_viterbi(hipStream_t stream, const VitModel& model_host, const VitModel* model_dev,
-                   const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp);
+                   const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp,
+                   const int* order = nullptr);
+int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order);   // order by descending T (n <= 8192)
 int launch_vit_traceback(hipStream_t stream, const VitModel* model_dev, const VitTask* tasks, const VitResult* results,
                          int32_t* const* paths, int n_tasks);
 

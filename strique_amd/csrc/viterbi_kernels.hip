@@ -72,15 +72,16 @@ static __device__ __forceinline__ int dpp_shr1_i32(int v)
 template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP>
 __global__ void __launch_bounds__(512)
 viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
-               int n_tasks, int* __restrict__ queue)
+               int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
 {
     extern __shared__ double lds_d[];
     const VitModel& M = *mp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n = M.n_states;
-    const int NP = (n + 2) & ~1;                    // value cells per buffer incl. the -inf cell v[n]
-    char* vbase = reinterpret_cast<char*>(lds_d + (size_t)wave * 2 * NP);                       // two f64 buffers per wave
-    char* cbase = reinterpret_cast<char*>(lds_d + (size_t)nw * 2 * NP) + (size_t)wave * 2 * NP * 4;   // two i32 buffers per wave
+    const int NP = (n + 2) & ~1;                    // cells per buffer incl. the -inf cell [n]
+    // one 16-byte cell per state: {double value; int count; int pad} -> one ds_read_b128 per in-edge
+    char* vbase = reinterpret_cast<char*>(lds_d) + (size_t)wave * 2 * NP * 16;
+    (void)nw;
 
     // ---- everything a lane needs about the states it owns lives in registers
     constexpr int DEMAX = DE_HI > DE_LO ? DE_HI : DE_LO;
@@ -121,33 +122,34 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
     }
     // header fields used inside the time loop: copy out of global memory once
     const int m_epl = M.epl, m_spl = M.spl, m_start = M.start, m_end = M.end;
+    const bool single_stage = M.single_stage != 0;
     (void)m_epl; (void)m_spl;
     const double NEGINF = -__builtin_inf();
-    auto ldv = [](const char* b, int off8) { return *reinterpret_cast<const double*>(b + off8); };
-    auto ldc = [](const char* b, int off8) { return *reinterpret_cast<const int*>(b + (off8 >> 1)); };
+    struct Cell { double v; int c; int pad; };
+    auto ldcell = [](const char* b, int off8) { return *reinterpret_cast<const Cell*>(b + 2 * off8); };
+    auto stcell = [](char* b, int state, double v, int c) { Cell x; x.v = v; x.c = c; x.pad = 0; *reinterpret_cast<Cell*>(b + 16 * state) = x; };
 
     for (;;) {
-        const int ti = vit_next_task(queue, lane);
-        if (ti >= n_tasks) break;
+        const int tq = vit_next_task(queue, lane);
+        if (tq >= n_tasks) break;
+        const int ti = order ? order[tq] : tq;        // longest observation windows first
         const VitTask tk = tasks[ti];
         const int64_t T = tk.T;
-        char* vcur = vbase; char* vnxt = vbase + (size_t)NP * 8;
-        char* ccur = cbase; char* cnxt = cbase + (size_t)NP * 4;
-        for (int i = lane; i < NP; i += 64) {
-            reinterpret_cast<double*>(vcur)[i] = NEGINF; reinterpret_cast<double*>(vnxt)[i] = NEGINF;
-            reinterpret_cast<int*>(ccur)[i] = 0; reinterpret_cast<int*>(cnxt)[i] = 0;
-        }
+        char* vcur = vbase; char* vnxt = vbase + (size_t)NP * 16;
+        for (int i = lane; i < NP; i += 64) { stcell(vcur, i, NEGINF, 0); stcell(vnxt, i, NEGINF, 0); }
         VIT_FENCE();
-        if (lane == 0) reinterpret_cast<double*>(vcur)[m_start] = 0.0;
+        if (lane == 0) stcell(vcur, m_start, 0.0, 0);
         VIT_FENCE();
 
         // Silent states of buffer `vb` (values) / `cb` (carried counts) to their fixed point.
         // `pin`: keep start at 0 (t = 0).
-        auto relax_silent = [&](char* vb, char* cb, bool pin, int64_t trow) {
+        uint32_t n_outer = 0, n_sweep = 0; uint64_t cyc_e = 0, cyc_s = 0;
+        auto relax_silent = [&](char* vb, bool pin, int64_t trow) {
             double y[SPL], base_prev[SPL]; int yc[SPL], arg[SPL];
 #pragma unroll
             for (int s = 0; s < SPL; ++s) { y[s] = NEGINF; yc[s] = 0; arg[s] = n; base_prev[s] = __builtin_nan(""); }
             for (int outer = 0;; ++outer) {
+                ++n_outer;
                 // (A) best non-chain in-edge of every silent state: emitting predecessors (final for
                 //     this time step) and silent predecessors that are not chain neighbours
                 bool base_changed = false;
@@ -157,9 +159,9 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
                     double best = NEGINF; int bc = 0, a = n;
 #pragma unroll
                     for (int j = 0; j < DS; ++j) {
-                        const double c = ldv(vb, soff[s][j]) + slp[s][j];
-                        const int cc = ldc(cb, soff[s][j]);
-                        if (c > best) { best = c; bc = cc; a = soff[s][j] >> 3; }
+                        const Cell pc = ldcell(vb, soff[s][j]);
+                        const double c = pc.v + slp[s][j];
+                        if (c > best) { best = c; bc = pc.c; a = soff[s][j] >> 3; }
                     }
                     if (pin && own_s[s] == m_start) { best = 0.0; bc = -sinc[s]; a = n; }
                     if (own_s[s] < 0) { best = NEGINF; bc = 0; a = n; }
@@ -178,6 +180,7 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
                         base_prev[s] = base[s];
                     }
                     for (;;) {
+                        ++n_sweep;
                         bool win_any = false;
 #pragma unroll
                         for (int s = 0; s < SPL; ++s) {
@@ -194,21 +197,18 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
 #pragma unroll
                     for (int s = 0; s < SPL; ++s) {
                         if (own_s[s] >= 0) {
-                            const double ov = ldv(vb, own_s[s] * 8); const int oc = ldc(cb, own_s[s] * 8);
-                            if (!(ov == y[s]) || oc != yc[s]) changed = true;
+                            const Cell oc = ldcell(vb, own_s[s] * 8);
+                            if (!(oc.v == y[s]) || oc.c != yc[s]) changed = true;
                         }
                     }
                 }
-                if (!__any(changed)) break;
+                if (!single_stage && !__any(changed)) break;
                 VIT_FENCE();
 #pragma unroll
-                for (int s = 0; s < SPL; ++s) {
-                    if (own_s[s] >= 0) {
-                        *reinterpret_cast<double*>(vb + own_s[s] * 8) = y[s];
-                        *reinterpret_cast<int*>(cb + own_s[s] * 4) = yc[s];
-                    }
-                }
+                for (int s = 0; s < SPL; ++s)
+                    if (own_s[s] >= 0) stcell(vb, own_s[s], y[s], yc[s]);
                 VIT_FENCE();
+                if (single_stage) break;     // nothing downstream of the chains inside this time step
             }
             if (BP) {
 #pragma unroll
@@ -217,7 +217,7 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
             }
         };
 
-        relax_silent(vcur, ccur, true, 0);
+        relax_silent(vcur, true, 0);
 
         double xchunk = 0.0;
         for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -243,6 +243,7 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
             for (int s0 = 0; s0 < send; ++s0) {
                 const double x = readlane_f64(xchunk, s0);
                 const int64_t t = t0 + s0;
+                const uint64_t c0 = __builtin_readcyclecounter();
                 double nv[EPL]; int nc[EPL], na[EPL];
 #pragma unroll
                 for (int s = 0; s < EPL; ++s) {
@@ -250,9 +251,9 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
 #pragma unroll
                     for (int j = 0; j < DEMAX; ++j) {
                         if (j < de_of(s)) {     // compile-time
-                            const double c = ldv(vcur, eoff[s][j]) + elp[s][j];
-                            const int cc = ldc(ccur, eoff[s][j]);
-                            if (c > best) { best = c; bc = cc; a = eoff[s][j] >> 3; }
+                            const Cell pc = ldcell(vcur, eoff[s][j]);
+                            const double c = pc.v + elp[s][j];
+                            if (c > best) { best = c; bc = pc.c; a = eoff[s][j] >> 3; }
                         }
                     }
                     double em;
@@ -264,26 +265,60 @@ viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ task
 #pragma unroll
                 for (int s = 0; s < EPL; ++s) {
                     if (own_e[s] >= 0) {
-                        *reinterpret_cast<double*>(vnxt + own_e[s] * 8) = nv[s];
-                        *reinterpret_cast<int*>(cnxt + own_e[s] * 4) = nc[s];
+                        stcell(vnxt, own_e[s], nv[s], nc[s]);
                         if (BP) tk.bp[(size_t)(t + 1) * n + own_e[s]] = (uint16_t)na[s];
                     }
                 }
 #pragma unroll
                 for (int s = 0; s < SPL; ++s)
-                    if (own_s[s] >= 0) { *reinterpret_cast<double*>(vnxt + own_s[s] * 8) = NEGINF; *reinterpret_cast<int*>(cnxt + own_s[s] * 4) = 0; }
+                    if (own_s[s] >= 0) stcell(vnxt, own_s[s], NEGINF, 0);
                 VIT_FENCE();
-                relax_silent(vnxt, cnxt, false, t + 1);
+                const uint64_t c1 = __builtin_readcyclecounter();
+                relax_silent(vnxt, false, t + 1);
+                cyc_e += c1 - c0; cyc_s += __builtin_readcyclecounter() - c1;
                 char* tv = vcur; vcur = vnxt; vnxt = tv;
-                char* tc = ccur; ccur = cnxt; cnxt = tc;
             }
         }
-        const double lp = *reinterpret_cast<const double*>(vcur + m_end * 8);
-        const int cnt = *reinterpret_cast<const int*>(ccur + m_end * 4);
+        const Cell fin = ldcell(vcur, m_end * 8);
+        const double lp = fin.v;
+        const int cnt = fin.c;
         VitResult r; r.logp = lp; r.counted = cnt; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
+        r.dbg[0] = n_outer; r.dbg[1] = n_sweep; r.dbg[2] = (uint32_t)(cyc_e >> 10); r.dbg[3] = (uint32_t)(cyc_s >> 10);
         results[ti] = r;     // every lane stores the same value
         VIT_FENCE();
     }
+}
+
+// order[] = task indices by descending T (bitonic sort in LDS, one workgroup; n <= 8192)
+__global__ void __launch_bounds__(1024)
+vit_sort_kernel(const VitTask* __restrict__ tasks, int n, int* __restrict__ order)
+{
+    __shared__ long long key[8192];
+    int np = 1; while (np < n) np <<= 1;
+    for (int i = threadIdx.x; i < np; i += blockDim.x)
+        key[i] = i < n ? (((long long)(0x7fffffff - (int)(tasks[i].T > 0x7fffffff ? 0x7fffffff : tasks[i].T))) << 32) | (unsigned)i : 0x7fffffffffffffffll;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const long long a = key[i], b = key[l];
+                    if ((a > b) == up) { key[i] = b; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = (int)(key[i] & 0xffffffff);
+}
+
+int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order)
+{
+    if (n <= 0) return 0;
+    if (n > 8192) return 2;
+    hipLaunchKernelGGL(vit_sort_kernel, dim3(1), dim3(1024), 0, stream, tasks, n, order);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 // one thread per task: follow the back-pointers from (T, end) and write the emitting state of
@@ -309,26 +344,26 @@ __global__ void vit_traceback_kernel(const VitModel* __restrict__ mp, const VitT
 }
 
 int launch_viterbi(hipStream_t stream, const VitModel& mh, const VitModel* model_dev, const VitTask* tasks,
-                   VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp)
+                   VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
 {
     const int NP = (mh.n_states + 2) & ~1;
-    // per wave: two f64 value buffers and two i32 count buffers; waves of a block are independent
+    // per wave: two buffers of 16-byte {value, count} cells; waves of a block are independent
     int nw = 8;
-    while (nw > 1 && (size_t)nw * 2 * NP * 12 > 64 * 1024) nw >>= 1;
-    const size_t lds = (size_t)nw * 2 * NP * 12;
+    while (nw > 1 && (size_t)nw * 2 * NP * 16 > 160 * 1024) nw >>= 1;
+    const size_t lds = (size_t)nw * 2 * NP * 16;
     if (lds > 160 * 1024) return 3;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    if (blocks_per_cu * nw > 16) blocks_per_cu = 16 / nw;
+    if (blocks_per_cu * nw > 8) blocks_per_cu = 8 / nw;        // 2 waves per SIMD (register budget)
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     const dim3 grid(n_cu * blocks_per_cu), block(64 * nw);
 #define VIT_LAUNCH(E_, S_, H_, L_, D_)                                                                      \
     do {                                                                                                    \
         if (want_bp) {                                                                                      \
             (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, true>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue); \
+            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, true>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue, order); \
         } else {                                                                                            \
             (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, false>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue); \
+            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, false>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue, order); \
         }                                                                                                   \
     } while (0)
     const int e = mh.epl, s = mh.spl;

@@ -10,7 +10,8 @@ STRique.py:431,490) does to such a graph before `viterbi()` can run on it:
      repeatedly -- this removes the unused start/end nodes of every embedded sub-model;
   2. every state whose out-edge probabilities do not sum to 1 (rounded to 8 decimals) is
      re-weighted in log space: logp -= log(round(sum, 8));
-  3. silent states with a single certain (p == 1) out-edge are spliced out;
+  3. silent states with a single certain (p == 1) out-edge are spliced out (also in front of the
+     model end: adding log(1) = 0.0 is exact, so no path value changes);
   4. emitting states first, sorted by name; silent states after them in topological order.
 
 The arrays go to the GPU through the C ABI (strq_model_create) and to the CPU oracle in tests.
@@ -255,7 +256,7 @@ def bake(g, count_states=(), tag_substring=None):
         for a in range(n):
             if not alive[a] or g.kinds[a] != SILENT or a == g.start or a not in out:
                 continue
-            if len(out[a]) == 1 and out[a][0][1] == 0.0 and out[a][0][0] != g.end and out[a][0][0] != a:
+            if len(out[a]) == 1 and out[a][0][1] == 0.0 and out[a][0][0] != a:
                 b = out[a][0][0]
                 edges = [(x, b if y == a else y, lp) for x, y, lp in edges if x != a]
                 alive[a] = False

@@ -74,5 +74,11 @@ def test_bake_invariants(pm, cfg):
             if l >= bk.silent_start and bk.in_src[e_] >= bk.silent_start:
                 assert bk.in_src[e_] < l                 # topological order of silent states
     mask = np.ones(bk.n_states, bool); mask[bk.end] = False
+    # states that reach `end` had two spliced paths to it (via e1 and via e2): bake keeps the better
+    # edge only, which is what Viterbi would pick, so their mass is below 1
+    into_end = set(int(bk.in_src[e_]) for e_ in range(bk.in_ptr[bk.end], bk.in_ptr[bk.end + 1]))
+    for st in into_end:
+        mask[st] = False
+        assert 0.5 < out[st] <= 1.0 + 1e-8
     assert np.allclose(out[mask], 1.0, atol=1e-8)
     assert bk.count_inc.sum() == 2 and all("dummy" in bk.names[i] for i in np.nonzero(bk.count_inc)[0])
