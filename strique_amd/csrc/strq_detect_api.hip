@@ -46,6 +46,7 @@ struct FinalizeArgs {
     const int32_t* trim;           // 2 per read: pre_trim of the prefix flank, post_trim of the suffix flank
     const int32_t* vit_slot;       // per read: index of its VitTask
     const ReadCond* rc;
+    const VitModel* const* model_of;   // per read
     const void* flt;               // filtered signal (int16 or double), concatenated
     int is_f64;
     PoreStats ps;
@@ -77,6 +78,7 @@ __global__ void finalize_kernel(FinalizeArgs a)
         }
         g.gate = (g.prefix_begin < g.suffix_end && g.score_prefix > 0.0 && g.score_suffix > 0.0) ? 1 : 0;
     }
+    vt.model = a.model_of[r];
     if (g.gate) {
         vt.T = g.suffix_end - g.prefix_begin;
         if (a.is_f64) { vt.sig = reinterpret_cast<const double*>(a.flt) + rc.off + g.prefix_begin; vt.src_kind = VIT_SRC_F64_AFFINE; }
@@ -206,14 +208,29 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     // ---- positions, gate, Viterbi tasks (grouped by HMM)
     std::vector<int32_t> task_of(na);
     for (int pos = 0; pos < na; ++pos) task_of[co.order[pos]] = pos;
-    std::map<int, std::vector<int>> by_model;
-    for (int i = 0; i < nr; ++i) by_model[d->targets[B.target[r0 + i]].model_id].push_back(i);
-    std::vector<int32_t> vit_slot(nr); std::vector<int> slot_read(nr);
-    struct VL { int model, first, count; };
+    std::map<int, std::vector<int>> by_shape;      // windows of all models with one kernel shape share a launch
+    std::vector<const VitModel*> model_of(nr);
+    for (int i = 0; i < nr; ++i) {
+        HostModel* hm = c->models[d->targets[B.target[r0 + i]].model_id];
+        model_of[i] = hm->dev;
+        const int shape = vit_shape_of(hm->h);
+        if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
+        by_shape[shape].push_back(i);
+    }
+    std::vector<int32_t> vit_slot(nr);
+    struct VL { int shape, first, count, max_states; };
     std::vector<VL> vls;
-    { int s = 0; for (auto& g : by_model) { vls.push_back({g.first, s, (int)g.second.size()}); for (int i : g.second) { vit_slot[i] = s; slot_read[s] = i; ++s; } } }
-    STRQ_HIP(c, d->idx.reserve((size_t)(na * 2 + nr) * 4 + 64));
+    { int s = 0;
+      for (auto& g : by_shape) {
+        int mx = 0;
+        for (int i : g.second) mx = std::max(mx, c->models[d->targets[B.target[r0 + i]].model_id]->h.n_states);
+        vls.push_back({g.first, s, (int)g.second.size(), mx});
+        for (int i : g.second) vit_slot[i] = s++;
+      } }
+    STRQ_HIP(c, d->idx.reserve((size_t)(na * 2 + nr) * 4 + (size_t)nr * 8 + 64));
     int32_t* d_task_of = d->idx.as<int32_t>(); int32_t* d_trim = d_task_of + na; int32_t* d_slot = d_trim + na;
+    const VitModel** d_model_of = reinterpret_cast<const VitModel**>(d->idx.as<char>() + (((size_t)(na * 2 + nr) * 4 + 15) & ~(size_t)15));
+    STRQ_HIP(c, hipMemcpyAsync(d_model_of, model_of.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(d_task_of, task_of.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(d_trim, trim.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(d_slot, vit_slot.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
@@ -223,20 +240,19 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     STRQ_HIP(c, d->order.reserve((size_t)nr * 4 + 64));
     FinalizeArgs fa;
     fa.tasks = co.d_tasks; fa.results = co.d_results; fa.task_of = d_task_of; fa.trim = d_trim; fa.vit_slot = d_slot;
-    fa.rc = d_rc; fa.flt = d->flt.p; fa.is_f64 = B.dtype; fa.ps = d->ps; fa.geom = d->geom.as<ReadGeom>(); fa.vit = d->vit.as<VitTask>(); fa.n_reads = nr;
+    fa.rc = d_rc; fa.model_of = d_model_of; fa.flt = d->flt.p; fa.is_f64 = B.dtype; fa.ps = d->ps; fa.geom = d->geom.as<ReadGeom>(); fa.vit = d->vit.as<VitTask>(); fa.n_reads = nr;
     hipLaunchKernelGGL(finalize_kernel, dim3((nr + 127) / 128), dim3(128), 0, st, fa);
     STRQ_HIP(c, hipGetLastError());
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
     STRQ_HIP(c, hipEventRecord(d->ev[2], st));
     { int qi = 0;
       for (auto& v : vls) {
-        HostModel* hm = c->models[v.model];
         int* d_order = nullptr;
         if (v.count <= 8192) {
             d_order = d->order.as<int>() + v.first;
             if (launch_vit_sort(st, d->vit.as<VitTask>() + v.first, v.count, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
         }
-        const int rc2 = launch_viterbi(st, hm->h, hm->dev, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
+        const int rc2 = launch_viterbi(st, v.shape, v.max_states, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
                                        c->queue.as<int>() + qi, c->n_cu, 0, d_order);
         if (rc2) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;

@@ -196,7 +196,7 @@ int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const doubl
         const int64_t i = order[pos];
         VitTask& t = tasks[pos];
         std::memset(&t, 0, sizeof(t));
-        t.sig = c->vit_x.as<double>() + x_off[i]; t.T = x_off[i + 1] - x_off[i]; t.src_kind = VIT_SRC_F64;
+        t.model = hm->dev; t.sig = c->vit_x.as<double>() + x_off[i]; t.T = x_off[i + 1] - x_off[i]; t.src_kind = VIT_SRC_F64;
         if (paths) { t.bp = c->vit_bp.as<uint16_t>() + bp_off; bp_off += (size_t)(t.T + 1) * n; hp[pos] = c->vit_path.as<int32_t>() + x_off[i]; }
     }
     STRQ_HIP(c, hipMemcpyAsync(d_tasks, tasks.data(), (size_t)n_seq * sizeof(VitTask), hipMemcpyHostToDevice, st));
@@ -204,11 +204,13 @@ int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const doubl
     STRQ_HIP(c, c->queue.reserve(256));
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
     STRQ_HIP(c, hipEventRecord(c->ev[0], st));
-    int rc = launch_viterbi(st, hm->h, hm->dev, d_tasks, d_res, (int)n_seq, c->queue.as<int>(), c->n_cu, paths ? 1 : 0);
+    const int shape = vit_shape_of(hm->h);
+    if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
+    int rc = launch_viterbi(st, shape, hm->h.n_states, d_tasks, d_res, (int)n_seq, c->queue.as<int>(), c->n_cu, paths ? 1 : 0);
     if (rc) { c->err = "viterbi launch failed"; return rc == 2 || rc == 3 ? STRQ_ERR_UNSUPPORTED : STRQ_ERR_DEVICE; }
     STRQ_HIP(c, hipEventRecord(c->ev[1], st));
     if (paths) {
-        if (launch_vit_traceback(st, hm->dev, d_tasks, d_res, d_paths, (int)n_seq)) { c->err = "traceback launch failed"; return STRQ_ERR_DEVICE; }
+        if (launch_vit_traceback(st, d_tasks, d_res, d_paths, (int)n_seq)) { c->err = "traceback launch failed"; return STRQ_ERR_DEVICE; }
     }
     STRQ_HIP(c, hipEventRecord(c->ev[2], st));
     std::vector<VitResult> res(n_seq);

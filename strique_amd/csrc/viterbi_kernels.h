@@ -36,6 +36,7 @@ struct VitModel {
 enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };
 
 struct VitTask {
+    const VitModel* model;   // device image of the HMM this window is decoded with
     const void* sig;         // first observation
     int64_t T;
     int32_t src_kind, pad_;
@@ -51,11 +52,13 @@ struct VitResult {
     uint32_t dbg[4];         // profiling aid: outer iterations, chain sweeps, emitting / silent kilo-cycles
 };
 
-int launch_viterbi(hipStream_t stream, const VitModel& model_host, const VitModel* model_dev,
-                   const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp,
-                   const int* order = nullptr);
+// One launch decodes windows of several models as long as they fit the same kernel shape
+// (`shape_of`); `max_states` = largest n_states among them (sizes the LDS buffers).
+int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fits
+int launch_viterbi(hipStream_t stream, int shape, int max_states, const VitTask* tasks, VitResult* results,
+                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);
 int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order);   // order by descending T (n <= 8192)
-int launch_vit_traceback(hipStream_t stream, const VitModel* model_dev, const VitTask* tasks, const VitResult* results,
+int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResult* results,
                          int32_t* const* paths, int n_tasks);
 
 }  // namespace strq

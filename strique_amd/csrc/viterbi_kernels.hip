@@ -71,69 +71,68 @@ static __device__ __forceinline__ int dpp_shr1_i32(int v)
 // (without their chain edge).  Padding edges read the -inf cell.
 template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP>
 __global__ void __launch_bounds__(512)
-viterbi_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
-               int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
+viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
+               int n_tasks, int* __restrict__ queue, const int* __restrict__ order, int max_states)
 {
     extern __shared__ double lds_d[];
-    const VitModel& M = *mp;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int n = M.n_states;
-    const int NP = (n + 2) & ~1;                    // cells per buffer incl. the -inf cell [n]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NPMAX = (max_states + 2) & ~1;          // cells per buffer incl. the -inf cell
     // one 16-byte cell per state: {double value; int count; int pad} -> one ds_read_b128 per in-edge
-    char* vbase = reinterpret_cast<char*>(lds_d) + (size_t)wave * 2 * NP * 16;
-    (void)nw;
-
-    // ---- everything a lane needs about the states it owns lives in registers
+    char* vbase = reinterpret_cast<char*>(lds_d) + (size_t)wave * 2 * NPMAX * 16;
     constexpr int DEMAX = DE_HI > DE_LO ? DE_HI : DE_LO;
     auto de_of = [](int s) constexpr { return s < (EPL + 1) / 2 ? DE_HI : DE_LO; };
+    const double NEGINF = -__builtin_inf();
+    struct Cell { double v; int c; int pad; };
+    auto ldcell = [](const char* b, int off8) { return *reinterpret_cast<const Cell*>(b + 2 * off8); };
+    auto stcell = [](char* b, int state, double v, int c) { Cell x; x.v = v; x.c = c; x.pad = 0; *reinterpret_cast<Cell*>(b + 16 * state) = x; };
+    const VitModel* cur_model = nullptr;
+    int n = 0, NP = 0, m_start = 0, m_end = 0; bool single_stage = false;
+    // everything a lane needs about the states it owns lives in registers (reloaded when the model changes)
     int own_e[EPL], ekind[EPL], einc[EPL], eoff[EPL][DEMAX];
     double ea[EPL], eb[EPL], ec[EPL], elp[EPL][DEMAX];
     int own_s[SPL], sinc[SPL], soff[SPL][DS], chain_src[SPL];
     double slp[SPL][DS], clp[SPL];
     bool has_chain[SPL];
-#pragma unroll
-    for (int s = 0; s < EPL; ++s) {
-        const bool on = s < M.epl;
-        own_e[s] = on ? M.own_e[s * 64 + lane] : -1;
-        ekind[s] = on ? M.emis_kind[s * 64 + lane] : 0;
-        ea[s] = on ? M.emis_a[s * 64 + lane] : 0.0; eb[s] = on ? M.emis_b[s * 64 + lane] : 0.0; ec[s] = on ? M.emis_c[s * 64 + lane] : 0.0;
-        einc[s] = own_e[s] >= 0 ? M.count_inc[own_e[s]] : 0;
-#pragma unroll
-        for (int j = 0; j < DEMAX; ++j) {
-            const bool ej = on && j < M.e_deg[s];
-            eoff[s][j] = (ej ? M.edge_src[(M.e_base[s] + j) * 64 + lane] : n) * 8;
-            elp[s][j] = ej ? M.edge_logp[(M.e_base[s] + j) * 64 + lane] : 0.0;
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < SPL; ++s) {
-        const bool on = s < M.spl;
-        own_s[s] = on ? M.own_s[s * 64 + lane] : -1;
-        sinc[s] = own_s[s] >= 0 ? M.count_inc[own_s[s]] : 0;
-        chain_src[s] = on ? M.chain_src[s * 64 + lane] : -1;
-        has_chain[s] = chain_src[s] >= 0;
-        clp[s] = has_chain[s] ? M.chain_logp[s * 64 + lane] : 0.0;
-#pragma unroll
-        for (int j = 0; j < DS; ++j) {
-            const bool ej = on && j < M.s_deg[s];
-            soff[s][j] = (ej ? M.edge_src[(M.s_base[s] + j) * 64 + lane] : n) * 8;
-            slp[s][j] = ej ? M.edge_logp[(M.s_base[s] + j) * 64 + lane] : 0.0;
-        }
-    }
-    // header fields used inside the time loop: copy out of global memory once
-    const int m_epl = M.epl, m_spl = M.spl, m_start = M.start, m_end = M.end;
-    const bool single_stage = M.single_stage != 0;
-    (void)m_epl; (void)m_spl;
-    const double NEGINF = -__builtin_inf();
-    struct Cell { double v; int c; int pad; };
-    auto ldcell = [](const char* b, int off8) { return *reinterpret_cast<const Cell*>(b + 2 * off8); };
-    auto stcell = [](char* b, int state, double v, int c) { Cell x; x.v = v; x.c = c; x.pad = 0; *reinterpret_cast<Cell*>(b + 16 * state) = x; };
 
     for (;;) {
         const int tq = vit_next_task(queue, lane);
         if (tq >= n_tasks) break;
         const int ti = order ? order[tq] : tq;        // longest observation windows first
         const VitTask tk = tasks[ti];
+        if (tk.model != cur_model) {
+            cur_model = tk.model;
+            const VitModel& M = *cur_model;
+            n = M.n_states; NP = (n + 2) & ~1; m_start = M.start; m_end = M.end; single_stage = M.single_stage != 0;
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {
+                const bool on = s < M.epl;
+                own_e[s] = on ? M.own_e[s * 64 + lane] : -1;
+                ekind[s] = on ? M.emis_kind[s * 64 + lane] : 0;
+                ea[s] = on ? M.emis_a[s * 64 + lane] : 0.0; eb[s] = on ? M.emis_b[s * 64 + lane] : 0.0; ec[s] = on ? M.emis_c[s * 64 + lane] : 0.0;
+                einc[s] = own_e[s] >= 0 ? M.count_inc[own_e[s]] : 0;
+#pragma unroll
+                for (int j = 0; j < DEMAX; ++j) {
+                    const bool ej = on && j < M.e_deg[s];
+                    eoff[s][j] = (ej ? M.edge_src[(M.e_base[s] + j) * 64 + lane] : n) * 8;
+                    elp[s][j] = ej ? M.edge_logp[(M.e_base[s] + j) * 64 + lane] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const bool on = s < M.spl;
+                own_s[s] = on ? M.own_s[s * 64 + lane] : -1;
+                sinc[s] = own_s[s] >= 0 ? M.count_inc[own_s[s]] : 0;
+                chain_src[s] = on ? M.chain_src[s * 64 + lane] : -1;
+                has_chain[s] = chain_src[s] >= 0;
+                clp[s] = has_chain[s] ? M.chain_logp[s * 64 + lane] : 0.0;
+#pragma unroll
+                for (int j = 0; j < DS; ++j) {
+                    const bool ej = on && j < M.s_deg[s];
+                    soff[s][j] = (ej ? M.edge_src[(M.s_base[s] + j) * 64 + lane] : n) * 8;
+                    slp[s][j] = ej ? M.edge_logp[(M.s_base[s] + j) * 64 + lane] : 0.0;
+                }
+            }
+        }
         const int64_t T = tk.T;
         char* vcur = vbase; char* vnxt = vbase + (size_t)NP * 16;
         for (int i = lane; i < NP; i += 64) { stcell(vcur, i, NEGINF, 0); stcell(vnxt, i, NEGINF, 0); }
@@ -323,13 +322,13 @@ int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order)
 
 // one thread per task: follow the back-pointers from (T, end) and write the emitting state of
 // every observation (first version: latency-bound, used by the modification pass and the parity API)
-__global__ void vit_traceback_kernel(const VitModel* __restrict__ mp, const VitTask* __restrict__ tasks,
+__global__ void vit_traceback_kernel(const VitTask* __restrict__ tasks,
                                      const VitResult* __restrict__ results, int32_t* const* __restrict__ paths, int n_tasks)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tasks) return;
-    const VitModel& M = *mp;
     const VitTask& tk = tasks[i];
+    const VitModel& M = *tk.model;
     if (results[i].status != 0 || !tk.bp || !paths[i]) return;
     int64_t t = tk.T; int l = M.end;
     const int n = M.n_states, ne = M.n_emit;
@@ -343,10 +342,25 @@ __global__ void vit_traceback_kernel(const VitModel* __restrict__ mp, const VitT
     }
 }
 
-int launch_viterbi(hipStream_t stream, const VitModel& mh, const VitModel* model_dev, const VitTask* tasks,
-                   VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
+// kernel shapes: (EPL, SPL, DE_HI, DE_LO, DS)
+int vit_shape_of(const VitModel& mh)
 {
-    const int NP = (mh.n_states + 2) & ~1;
+    const int e = mh.epl, s = mh.spl;
+    int hi = 0, lo = 0, ds = 0;
+    for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
+    for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
+    if (e <= 4 && s <= 2 && e > 2 && hi <= 6 && lo <= 3 && ds <= 3) return 0;      // flanked-repeat models
+    if (e <= 1 && s <= 1 && hi <= 8 && ds <= 4) return 1;                          // modification models
+    if (e <= 2 && s <= 2 && hi <= 8 && lo <= 8 && ds <= 4) return 2;
+    if (e <= 4 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) return 3;
+    if (e <= 8 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) return 4;
+    return -1;
+}
+
+int launch_viterbi(hipStream_t stream, int shape, int max_states, const VitTask* tasks, VitResult* results,
+                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
+{
+    const int NP = (max_states + 2) & ~1;
     // per wave: two buffers of 16-byte {value, count} cells; waves of a block are independent
     int nw = 8;
     while (nw > 1 && (size_t)nw * 2 * NP * 16 > 160 * 1024) nw >>= 1;
@@ -360,31 +374,29 @@ int launch_viterbi(hipStream_t stream, const VitModel& mh, const VitModel* model
     do {                                                                                                    \
         if (want_bp) {                                                                                      \
             (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, true>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue, order); \
+            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, true>), grid, block, lds, stream, tasks, results, n_tasks, queue, order, max_states); \
         } else {                                                                                            \
             (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, false>), grid, block, lds, stream, model_dev, tasks, results, n_tasks, queue, order); \
+            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, false>), grid, block, lds, stream, tasks, results, n_tasks, queue, order, max_states); \
         }                                                                                                   \
     } while (0)
-    const int e = mh.epl, s = mh.spl;
-    int hi = 0, lo = 0, ds = 0;
-    for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
-    for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
-    if (e <= 4 && s <= 2 && e > 2 && hi <= 6 && lo <= 3 && ds <= 3) VIT_LAUNCH(4, 2, 6, 3, 3);      // flanked-repeat models
-    else if (e <= 1 && s <= 1 && hi <= 8 && ds <= 4) VIT_LAUNCH(1, 1, 8, 8, 4);                       // modification models
-    else if (e <= 2 && s <= 2 && hi <= 8 && lo <= 8 && ds <= 4) VIT_LAUNCH(2, 2, 8, 8, 4);
-    else if (e <= 4 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) VIT_LAUNCH(4, 4, 8, 8, 8);
-    else if (e <= 8 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) VIT_LAUNCH(8, 4, 8, 8, 8);
-    else return 2;
+    switch (shape) {
+        case 0: VIT_LAUNCH(4, 2, 6, 3, 3); break;
+        case 1: VIT_LAUNCH(1, 1, 8, 8, 4); break;
+        case 2: VIT_LAUNCH(2, 2, 8, 8, 4); break;
+        case 3: VIT_LAUNCH(4, 4, 8, 8, 8); break;
+        case 4: VIT_LAUNCH(8, 4, 8, 8, 8); break;
+        default: return 2;
+    }
 #undef VIT_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-int launch_vit_traceback(hipStream_t stream, const VitModel* model_dev, const VitTask* tasks, const VitResult* results,
+int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResult* results,
                          int32_t* const* paths, int n_tasks)
 {
     if (n_tasks <= 0) return 0;
-    hipLaunchKernelGGL(vit_traceback_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, stream, model_dev, tasks, results, paths, n_tasks);
+    hipLaunchKernelGGL(vit_traceback_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, stream, tasks, results, paths, n_tasks);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
