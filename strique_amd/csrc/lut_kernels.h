@@ -17,7 +17,7 @@ struct LutJob {
     int32_t* band_lo;         // k
     int32_t k, pad_;
 };
-struct LutInfo { int32_t tw, n_hard; };
+struct LutInfo { int32_t tw, n_hard, need, pad_; };
 struct HardEntry { int32_t job, k, level, index; };
 
 int launch_lut_build(hipStream_t stream, const LutJob* jobs, LutInfo* info, int n_jobs, int max_k,

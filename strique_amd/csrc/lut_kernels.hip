@@ -84,7 +84,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
     for (int k = q; k < jb.k; k += 256) atomicMax(&width, edge_r(k) - edge_l(k) + 1);
     __syncthreads();
     const int need = width;
-    const int tw = need <= 64 ? 64 : (need <= 128 ? 128 : 258);
+    const int tw = need <= 48 ? 48 : (need <= 64 ? 64 : (need <= 128 ? 128 : 258));
     const int stride = tw + 1;
     for (int idx = q; idx < jb.k * stride; idx += 256) {
         const int k = idx / stride, w = idx - k * stride;
@@ -103,6 +103,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
             if (lv < edge_l(k) || lv > edge_r(k)) { nh = -1; break; }
         }
         info[blockIdx.x].tw = tw;
+        info[blockIdx.x].need = need;
         info[blockIdx.x].n_hard = nh;
         for (int i = 0; i < nh; ++i) {
             const int k = local_hard[i][0], lv = local_hard[i][1];

@@ -116,6 +116,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipMemcpyAsync(&hard_count, d_hard_count, 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
     STRQ_DBG("lut done nb=%d hard=%d tw0=%d", nb, hard_count, info[0].tw);
+    if (getenv("STRQ_DEBUG")) { int hist[9] = {0}; for (int i = 0; i < nb; ++i) hist[std::min(8, info[i].need / 8)]++; STRQ_DBG("band need histogram (x8 levels): %d %d %d %d %d %d %d %d %d", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]); }
     if (hard_count > hard_cap) { c->err = "too many borderline table entries"; return STRQ_ERR_DEVICE; }
     bool any_rebuild = false;
     for (int i = 0; i < nb; ++i) any_rebuild |= info[i].n_hard < 0;
@@ -184,7 +185,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipMemsetAsync(d_res, 0, (size_t)nb * sizeof(AlignResult), st));
     size_t scratch_words = 0;
     for (auto& L : launches) scratch_words = std::max(scratch_words, align_trace_scratch_words_per_wave(L.R));
-    STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * 4));
+    STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * 6));
     int qi = 0;
     STRQ_HIP(c, hipEventRecord(c->ev[2], st));
     for (int phase = 0; phase < 2; ++phase) {
@@ -194,7 +195,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             const int lds_floats = max_kk * (L.tw + 1);
             int wpb = (160 * 1024) / (lds_floats * 4);
             if (wpb < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
-            if (wpb > 4) wpb = 4;
+            if (wpb > 6) wpb = 6;
             if (launch_align(st, L.R, S, d_tasks + L.first, d_res + L.first, L.count, c->queue.as<int>() + qi,
                              c->ap, lds_floats, wpb, c->n_cu, c->scratch.as<uint64_t>(), phase)) {
                 c->err = "align launch failed"; return STRQ_ERR_DEVICE;
