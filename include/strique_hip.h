@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);
+int strq_abi_version(void);   /* currently 2 */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -96,12 +96,16 @@ int strq_align_batch(strq_ctx* ctx, int64_t n_align, int64_t n_reads,
  *              2 = Uniform(lo, hi):    a = lo, b = hi,            c = -log(hi - lo)
  *   count_inc  n_states ints (nullable): states whose visits along the best path are counted
  *              (the two dummy states of repeatHMM, scripts/STRique.py:374-378)
- * Limits: <= 512 emitting and <= 256 silent states.
+ *   state_tag  n_states ints (nullable): 1 = state belongs to the repeat section (flanked model,
+ *              `'repeat' in name`, STRique.py:608) or to the modified branch (modification model,
+ *              `'mod' in name`, STRique.py:497); 2 = hub state s0/e0 of the modification model
+ * Limits: <= 512 emitting and <= 256 silent states, <= 8 in-edges per state.
  */
 int strq_model_create(strq_ctx* ctx, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                       const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                       const int32_t* emis_kind, const double* emis_a, const double* emis_b,
-                      const double* emis_c, const int32_t* count_inc, int32_t* model_id);
+                      const double* emis_c, const int32_t* count_inc, const int32_t* state_tag,
+                      int32_t* model_id);
 
 /*
  * HiddenMarkovModel.viterbi(x) (scripts/STRique.py:434,493).
@@ -150,6 +154,13 @@ int strq_set_pore_stats(strq_ctx* ctx, double tail_lo, double tail_hi, double mo
 int strq_target_add(strq_ctx* ctx, const float* prefix_ext, int64_t m_prefix, const float* suffix_ext,
                     int64_t m_suffix, int32_t trim_prefix, int32_t trim_suffix, int32_t samples,
                     int32_t hmm_model_id, int32_t count_bias, int32_t* target_id);
+/* Base-modification pass of a target (repeatModHMM, STRique.py:447-500,605-609): the dual
+ * (unmodified | modified) repeat-unit model uploaded with strq_model_create and its emission range
+ * min(model_mins), max(model_maxs).  Reads of such a target also get a modification pattern. */
+int strq_target_set_mod(strq_ctx* ctx, int32_t target_id, int32_t mod_model_id, double mod_min, double mod_max);
+/* Modification patterns of the last batch: pattern of read i is pool[off[i] .. off[i+1]) ('0'/'1'
+ * per repeat unit, "-" when there is none).  pool may be NULL to query the total size in off[n]. */
+int strq_batch_fetch_mod(strq_ctx* ctx, char* pool, int64_t pool_cap, int64_t* off);
 int strq_detect_batch(strq_ctx* ctx, int64_t n_reads, const void* signals, int32_t dtype,
                       const int64_t* offsets, const int32_t* target_id, const double* host_stats,
                       strq_result* out);

@@ -60,6 +60,9 @@ class repeatCounter(object):
         flanked.model_id = self.ctx.model_create(flanked.baked)
         tid = self.ctx.target_add(pe, se, len(pe) - len(p), len(se) - len(s), self.samples, flanked.model_id,
                                   flanked.count_bias)
+        if mod is not None:
+            mod.model_id = self.ctx.model_create(mod.baked)
+            self.ctx.target_set_mod(tid, mod.model_id, mod.model_min, mod.model_max)
         return target_classifier(p, s, pe, se, flanked, mod, tid)
 
     def add_target(self, target_name, repeat, prefix, suffix):
@@ -110,10 +113,11 @@ class repeatCounter(object):
             stats = np.array([self._host_stats(a) for a in arrs])
         off = np.zeros(len(arrs) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in arrs])
         res = self.ctx.detect_batch(np.concatenate(arrs), off, [tc.target_id for tc in tcs], stats)
+        mods = self.ctx.batch_fetch_mod() if self.pm is not self.pm_mod else ['-'] * len(res)
         out = []
-        for r in res:
+        for r, m in zip(res, mods):
             n = int(r['count']); p = float(r['log_p']) if n or r['log_p'] != 0 else 0
-            out.append((n, float(r['score_prefix']), float(r['score_suffix']), p, int(r['offset']), int(r['ticks']), '-'))
+            out.append((n, float(r['score_prefix']), float(r['score_suffix']), p, int(r['offset']), int(r['ticks']), m))
         return out
 
     def detect(self, target_name, raw_signal, strand):

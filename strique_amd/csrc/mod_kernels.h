@@ -1,0 +1,28 @@
+// Internal: modification-pass helper kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace strq {
+
+struct ModTask {
+    const int32_t* path;     // emitting state of every sample of the window (flanked model), null = skip
+    const int32_t* tag;      // state tags of that model (1 = repeat section)
+    const void* raw;         // raw signal at prefix_begin
+    double* out;             // compacted, normalised, clipped samples
+    int64_t T;
+    int32_t is_f64, pad_;
+    double c1, h1, h2, c2, clip_lo, clip_hi, mod_lo, mod_hi;
+};
+struct PatTask {
+    const int32_t* path;     // emitting states of the modification model
+    const int32_t* tag;      // 2 = hub (s0/e0), 1 = modified branch
+    char* out;
+    int64_t T;
+    int32_t ok, pad_;
+};
+
+int launch_mod_compact(hipStream_t s, const ModTask* tasks, int n, int64_t* out_len);
+int launch_mod_pattern(hipStream_t s, const PatTask* tasks, int n, int64_t* out_len);
+
+}  // namespace strq

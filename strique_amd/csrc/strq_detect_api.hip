@@ -8,11 +8,13 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <string>
 #include <vector>
 #include "../../include/strique_hip.h"
 #include "strq_ctx.h"
 #include "cond_kernels.h"
 #include "viterbi_kernels.h"
+#include "mod_kernels.h"
 
 using namespace strq;
 
@@ -94,6 +96,7 @@ struct Target {
     int trim_prefix = 0, trim_suffix = 0, samples = 6;
     int kp = 0, Rp = 0, ks = 0, Rs = 0;
     int model_id = -1, count_bias = 0;
+    int mod_model_id = -1; double mod_min = 0, mod_max = 0;
 };
 
 struct Batch {
@@ -104,6 +107,7 @@ struct Batch {
     std::vector<double> host_stats;      // 6 per read (float64 input only)
     DevBuf raw;                          // all reads, resident
     std::vector<strq_result> results;
+    std::vector<std::string> mod;        // modification pattern per read ('-' if none)
     float t_cond = 0, t_lut = 0, t_fwd = 0, t_trace = 0, t_vit = 0, t_total = 0;
     double n_hard = 0;
     int n_fwd_launches = 0;
@@ -114,7 +118,7 @@ struct DetectState {
     bool have_ps = false;
     std::vector<Target> targets;
     Batch batch;
-    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order;
+    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
 };
@@ -129,10 +133,124 @@ void detect_state_free(strq_ctx* c)
 {
     if (!c->detect) return;
     DetectState* d = static_cast<DetectState*>(c->detect);
-    for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx, &d->order}) b->release();
+    for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx, &d->order,
+                      &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern}) b->release();
     if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
     delete d;
     c->detect = nullptr;
+}
+
+// Modification pass for the reads of one sub-batch whose target has a modification model.
+static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const std::vector<ReadCond>& rc,
+                        const std::vector<ReadGeom>& geom, const std::vector<VitResult>& vres,
+                        const std::vector<int32_t>& vit_slot, const std::vector<VitTask>& h_vit,
+                        const std::vector<size_t>& path_off)
+{
+    Batch& B = d->batch;
+    hipStream_t st = c->stream;
+    const int esz = B.dtype == 0 ? 2 : 8;
+    const int64_t s0 = B.off[r0];
+    std::vector<int> who;                      // reads that reach the modification model
+    for (int i = 0; i < nr; ++i) {
+        const Target& t = d->targets[B.target[r0 + i]];
+        if (t.mod_model_id >= 0 && geom[i].gate && vres[vit_slot[i]].status == 0 && rc[i].status == COND_OK) who.push_back(i);
+    }
+    const int nm = (int)who.size();
+    if (!nm) return STRQ_OK;
+    // 1. state paths of the flanked model
+    std::vector<VitTask> tb(nm); std::vector<VitResult> tr(nm); std::vector<int32_t*> tp(nm);
+    size_t sig_tot = 0; std::vector<size_t> sig_off(nm);
+    for (int k = 0; k < nm; ++k) {
+        const int i = who[k];
+        tb[k] = h_vit[vit_slot[i]]; tr[k] = vres[vit_slot[i]];
+        tp[k] = d->path.as<int32_t>() + path_off[i];
+        sig_off[k] = sig_tot; sig_tot += (size_t)tb[k].T;
+    }
+    STRQ_HIP(c, d->modtask.reserve((size_t)nm * (sizeof(VitTask) + sizeof(VitResult) + 8 + sizeof(ModTask) + sizeof(PatTask)) + 256));
+    VitTask* d_tb = d->modtask.as<VitTask>();
+    VitResult* d_tr = reinterpret_cast<VitResult*>(d_tb + nm);
+    int32_t** d_tp = reinterpret_cast<int32_t**>(d_tr + nm);
+    ModTask* d_mt = reinterpret_cast<ModTask*>(d_tp + nm);
+    PatTask* d_pt = reinterpret_cast<PatTask*>(d_mt + nm);
+    STRQ_HIP(c, hipMemcpyAsync(d_tb, tb.data(), (size_t)nm * sizeof(VitTask), hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemcpyAsync(d_tr, tr.data(), (size_t)nm * sizeof(VitResult), hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemcpyAsync(d_tp, tp.data(), (size_t)nm * 8, hipMemcpyHostToDevice, st));
+    if (launch_vit_traceback(st, d_tb, d_tr, d_tp, nm)) { c->err = "traceback launch failed"; return STRQ_ERR_DEVICE; }
+    // 2. samples decoded into repeat states, renormalised from the raw signal and clipped
+    STRQ_HIP(c, d->modsig.reserve(sig_tot * 8 + 64));
+    STRQ_HIP(c, d->modlen.reserve((size_t)nm * 16 + 64));
+    std::vector<ModTask> mt(nm);
+    for (int k = 0; k < nm; ++k) {
+        const int i = who[k]; const Target& t = d->targets[B.target[r0 + i]];
+        ModTask& m = mt[k];
+        m.path = tp[k]; m.tag = c->models[t.model_id]->h.state_tag;
+        m.raw = d->batch.raw.as<char>() + (size_t)(s0 + rc[i].off + geom[i].prefix_begin) * esz;
+        m.out = d->modsig.as<double>() + sig_off[k]; m.T = tb[k].T; m.is_f64 = B.dtype; m.pad_ = 0;
+        m.c1 = rc[i].r_c1; m.h1 = rc[i].r_h1; m.h2 = rc[i].h2; m.c2 = rc[i].c2;
+        m.clip_lo = d->ps.clip_lo; m.clip_hi = d->ps.clip_hi; m.mod_lo = t.mod_min; m.mod_hi = t.mod_max;
+    }
+    int64_t* d_len = d->modlen.as<int64_t>();
+    STRQ_HIP(c, hipMemcpyAsync(d_mt, mt.data(), (size_t)nm * sizeof(ModTask), hipMemcpyHostToDevice, st));
+    if (launch_mod_compact(st, d_mt, nm, d_len)) { c->err = "compaction launch failed"; return STRQ_ERR_DEVICE; }
+    std::vector<int64_t> len(nm);
+    STRQ_HIP(c, hipMemcpyAsync(len.data(), d_len, (size_t)nm * 8, hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipStreamSynchronize(st));
+    // 3. Viterbi on the modification model, with state path
+    std::map<int, std::vector<int>> by_shape;
+    for (int k = 0; k < nm; ++k) {
+        HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
+        const int shape = vit_shape_of(hm->h);
+        if (shape < 0) { c->err = "modification model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
+        by_shape[shape].push_back(k);
+    }
+    std::vector<VitTask> vt2(nm); std::vector<int> slot2(nm); std::vector<int32_t*> tp2(nm);
+    size_t bp2 = 0, p2 = 0; std::vector<size_t> bp2_off(nm), p2_off(nm);
+    for (int k = 0; k < nm; ++k) {
+        HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
+        bp2_off[k] = bp2; bp2 += (size_t)(len[k] + 1) * hm->h.n_states; p2_off[k] = p2; p2 += (size_t)len[k] + 1;
+    }
+    // the flanked model's back-pointers are no longer needed: reuse the buffers
+    STRQ_HIP(c, d->bp.reserve(bp2 * 2 + 64));
+    STRQ_HIP(c, d->pattern.reserve(p2 * 5 + (size_t)nm * 8 + 64));
+    int32_t* d_path2 = d->pattern.as<int32_t>(); char* d_chars = reinterpret_cast<char*>(d_path2 + p2);
+    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
+    { int sidx = 0, qi = 0;
+      for (auto& g : by_shape) {
+        const int first = sidx; int mx = 0;
+        for (int k : g.second) {
+            HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
+            VitTask& v = vt2[sidx]; v = VitTask();
+            v.model = hm->dev; v.sig = mt[k].out; v.T = len[k]; v.src_kind = VIT_SRC_F64; v.bp = d->bp.as<uint16_t>() + bp2_off[k];
+            slot2[k] = sidx; tp2[sidx] = d_path2 + p2_off[k]; mx = std::max(mx, hm->h.n_states); ++sidx;
+        }
+        STRQ_HIP(c, hipMemcpyAsync(d_tb + first, vt2.data() + first, (size_t)(sidx - first) * sizeof(VitTask), hipMemcpyHostToDevice, st));
+        if (launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, 1, nullptr)) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
+        ++qi;
+      } }
+    STRQ_HIP(c, hipMemcpyAsync(d_tp, tp2.data(), (size_t)nm * 8, hipMemcpyHostToDevice, st));
+    if (launch_vit_traceback(st, d_tb, d_tr, d_tp, nm)) { c->err = "traceback launch failed"; return STRQ_ERR_DEVICE; }
+    std::vector<VitResult> r2(nm);
+    STRQ_HIP(c, hipMemcpyAsync(r2.data(), d_tr, (size_t)nm * sizeof(VitResult), hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipStreamSynchronize(st));
+    // 4. pattern strings
+    std::vector<PatTask> pt(nm);
+    for (int k = 0; k < nm; ++k) {
+        const int sl = slot2[k];
+        HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
+        pt[sl].path = tp2[sl]; pt[sl].tag = hm->h.state_tag; pt[sl].out = d_chars + p2_off[k]; pt[sl].T = len[k];
+        pt[sl].ok = r2[sl].status == 0 ? 1 : 0; pt[sl].pad_ = 0;
+    }
+    STRQ_HIP(c, hipMemcpyAsync(d_pt, pt.data(), (size_t)nm * sizeof(PatTask), hipMemcpyHostToDevice, st));
+    if (launch_mod_pattern(st, d_pt, nm, d_len)) { c->err = "pattern launch failed"; return STRQ_ERR_DEVICE; }
+    std::vector<int64_t> plen(nm); std::vector<char> chars(p2);
+    STRQ_HIP(c, hipMemcpyAsync(plen.data(), d_len, (size_t)nm * 8, hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipMemcpyAsync(chars.data(), d_chars, p2, hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipStreamSynchronize(st));
+    for (int k = 0; k < nm; ++k) {
+        const int sl = slot2[k];
+        B.mod[r0 + who[k]] = std::string(chars.data() + p2_off[k], (size_t)plen[sl]);
+    }
+    return STRQ_OK;
 }
 
 static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
@@ -172,10 +290,19 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     // ---- conditioning (STRique.py:590-597)
     const char* raw = d->batch.raw.as<char>() + (size_t)s0 * esz;
     int bad = 0;
+    bool any_mod = false;
+    for (int i = 0; i < nr; ++i) any_mod |= d->targets[B.target[r0 + i]].mod_model_id >= 0;
     if (B.dtype == 0) {
         STRQ_HIP(c, hipMemsetAsync(d->hist16.p, 0, (size_t)nr * 65536 * 4, st));
-        bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), d->flt.as<int16_t>(), d_rc, nr, max_n, d->hist16.as<uint32_t>(), nullptr);
+        uint32_t* d_hist_raw = nullptr;
+        if (any_mod) {
+            STRQ_HIP(c, d->hist_raw.reserve((size_t)nr * 65536 * 4));
+            STRQ_HIP(c, hipMemsetAsync(d->hist_raw.p, 0, (size_t)nr * 65536 * 4, st));
+            d_hist_raw = d->hist_raw.as<uint32_t>();
+        }
+        bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), d->flt.as<int16_t>(), d_rc, nr, max_n, d->hist16.as<uint32_t>(), d_hist_raw);
         bad |= launch_hist_stats(st, d->hist16.as<uint32_t>(), 65536, -32768, d_rc, nr, d->ps, 0, nullptr);
+        if (any_mod) bad |= launch_hist_stats(st, d_hist_raw, 65536, -32768, d_rc, nr, d->ps, 2, nullptr);
         bad |= launch_quant_morph_i16(st, d->flt.as<int16_t>(), c->levels.as<uint8_t>(), d_rc, nr, max_n, d->hist8.as<uint32_t>());
     } else {
         bad |= launch_medfilt_f64(st, reinterpret_cast<const double*>(raw), d->flt.as<double>(), d_rc, nr, max_n);
@@ -244,6 +371,28 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     hipLaunchKernelGGL(finalize_kernel, dim3((nr + 127) / 128), dim3(128), 0, st, fa);
     STRQ_HIP(c, hipGetLastError());
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
+    // modification pass needs the state path of the flanked model: size the back-pointer arrays
+    std::vector<VitTask> h_vit;
+    std::vector<size_t> bp_off(nr, 0), path_off(nr, 0);
+    if (any_mod) {
+        h_vit.resize(nr);
+        STRQ_HIP(c, hipMemcpyAsync(h_vit.data(), d->vit.p, (size_t)nr * sizeof(VitTask), hipMemcpyDeviceToHost, st));
+        STRQ_HIP(c, hipStreamSynchronize(st));
+        size_t bp_cells = 0, path_cells = 0;
+        for (int i = 0; i < nr; ++i) {
+            const Target& t = d->targets[B.target[r0 + i]];
+            if (t.mod_model_id < 0) continue;
+            const VitTask& vt = h_vit[vit_slot[i]];
+            bp_off[i] = bp_cells; bp_cells += (size_t)(vt.T + 1) * c->models[t.model_id]->h.n_states;
+            path_off[i] = path_cells; path_cells += (size_t)vt.T + 1;
+        }
+        if (bp_cells * 2 > ((size_t)160 << 30)) { c->err = "modification pass: too many reads in one batch"; return STRQ_ERR_NOMEM; }
+        STRQ_HIP(c, d->bp.reserve(bp_cells * 2 + 64));
+        STRQ_HIP(c, d->path.reserve(path_cells * 4 + 64));
+        for (int i = 0; i < nr; ++i)
+            if (d->targets[B.target[r0 + i]].mod_model_id >= 0) h_vit[vit_slot[i]].bp = d->bp.as<uint16_t>() + bp_off[i];
+        STRQ_HIP(c, hipMemcpyAsync(d->vit.p, h_vit.data(), (size_t)nr * sizeof(VitTask), hipMemcpyHostToDevice, st));
+    }
     STRQ_HIP(c, hipEventRecord(d->ev[2], st));
     { int qi = 0;
       for (auto& v : vls) {
@@ -253,7 +402,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
             if (launch_vit_sort(st, d->vit.as<VitTask>() + v.first, v.count, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
         }
         const int rc2 = launch_viterbi(st, v.shape, v.max_states, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
-                                       c->queue.as<int>() + qi, c->n_cu, 0, d_order);
+                                       c->queue.as<int>() + qi, c->n_cu, any_mod ? 1 : 0, d_order);
         if (rc2) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
       } }
@@ -277,6 +426,10 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
             o.count = (int32_t)v.counted + d->targets[B.target[r0 + i]].count_bias;
             o.log_p = v.logp;
         }
+    }
+    if (any_mod) {
+        const int rcm = run_mod_pass(c, d, r0, nr, rc_out, geom, vres, vit_slot, h_vit, path_off);
+        if (rcm) return rcm;
     }
     float ms;
     STRQ_HIP(c, hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); B.t_cond += ms;
@@ -316,6 +469,30 @@ int strq_target_add(strq_ctx* c, const float* prefix_ext, int64_t m_prefix, cons
     return STRQ_OK;
 }
 
+int strq_target_set_mod(strq_ctx* c, int32_t target_id, int32_t mod_model_id, double mod_min, double mod_max)
+{
+    if (!c) return STRQ_ERR_ARG;
+    DetectState* d = dstate(c);
+    if (target_id < 0 || target_id >= (int32_t)d->targets.size() || mod_model_id < 0 || mod_model_id >= (int32_t)c->models.size()) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+    d->targets[target_id].mod_model_id = mod_model_id; d->targets[target_id].mod_min = mod_min; d->targets[target_id].mod_max = mod_max;
+    return STRQ_OK;
+}
+
+int strq_batch_fetch_mod(strq_ctx* c, char* pool, int64_t pool_cap, int64_t* off)
+{
+    if (!c || !off) return STRQ_ERR_ARG;
+    DetectState* d = dstate(c);
+    int64_t pos = 0;
+    for (size_t i = 0; i < d->batch.mod.size(); ++i) {
+        off[i] = pos;
+        const std::string& m = d->batch.mod[i];
+        if (pool) { if (pos + (int64_t)m.size() > pool_cap) { c->err = "pattern pool too small"; return STRQ_ERR_ARG; } std::memcpy(pool + pos, m.data(), m.size()); }
+        pos += (int64_t)m.size();
+    }
+    off[d->batch.mod.size()] = pos;
+    return STRQ_OK;
+}
+
 int strq_batch_upload(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
                       const int32_t* target_id, const double* host_stats)
 {
@@ -339,6 +516,7 @@ int strq_batch_upload(strq_ctx* c, int64_t n_reads, const void* signals, int32_t
     if (bytes) STRQ_HIP(c, hipMemcpyAsync(B.raw.p, signals, bytes, hipMemcpyHostToDevice, c->stream));
     STRQ_HIP(c, hipStreamSynchronize(c->stream));
     B.results.assign((size_t)n_reads, strq_result());
+    B.mod.assign((size_t)n_reads, std::string("-"));
     if (!d->ev_ok) { for (auto& e : d->ev) STRQ_HIP(c, hipEventCreate(&e)); d->ev_ok = true; }
     return STRQ_OK;
 }
@@ -353,7 +531,10 @@ int strq_batch_run(strq_ctx* c)
     int64_t r0 = 0;
     while (r0 < B.n_reads) {
         int64_t r1 = r0; size_t ck = 0; int64_t samples = 0;
-        while (r1 < B.n_reads && r1 - r0 < 4096) {
+        bool mod_batch = false;
+        for (int64_t r = r0; r < B.n_reads && r < r0 + 4096; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
+        const int64_t cap = mod_batch ? 512 : 4096;      // back-pointer memory bounds the modification pass
+        while (r1 < B.n_reads && r1 - r0 < cap) {
             const Target& t = d->targets[B.target[r1]];
             const int n = (int)(B.off[r1 + 1] - B.off[r1]);
             const size_t need = (size_t)align_num_ckpts(n) * 64 * 4 * (STRQ_CKPT_FIELDS(t.Rp) + STRQ_CKPT_FIELDS(t.Rs));

@@ -17,7 +17,7 @@ namespace strq {
 int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                     const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                     const int32_t* emis_kind, const double* emis_a, const double* emis_b, const double* emis_c,
-                    const int32_t* count_inc, HostModel** out)
+                    const int32_t* count_inc, const int32_t* state_tag, HostModel** out)
 {
     const int ne = silent_start, ns = n_states - silent_start;
     if (n_states < 2 || ne < 1 || ns < 2 || start < ne || end < ne || start >= n_states || end >= n_states) {
@@ -114,13 +114,16 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     for (int i = 0; i < epl * 64; ++i) if (own_e[i] >= 0) { const int e = own_e[i]; kind[i] = emis_kind[e]; a[i] = emis_a[e]; b[i] = emis_b[e]; cc[i] = emis_c[e]; }
     std::vector<int32_t> inc((size_t)n_states + 1, 0);
     if (count_inc) std::copy(count_inc, count_inc + n_states, inc.begin());
+    std::vector<int32_t> tagv((size_t)n_states + 1, 0);
+    if (state_tag) std::copy(state_tag, state_tag + n_states, tagv.begin());
     // one device blob
     struct Part { const void* p; size_t bytes; size_t off; };
     std::vector<Part> parts = {
         {lp.data(), lp.size() * 8, 0}, {a.data(), a.size() * 8, 0}, {b.data(), b.size() * 8, 0}, {cc.data(), cc.size() * 8, 0},
         {src.data(), src.size() * 4, 0}, {kind.data(), kind.size() * 4, 0}, {inc.data(), inc.size() * 4, 0},
         {own_e.data(), own_e.size() * 4, 0}, {own_s.data(), own_s.size() * 4, 0},
-        {chain_src_v.data(), chain_src_v.size() * 4, 0}, {chain_lp_v.data(), chain_lp_v.size() * 8, 0}};
+        {chain_src_v.data(), chain_src_v.size() * 4, 0}, {chain_lp_v.data(), chain_lp_v.size() * 8, 0},
+        {tagv.data(), tagv.size() * 4, 0}};
     size_t total = 0;
     for (auto& pt : parts) { pt.off = total; total += (pt.bytes + 15) & ~(size_t)15; }
     const size_t o_m = total; total += sizeof(VitModel);
@@ -137,6 +140,7 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     m.own_s = reinterpret_cast<const int32_t*>(d + parts[8].off);
     m.chain_src = reinterpret_cast<const int32_t*>(d + parts[9].off);
     m.chain_logp = reinterpret_cast<const double*>(d + parts[10].off);
+    m.state_tag = reinterpret_cast<const int32_t*>(d + parts[11].off);
     hm->dev = reinterpret_cast<const VitModel*>(d + o_m);
     std::vector<char> host(total, 0);
     for (auto& pt : parts) std::memcpy(&host[pt.off], pt.p, pt.bytes);
@@ -153,13 +157,13 @@ extern "C" {
 int strq_model_create(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                       const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                       const int32_t* emis_kind, const double* emis_a, const double* emis_b, const double* emis_c,
-                      const int32_t* count_inc, int32_t* model_id)
+                      const int32_t* count_inc, const int32_t* state_tag, int32_t* model_id)
 {
     if (!c) return STRQ_ERR_ARG;
     if (!in_ptr || !in_src || !in_logp || !emis_kind || !emis_a || !emis_b || !emis_c || !model_id) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
     HostModel* hm = nullptr;
-    const int rc = build_vit_model(c, n_states, silent_start, start, end, in_ptr, in_src, in_logp, emis_kind, emis_a, emis_b, emis_c, count_inc, &hm);
+    const int rc = build_vit_model(c, n_states, silent_start, start, end, in_ptr, in_src, in_logp, emis_kind, emis_a, emis_b, emis_c, count_inc, state_tag, &hm);
     if (rc) return rc;
     c->models.push_back(hm);
     *model_id = (int32_t)c->models.size() - 1;

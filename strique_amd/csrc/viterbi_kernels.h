@@ -31,6 +31,7 @@ struct VitModel {
     const double* emis_b;             // 1/(2 sigma^2) | hi
     const double* emis_c;             // -log(sigma sqrt(2pi)) | -log(hi - lo)
     const int32_t* count_inc;         // n_states + 1, by state
+    const int32_t* state_tag;         // n_states + 1, by state
 };
 
 enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };

@@ -212,7 +212,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             if (BP) {
 #pragma unroll
                 for (int s = 0; s < SPL; ++s)
-                    if (own_s[s] >= 0) tk.bp[(size_t)trow * n + own_s[s]] = (uint16_t)arg[s];
+                    if (own_s[s] >= 0 && tk.bp) tk.bp[(size_t)trow * n + own_s[s]] = (uint16_t)arg[s];
             }
         };
 
@@ -265,7 +265,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 for (int s = 0; s < EPL; ++s) {
                     if (own_e[s] >= 0) {
                         stcell(vnxt, own_e[s], nv[s], nc[s]);
-                        if (BP) tk.bp[(size_t)(t + 1) * n + own_e[s]] = (uint16_t)na[s];
+                        if (BP && tk.bp) tk.bp[(size_t)(t + 1) * n + own_e[s]] = (uint16_t)na[s];
                     }
                 }
 #pragma unroll

@@ -121,7 +121,7 @@ class Context(object):
         mid = ctypes.c_int32(-1)
         arrs = [_c(baked.in_ptr, np.int32), _c(baked.in_src, np.int32), _c(baked.in_logp, np.float64),
                 _c(baked.emis_kind, np.int32), _c(baked.emis_a, np.float64), _c(baked.emis_b, np.float64),
-                _c(baked.emis_c, np.float64), _c(baked.count_inc, np.int32)]
+                _c(baked.emis_c, np.float64), _c(baked.count_inc, np.int32), _c(baked.tag, np.int32)]
         self._check(self._lib.strq_model_create(self._h, ctypes.c_int32(baked.n_states), ctypes.c_int32(baked.silent_start),
                                                 ctypes.c_int32(baked.start), ctypes.c_int32(baked.end),
                                                 *[_ptr(a) for a in arrs], ctypes.byref(mid)))
@@ -158,6 +158,18 @@ class Context(object):
                                               ctypes.c_int32(trim_prefix), ctypes.c_int32(trim_suffix), ctypes.c_int32(samples),
                                               ctypes.c_int32(model_id), ctypes.c_int32(count_bias), ctypes.byref(tid)))
         return tid.value
+
+    def target_set_mod(self, target_id, mod_model_id, mod_min, mod_max):
+        self._check(self._lib.strq_target_set_mod(self._h, ctypes.c_int32(target_id), ctypes.c_int32(mod_model_id),
+                                                  ctypes.c_double(mod_min), ctypes.c_double(mod_max)))
+
+    def batch_fetch_mod(self):
+        off = np.zeros(self._n_batch + 1, np.int64)
+        self._check(self._lib.strq_batch_fetch_mod(self._h, None, ctypes.c_int64(0), _ptr(off)))
+        pool = np.zeros(max(1, int(off[-1])), np.uint8)
+        self._check(self._lib.strq_batch_fetch_mod(self._h, _ptr(pool), ctypes.c_int64(len(pool)), _ptr(off)))
+        raw = pool.tobytes()
+        return [raw[off[i]:off[i + 1]].decode() for i in range(self._n_batch)]
 
     def batch_upload(self, signals, offsets, target_ids, host_stats=None):
         """signals: one concatenated int16 or float64 array; offsets: n_reads + 1."""

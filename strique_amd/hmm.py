@@ -207,7 +207,8 @@ class RepeatModModel(object):
         g.add_transition(e0, s0, 1 - tp['leave_repeat'])
         self.graph = g
         self.hub_states = (s0, e0)
-        self.baked = bake(g, count_states=(), tag_substring='mod')
+        # tag 2 = hub states s0/e0 (group separators of mod_repeats, STRique.py:496), 1 = modified branch
+        self.baked = bake(g, count_states=(), tag_substring='mod', tag2_states=(s0, e0))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -221,7 +222,7 @@ BakedHMM = namedtuple("BakedHMM", [
 ])
 
 
-def bake(g, count_states=(), tag_substring=None):
+def bake(g, count_states=(), tag_substring=None, tag2_states=()):
     n = len(g.names)
     alive = [True] * n
     edges = [(a, b, math.log(p) if p > 0 else -math.inf) for a, b, p in g.edges]
@@ -333,7 +334,8 @@ def bake(g, count_states=(), tag_substring=None):
     count_inc = np.zeros(m, np.int32)
     for s in count_states:
         count_inc[new[s]] = 1
-    tag = np.array([1 if (tag_substring and tag_substring in g.names[old]) else 0 for old in final], np.int32)
+    tag = np.array([2 if old in tag2_states else (1 if (tag_substring and tag_substring in g.names[old]) else 0)
+                    for old in final], np.int32)
     return BakedHMM(m, ne, new[g.start], new[g.end], in_ptr, np.array(in_src, np.int32),
                     np.array(in_logp, np.float64), kind, ea, eb, ec, count_inc, tag,
                     [g.names[i] for i in final], np.array(final, np.int32))

@@ -95,3 +95,34 @@ def test_full_size_reads_properties(gpu_counter, orc, opm, pm, cfg):
         assert 0 < r[4] < len(s) and 6 * 6 * n * 0.9 < r[5] < 9 * 6 * n * 1.1      # ticks ~ 6 nt x n x dwell
     want, _ = orc.detect(sigs[0], oracle_tc(gpu_counter, "c9orf72", "+"), opm, orc.align_params(cfg["align"]))
     assert tuple(a[0][:6]) == tuple(want[:6])
+
+
+def test_modification_pass(pm, pm_mod, cfg, orc, opm):
+    """detect steps 12-14 (STRique.py:605-609) and repeatModHMM.mod_repeats (:492-500): the
+    pattern string must equal the oracle's, for signals drawn from the base and from the mCpG model
+    (the reference's own test_Modification, scripts/STRique_test.py:104-124, only asserts the count)."""
+    from strique_amd.counter import repeatCounter
+    from strique_amd import hmm
+    rc = repeatCounter(pm, mod_model_file=pm_mod, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    rc.add_target("c9orf72", repeat, prefix, suffix)
+    rng = np.random.default_rng(12)
+    backbone = "".join(rng.choice(list("ACTG"), 2000))
+    items, truth = [], []
+    for i, model in ((40, pm), (40, pm_mod), (110, pm_mod), (7, pm)):
+        seq = backbone[:1000] + prefix + repeat * i + suffix + backbone[-1000:]
+        sig = model.generate_signal(seq, samples=8, noise=True, rng=rng)
+        items.append(("c9orf72", sig, "+")); truth.append(i)
+        items.append(("c9orf72", np.round(sig * (8192 / 1400.0) - 10).astype(np.int16), "+")); truth.append(i)
+    flt_items = [it for it in items if it[1].dtype != np.int16]
+    int_items = [it for it in items if it[1].dtype == np.int16]
+    tcp = rc._classifier_for("c9orf72", "+")
+    tc = dict(prefix=tcp.prefix, suffix=tcp.suffix, prefix_ext=tcp.prefix_ext, suffix_ext=tcp.suffix_ext,
+              hmm=tcp.repeatHMM, mod=tcp.modHMM)
+    params = orc.align_params(cfg["align"])
+    for group in (flt_items, int_items):
+        got = rc.detect_batch(group)
+        for (name, sig, strand), g in zip(group, got):
+            want, _ = orc.detect(sig, tc, opm, params, pm_mod=pm_mod)
+            assert tuple(g) == tuple(want), (g, want)
+            assert set(g[6]) <= set("01") and abs(len(g[6]) - g[0]) <= 3
