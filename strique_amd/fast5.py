@@ -1,0 +1,278 @@
+"""Minimal HDF5 reader for nanopore fast5 raw signals (no h5py in the target image).
+
+Covers what STRique's fast5Index.get_raw needs for single- and multi-read fast5 files
+(reference STRique_lib/fast5Index.py:76-84,220-233): old-style groups (symbol tables, B-tree v1,
+local heaps), version-1 object headers with continuation blocks, chunked int16 datasets with the
+deflate (and optional shuffle) filter, contiguous datasets, and the string / integer attributes that
+carry `read_id`.  HDF5 features outside that subset raise NotImplementedError.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+_SIG = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class H5File(object):
+    def __init__(self, path_or_bytes):
+        if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
+            self.buf = bytes(path_or_bytes)
+        else:
+            with open(path_or_bytes, "rb") as fp:
+                self.buf = fp.read()
+        b = self.buf
+        if b[:8] != _SIG:
+            raise ValueError("not an HDF5 file")
+        ver = b[8]
+        if ver not in (0, 1):
+            raise NotImplementedError("HDF5 superblock version %d" % ver)
+        self.so, self.sl = b[13], b[14]          # size of offsets / lengths
+        if self.so != 8 or self.sl != 8:
+            raise NotImplementedError("only 8-byte offsets/lengths")
+        self.leaf_k, self.int_k = struct.unpack_from("<HH", b, 16)
+        p = 24 if ver == 0 else 28
+        self.base, = struct.unpack_from("<Q", b, p)
+        p += 32                                   # base, free-space, eof, driver-info addresses
+        # root group symbol table entry
+        self.root = self._symbol_entry(p)
+
+    # ---- low level -----------------------------------------------------------------------
+    def _symbol_entry(self, p):
+        name_off, ohdr, cache_type = struct.unpack_from("<QQI", self.buf, p)
+        scratch = self.buf[p + 24:p + 40]
+        return {"name_off": name_off, "ohdr": ohdr, "cache": cache_type, "scratch": scratch}
+
+    def _messages(self, addr):
+        """Yield (type, flags, payload bytes) of a version-1 object header incl. continuations."""
+        b = self.buf
+        ver = b[addr]
+        if ver != 1:
+            raise NotImplementedError("object header version %d" % ver)
+        nmsg, = struct.unpack_from("<H", b, addr + 2)
+        hsize, = struct.unpack_from("<I", b, addr + 8)
+        blocks = [(addr + 16, hsize)]
+        seen = 0
+        while blocks and seen < nmsg:
+            p, size = blocks.pop(0)
+            end = p + size
+            while p + 8 <= end and seen < nmsg:
+                mtype, msize, mflags = struct.unpack_from("<HHB", b, p)
+                payload = b[p + 8:p + 8 + msize]
+                p += 8 + msize
+                seen += 1
+                if mtype == 0x10:                    # continuation
+                    caddr, clen = struct.unpack_from("<QQ", payload, 0)
+                    blocks.append((caddr, clen))
+                else:
+                    yield mtype, mflags, payload
+
+    def _heap_string(self, heap_addr, off):
+        b = self.buf
+        if b[heap_addr:heap_addr + 4] != b"HEAP":
+            raise ValueError("bad local heap")
+        data_addr, = struct.unpack_from("<Q", b, heap_addr + 24)
+        p = data_addr + off
+        e = b.index(b"\x00", p)
+        return b[p:e].decode()
+
+    def _group_entries(self, ohdr):
+        """name -> object header address of an old-style group."""
+        btree = heap = None
+        out = {}
+        dense = False
+        for mtype, _, pl in self._messages(ohdr):
+            if mtype == 0x11:
+                btree, heap = struct.unpack_from("<QQ", pl, 0)
+            elif mtype == 0x06:                         # new-style group, link stored in the header
+                flags = pl[1]
+                p = 2
+                ltype = 0
+                if flags & 0x08:
+                    ltype = pl[p]; p += 1
+                if flags & 0x04:
+                    p += 8
+                if flags & 0x10:
+                    p += 1
+                lsz = 1 << (flags & 0x03)
+                nlen = int.from_bytes(pl[p:p + lsz], "little"); p += lsz
+                name = pl[p:p + nlen].decode(); p += nlen
+                if ltype == 0:
+                    out[name], = struct.unpack_from("<Q", pl, p)
+            elif mtype == 0x02:                         # link info: dense storage lives in a fractal heap
+                flags = pl[1]
+                p = 2 + (8 if flags & 0x01 else 0)
+                fheap, = struct.unpack_from("<Q", pl, p)
+                dense = fheap != UNDEF
+        if btree is not None:
+            self._walk_group_btree(btree, heap, out)
+        elif dense and not out:
+            raise NotImplementedError("new-style group with dense link storage")
+        return out
+
+    def _walk_group_btree(self, addr, heap, out):
+        b = self.buf
+        if b[addr:addr + 4] == b"SNOD":
+            n, = struct.unpack_from("<H", b, addr + 6)
+            p = addr + 8
+            for _ in range(n):
+                e = self._symbol_entry(p)
+                out[self._heap_string(heap, e["name_off"])] = e["ohdr"]
+                p += 40
+            return
+        if b[addr:addr + 4] != b"TREE":
+            raise ValueError("bad group B-tree node")
+        level = b[addr + 5]
+        n, = struct.unpack_from("<H", b, addr + 6)
+        p = addr + 24                                   # skip siblings
+        for i in range(n):
+            p += 8                                      # key i
+            child, = struct.unpack_from("<Q", b, p); p += 8
+            self._walk_group_btree(child, heap, out)
+
+    # ---- public ---------------------------------------------------------------------------
+    def listdir(self, path="/"):
+        return sorted(self._group_entries(self._resolve(path)).keys())
+
+    def _resolve(self, path):
+        addr = self.root["ohdr"]
+        for part in [x for x in path.split("/") if x]:
+            ents = self._group_entries(addr)
+            if part not in ents:
+                raise KeyError(path)
+            addr = ents[part]
+        return addr
+
+    def attrs(self, path):
+        out = {}
+        for mtype, _, pl in self._messages(self._resolve(path)):
+            if mtype != 0x0C:
+                continue
+            ver = pl[0]
+            if ver not in (1, 2, 3):
+                continue
+            nsz, tsz, ssz = struct.unpack_from("<HHH", pl, 2)
+            p = 8 if ver == 1 else (8 if ver == 2 else 9)
+            pad = (lambda x: (x + 7) & ~7) if ver == 1 else (lambda x: x)
+            name = pl[p:p + nsz].split(b"\x00")[0].decode(); p += pad(nsz)
+            dt = pl[p:p + tsz]; p += pad(tsz)
+            p += pad(ssz)
+            cls = dt[0] & 0x0F
+            size, = struct.unpack_from("<I", dt, 4)
+            raw = pl[p:p + size]
+            if cls == 3:
+                out[name] = raw.split(b"\x00")[0].decode(errors="replace")
+            elif cls == 0 and size in (1, 2, 4, 8):
+                signed = bool(dt[1] & 0x08)
+                out[name] = int.from_bytes(raw, "little", signed=signed)
+            elif cls == 1 and size in (4, 8):
+                out[name] = struct.unpack("<f" if size == 4 else "<d", raw)[0]
+        return out
+
+    def dataset(self, path):
+        b = self.buf
+        shape = None; dtype = None; layout = None; filters = []
+        for mtype, _, pl in self._messages(self._resolve(path)):
+            if mtype == 0x01:
+                ver, rank, flags = pl[0], pl[1], pl[2]
+                p = 8 if ver == 1 else 4
+                shape = struct.unpack_from("<%dQ" % rank, pl, p)
+            elif mtype == 0x03:
+                cls = pl[0] & 0x0F
+                size, = struct.unpack_from("<I", pl, 4)
+                if cls == 0:
+                    dtype = np.dtype("<%s%d" % ("i" if pl[1] & 0x08 else "u", size))
+                elif cls == 1:
+                    dtype = np.dtype("<f%d" % size)
+                else:
+                    raise NotImplementedError("datatype class %d" % cls)
+            elif mtype == 0x08:
+                ver = pl[0]
+                if ver != 3:
+                    raise NotImplementedError("data layout version %d" % ver)
+                lclass = pl[1]
+                if lclass == 1:
+                    addr, size = struct.unpack_from("<QQ", pl, 2)
+                    layout = ("contiguous", addr, size)
+                elif lclass == 2:
+                    rank = pl[2]
+                    addr, = struct.unpack_from("<Q", pl, 3)
+                    dims = struct.unpack_from("<%dI" % rank, pl, 11)
+                    layout = ("chunked", addr, dims)
+                else:
+                    raise NotImplementedError("compact layout")
+            elif mtype == 0x0B:
+                ver, nf = pl[0], pl[1]
+                p = 8 if ver == 1 else 2
+                for _ in range(nf):
+                    fid, nlen, fflags, ncd = struct.unpack_from("<HHHH", pl, p); p += 8
+                    if ver == 1 or fid >= 256:
+                        p += (nlen + 7) & ~7 if ver == 1 else nlen
+                    p += 4 * ncd
+                    if ver == 1 and ncd % 2:
+                        p += 4
+                    filters.append(fid)
+        if shape is None or dtype is None or layout is None:
+            raise ValueError("not a dataset: %s" % path)
+        n = int(np.prod(shape)) if shape else 1
+        if layout[0] == "contiguous":
+            return np.frombuffer(b, dtype, n, layout[1]).reshape(shape).copy()
+        if len(shape) != 1:
+            raise NotImplementedError("only 1-D chunked datasets")
+        out = np.zeros(n, dtype)
+        csize = layout[2][0]
+        for off, data in self._chunks(layout[1], len(shape)):
+            for fid in reversed(filters):
+                if fid == 1:
+                    data = zlib.decompress(data)
+                elif fid == 2:
+                    a = np.frombuffer(data, np.uint8).reshape(dtype.itemsize, -1)
+                    data = a.T.tobytes()
+                else:
+                    raise NotImplementedError("HDF5 filter %d" % fid)
+            vals = np.frombuffer(data, dtype)
+            k = min(len(vals), csize, n - off)
+            out[off:off + k] = vals[:k]
+        return out
+
+    def _chunks(self, addr, rank):
+        b = self.buf
+        if addr == UNDEF:
+            return
+        if b[addr:addr + 4] != b"TREE":
+            raise ValueError("bad chunk B-tree node")
+        level = b[addr + 5]
+        n, = struct.unpack_from("<H", b, addr + 6)
+        p = addr + 24
+        keysz = 8 + 8 * (rank + 1)
+        for i in range(n):
+            csize, fmask = struct.unpack_from("<II", b, p)
+            offs = struct.unpack_from("<%dQ" % (rank + 1), b, p + 8)
+            child, = struct.unpack_from("<Q", b, p + keysz)
+            p += keysz + 8
+            if level == 0:
+                if fmask:
+                    raise NotImplementedError("chunk with skipped filters")
+                yield offs[0], b[child:child + csize]
+            else:
+                for x in self._chunks(child, rank):
+                    yield x
+
+
+def read_raw(path):
+    """[(read_id, int16 signal)] of a single-read (`/Raw/Reads/Read_*`) or multi-read
+    (`/read_*/Raw`) fast5 file."""
+    f = H5File(path)
+    out = []
+    top = f.listdir("/")
+    if "Raw" in top:
+        for rd in f.listdir("/Raw/Reads"):
+            g = "/Raw/Reads/" + rd
+            out.append((f.attrs(g).get("read_id", rd), f.dataset(g + "/Signal")))
+    else:
+        for rd in top:
+            if rd.startswith("read_"):
+                g = "/%s/Raw" % rd
+                out.append((f.attrs(g).get("read_id", rd[5:]), f.dataset(g + "/Signal")))
+    return out

@@ -16,6 +16,7 @@ Fixtures written (all small):
     normalize.npz          normalize2model('minmax') input/output pairs    (STRique.py:150-180)
     config.json            parse_config() of the bundled tsv + json        (STRique.py:836-868)
     sam.json               SAM decode + target intersection of data/*.sam  (STRique.py:648-679)
+    bundled_read.npz       raw int16 signal + read id of data/c9orf72.fast5
     hmm_topology.json      states / edges emitted by the reference's HMM classes run against a
                            recording stand-in for pomegranate              (STRique.py:201-500)
 """
@@ -222,6 +223,13 @@ def main():
     json.dump({"records": recs, "cigar": cig, "ops": ops,
                "len_MIS=X": rd.__ops_length__(ops), "len_MDN=X": rd.__ops_length__(ops, recOps="MDN=X")},
               open(os.path.join(OUT, "sam.json"), "w"), indent=1)
+    # ---- raw signal of the bundled read (data/c9orf72.fast5), read with the repository's own
+    #      HDF5 reader (h5py is not installed): input of the documented known answer
+    #      docs/installation/test.md:15-16
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from strique_amd import fast5
+    rid, sig = fast5.read_raw(os.path.join(REF, "data", "c9orf72.fast5"))[0]
+    np.savez_compressed(os.path.join(OUT, "bundled_read.npz"), signal=sig, read_id=np.array(rid))
     print("fixtures written to", OUT)
 
 
