@@ -1,0 +1,265 @@
+"""`STRique.py`-compatible command line: `index` and `count`.
+
+Mirrors the reference's CLI surface (scripts/STRique.py:874-945): same positional arguments and
+flags, the same `repeat_config.tsv` / JSON config format (parse_config, :836-868), SAM record
+decoding and locus intersection (repeatDetector, :648-705) and TSV output (outputWriter, :711-727).
+What changes is the engine: instead of `--t` worker processes calling the CPU aligner one read at
+a time, the records of the SAM stream are collected and handed to the GPU in batches
+(`repeatCounter.detect_batch`); rows are written in input order.
+"""
+import argparse
+import glob
+import json
+import os
+import re
+import sys
+import tarfile
+import tempfile
+from collections import defaultdict
+
+HEADER = ['ID', 'target', 'strand', 'count', 'score_prefix', 'score_suffix', 'log_p', 'offset', 'ticks', 'mod']
+LEVELS = ['error', 'warning', 'info', 'debug']
+
+
+class Log(object):
+    def __init__(self, level='warning'):
+        self.level = LEVELS.index(level)
+
+    def __call__(self, message, level='info'):
+        if LEVELS.index(level) <= self.level:
+            print("[%s] %s" % (level.upper(), message), file=sys.stderr)
+
+
+def parse_config(repeat_config_file, param_config_file=None, log=None):
+    """{'repeat': {name: (chr, begin, end, repeat, prefix, suffix)}, 'align': dict|None, 'HMM': dict|None}"""
+    repeats = {}
+    with open(repeat_config_file, 'r') as fp:
+        next(fp)                                         # header line
+        for line in fp:
+            cols = line.rstrip().split()
+            if len(cols) == 7:
+                repeats[cols[3]] = (cols[0], int(cols[1]), int(cols[2]), cols[4], cols[5], cols[6])
+            elif log:
+                log("Config: Repeat config column mismatch while parsing \n%s" % line, 'error')
+    config = {'repeat': repeats, 'align': None, 'HMM': None}
+    if param_config_file:
+        with open(param_config_file) as fp:
+            ld_conf = json.load(fp)
+        if not isinstance(ld_conf, dict):
+            raise SystemExit('Config: file format broken')
+        for key in ('align', 'HMM'):
+            if key not in ld_conf:
+                raise SystemExit('Config: Error loading HMM config file, missing %s' % key)
+            if not isinstance(ld_conf[key], dict):
+                raise SystemExit('Config: file format broken')
+        config['align'] = ld_conf['align']
+        config['HMM'] = ld_conf['HMM']
+    return config
+
+
+class SamRecord(object):
+    __slots__ = ('QNAME', 'FLAG', 'RNAME', 'POS', 'TLEN', 'CLIP_BEGIN', 'CLIP_END')
+
+    def __init__(self):
+        self.QNAME = ''; self.FLAG = 0; self.RNAME = ''; self.POS = 0; self.TLEN = 0; self.CLIP_BEGIN = 0; self.CLIP_END = 0
+
+
+def decode_cigar(cigar):
+    return [(int(op[:-1]), op[-1]) for op in re.findall(r'(\d*\D)', cigar)]
+
+
+def ops_length(ops, recOps='MIS=X'):
+    return sum(n for n, op in ops if op in recOps)
+
+
+def decode_sam(sam_line):
+    """QNAME, FLAG, RNAME, POS, reference span from the CIGAR, soft/hard clips (STRique.py:656-671)."""
+    cols = sam_line.rstrip().split('\t')
+    sr = SamRecord()
+    if len(cols) >= 11:
+        try:
+            sr.QNAME = cols[0]; sr.FLAG = int(cols[1]); sr.RNAME = cols[2]; sr.POS = int(cols[3])
+            ops = decode_cigar(cols[5])
+            sr.TLEN = ops_length(ops, recOps='MDN=X')
+            sr.CLIP_BEGIN = sum(n for n, op in ops[:2] if op in 'SH')
+            sr.CLIP_END = sum(n for n, op in ops[-2:] if op in 'SH')
+        except Exception:
+            return SamRecord()
+    return sr
+
+
+def intersect_targets(sr, loci):
+    """Targets whose locus lies inside the (clip-extended) alignment (STRique.py:673-679)."""
+    return [name for name, begin, end in loci.get(sr.RNAME, [])
+            if begin > sr.POS - sr.CLIP_BEGIN and end < sr.POS + sr.TLEN + sr.CLIP_END]
+
+
+class Fast5Index(object):
+    """`path[.fast5/group | .tar/member]<TAB>read_id` index (STRique_lib/fast5Index.py:45-60,220-233)."""
+
+    def __init__(self, index_file):
+        if not os.path.exists(index_file):
+            raise RuntimeError("[Error] Raw fast5 index file %s not found." % index_file)
+        with open(index_file) as fp:
+            self.index = {rid: path for path, rid in (line.split('\t') for line in fp.read().split('\n') if line)}
+        self.dir = os.path.dirname(index_file)
+
+    def get_raw(self, read_id):
+        from . import fast5
+        if read_id not in self.index:
+            return None
+        parts = re.split(r'(\.fast5|\.tar)/', self.index[read_id])
+        if len(parts) == 1:
+            f = fast5.H5File(os.path.join(self.dir, parts[0]))
+            grp = "/Raw/Reads/" + f.listdir("/Raw/Reads")[0]
+            return f.dataset(grp + "/Signal")
+        if parts[1] == '.fast5':
+            f = fast5.H5File(os.path.join(self.dir, parts[0] + '.fast5'))
+            return f.dataset("/%s/Raw/Signal" % parts[2].strip('/'))
+        with tarfile.open(os.path.join(self.dir, parts[0] + '.tar')) as tar:
+            data = tar.extractfile(tar.getmember(parts[2])).read()
+        f = fast5.H5File(data)
+        return f.dataset("/Raw/Reads/" + f.listdir("/Raw/Reads")[0] + "/Signal")
+
+    @staticmethod
+    def index_records(path, recursive=False, out_prefix=""):
+        from . import fast5
+        if os.path.isfile(path):
+            files = [path]
+        elif recursive:
+            files = [os.path.join(d, f) for d, _, fs in os.walk(path) for f in fs if f.endswith(('.fast5', '.tar'))]
+        else:
+            files = glob.glob(os.path.join(path, '*.fast5')) + glob.glob(os.path.join(path, '*.tar'))
+        for fpath in sorted(files):
+            rel = os.path.normpath(os.path.join(out_prefix, os.path.dirname(os.path.relpath(fpath, start=path)), os.path.basename(fpath)))
+            if fpath.endswith('.tar'):
+                with tarfile.open(fpath) as tar:
+                    for m in tar.getmembers():
+                        if m.name.endswith('.fast5'):
+                            try:
+                                rid = fast5.read_raw(tar.extractfile(m).read())[0][0]
+                                yield "\t".join([os.path.normpath(os.path.join(rel, m.name)), rid])
+                            except Exception:
+                                print("[ERROR] Failed to open %s, skip file for indexing" % m.name, file=sys.stderr)
+                continue
+            f = fast5.H5File(fpath)
+            top = f.listdir("/")
+            if "Raw" in top:
+                grp = "/Raw/Reads/" + f.listdir("/Raw/Reads")[0]
+                yield "\t".join([rel, f.attrs(grp)["read_id"]])
+            else:
+                for g in top:
+                    if g.startswith("read_"):
+                        yield "\t".join([os.path.join(rel, g), f.attrs("/%s/Raw" % g).get("read_id", g[5:])])
+
+
+def count(argv):
+    parser = argparse.ArgumentParser(description="STR Detection in raw nanopore data")
+    parser.add_argument("f5Index", help="Fast5 index")
+    parser.add_argument("model", help="Pore model")
+    parser.add_argument("repeat", help="Repeat region config file")
+    parser.add_argument("--out", default=None, help="Output file name, if not given print to stdout")
+    parser.add_argument("--algn", default=None, help="Alignment in sam format, if not given read from stdin")
+    parser.add_argument("--mod_model", default=None, help="Base modification pore model")
+    parser.add_argument("--config", help="Config file with HMM transition probabilities")
+    parser.add_argument("--t", type=int, default=1, help="Accepted for compatibility: the GPU batch replaces the worker processes")
+    parser.add_argument("--log_level", default='warning', choices=LEVELS, help="Log level")
+    parser.add_argument("--batch", type=int, default=2048, help="Reads per GPU batch")
+    parser.add_argument("--device", type=int, default=0, help="HIP device")
+    args = parser.parse_args(argv)
+    log = Log(args.log_level)
+    config = parse_config(args.repeat, args.config, log)
+    for path, what in ((args.f5Index, "Fast5 index file"), (args.model, "Pore model file")):
+        if not os.path.isfile(path):
+            log("Main: %s does not exist." % what, 'error'); raise SystemExit(1)
+    if args.mod_model and not os.path.isfile(args.mod_model):
+        log("Main: Modification pore model file does not exist.", 'error'); raise SystemExit(1)
+    from .counter import repeatCounter
+    counter = repeatCounter(args.model, mod_model_file=args.mod_model, align_config=config['align'],
+                            HMM_config=config['HMM'], device=args.device)
+    loci = defaultdict(list)
+    for name, (chrom, begin, end, repeat, prefix, suffix) in config['repeat'].items():
+        counter.add_target(name, repeat, prefix, suffix)
+        loci[chrom].append((name, begin, end))
+    f5 = Fast5Index(args.f5Index)
+    out = open(args.out, 'w') if args.out else sys.stdout
+    print('\t'.join(HEADER), file=out)
+
+    def flush(batch):
+        if not batch:
+            return
+        try:
+            results = counter.detect_batch([(t, raw, s) for _, t, s, raw in batch])
+        except Exception as e:                                    # a bad batch never kills the run
+            log("Detector: batch failed (%s), retrying read by read" % e, 'warning')
+            results = []
+            for _, t, s, raw in batch:
+                try:
+                    results.append(counter.detect(t, raw, s))
+                except Exception as e1:
+                    log("Detector: read failed: %s" % e1, 'warning'); results.append(None)
+        for (qname, target, strand, _), res in zip(batch, results):
+            if res is not None:
+                print('\t'.join(str(x) for x in (qname, target, strand) + tuple(res)), file=out)
+        out.flush()
+
+    batch = []
+    stream = open(args.algn) if args.algn else sys.stdin
+    for line in stream:
+        if line.startswith('@'):
+            continue
+        sr = decode_sam(line)
+        if not sr.QNAME:
+            log("Detector: Error parsing alignment \n%s" % line, 'error'); continue
+        strand = '+' if sr.FLAG & 0x10 == 0 else '-'
+        targets = intersect_targets(sr, loci)
+        if not targets:
+            log("Detector: No target for %s" % sr.QNAME, 'debug'); continue
+        try:
+            raw = f5.get_raw(sr.QNAME)
+        except Exception as e:
+            log("Detector: cannot read %s: %s" % (sr.QNAME, e), 'warning'); raw = None
+        if raw is None:
+            log("Detector: No fast5 for ID %s" % sr.QNAME, 'warning'); continue
+        for t in targets:
+            batch.append((sr.QNAME, t, strand, raw))
+        if len(batch) >= args.batch:
+            flush(batch); batch = []
+    flush(batch)
+    if args.out:
+        out.close()
+
+
+def index(argv):
+    parser = argparse.ArgumentParser(description="Fast5 raw data archive indexing")
+    parser.add_argument("input", help="Input batch or directory of batches")
+    parser.add_argument("--recursive", action='store_true', help="Recursively scan input")
+    parser.add_argument("--out_prefix", default="", help="Prefix for file paths in output")
+    parser.add_argument("--tmp_prefix", default=None, help="Prefix for temporary data")
+    args = parser.parse_args(argv)
+    for record in Fast5Index.index_records(args.input, recursive=args.recursive, out_prefix=args.out_prefix):
+        print(record)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    parser = argparse.ArgumentParser(description='STRique: a nanopore raw signal repeat detection pipeline (MI355X engine)',
+                                     usage='''STRique.py <command> [<args>]
+Available commands are:
+   index      Index batch(es) of bulk-fast5 or tar archived single fast5
+   count      Count single read repeat expansions
+''')
+    parser.add_argument('command', help='Subcommand to run')
+    args = parser.parse_args(argv[:1])
+    if args.command == 'count':
+        count(argv[1:])
+    elif args.command == 'index':
+        index(argv[1:])
+    else:
+        print('Unrecognized command', file=sys.stderr)
+        parser.print_help(file=sys.stderr)
+        raise SystemExit(1)
+
+
+if __name__ == '__main__':
+    main()
