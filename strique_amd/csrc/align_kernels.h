@@ -14,15 +14,19 @@ struct AlignParams {   // reference: scripts/STRique.py:507-523 -> src/align_raw
     float open_h, ext_h, open_v, ext_v, dist_offset, dist_min;
 };
 
-// read-only description of one alignment (flank x read)
+// read-only description of one strip of one alignment (flank x read)
 struct AlignTask {
-    const uint8_t* levels;   // n levels of the read (column j <-> levels[j-1]); 2-byte aligned
-    const float* table;      // k x (tw+1) banded scores; index 0 and tw-1 of each row hold dist_min
+    const uint8_t* levels;   // n levels of the read (column j <-> levels[j-1])
+    const float* table;      // k x (tw+1) banded scores of the classes this strip touches
     const int32_t* band_lo;  // k: level that maps to table index 0
-    const float* col0;       // m+1: S[i][0] (column 0 is not free)
-    float* ckpt;             // wavefront checkpoints of the forward pass
-    int32_t* rec;            // m: per flank row (j << 1) | is_vertical   (trace pass output)
-    int32_t n, m, k, tw;
+    const float* col0;       // m+1: S[row0 + i][0] (column 0 is not free)
+    float* ckpt;             // wavefront checkpoints of the forward pass (per strip)
+    int32_t* rec;            // m_total: per flank row (j << 1) | is_vertical   (trace pass output)
+    const float* bnd_in;     // {S, V} of row `row0` for columns 1..n (from the strip above) or null
+    float* bnd_out;          // {S, V} of this strip's last row for the strip below, or null
+    const AlignTask* up;     // task of the strip above (trace pass), or null
+    int32_t n, m, k, tw;     // columns; rows / classes of this strip; table width
+    int32_t row0, m_total;   // rows above this strip; rows of the whole flank
 };
 
 struct AlignResult {
@@ -35,11 +39,13 @@ struct AlignResult {
 static inline int align_num_steps(int n) { return (n + 1) / 2 + 63; }
 static inline int align_num_ckpts(int n) { return (align_num_steps(n) - 1) / STRQ_CKPT_STEPS; }
 
-int align_pick_rows_per_lane(int m, int samples);   // 0 if no compiled shape fits
+// rows per lane and number of strips for a flank of m rows; 0 if no compiled shape fits
+int align_plan(int m, int samples, int* rows_per_lane, int* n_strips);
 // phase 0 = forward, 1 = trace.  `queue`: one zero-initialised int per launch.
+// mode (forward only): bit 0 = strip has an input boundary, bit 1 = strip has an output boundary.
 int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* results,
                  int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
-                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase);
+                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode);
 size_t align_trace_scratch_words_per_wave(int R);
 int align_set_debug_buffer(int* host_pinned);   // debug only
 

@@ -5,8 +5,13 @@
 //           Score<float,Distance>::score + gap accessors (src/score_distance.h:115-122,140-226),
 //           i.e. the SeqAn2 globalAlignment(AlignConfig<true,false,false,true>, AffineGaps) call.
 //
-// Mapping (one wave64 per alignment, persistent waves, one per SIMD):
-//   * lane l owns rows [l*R, l*R+R) of the flank in registers (R rows per lane);
+// Mapping (persistent waves pulling tasks from a queue):
+//   * the flank rows are cut into strips of 64*R rows; a strip is one task of one wave64, and the
+//     strips of an alignment run in consecutive launches, the bottom row (S, V) of a strip being
+//     streamed through HBM to the next one (8 B per column).  Two strips per flank halve the score
+//     table each wave keeps in LDS, so two waves share a SIMD -- a single wave can issue only one
+//     VALU instruction per ~4 cycles on this chip;
+//   * lane l owns rows [l*R, l*R+R) of its strip in registers (R rows per lane);
 //   * the wave marches an anti-diagonal wavefront, two DP columns per lane per step (two
 //     independent dependency chains -> ILP 2 inside one wave): at step t lane l computes
 //     columns 2(t-l)-1 and 2(t-l).  Cross-lane traffic per step is the bottom cells of lane
@@ -24,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "align_kernels.h"
+#include <stdlib.h>
 
 namespace strq {
 
@@ -47,6 +53,12 @@ static __device__ __forceinline__ float dpp_shr1_f(float v, float fill)
 static __device__ __forceinline__ int dpp_shr1_i(int v, int fill)
 {
     return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false);
+}
+template <class T> static __device__ __forceinline__ const T* uniform_ptr(const T* p)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
 }
 static __device__ __forceinline__ int med3i(int a, int lo, int hi)
 {
@@ -130,6 +142,17 @@ static __device__ __forceinline__ void expand_scores(const float (&sc)[Shape<R, 
     }
 }
 
+// runtime-indexed read of x[rM] (rM wave-uniform, in an SGPR)
+template <int R>
+static __device__ __forceinline__ float pick_row(const float (&x)[R], int rM)
+{
+    typedef float vec_t __attribute__((ext_vector_type(R <= 16 ? 16 : 32)));
+    vec_t v;
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = x[r];
+    return v[rM];
+}
+
 struct TraceWords { uint64_t a[2], b[2]; };
 
 // Two DP columns (jA, jB) for this lane.
@@ -141,7 +164,8 @@ struct TraceWords { uint64_t a[2], b[2]; };
 template <int R, bool LH, bool LV, bool KEEP, bool TRACE>
 static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[R], const float (&rsB)[R],
                                                 float upA, float upB, float upVA, float upVB,
-                                                const AlignParams& p, TraceWords* tw)
+                                                const AlignParams& p, TraceWords* tw,
+                                                int rM, float* candA, float* candB)
 {
     float SA[R], SB[R];
     float HA[R], HB[R];
@@ -215,14 +239,15 @@ static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[
     st.SbotA = SA[R - 1];
     if constexpr (TRACE || !LV || KEEP) { st.VbotA = vA; st.VbotB = vB; }
     st.upS = upB;
+    if (candA) { *candA = pick_row<R>(SA, rM); *candB = pick_row<R>(SB, rM); }   // last flank row in an interior register
 }
 
 template <int R, int S>
 static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int lane, int lds_base,
                                                         LaneConst& lc, uint64_t (&pm)[Shape<R, S>::NMASK])
 {
-    const int row0 = lane * R;
-    const int kbase = row0 / S, phase = row0 % S;
+    const int row0 = tk.row0 + lane * R;                 // global (0-based) index of the lane's first row
+    const int kbase = row0 / S - tk.row0 / S, phase = row0 % S;
     const int tstride = tk.tw + 1;
 #pragma unroll
     for (int c = 0; c < Shape<R, S>::C; ++c) {
@@ -233,7 +258,12 @@ static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int
         lc.off[c] = lds_base + k * tstride * 4 - lo * 4;
     }
 #pragma unroll
-    for (int x = 0; x < Shape<R, S>::NMASK; ++x) pm[x] = __ballot(phase >= S - x * Shape<R, S>::G);
+    for (int x = 0; x < Shape<R, S>::NMASK; ++x) {
+        const uint64_t b = __ballot(phase >= S - x * Shape<R, S>::G);
+        // keep the mask in an SGPR pair whatever the compiler thinks of the surrounding control flow
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+        pm[x] = ((uint64_t)hi << 32) | lo;
+    }
 }
 
 // stage the banded score table of one alignment into this wave's LDS slice
@@ -267,6 +297,17 @@ static __device__ __forceinline__ int load_chunk(const AlignTask& tk, int chunk,
     return (a << 2) | (b << 18);
 }
 
+// boundary {S, V} of the row above the strip for columns 2*(64*chunk+lane)+1 and +2
+struct Bnd4 { float sA, vA, sB, vB; };
+static __device__ __forceinline__ Bnd4 load_bnd(const AlignTask& tk, int chunk, int lane)
+{
+    const int idx = (chunk * 64 + lane) * 2;          // column idx+1 -> entry idx
+    Bnd4 b{0.0f, STRQ_NINF, 0.0f, STRQ_NINF};
+    if (idx < tk.n) { b.sA = tk.bnd_in[2 * idx]; b.vA = tk.bnd_in[2 * idx + 1]; }
+    if (idx + 1 < tk.n) { b.sB = tk.bnd_in[2 * idx + 2]; b.vB = tk.bnd_in[2 * idx + 3]; }
+    return b;
+}
+
 template <int R>
 static __device__ __forceinline__ void save_ckpt(float* c, int lane, const Lane<R>& st)
 {
@@ -292,22 +333,14 @@ static __device__ __forceinline__ void load_ckpt(const float* c, int lane, Lane<
     st.upS = c[(2 * R + 3) * 64 + lane];
 }
 
-// runtime-indexed read of x[rM] (rM wave-uniform, in an SGPR)
-template <int R>
-static __device__ __forceinline__ float pick_row(const float (&x)[R], int rM)
-{
-    typedef float vec_t __attribute__((ext_vector_type(R <= 16 ? 16 : 32)));
-    vec_t v;
-#pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = x[r];
-    return v[rM];
-}
-
 // ------------------------------------------------------------------------------------------
 // forward pass: best score of the last flank row, its column, and wavefront checkpoints
 // ------------------------------------------------------------------------------------------
-template <int R, int S, bool LH, bool LV, bool RM_LAST>
+// MODE: which boundaries the strip has.  bit 0: input from the strip above (else the free top row),
+//       bit 1: output to the strip below (else this strip holds the last flank row and tracks the best).
+template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST>
 struct Forward {
+    static constexpr bool HAS_IN = (MODE & 1) != 0, HAS_OUT = (MODE & 2) != 0;
     const AlignTask& tk;
     const AlignParams& p;
     const char* ldsb;
@@ -317,16 +350,26 @@ struct Forward {
     Lane<R> st;
     float best; int bestj;
     int qq;
+    Bnd4 bcur;
 
     // PRED: lanes may be idle (before their first / after their last column)
     template <bool PRED, bool KEEP>
-    __device__ __forceinline__ void step(int t, int qin)
+    __device__ __forceinline__ void step(int t, int s, int qcur)
     {
-        qq = dpp_shr1_i(qq, qin);
-        const float upA = dpp_shr1_f(st.SbotA, 0.0f);
-        const float upB = dpp_shr1_f(st.S[R - 1], 0.0f);
+        qq = dpp_shr1_i(qq, __builtin_amdgcn_readlane(qcur, s));
+        float fA = 0.0f, fB = 0.0f, fVA = STRQ_NINF, fVB = STRQ_NINF;
+        if constexpr (HAS_IN) {
+            fA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.sA), s));
+            fB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.sB), s));
+            if constexpr (!LV) {
+                fVA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.vA), s));
+                fVB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.vB), s));
+            }
+        }
+        const float upA = dpp_shr1_f(st.SbotA, fA);
+        const float upB = dpp_shr1_f(st.S[R - 1], fB);
         float upVA = STRQ_NINF, upVB = STRQ_NINF;
-        if constexpr (!LV) { upVA = dpp_shr1_f(st.VbotA, STRQ_NINF); upVB = dpp_shr1_f(st.VbotB, STRQ_NINF); }
+        if constexpr (!LV) { upVA = dpp_shr1_f(st.VbotA, fVA); upVB = dpp_shr1_f(st.VbotB, fVB); }
         const int jB = 2 * (t - lane), jA = jB - 1;
         bool act = true;
         if constexpr (PRED) act = (jA >= 1) && (jA <= tk.n);
@@ -336,85 +379,81 @@ struct Forward {
             fetch_scores<R, S>(ldsb, lc, (int)((unsigned)qq >> 16), scB);
             expand_scores<R, S>(scA, pm, rsA);
             expand_scores<R, S>(scB, pm, rsB);
-            float candA, candB;
-            if constexpr (RM_LAST) {
-                dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr);
-                candA = st.SbotA;
-                candB = st.S[R - 1];
-            } else {
-                // the last flank row sits in an interior register: column A is not retained by the
-                // state, so redo column A alone from a copy (rare shapes only)
-                const Lane<R> before = st;
-                dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr);
-                float SAonly[R];
-                float up = upA, vA = upVA;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float diag = r == 0 ? before.upS : before.S[r > 0 ? r - 1 : 0];
-                    const float D = diag + rsA[r];
-                    float Hn, Vn;
-                    if constexpr (LH) Hn = before.S[r] + p.ext_h;
-                    else Hn = __builtin_fmaxf(before.H[r] + p.ext_h, before.S[r] + p.open_h);
-                    if constexpr (LV) Vn = up + p.ext_v;
-                    else Vn = __builtin_fmaxf(vA + p.ext_v, up + p.open_v);
-                    SAonly[r] = __builtin_fmaxf(__builtin_fmaxf(D, Hn), Vn);
-                    up = SAonly[r]; vA = Vn;
-                }
-                candA = pick_row<R>(SAonly, rM);
-                candB = pick_row<R>(st.S, rM);
-            }
-            if (candA > best) { best = candA; bestj = jA; }
             bool okB = true;
             if constexpr (PRED) okB = jB <= tk.n;
-            if (okB && candB > best) { best = candB; bestj = jB; }
+            if constexpr (HAS_OUT) {
+                // the strip below needs S and V of this strip's last row (lane 63, register R-1);
+                // KEEP materialises V in the collapsed recurrence at no extra arithmetic
+                dp_step2<R, LH, LV, true, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, 0, nullptr, nullptr);
+                if (lane == 63) {
+                    float* o = tk.bnd_out + 2 * (size_t)(jA - 1);
+                    o[0] = st.SbotA; o[1] = st.VbotA;
+                    if (okB) { o[2] = st.S[R - 1]; o[3] = st.VbotB; }
+                }
+            } else {
+                float candA, candB;
+                if constexpr (RM_LAST) {
+                    dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, 0, nullptr, nullptr);
+                    candA = st.SbotA; candB = st.S[R - 1];
+                } else {
+                    dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, rM, &candA, &candB);
+                }
+                if (candA > best) { best = candA; bestj = jA; }
+                if (okB && candB > best) { best = candB; bestj = jB; }
+            }
         }
     }
 };
 
-template <int R, int S, bool LH, bool LV, bool RM_LAST>
+template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST>
 static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignResult* res, const AlignParams& p,
                                                    float* lds, int lds_base, const char* ldsb, int lane)
 {
+    constexpr bool HAS_IN = (MODE & 1) != 0, HAS_OUT = (MODE & 2) != 0;
     stage_table(tk, lds, lane);
     LaneConst lc; uint64_t pm[Shape<R, S>::NMASK];
     load_lane_consts<R, S>(tk, lane, lds_base, lc, pm);
     const int lM = (tk.m - 1) / R, rM = (tk.m - 1) % R;
-    Forward<R, S, LH, LV, RM_LAST> f{tk, p, ldsb, lc, pm, lane, rM};
+    Forward<R, S, LH, LV, MODE, RM_LAST> f{tk, p, ldsb, lc, pm, lane, rM};
     init_lane<R>(tk, lane, f.st);
     f.best = tk.col0[tk.m]; f.bestj = 0; f.qq = 0;
     __builtin_amdgcn_s_waitcnt(0);   // LDS table written by this wave is visible to it
 
     const int nsteps = (tk.n + 1) / 2 + 63;
     int qcur = load_chunk(tk, 0, lane);
+    Bnd4 bnext{0.0f, STRQ_NINF, 0.0f, STRQ_NINF};
+    if constexpr (HAS_IN) f.bcur = load_bnd(tk, 0, lane); else f.bcur = bnext;
     for (int t0 = 0; t0 < nsteps; t0 += 64) {
-        STRQ_MARK(3, t0 + 1);
         const int qnext = load_chunk(tk, t0 / 64 + 1, lane);   // prefetch next 128 columns
+        if constexpr (HAS_IN) bnext = load_bnd(tk, t0 / 64 + 1, lane);
         // every lane busy with two valid columns for all 64 steps?
         const bool full = (t0 >= 63) && (2 * (t0 + 64) <= tk.n);
         const bool ckpt_here = ((t0 + 64) % STRQ_CKPT_STEPS) == 0 && (t0 + 64) < nsteps;
         const int send = nsteps - t0 < 64 ? nsteps - t0 : 64;
         if (full) {
-            for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, __builtin_amdgcn_readlane(qcur, s));
-            if (ckpt_here) f.template step<false, true>(t0 + 64, __builtin_amdgcn_readlane(qcur, 63));
-            else f.template step<false, false>(t0 + 64, __builtin_amdgcn_readlane(qcur, 63));
+            for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, s, qcur);
+            if (ckpt_here) f.template step<false, true>(t0 + 64, 63, qcur);
+            else f.template step<false, false>(t0 + 64, 63, qcur);
         } else {
             for (int s = 0; s < send; ++s) {
-                if (ckpt_here && s == 63) f.template step<true, true>(t0 + s + 1, __builtin_amdgcn_readlane(qcur, s));
-                else f.template step<true, false>(t0 + s + 1, __builtin_amdgcn_readlane(qcur, s));
+                if (ckpt_here && s == 63) f.template step<true, true>(t0 + s + 1, s, qcur);
+                else f.template step<true, false>(t0 + s + 1, s, qcur);
             }
         }
         if (ckpt_here)
             save_ckpt<R>(tk.ckpt + (size_t)((t0 + 64) / STRQ_CKPT_STEPS - 1) * (STRQ_CKPT_FIELDS(R) * 64), lane, f.st);
         qcur = qnext;
+        if constexpr (HAS_IN) f.bcur = bnext;
     }
-    STRQ_MARK(4, 1);
-    const float b = __shfl(f.best, lM, 64);
-    const int bj = __shfl(f.bestj, lM, 64);
-    res->best = b; res->j_end = bj;   // every lane stores the same value
+    if constexpr (!HAS_OUT) {
+        const float b = __shfl(f.best, lM, 64);
+        const int bj = __shfl(f.bestj, lM, 64);
+        res->best = b; res->j_end = bj;   // every lane stores the same value
+    }
 }
 
-template <int R, int S, bool LH, bool LV>
-__global__ void __launch_bounds__(384, 1)
+template <int R, int S, bool LH, bool LV, int MODE>
+__global__ void __launch_bounds__(640, 2)
 align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
                      int* __restrict__ queue, AlignParams p, int lds_floats_per_wave)
 {
@@ -427,9 +466,11 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
         const int ti = next_task(queue, lane);
         if (ti >= n_tasks) break;
         const AlignTask& tk = tasks[ti];
-        STRQ_MARK(0, ti + 1); STRQ_MARK(1, tk.n); STRQ_MARK(2, tk.m);
-        if ((tk.m - 1) % R == R - 1) forward_one<R, S, LH, LV, true>(tk, results + ti, p, lds, lds_base, ldsb, lane);
-        else forward_one<R, S, LH, LV, false>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+        if constexpr ((MODE & 2) != 0) forward_one<R, S, LH, LV, MODE, true>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+        else {
+            if ((tk.m - 1) % R == R - 1) forward_one<R, S, LH, LV, MODE, true>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+            else forward_one<R, S, LH, LV, MODE, false>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+        }
     }
 }
 
@@ -438,7 +479,7 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
 // walk back, and emit one record per flank row.
 // ------------------------------------------------------------------------------------------
 template <int R, int S>
-__global__ void __launch_bounds__(384, 1)
+__global__ void __launch_bounds__(640, 2)
 align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
                    int* __restrict__ queue, AlignParams p, int lds_floats_per_wave,
                    uint64_t* __restrict__ scratch_all)
@@ -455,18 +496,31 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
     for (;;) {
         const int ti = next_task(queue, lane);
         if (ti >= n_tasks) break;
-        const AlignTask& tk = tasks[ti];
-        int32_t* rec = tk.rec;
-
-        stage_table(tk, lds, lane);
+        const AlignTask* cur = &tasks[ti];             // the strip that holds the last flank row
+        const AlignTask* staged = nullptr;
+        int32_t* rec = cur->rec;
         LaneConst lc; uint64_t pm[Shape<R, S>::NMASK];
-        load_lane_consts<R, S>(tk, lane, lds_base, lc, pm);
-        __builtin_amdgcn_s_waitcnt(0);
 
-        int ci = tk.m, cj = results[ti].j_end, state = 0;     // walker position (wave-uniform)
+        int ci = cur->m_total, cj = __builtin_amdgcn_readfirstlane(results[ti].j_end), state = 0;     // walker position (wave-uniform)
         while (ci > 0 && cj > 0) {
+            while (ci <= cur->row0) cur = uniform_ptr(cur->up);       // the strip that holds row ci
+            if (cur != staged) {
+                __builtin_amdgcn_s_waitcnt(0);
+                stage_table(*cur, lds, lane);
+                load_lane_consts<R, S>(*cur, lane, lds_base, lc, pm);
+                __builtin_amdgcn_s_waitcnt(0);
+                staged = cur;
+            }
+            const AlignTask& tk = *cur;
+            const bool has_in = tk.bnd_in != nullptr;
+            uint64_t pmu[Shape<R, S>::NMASK];       // lane masks, re-pinned to SGPRs inside this (data dependent) loop
+#pragma unroll
+            for (int x = 0; x < Shape<R, S>::NMASK; ++x) {
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)pm[x]), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(pm[x] >> 32));
+                pmu[x] = ((uint64_t)hi << 32) | lo;
+            }
             // step at which the walker's current cell was computed
-            const int tcur = (ci - 1) / R + (cj + 1) / 2;
+            const int tcur = (ci - tk.row0 - 1) / R + (cj + 1) / 2;
             const int blk = (tcur - 1) / STRQ_CKPT_STEPS;
             const int tb = blk * STRQ_CKPT_STEPS;          // state after step tb is the restart point
             Lane<R> st;
@@ -482,25 +536,32 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
                 qq = (a << 2) | (b << 18);
             }
             int qcur = load_chunk(tk, tb / 64, lane);
+            Bnd4 bcur{0.0f, STRQ_NINF, 0.0f, STRQ_NINF}, bnext = bcur;
+            if (has_in) bcur = load_bnd(tk, tb / 64, lane);
             for (int t0 = tb; t0 < tcur; t0 += 64) {
                 const int qnext = load_chunk(tk, t0 / 64 + 1, lane);
+                if (has_in) bnext = load_bnd(tk, t0 / 64 + 1, lane);
                 const int send = tcur - t0 < 64 ? tcur - t0 : 64;
                 for (int s = 0; s < send; ++s) {
                     const int t = t0 + s + 1;
                     qq = dpp_shr1_i(qq, __builtin_amdgcn_readlane(qcur, s));
-                    const float upA = dpp_shr1_f(st.SbotA, 0.0f);
-                    const float upB = dpp_shr1_f(st.S[R - 1], 0.0f);
-                    const float upVA = dpp_shr1_f(st.VbotA, STRQ_NINF);
-                    const float upVB = dpp_shr1_f(st.VbotB, STRQ_NINF);
+                    const float fA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.sA), s));
+                    const float fB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.sB), s));
+                    const float fVA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.vA), s));
+                    const float fVB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.vB), s));
+                    const float upA = dpp_shr1_f(st.SbotA, fA);
+                    const float upB = dpp_shr1_f(st.S[R - 1], fB);
+                    const float upVA = dpp_shr1_f(st.VbotA, fVA);
+                    const float upVB = dpp_shr1_f(st.VbotB, fVB);
                     const int jB = 2 * (t - lane), jA = jB - 1;
                     TraceWords w; w.a[0] = w.a[1] = w.b[0] = w.b[1] = 0;
                     if (jA >= 1 && jA <= tk.n) {
                         float scA[Shape<R, S>::C], scB[Shape<R, S>::C], rsA[R], rsB[R];
                         fetch_scores<R, S>(ldsb, lc, qq & 0xffff, scA);
                         fetch_scores<R, S>(ldsb, lc, (int)((unsigned)qq >> 16), scB);
-                        expand_scores<R, S>(scA, pm, rsA);
-                        expand_scores<R, S>(scB, pm, rsB);
-                        dp_step2<R, false, false, true, true>(st, rsA, rsB, upA, upB, upVA, upVB, p, &w);
+                        expand_scores<R, S>(scA, pmu, rsA);
+                        expand_scores<R, S>(scB, pmu, rsB);
+                        dp_step2<R, false, false, true, true>(st, rsA, rsB, upA, upB, upVA, upVB, p, &w, 0, nullptr, nullptr);
                     }
                     uint64_t* dst = scratch + (size_t)(t - tb - 1) * STEP_WORDS;
 #pragma unroll
@@ -509,12 +570,13 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
                         dst[(1 * W + x) * 64 + lane] = w.b[x];
                     }
                 }
-                qcur = qnext;
+                qcur = qnext; bcur = bnext;
             }
             __threadfence();   // the walker below reads words written by other lanes of this wave
-            // walk back while the current cell lies inside this block
-            while (ci > 0 && cj > 0) {
-                const int l = (ci - 1) / R, r = (ci - 1) % R;
+            // walk back while the current cell lies inside this strip and this block
+            while (ci > tk.row0 && cj > 0) {
+                const int il = ci - tk.row0;
+                const int l = (il - 1) / R, r = (il - 1) % R;
                 const int t = l + (cj + 1) / 2;
                 if (t <= tb) break;
                 const int colsel = (cj & 1) ? 0 : 1;
@@ -544,17 +606,22 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
 template <int R, int S>
 static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult* results, int n_tasks,
                         int* queue, const AlignParams& p, int lds_floats_per_wave, int waves_per_block,
-                        int n_blocks, uint64_t* scratch, int phase)
+                        int n_blocks, uint64_t* scratch, int phase, int mode)
 {
     const size_t lds_bytes = (size_t)lds_floats_per_wave * 4 * waves_per_block;
     const dim3 grid(n_blocks), block(64 * waves_per_block);
     const bool lh = p.open_h == p.ext_h, lv = p.open_v == p.ext_v;
+#define STRQ_FWD1(LH_, LV_, MODE_)                                                                      \
+    do {                                                                                                \
+        (void)hipFuncSetAttribute((const void*)align_forward_kernel<R, S, LH_, LV_, MODE_>,             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);          \
+        hipLaunchKernelGGL((align_forward_kernel<R, S, LH_, LV_, MODE_>), grid, block, lds_bytes, stream,\
+                           tasks, results, n_tasks, queue, p, lds_floats_per_wave);                     \
+    } while (0)
 #define STRQ_FWD(LH_, LV_)                                                                              \
     do {                                                                                                \
-        (void)hipFuncSetAttribute((const void*)align_forward_kernel<R, S, LH_, LV_>,                    \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);          \
-        hipLaunchKernelGGL((align_forward_kernel<R, S, LH_, LV_>), grid, block, lds_bytes, stream,       \
-                           tasks, results, n_tasks, queue, p, lds_floats_per_wave);                     \
+        if (mode == 0) STRQ_FWD1(LH_, LV_, 0); else if (mode == 1) STRQ_FWD1(LH_, LV_, 1);              \
+        else if (mode == 2) STRQ_FWD1(LH_, LV_, 2); else STRQ_FWD1(LH_, LV_, 3);                        \
     } while (0)
     if (phase == 0) {
         if (lh && lv) STRQ_FWD(true, true);
@@ -568,22 +635,32 @@ static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult*
                            n_tasks, queue, p, lds_floats_per_wave, scratch);
     }
 #undef STRQ_FWD
+#undef STRQ_FWD1
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-#define STRQ_SHAPES(X) X(6, 6) X(12, 6) X(15, 6) X(18, 6) X(24, 6)
+#define STRQ_SHAPES(X) X(6, 6) X(7, 6) X(8, 6) X(12, 6) X(15, 6)
 
 int align_set_debug_buffer(int* p)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_strq_dbg), &p, sizeof(p)) == hipSuccess ? 0 : 1;
 }
 
-int align_pick_rows_per_lane(int m, int samples)
+// Rows per lane R and number of strips for a flank of m rows.
+int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
 {
     if (samples != 6 || m < 1) return 0;
-    // 870 = 58 lanes x 15 rows: last flank row lands in the last register of its lane
-    const int cand[] = {6, 12, 15, 18, 24};
-    for (int r : cand) if (64 * r >= m) return r;
+    // Measured on MI355X (50 kb reads, 870-row flanks): two strips at two waves per SIMD take as long
+    // as one strip at one wave per SIMD -- the per-step overhead is amortised over half the rows --
+    // so one strip is preferred whenever a single-strip shape fits.  STRQ_STRIPS=2 forces two.
+    const char* e = getenv("STRQ_STRIPS");
+    const bool force_two = e && e[0] == '2';
+    const int single[] = {6, 7, 8, 12, 15};
+    const int two[] = {6, 7, 8, 12};
+    if (!force_two)
+        for (int r : single) if (64 * r >= m) { *rows_per_lane = r; *n_strips = 1; return r; }
+    for (int r : two) if (64 * r < m && 128 * r >= m) { *rows_per_lane = r; *n_strips = 2; return r; }
+    for (int r : single) if (64 * r >= m) { *rows_per_lane = r; *n_strips = 1; return r; }
     return 0;
 }
 
@@ -594,12 +671,12 @@ size_t align_trace_scratch_words_per_wave(int R)
 
 int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* results,
                  int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
-                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase)
+                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode)
 {
 #define STRQ_CASE(R_, S_)                                                                               \
     if (R == R_ && S == S_)                                                                             \
         return launch_shape<R_, S_>(stream, tasks, results, n_tasks, queue, p, lds_floats_per_wave,     \
-                                    waves_per_block, n_blocks, scratch, phase);
+                                    waves_per_block, n_blocks, scratch, phase, mode);
     STRQ_SHAPES(STRQ_CASE)
 #undef STRQ_CASE
     return 2;

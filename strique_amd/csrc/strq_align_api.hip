@@ -8,6 +8,7 @@
 #include <time.h>
 #include <unistd.h>
 #include <map>
+#include <tuple>
 #include <numeric>
 #include <vector>
 #include "../../include/strique_hip.h"
@@ -57,8 +58,8 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
 {
     const int nb = in.nb, S = in.samples;
     hipStream_t st = c->stream;
-    size_t cls_tot = 0, col0_tot = 0, rec_tot = 0, tab_tot = 0, ck_floats = 0;
-    std::vector<size_t> cls_off(nb), col0_off(nb), tab_off(nb), ck_off(nb);
+    size_t cls_tot = 0, col0_tot = 0, rec_tot = 0, tab_tot = 0, ck_floats = 0, bnd_floats = 0;
+    std::vector<size_t> cls_off(nb), col0_off(nb), tab_off(nb), ck_off(nb), bnd_off(nb);
     out.rec_off.assign(nb, 0);
     int max_k = 0;
     for (int i = 0; i < nb; ++i) {
@@ -66,7 +67,8 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         col0_off[i] = col0_tot; col0_tot += in.m[i] + 1;
         out.rec_off[i] = rec_tot; rec_tot += in.m[i];
         tab_off[i] = tab_tot; tab_tot += STRQ_TABLE_SLOT_FLOATS(in.k[i]);
-        ck_off[i] = ck_floats; ck_floats += (size_t)align_num_ckpts(in.n[i]) * STRQ_CKPT_FIELDS(in.R[i]) * 64;
+        ck_off[i] = ck_floats; ck_floats += (size_t)in.NS[i] * align_num_ckpts(in.n[i]) * STRQ_CKPT_FIELDS(in.R[i]) * 64;
+        bnd_off[i] = bnd_floats; if (in.NS[i] > 1) bnd_floats += (size_t)(in.NS[i] - 1) * 2 * ((size_t)in.n[i] + 2);
         max_k = std::max(max_k, in.k[i]);
     }
     out.rec_total = rec_tot;
@@ -81,16 +83,17 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, c->band_lo.reserve(cls_tot * 4));
     STRQ_HIP(c, c->tables.reserve(tab_tot * 4));
     STRQ_HIP(c, c->ckpt.reserve(ck_floats * 4 + 256));
+    STRQ_HIP(c, c->bnd.reserve(bnd_floats * 4 + 256));
     STRQ_HIP(c, c->rec.reserve(rec_tot * 4 + 256));
-    STRQ_HIP(c, c->tasks.reserve((size_t)nb * sizeof(AlignTask)));
+    STRQ_HIP(c, c->tasks.reserve((size_t)nb * 2 * sizeof(AlignTask)));
     STRQ_HIP(c, c->results.reserve((size_t)nb * sizeof(AlignResult)));
     STRQ_HIP(c, c->lutinfo.reserve((size_t)nb * (sizeof(LutJob) + sizeof(LutInfo))));
     const int hard_cap = 1 << 16;
     STRQ_HIP(c, c->hard.reserve((size_t)hard_cap * (sizeof(HardEntry) + 4) + 64));
-    STRQ_HIP(c, c->queue.reserve(256));
+    STRQ_HIP(c, c->queue.reserve(1024));
     STRQ_HIP(c, hipMemcpyAsync(c->flank_cls.p, h_cls.data(), cls_tot * 4, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(c->col0.p, h_col0.data(), col0_tot * 4, hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
+    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
 
     // ---- score tables
     std::vector<LutJob> jobs(nb);
@@ -106,7 +109,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipMemcpyAsync(d_jobs, jobs.data(), (size_t)nb * sizeof(LutJob), hipMemcpyHostToDevice, st));
     HardEntry* d_hard = c->hard.as<HardEntry>();
     float* d_hard_vals = reinterpret_cast<float*>(d_hard + hard_cap);
-    int* d_hard_count = c->queue.as<int>() + 32;
+    int* d_hard_count = c->queue.as<int>() + 224;
     STRQ_HIP(c, hipEventRecord(c->ev[0], st));
     if (launch_lut_build(st, d_jobs, d_info, nb, max_k, d_hard, d_hard_count, hard_cap, c->ap)) { c->err = "lut launch failed"; return STRQ_ERR_DEVICE; }
     STRQ_HIP(c, hipEventRecord(c->ev[1], st));
@@ -155,57 +158,97 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     }
     out.n_hard = hard_count;
 
-    // ---- tasks, grouped by (R, table width class), longest first
-    std::vector<AlignTask> tasks(nb);
-    std::map<std::pair<int, int>, std::vector<int>> groups;
-    for (int i = 0; i < nb; ++i) groups[{in.R[i], info[i].tw}].push_back(i);
+    // ---- tasks.  Alignments are grouped by (rows per lane, strips, table width), longest first.
+    // Layout of the task array: [last strips of every alignment, in result order][first strips of
+    // the two-strip alignments]; results / finalize address the first part.
+    std::map<std::tuple<int, int, int>, std::vector<int>> groups;
+    for (int i = 0; i < nb; ++i) groups[std::make_tuple(in.R[i], in.NS[i], info[i].tw)].push_back(i);
     out.order.clear(); out.order.reserve(nb);
-    struct Launch { int R, tw, first, count; };
+    struct Launch { int R, NS, tw, first, count, first_up; };
     std::vector<Launch> launches;
+    int n_up = 0;
     for (auto& g : groups) {
         auto& v = g.second;
         std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return in.n[x] > in.n[y]; });
-        launches.push_back({g.first.first, g.first.second, (int)out.order.size(), (int)v.size()});
+        const int NS = std::get<1>(g.first);
+        launches.push_back({std::get<0>(g.first), NS, std::get<2>(g.first), (int)out.order.size(), (int)v.size(), nb + n_up});
         out.order.insert(out.order.end(), v.begin(), v.end());
+        if (NS > 1) n_up += (int)v.size();
     }
-    for (auto& L : launches) STRQ_DBG("launch group R=%d tw=%d count=%d", L.R, L.tw, L.count);
-    for (int pos = 0; pos < nb; ++pos) {
-        const int i = out.order[pos];
-        AlignTask& t = tasks[pos];
-        t.levels = in.d_levels + in.read_off[in.read[i]];
-        t.table = jobs[i].table; t.band_lo = jobs[i].band_lo;
-        t.col0 = c->col0.as<float>() + col0_off[i];
-        t.ckpt = c->ckpt.as<float>() + ck_off[i];
-        t.rec = c->rec.as<int32_t>() + out.rec_off[i];
-        t.n = in.n[i]; t.m = in.m[i]; t.k = in.k[i]; t.tw = info[i].tw;
-    }
+    std::vector<AlignTask> tasks((size_t)nb + n_up);
     AlignTask* d_tasks = c->tasks.as<AlignTask>();
     AlignResult* d_res = c->results.as<AlignResult>();
-    STRQ_HIP(c, hipMemcpyAsync(d_tasks, tasks.data(), (size_t)nb * sizeof(AlignTask), hipMemcpyHostToDevice, st));
+    for (auto& L : launches) {
+        for (int x = 0; x < L.count; ++x) {
+            const int pos = L.first + x, i = out.order[pos];
+            const int R = in.R[i], M = in.m[i], tstride = info[i].tw + 1;
+            const size_t ck_per_strip = (size_t)align_num_ckpts(in.n[i]) * STRQ_CKPT_FIELDS(R) * 64;
+            AlignTask base; std::memset(&base, 0, sizeof(base));
+            base.levels = in.d_levels + in.read_off[in.read[i]];
+            base.rec = c->rec.as<int32_t>() + out.rec_off[i];
+            base.n = in.n[i]; base.tw = info[i].tw; base.m_total = M;
+            auto strip = [&](int row0, int rows, int sidx) {
+                AlignTask t = base;
+                const int k0 = row0 / S, k1 = (row0 + rows - 1) / S;
+                t.row0 = row0; t.m = rows; t.k = k1 - k0 + 1;
+                t.table = jobs[i].table + (size_t)k0 * tstride; t.band_lo = jobs[i].band_lo + k0;
+                t.col0 = c->col0.as<float>() + col0_off[i] + row0;
+                t.ckpt = c->ckpt.as<float>() + ck_off[i] + (size_t)sidx * ck_per_strip;
+                return t;
+            };
+            if (L.NS == 1) tasks[pos] = strip(0, M, 0);
+            else {
+                const int rows0 = 64 * R;
+                AlignTask top = strip(0, rows0, 0), bot = strip(rows0, M - rows0, 1);
+                float* bnd = c->bnd.as<float>() + bnd_off[i];
+                top.bnd_out = bnd; bot.bnd_in = bnd;
+                bot.up = d_tasks + L.first_up + x;
+                tasks[pos] = bot; tasks[(size_t)L.first_up + x] = top;
+            }
+        }
+    }
+    STRQ_HIP(c, hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(AlignTask), hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemsetAsync(d_res, 0, (size_t)nb * sizeof(AlignResult), st));
     size_t scratch_words = 0;
     for (auto& L : launches) scratch_words = std::max(scratch_words, align_trace_scratch_words_per_wave(L.R));
-    STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * 6));
+    int max_wpb = 10;
+    if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 10) max_wpb = v; }
+    STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * max_wpb));
     int qi = 0;
+    auto lds_plan = [&](const AlignTask* t, int count, int tw, int* lds_floats, int* wpb) {
+        int max_kk = 0;
+        for (int x = 0; x < count; ++x) max_kk = std::max(max_kk, t[x].k);
+        *lds_floats = max_kk * (tw + 1);
+        int w = (160 * 1024) / (*lds_floats * 4);
+        if (w > max_wpb) w = max_wpb;
+        *wpb = w;
+    };
     STRQ_HIP(c, hipEventRecord(c->ev[2], st));
-    for (int phase = 0; phase < 2; ++phase) {
+    out.n_launches = 0;
+    for (int level = 0; level < 2; ++level) {          // first strips, then the strips below them
         for (auto& L : launches) {
-            int max_kk = 0;
-            for (int x = 0; x < L.count; ++x) max_kk = std::max(max_kk, tasks[L.first + x].k);
-            const int lds_floats = max_kk * (L.tw + 1);
-            int wpb = (160 * 1024) / (lds_floats * 4);
+            if (level == 1 && L.NS == 1) continue;
+            const AlignTask* ht = level == 0 && L.NS > 1 ? &tasks[L.first_up] : &tasks[L.first];
+            const AlignTask* dt = level == 0 && L.NS > 1 ? d_tasks + L.first_up : d_tasks + L.first;
+            const int mode = L.NS == 1 ? 0 : (level == 0 ? 2 : 1);
+            int lds_floats, wpb; lds_plan(ht, L.count, L.tw, &lds_floats, &wpb);
             if (wpb < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
-            if (wpb > 6) wpb = 6;
-            if (launch_align(st, L.R, S, d_tasks + L.first, d_res + L.first, L.count, c->queue.as<int>() + qi,
-                             c->ap, lds_floats, wpb, c->n_cu, c->scratch.as<uint64_t>(), phase)) {
-                c->err = "align launch failed"; return STRQ_ERR_DEVICE;
-            }
-            ++qi;
+            STRQ_DBG("forward launch R=%d strips=%d tw=%d level=%d count=%d waves/CU=%d", L.R, L.NS, L.tw, level, L.count, wpb);
+            if (launch_align(st, L.R, S, dt, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, lds_floats, wpb, c->n_cu,
+                             c->scratch.as<uint64_t>(), 0, mode)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
+            ++qi; ++out.n_launches;
         }
-        STRQ_HIP(c, hipEventRecord(c->ev[3 + phase], st));
     }
+    STRQ_HIP(c, hipEventRecord(c->ev[3], st));
+    for (auto& L : launches) {
+        int lds_floats, wpb; lds_plan(&tasks[L.first], L.count, L.tw, &lds_floats, &wpb);
+        if (L.NS > 1) { int l2, w2; lds_plan(&tasks[L.first_up], L.count, L.tw, &l2, &w2); lds_floats = std::max(lds_floats, l2); wpb = std::min(wpb, w2); }
+        if (launch_align(st, L.R, S, d_tasks + L.first, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, lds_floats, wpb, c->n_cu,
+                         c->scratch.as<uint64_t>(), 1, 0)) { c->err = "trace launch failed"; return STRQ_ERR_DEVICE; }
+        ++qi;
+    }
+    STRQ_HIP(c, hipEventRecord(c->ev[4], st));
     out.d_tasks = d_tasks; out.d_results = d_res; out.d_rec = c->rec.as<int32_t>();
-    out.n_launches = (int)launches.size();
     return STRQ_OK;
 }
 
@@ -218,14 +261,22 @@ int align_core_times(strq_ctx* c, float* t_lut, float* t_fwd, float* t_tr)
     return STRQ_OK;
 }
 
-int align_validate_flank(strq_ctx* c, const float* f, int64_t mm, int S, int* k_out, int* R_out)
+size_t align_workspace_bytes(int n, int m, int R, int NS)
+{
+    size_t b = (size_t)NS * align_num_ckpts(n) * STRQ_CKPT_FIELDS(R) * 64 * 4;
+    if (NS > 1) b += (size_t)(NS - 1) * ((size_t)n + 2) * 8;
+    (void)m;
+    return b;
+}
+
+int align_validate_flank(strq_ctx* c, const float* f, int64_t mm, int S, int* k_out, int* R_out, int* NS_out)
 {
     if (mm < 1 || S < 1 || mm % S != 0) { c->err = "flank length must be a positive multiple of `samples`"; return STRQ_ERR_UNSUPPORTED; }
     for (int64_t i = 0; i < mm; ++i)
         if (std::memcmp(&f[i], &f[i - i % S], 4) != 0) { c->err = "flank is not made of runs of `samples` equal values"; return STRQ_ERR_UNSUPPORTED; }
-    const int R = align_pick_rows_per_lane((int)mm, S);
-    if (!R || mm / S > STRQ_LUT_MAX_K) { c->err = "flank shape not covered by the compiled kernels"; return STRQ_ERR_UNSUPPORTED; }
-    *k_out = (int)(mm / S); *R_out = R;
+    int R = 0, NS = 0;
+    if (!align_plan((int)mm, S, &R, &NS) || mm / S > STRQ_LUT_MAX_K) { c->err = "flank shape not covered by the compiled kernels"; return STRQ_ERR_UNSUPPORTED; }
+    *k_out = (int)(mm / S); *R_out = R; *NS_out = NS;
     return STRQ_OK;
 }
 
@@ -235,14 +286,14 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
     const int64_t NA = in.n_align;
     std::fill(c->timing, c->timing + 8, 0.0f);
     if (NA == 0) return STRQ_OK;
-    std::vector<int> m(NA), k(NA), R(NA), n(NA);
+    std::vector<int> m(NA), k(NA), R(NA), n(NA), NS(NA);
     for (int64_t a = 0; a < NA; ++a) {
         const int64_t mm = in.flank_off[a + 1] - in.flank_off[a];
         const int rd = in.align_read[a];
         if (rd < 0 || rd >= in.n_reads) { c->err = "align_read out of range"; return STRQ_ERR_ARG; }
         const int64_t nn = in.read_off[rd + 1] - in.read_off[rd];
         if (nn < 0 || nn > (int64_t)1 << 30) { c->err = "bad read length"; return STRQ_ERR_ARG; }
-        const int rc = align_validate_flank(c, in.flank + in.flank_off[a], mm, S, &k[a], &R[a]);
+        const int rc = align_validate_flank(c, in.flank + in.flank_off[a], mm, S, &k[a], &R[a], &NS[a]);
         if (rc) return rc;
         m[a] = (int)mm; n[a] = (int)nn;
     }
@@ -257,7 +308,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
     while (a0 < NA) {
         int64_t a1 = a0; size_t ck_bytes = 0;
         while (a1 < NA) {
-            const size_t need = (size_t)align_num_ckpts(n[a1]) * STRQ_CKPT_FIELDS(R[a1]) * 64 * 4;
+            const size_t need = align_workspace_bytes(n[a1], m[a1], R[a1], NS[a1]);
             if (a1 > a0 && ck_bytes + need > c->max_ws_bytes) break;
             ck_bytes += need; ++a1;
         }
@@ -267,7 +318,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
         ci.d_level_val = c->level_val.as<float>();
         std::vector<const float*> fl(nb);
         for (int i = 0; i < nb; ++i) fl[i] = in.flank + in.flank_off[a0 + i];
-        ci.read = in.align_read + a0; ci.n = &n[a0]; ci.m = &m[a0]; ci.k = &k[a0]; ci.R = &R[a0]; ci.flank = fl.data();
+        ci.read = in.align_read + a0; ci.n = &n[a0]; ci.m = &m[a0]; ci.k = &k[a0]; ci.R = &R[a0]; ci.NS = &NS[a0]; ci.flank = fl.data();
         int rc = align_core(c, ci, co);
         if (rc) return rc;
         std::vector<AlignResult> res(nb);
@@ -323,7 +374,7 @@ void strq_ctx_destroy(strq_ctx* c)
     detect_state_free(c);
     for (DevBuf* b : {&c->levels, &c->level_val, &c->flank_cls, &c->tables, &c->band_lo, &c->col0, &c->ckpt,
                       &c->rec, &c->tasks, &c->results, &c->queue, &c->scratch, &c->lutinfo, &c->hard, &c->misc,
-                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path})
+                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd})
         b->release();
     for (HostModel* m : c->models) if (m) { m->blob.release(); delete m; }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);

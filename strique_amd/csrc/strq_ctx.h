@@ -35,6 +35,7 @@ struct AlignCoreIn {
     const float* d_level_val = nullptr;    // device: 256 level values per read
     const int32_t* read = nullptr;         // host, per alignment
     const int* n = nullptr; const int* m = nullptr; const int* k = nullptr; const int* R = nullptr;
+    const int* NS = nullptr;               // strips per alignment (1 or 2)
     const float* const* flank = nullptr;   // host: flank template of each alignment
 };
 struct AlignCoreOut {
@@ -64,16 +65,17 @@ struct strq_ctx {
     float timing[8] = {};
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, band_lo, col0, ckpt, rec, tasks, results,
-        queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path;
+        queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd;
     std::vector<strq::HostModel*> models;
     void* detect = nullptr;                   // DetectState (strq_detect_api.hip)
-    size_t max_ws_bytes = (size_t)48 << 30;   // cap for checkpoint workspace per sub-batch
+    size_t max_ws_bytes = (size_t)96 << 30;   // cap for checkpoint workspace per sub-batch
 };
 
 namespace strq {
 int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out);
 int align_core_times(strq_ctx* c, float* t_lut, float* t_fwd, float* t_tr);
-int align_validate_flank(strq_ctx* c, const float* f, int64_t m, int samples, int* k_out, int* R_out);
+int align_validate_flank(strq_ctx* c, const float* f, int64_t m, int samples, int* k_out, int* R_out, int* NS_out);
+size_t align_workspace_bytes(int n, int m, int R, int NS);   // checkpoints + strip boundary of one alignment
 float host_cell_score(const AlignParams& p, float h, float v);
 void detect_state_free(strq_ctx* c);
 }

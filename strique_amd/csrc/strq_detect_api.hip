@@ -67,16 +67,16 @@ __global__ void finalize_kernel(FinalizeArgs a)
         const AlignTask& tp = a.tasks[a.task_of[2 * r]]; const AlignResult& rp = a.results[a.task_of[2 * r]];
         const AlignTask& ts = a.tasks[a.task_of[2 * r + 1]]; const AlignResult& rs = a.results[a.task_of[2 * r + 1]];
         {
-            const int64_t b = row_position(tp.rec, tp.m, 0, tp.n), e = row_position(tp.rec, tp.m, tp.m - 1, tp.n);
+            const int64_t b = row_position(tp.rec, tp.m_total, 0, tp.n), e = row_position(tp.rec, tp.m_total, tp.m_total - 1, tp.n);
             g.score_prefix = e > b ? (double)rp.best / (double)(e - b) : 0.0;
-            g.prefix_begin = row_position(tp.rec, tp.m, a.trim[2 * r], tp.n);
+            g.prefix_begin = row_position(tp.rec, tp.m_total, a.trim[2 * r], tp.n);
             g.prefix_end = e;
         }
         {
-            const int64_t b = row_position(ts.rec, ts.m, 0, ts.n), e = row_position(ts.rec, ts.m, ts.m - 1, ts.n);
+            const int64_t b = row_position(ts.rec, ts.m_total, 0, ts.n), e = row_position(ts.rec, ts.m_total, ts.m_total - 1, ts.n);
             g.score_suffix = e > b ? (double)rs.best / (double)(e - b) : 0.0;
             g.suffix_begin = b;
-            g.suffix_end = row_position(ts.rec, ts.m, ts.m - 1 - a.trim[2 * r + 1], ts.n);
+            g.suffix_end = row_position(ts.rec, ts.m_total, ts.m_total - 1 - a.trim[2 * r + 1], ts.n);
         }
         g.gate = (g.prefix_begin < g.suffix_end && g.score_prefix > 0.0 && g.score_suffix > 0.0) ? 1 : 0;
     }
@@ -94,7 +94,7 @@ __global__ void finalize_kernel(FinalizeArgs a)
 struct Target {
     std::vector<float> prefix_ext, suffix_ext;
     int trim_prefix = 0, trim_suffix = 0, samples = 6;
-    int kp = 0, Rp = 0, ks = 0, Rs = 0;
+    int kp = 0, Rp = 0, NSp = 1, ks = 0, Rs = 0, NSs = 1;
     int model_id = -1, count_bias = 0;
     int mod_model_id = -1; double mod_min = 0, mod_max = 0;
 };
@@ -213,7 +213,7 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     STRQ_HIP(c, d->bp.reserve(bp2 * 2 + 64));
     STRQ_HIP(c, d->pattern.reserve(p2 * 5 + (size_t)nm * 8 + 64));
     int32_t* d_path2 = d->pattern.as<int32_t>(); char* d_chars = reinterpret_cast<char*>(d_path2 + p2);
-    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
+    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
     { int sidx = 0, qi = 0;
       for (auto& g : by_shape) {
         const int first = sidx; int mx = 0;
@@ -314,7 +314,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
 
     // ---- the two flank alignments of every read
     const int na = 2 * nr;
-    std::vector<int32_t> a_read(na); std::vector<int> n(na), m(na), k(na), R(na); std::vector<const float*> fl(na);
+    std::vector<int32_t> a_read(na); std::vector<int> n(na), m(na), k(na), R(na), NS(na); std::vector<const float*> fl(na);
     std::vector<int32_t> trim(na);
     int S = 6;
     for (int i = 0; i < nr; ++i) {
@@ -322,12 +322,12 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
         S = t.samples;
         a_read[2 * i] = a_read[2 * i + 1] = i;
         n[2 * i] = n[2 * i + 1] = rc[i].n;
-        m[2 * i] = (int)t.prefix_ext.size(); k[2 * i] = t.kp; R[2 * i] = t.Rp; fl[2 * i] = t.prefix_ext.data(); trim[2 * i] = t.trim_prefix;
-        m[2 * i + 1] = (int)t.suffix_ext.size(); k[2 * i + 1] = t.ks; R[2 * i + 1] = t.Rs; fl[2 * i + 1] = t.suffix_ext.data(); trim[2 * i + 1] = t.trim_suffix;
+        m[2 * i] = (int)t.prefix_ext.size(); k[2 * i] = t.kp; R[2 * i] = t.Rp; NS[2 * i] = t.NSp; fl[2 * i] = t.prefix_ext.data(); trim[2 * i] = t.trim_prefix;
+        m[2 * i + 1] = (int)t.suffix_ext.size(); k[2 * i + 1] = t.ks; R[2 * i + 1] = t.Rs; NS[2 * i + 1] = t.NSs; fl[2 * i + 1] = t.suffix_ext.data(); trim[2 * i + 1] = t.trim_suffix;
     }
     AlignCoreIn ci; AlignCoreOut co;
     ci.nb = na; ci.samples = S; ci.d_levels = c->levels.as<uint8_t>(); ci.read_off = loff.data(); ci.d_level_val = c->level_val.as<float>();
-    ci.read = a_read.data(); ci.n = n.data(); ci.m = m.data(); ci.k = k.data(); ci.R = R.data(); ci.flank = fl.data();
+    ci.read = a_read.data(); ci.n = n.data(); ci.m = m.data(); ci.k = k.data(); ci.R = R.data(); ci.NS = NS.data(); ci.flank = fl.data();
     int rcode = align_core(c, ci, co);
     if (rcode) return rcode;
     B.n_hard += co.n_hard; B.n_fwd_launches += co.n_launches;
@@ -370,7 +370,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     fa.rc = d_rc; fa.model_of = d_model_of; fa.flt = d->flt.p; fa.is_f64 = B.dtype; fa.ps = d->ps; fa.geom = d->geom.as<ReadGeom>(); fa.vit = d->vit.as<VitTask>(); fa.n_reads = nr;
     hipLaunchKernelGGL(finalize_kernel, dim3((nr + 127) / 128), dim3(128), 0, st, fa);
     STRQ_HIP(c, hipGetLastError());
-    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
+    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
     // modification pass needs the state path of the flanked model: size the back-pointer arrays
     std::vector<VitTask> h_vit;
     std::vector<size_t> bp_off(nr, 0), path_off(nr, 0);
@@ -460,8 +460,8 @@ int strq_target_add(strq_ctx* c, const float* prefix_ext, int64_t m_prefix, cons
         trim_prefix < 0 || trim_suffix < 0 || trim_prefix >= m_prefix || trim_suffix >= m_suffix) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     DetectState* d = dstate(c);
     Target t;
-    int rc = align_validate_flank(c, prefix_ext, m_prefix, samples, &t.kp, &t.Rp); if (rc) return rc;
-    rc = align_validate_flank(c, suffix_ext, m_suffix, samples, &t.ks, &t.Rs); if (rc) return rc;
+    int rc = align_validate_flank(c, prefix_ext, m_prefix, samples, &t.kp, &t.Rp, &t.NSp); if (rc) return rc;
+    rc = align_validate_flank(c, suffix_ext, m_suffix, samples, &t.ks, &t.Rs, &t.NSs); if (rc) return rc;
     t.prefix_ext.assign(prefix_ext, prefix_ext + m_prefix); t.suffix_ext.assign(suffix_ext, suffix_ext + m_suffix);
     t.trim_prefix = trim_prefix; t.trim_suffix = trim_suffix; t.samples = samples; t.model_id = hmm_model_id; t.count_bias = count_bias;
     d->targets.push_back(t);
@@ -537,7 +537,7 @@ int strq_batch_run(strq_ctx* c)
         while (r1 < B.n_reads && r1 - r0 < cap) {
             const Target& t = d->targets[B.target[r1]];
             const int n = (int)(B.off[r1 + 1] - B.off[r1]);
-            const size_t need = (size_t)align_num_ckpts(n) * 64 * 4 * (STRQ_CKPT_FIELDS(t.Rp) + STRQ_CKPT_FIELDS(t.Rs));
+            const size_t need = align_workspace_bytes(n, 0, t.Rp, t.NSp) + align_workspace_bytes(n, 0, t.Rs, t.NSs);
             if (r1 > r0 && (ck + need > c->max_ws_bytes || samples + n > ((int64_t)3 << 30))) break;
             ck += need; samples += n; ++r1;
         }

@@ -205,8 +205,8 @@ int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const doubl
     }
     STRQ_HIP(c, hipMemcpyAsync(d_tasks, tasks.data(), (size_t)n_seq * sizeof(VitTask), hipMemcpyHostToDevice, st));
     if (paths) STRQ_HIP(c, hipMemcpyAsync(d_paths, hp.data(), (size_t)n_seq * 8, hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, c->queue.reserve(256));
-    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 256, st));
+    STRQ_HIP(c, c->queue.reserve(1024));
+    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
     STRQ_HIP(c, hipEventRecord(c->ev[0], st));
     const int shape = vit_shape_of(hm->h);
     if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }

@@ -117,3 +117,20 @@ def test_unsupported_inputs(ctx):
     with pytest.raises(ffi.StriqueHipError):
         ctx.align_overlap(np.ones(100), rng.uniform(60, 120, 60))                                 # no runs of 6
     assert np.array_equal(ctx.get_align_params(), ctx.get_align_params())
+
+
+def test_two_strip_path(orc, monkeypatch):
+    """Flank rows cut into two strips (bottom row streamed through HBM, trace crossing the strip
+    boundary): same results as the oracle.  Forced through STRQ_STRIPS=2."""
+    from strique_amd import ffi
+    monkeypatch.setenv("STRQ_STRIPS", "2")
+    ctx2 = ffi.Context(0)
+    rng = np.random.default_rng(21)
+    for params in ([-1, -1, -16, -16, 16, 0], [-2, -8, -2, -8, 8, -16]):
+        p = np.array(params, np.float32)
+        ctx2.set_align_params(*[float(v) for v in p])
+        for n, k in ((40, 145), (3000, 145), (20011, 145), (5000, 100), (2500, 158)):
+            lv, lval, flank = _toy(rng, n, k=k)
+            a = lval[lv]
+            _same(orc.align_overlap(a, flank, p), ctx2.align_overlap(a, flank))
+    ctx2.close()
