@@ -183,7 +183,7 @@ def main():
                                    % (args.reads, args.read_nt, n_samples // max(1, len(sigs))),
                        "reads_per_gpu_per_step": args.reads, "read_nt": args.read_nt, "sharding": "reads over ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": _traffic_from_profiles(),
+                         "traffic": _traffic_from_profiles(2 * args.reads / launches_per_step) if args.read_nt == 50000 else None,
                          "kernel": "align_forward_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": bytes_per_step / launches_per_step,
                          "gcups": cells / (fwd_ms / 1e3 / max(1, args.steps)) / 1e9 if fwd_ms > 0 else None,
@@ -219,12 +219,13 @@ def _cpu_check(sig, strand):
     return time.time() - t0, int(res[0])
 
 
-def _traffic_from_profiles():
-    """HBM bytes per forward-DP launch from the committed rocprofv3 PMC passes, if present."""
+def _traffic_from_profiles(alignments_per_launch=None):
+    """HBM bytes per forward-DP launch from the committed rocprofv3 PMC passes (profiles/r01_pmc.md):
+    measured bytes per alignment at the same read length x alignments of this launch."""
     p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(p):
+    if os.path.exists(p) and alignments_per_launch:
         try:
-            return json.load(open(p)).get("align_forward_kernel_bytes_per_launch")
+            return json.load(open(p))["align_forward_kernel_bytes_per_alignment"] * alignments_per_launch
         except Exception:
             return None
     return None
