@@ -96,22 +96,25 @@ def main():
     ap.add_argument("--read-nt", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=2, help="reads verified against the CPU oracle (LUT variant)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true", help="testing only: all ranks use HIP device 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     dist = None
+    device = 0 if args.share_device else local
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from strique_amd.counter import repeatCounter
     from strique_amd import ffi, dist as sdist
     pm, cfg = load_inputs()
-    counter = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=local)
+    counter = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=device)
     chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
     counter.add_target("c9orf72", repeat, prefix, suffix)
 
@@ -137,7 +140,8 @@ def main():
         ctx.batch_run()
         res = ctx.batch_fetch()
         if dist is not None:
-            sdist.gather_records(res, np.arange(rank * args.reads, (rank + 1) * args.reads), world * args.reads)
+            sdist.gather_records(res, np.arange(rank * args.reads, (rank + 1) * args.reads), world * args.reads,
+                                 device="cuda" if args.backend == "nccl" else "cpu")
         return res
 
     for _ in range(args.warmup):
@@ -153,7 +157,7 @@ def main():
     elapsed = time.time() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
