@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 2 */
+int strq_abi_version(void);   /* currently 3 */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -99,13 +99,17 @@ int strq_align_batch(strq_ctx* ctx, int64_t n_align, int64_t n_reads,
  *   state_tag  n_states ints (nullable): 1 = state belongs to the repeat section (flanked model,
  *              `'repeat' in name`, STRique.py:608) or to the modified branch (modification model,
  *              `'mod' in name`, STRique.py:497); 2 = hub state s0/e0 of the modification model
+ *   hint_slot / hint_lane  n_states ints each (nullable): where to keep an emitting state on the
+ *              wave -- states of one profile column type in one slot, lane = profile position -- so
+ *              that the LDS reads of neighbouring lanes are contiguous.  Purely a performance hint:
+ *              an invalid or missing hint falls back to an automatic placement, results are identical.
  * Limits: <= 512 emitting and <= 256 silent states, <= 8 in-edges per state.
  */
 int strq_model_create(strq_ctx* ctx, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                       const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                       const int32_t* emis_kind, const double* emis_a, const double* emis_b,
                       const double* emis_c, const int32_t* count_inc, const int32_t* state_tag,
-                      int32_t* model_id);
+                      const int32_t* hint_slot, const int32_t* hint_lane, int32_t* model_id);
 
 /*
  * HiddenMarkovModel.viterbi(x) (scripts/STRique.py:434,493).

@@ -221,7 +221,7 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
             HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
             VitTask& v = vt2[sidx]; v = VitTask();
             v.model = hm->dev; v.sig = mt[k].out; v.T = len[k]; v.src_kind = VIT_SRC_F64; v.bp = d->bp.as<uint16_t>() + bp2_off[k];
-            slot2[k] = sidx; tp2[sidx] = d_path2 + p2_off[k]; mx = std::max(mx, hm->h.n_states); ++sidx;
+            slot2[k] = sidx; tp2[sidx] = d_path2 + p2_off[k]; mx = std::max(mx, hm->h.n_cells); ++sidx;
         }
         STRQ_HIP(c, hipMemcpyAsync(d_tb + first, vt2.data() + first, (size_t)(sidx - first) * sizeof(VitTask), hipMemcpyHostToDevice, st));
         if (launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, 1, nullptr)) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
@@ -350,7 +350,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     { int s = 0;
       for (auto& g : by_shape) {
         int mx = 0;
-        for (int i : g.second) mx = std::max(mx, c->models[d->targets[B.target[r0 + i]].model_id]->h.n_states);
+        for (int i : g.second) mx = std::max(mx, c->models[d->targets[B.target[r0 + i]].model_id]->h.n_cells);
         vls.push_back({g.first, s, (int)g.second.size(), mx});
         for (int i : g.second) vit_slot[i] = s++;
       } }

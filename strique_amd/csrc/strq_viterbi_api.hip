@@ -17,7 +17,8 @@ namespace strq {
 int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                     const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                     const int32_t* emis_kind, const double* emis_a, const double* emis_b, const double* emis_c,
-                    const int32_t* count_inc, const int32_t* state_tag, HostModel** out)
+                    const int32_t* count_inc, const int32_t* state_tag,
+                    const int32_t* hint_slot, const int32_t* hint_lane, HostModel** out)
 {
     const int ne = silent_start, ns = n_states - silent_start;
     if (n_states < 2 || ne < 1 || ns < 2 || start < ne || end < ne || start >= n_states || end >= n_states) {
@@ -42,7 +43,15 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     for (int i = 0; i < ne; ++i) eord[i] = i;
     std::stable_sort(eord.begin(), eord.end(), [&](int a, int b) { return deg_of(a) > deg_of(b); });
     std::vector<int32_t> own_e((size_t)epl * 64, -1);
-    for (int i = 0; i < ne; ++i) own_e[i] = eord[i];
+    bool hinted = hint_slot && hint_lane;
+    if (hinted) {      // caller-provided (slot, lane) of every emitting state: must be a valid injective map
+        for (int e = 0; e < ne && hinted; ++e) {
+            const int sl = hint_slot[e], ln = hint_lane[e];
+            if (sl < 0 || sl >= epl || ln < 0 || ln >= 64 || own_e[sl * 64 + ln] >= 0) hinted = false; else own_e[sl * 64 + ln] = e;
+        }
+        if (!hinted) std::fill(own_e.begin(), own_e.end(), -1);
+    }
+    if (!hinted) for (int i = 0; i < ne; ++i) own_e[i] = eord[i];
     // silent states: chains.  The chain predecessor of b is its highest-numbered silent predecessor
     // (the last in-edge in evaluation order, so a strict '>' reproduces the tie rule) if that state
     // does not already lead another chain.
@@ -98,12 +107,18 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     for (int b = ne; b < n_states; ++b) for (int e = in_ptr[b]; e < in_ptr[b + 1]; ++e) if (in_src[e] >= ne && !is_chain_edge(b, in_src[e])) m.single_stage = 0;
     for (int s = 0; s < 8; ++s) if (m.e_deg[s] > 8 || m.s_deg[s] > 8) { delete hm; c->err = "a state has more than 8 in-edges"; return STRQ_ERR_UNSUPPORTED; }
     m.n_edge_rows = rows;
-    std::vector<int32_t> src((size_t)std::max(rows, 1) * 64, n_states);   // padding -> the -inf cell
+    // LDS cells: the owner (slot, lane) of a state is its cell; the last cell is the -inf cell
+    m.n_cells = (epl + spl2) * 64 + 1;
+    std::vector<int32_t> cell_of(n_states, -1), cell_state((size_t)m.n_cells, -1);
+    for (int i = 0; i < epl * 64; ++i) if (own_e[i] >= 0) { cell_of[own_e[i]] = i; cell_state[i] = own_e[i]; }
+    for (int i = 0; i < spl2 * 64; ++i) if (own_s[i] >= 0) { cell_of[own_s[i]] = epl * 64 + i; cell_state[epl * 64 + i] = own_s[i]; }
+    m.start_cell = cell_of[start]; m.end_cell = cell_of[end];
+    std::vector<int32_t> src((size_t)std::max(rows, 1) * 64, m.n_cells - 1);   // padding -> the -inf cell
     std::vector<double> lp((size_t)std::max(rows, 1) * 64, 0.0);
     auto fill = [&](int state, int base, int lane) {
         for (int e = in_ptr[state], j = 0; e < in_ptr[state + 1]; ++e) {
             if (state >= ne && is_chain_edge(state, in_src[e])) continue;
-            src[(size_t)(base + j) * 64 + lane] = in_src[e];
+            src[(size_t)(base + j) * 64 + lane] = cell_of[in_src[e]];
             lp[(size_t)(base + j) * 64 + lane] = in_logp[e];
             ++j;
         }
@@ -123,7 +138,7 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
         {src.data(), src.size() * 4, 0}, {kind.data(), kind.size() * 4, 0}, {inc.data(), inc.size() * 4, 0},
         {own_e.data(), own_e.size() * 4, 0}, {own_s.data(), own_s.size() * 4, 0},
         {chain_src_v.data(), chain_src_v.size() * 4, 0}, {chain_lp_v.data(), chain_lp_v.size() * 8, 0},
-        {tagv.data(), tagv.size() * 4, 0}};
+        {tagv.data(), tagv.size() * 4, 0}, {cell_state.data(), cell_state.size() * 4, 0}};
     size_t total = 0;
     for (auto& pt : parts) { pt.off = total; total += (pt.bytes + 15) & ~(size_t)15; }
     const size_t o_m = total; total += sizeof(VitModel);
@@ -141,6 +156,7 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     m.chain_src = reinterpret_cast<const int32_t*>(d + parts[9].off);
     m.chain_logp = reinterpret_cast<const double*>(d + parts[10].off);
     m.state_tag = reinterpret_cast<const int32_t*>(d + parts[11].off);
+    m.cell_state = reinterpret_cast<const int32_t*>(d + parts[12].off);
     hm->dev = reinterpret_cast<const VitModel*>(d + o_m);
     std::vector<char> host(total, 0);
     for (auto& pt : parts) std::memcpy(&host[pt.off], pt.p, pt.bytes);
@@ -157,13 +173,14 @@ extern "C" {
 int strq_model_create(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                       const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                       const int32_t* emis_kind, const double* emis_a, const double* emis_b, const double* emis_c,
-                      const int32_t* count_inc, const int32_t* state_tag, int32_t* model_id)
+                      const int32_t* count_inc, const int32_t* state_tag,
+                      const int32_t* hint_slot, const int32_t* hint_lane, int32_t* model_id)
 {
     if (!c) return STRQ_ERR_ARG;
     if (!in_ptr || !in_src || !in_logp || !emis_kind || !emis_a || !emis_b || !emis_c || !model_id) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
     HostModel* hm = nullptr;
-    const int rc = build_vit_model(c, n_states, silent_start, start, end, in_ptr, in_src, in_logp, emis_kind, emis_a, emis_b, emis_c, count_inc, state_tag, &hm);
+    const int rc = build_vit_model(c, n_states, silent_start, start, end, in_ptr, in_src, in_logp, emis_kind, emis_a, emis_b, emis_c, count_inc, state_tag, hint_slot, hint_lane, &hm);
     if (rc) return rc;
     c->models.push_back(hm);
     *model_id = (int32_t)c->models.size() - 1;
@@ -210,7 +227,7 @@ int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const doubl
     STRQ_HIP(c, hipEventRecord(c->ev[0], st));
     const int shape = vit_shape_of(hm->h);
     if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
-    int rc = launch_viterbi(st, shape, hm->h.n_states, d_tasks, d_res, (int)n_seq, c->queue.as<int>(), c->n_cu, paths ? 1 : 0);
+    int rc = launch_viterbi(st, shape, hm->h.n_cells, d_tasks, d_res, (int)n_seq, c->queue.as<int>(), c->n_cu, paths ? 1 : 0);
     if (rc) { c->err = "viterbi launch failed"; return rc == 2 || rc == 3 ? STRQ_ERR_UNSUPPORTED : STRQ_ERR_DEVICE; }
     STRQ_HIP(c, hipEventRecord(c->ev[1], st));
     if (paths) {

@@ -6,8 +6,10 @@
 namespace strq {
 
 // Device image of a baked model (strique_amd/hmm.py: bake), laid out for one wave64.
-// Every lane owns up to `epl` emitting and `spl` silent states (slot-major: entry slot*64 + lane);
-// states are dealt to slots by descending in-degree so that the padded in-edge lists are short.
+// Every lane owns up to `epl` emitting and `spl` silent states (slot-major: entry slot*64 + lane).
+// With layout hints (strq_model_create) a state sits in the lane of its profile position, so that
+// the j-th in-edge of all lanes of a slot reads consecutive LDS cells (no bank conflicts);
+// otherwise states are dealt to slots by descending in-degree.
 // Silent states are laid out in chains: when the highest-numbered silent predecessor of a silent
 // state is free, the pair becomes lane neighbours (lane-1 -> lane) of one slot and that edge leaves
 // the edge list (chain_src / chain_logp).
@@ -20,7 +22,9 @@ struct VitModel {
     int32_t s_deg[8], s_base[8];
     int32_t n_edge_rows;
     int32_t single_stage;             // 1: no silent state has a silent predecessor outside its chain
-    const int32_t* edge_src;          // n_edge_rows * 64
+    int32_t n_cells, start_cell, end_cell;   // LDS cells: emitting slot s lane l -> s*64+l, silent -> (epl+s)*64+l, last = -inf
+    const int32_t* edge_src;          // n_edge_rows * 64: LDS cell of the source state
+    const int32_t* cell_state;        // n_cells: state held by a cell, -1 if none
     const double* edge_logp;          // n_edge_rows * 64
     const int32_t* own_e;             // epl * 64: state owned by (slot, lane) or -1
     const int32_t* own_s;             // spl * 64

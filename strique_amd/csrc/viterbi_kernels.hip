@@ -76,7 +76,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 {
     extern __shared__ double lds_d[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int NPMAX = (max_states + 2) & ~1;          // cells per buffer incl. the -inf cell
+    const int NPMAX = max_states;                      // cells per buffer incl. the -inf cell (launcher passes the cell count)
     // one 16-byte cell per state: {double value; int count; int pad} -> one ds_read_b128 per in-edge
     char* vbase = reinterpret_cast<char*>(lds_d) + (size_t)wave * 2 * NPMAX * 16;
     constexpr int DEMAX = DE_HI > DE_LO ? DE_HI : DE_LO;
@@ -86,7 +86,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     auto ldcell = [](const char* b, int off8) { return *reinterpret_cast<const Cell*>(b + 2 * off8); };
     auto stcell = [](char* b, int state, double v, int c) { Cell x; x.v = v; x.c = c; x.pad = 0; *reinterpret_cast<Cell*>(b + 16 * state) = x; };
     const VitModel* cur_model = nullptr;
-    int n = 0, NP = 0, m_start = 0, m_end = 0; bool single_stage = false;
+    int n = 0, NP = 0, m_start = 0, m_end = 0, ecell0 = 0, scell0 = 0, dummy = 0, start_state = 0; bool single_stage = false;
     // everything a lane needs about the states it owns lives in registers (reloaded when the model changes)
     int own_e[EPL], ekind[EPL], einc[EPL], eoff[EPL][DEMAX];
     double ea[EPL], eb[EPL], ec[EPL], elp[EPL][DEMAX];
@@ -102,7 +102,8 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         if (tk.model != cur_model) {
             cur_model = tk.model;
             const VitModel& M = *cur_model;
-            n = M.n_states; NP = (n + 2) & ~1; m_start = M.start; m_end = M.end; single_stage = M.single_stage != 0;
+            n = M.n_states; NP = M.n_cells; m_start = M.start_cell; m_end = M.end_cell; single_stage = M.single_stage != 0;
+            ecell0 = 0; scell0 = M.epl * 64; dummy = M.n_cells - 1; start_state = M.start;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 const bool on = s < M.epl;
@@ -113,7 +114,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j) {
                     const bool ej = on && j < M.e_deg[s];
-                    eoff[s][j] = (ej ? M.edge_src[(M.e_base[s] + j) * 64 + lane] : n) * 8;
+                    eoff[s][j] = (ej ? M.edge_src[(M.e_base[s] + j) * 64 + lane] : dummy) * 8;
                     elp[s][j] = ej ? M.edge_logp[(M.e_base[s] + j) * 64 + lane] : 0.0;
                 }
             }
@@ -124,11 +125,11 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 sinc[s] = own_s[s] >= 0 ? M.count_inc[own_s[s]] : 0;
                 chain_src[s] = on ? M.chain_src[s * 64 + lane] : -1;
                 has_chain[s] = chain_src[s] >= 0;
-                clp[s] = has_chain[s] ? M.chain_logp[s * 64 + lane] : 0.0;
+                clp[s] = has_chain[s] ? M.chain_logp[s * 64 + lane] : NEGINF;
 #pragma unroll
                 for (int j = 0; j < DS; ++j) {
                     const bool ej = on && j < M.s_deg[s];
-                    soff[s][j] = (ej ? M.edge_src[(M.s_base[s] + j) * 64 + lane] : n) * 8;
+                    soff[s][j] = (ej ? M.edge_src[(M.s_base[s] + j) * 64 + lane] : dummy) * 8;
                     slp[s][j] = ej ? M.edge_logp[(M.s_base[s] + j) * 64 + lane] : 0.0;
                 }
             }
@@ -146,7 +147,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         auto relax_silent = [&](char* vb, bool pin, int64_t trow) {
             double y[SPL], base_prev[SPL]; int yc[SPL], arg[SPL];
 #pragma unroll
-            for (int s = 0; s < SPL; ++s) { y[s] = NEGINF; yc[s] = 0; arg[s] = n; base_prev[s] = __builtin_nan(""); }
+            for (int s = 0; s < SPL; ++s) { y[s] = NEGINF; yc[s] = 0; arg[s] = dummy; base_prev[s] = __builtin_nan(""); }
             for (int outer = 0;; ++outer) {
                 ++n_outer;
                 // (A) best non-chain in-edge of every silent state: emitting predecessors (final for
@@ -155,15 +156,18 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 double base[SPL]; int basec[SPL], basea[SPL];
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    double best = NEGINF; int bc = 0, a = n;
+                    double best = NEGINF; int bc = 0, a = dummy;
 #pragma unroll
                     for (int j = 0; j < DS; ++j) {
                         const Cell pc = ldcell(vb, soff[s][j]);
                         const double c = pc.v + slp[s][j];
-                        if (c > best) { best = c; bc = pc.c; a = soff[s][j] >> 3; }
+                        const bool gt = c > best;          // strict: the first of equal candidates wins
+                        bc = gt ? pc.c : bc;
+                        if (BP) a = gt ? soff[s][j] >> 3 : a;
+                        best = __builtin_fmax(best, c);
                     }
-                    if (pin && own_s[s] == m_start) { best = 0.0; bc = -sinc[s]; a = n; }
-                    if (own_s[s] < 0) { best = NEGINF; bc = 0; a = n; }
+                    if (pin && own_s[s] == start_state) { best = 0.0; bc = -sinc[s]; a = dummy; }
+                    if (own_s[s] < 0) { best = NEGINF; bc = 0; a = dummy; }
                     base[s] = best; basec[s] = bc + sinc[s]; basea[s] = a;
                     if (!(best == base_prev[s]) && !(best != best)) base_changed = true;
                     if (outer == 0) base_changed = true;
@@ -185,10 +189,10 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         for (int s = 0; s < SPL; ++s) {
                             const double tin = dpp_shr1_f64(y[s]) + clp[s];
                             const int cin = dpp_shr1_i32(yc[s]) + sinc[s];
-                            const bool win = has_chain[s] && tin > y[s];     // the chain edge is the last in-edge: strict
-                            y[s] = win ? tin : y[s];
+                            const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
+                            y[s] = __builtin_fmax(y[s], tin);
                             yc[s] = win ? cin : yc[s];
-                            arg[s] = win ? chain_src[s] : arg[s];
+                            if (BP) arg[s] = win ? scell0 + s * 64 + lane - 1 : arg[s];     // the chain predecessor's cell
                             win_any |= win;
                         }
                         if (!__any(win_any)) break;
@@ -196,7 +200,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #pragma unroll
                     for (int s = 0; s < SPL; ++s) {
                         if (own_s[s] >= 0) {
-                            const Cell oc = ldcell(vb, own_s[s] * 8);
+                            const Cell oc = ldcell(vb, (scell0 + s * 64 + lane) * 8);
                             if (!(oc.v == y[s]) || oc.c != yc[s]) changed = true;
                         }
                     }
@@ -205,7 +209,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 VIT_FENCE();
 #pragma unroll
                 for (int s = 0; s < SPL; ++s)
-                    if (own_s[s] >= 0) stcell(vb, own_s[s], y[s], yc[s]);
+                    if (own_s[s] >= 0) stcell(vb, scell0 + s * 64 + lane, y[s], yc[s]);
                 VIT_FENCE();
                 if (single_stage) break;     // nothing downstream of the chains inside this time step
             }
@@ -246,13 +250,16 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 double nv[EPL]; int nc[EPL], na[EPL];
 #pragma unroll
                 for (int s = 0; s < EPL; ++s) {
-                    double best = NEGINF; int bc = 0, a = n;
+                    double best = NEGINF; int bc = 0, a = dummy;
 #pragma unroll
                     for (int j = 0; j < DEMAX; ++j) {
                         if (j < de_of(s)) {     // compile-time
                             const Cell pc = ldcell(vcur, eoff[s][j]);
                             const double c = pc.v + elp[s][j];
-                            if (c > best) { best = c; bc = pc.c; a = eoff[s][j] >> 3; }
+                            const bool gt = c > best;
+                            bc = gt ? pc.c : bc;
+                            if (BP) a = gt ? eoff[s][j] >> 3 : a;
+                            best = __builtin_fmax(best, c);
                         }
                     }
                     double em;
@@ -264,13 +271,13 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #pragma unroll
                 for (int s = 0; s < EPL; ++s) {
                     if (own_e[s] >= 0) {
-                        stcell(vnxt, own_e[s], nv[s], nc[s]);
+                        stcell(vnxt, ecell0 + s * 64 + lane, nv[s], nc[s]);
                         if (BP && tk.bp) tk.bp[(size_t)(t + 1) * n + own_e[s]] = (uint16_t)na[s];
                     }
                 }
 #pragma unroll
                 for (int s = 0; s < SPL; ++s)
-                    if (own_s[s] >= 0) stcell(vnxt, own_s[s], NEGINF, 0);
+                    if (own_s[s] >= 0) stcell(vnxt, scell0 + s * 64 + lane, NEGINF, 0);
                 VIT_FENCE();
                 const uint64_t c1 = __builtin_readcyclecounter();
                 relax_silent(vnxt, false, t + 1);
@@ -334,8 +341,9 @@ __global__ void vit_traceback_kernel(const VitTask* __restrict__ tasks,
     const int n = M.n_states, ne = M.n_emit;
     int guard = 0;
     while (!(t == 0 && l == M.start)) {
-        const int prev = tk.bp[(size_t)t * n + l];
-        if (prev >= n) break;
+        const int pcell = tk.bp[(size_t)t * n + l];
+        const int prev = M.cell_state[pcell];     // back-pointers name LDS cells
+        if (prev < 0 || prev >= n) break;
         if (l < ne) { paths[i][t - 1] = l; --t; guard = 0; }
         else if (++guard > n) break;
         l = prev;
@@ -360,7 +368,7 @@ int vit_shape_of(const VitModel& mh)
 int launch_viterbi(hipStream_t stream, int shape, int max_states, const VitTask* tasks, VitResult* results,
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
 {
-    const int NP = (max_states + 2) & ~1;
+    const int NP = max_states;      // = largest n_cells of the models in this launch
     // per wave: two buffers of 16-byte {value, count} cells; waves of a block are independent
     int nw = 8;
     while (nw > 1 && (size_t)nw * 2 * NP * 16 > 160 * 1024) nw >>= 1;

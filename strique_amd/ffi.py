@@ -122,6 +122,8 @@ class Context(object):
         arrs = [_c(baked.in_ptr, np.int32), _c(baked.in_src, np.int32), _c(baked.in_logp, np.float64),
                 _c(baked.emis_kind, np.int32), _c(baked.emis_a, np.float64), _c(baked.emis_b, np.float64),
                 _c(baked.emis_c, np.float64), _c(baked.count_inc, np.int32), _c(baked.tag, np.int32)]
+        hints = getattr(baked, 'hint_slot', None) is not None and (np.asarray(baked.hint_slot)[:baked.silent_start] >= 0).all()
+        arrs += [_c(baked.hint_slot, np.int32) if hints else None, _c(baked.hint_lane, np.int32) if hints else None]
         self._check(self._lib.strq_model_create(self._h, ctypes.c_int32(baked.n_states), ctypes.c_int32(baked.silent_start),
                                                 ctypes.c_int32(baked.start), ctypes.c_int32(baked.end),
                                                 *[_ptr(a) for a in arrs], ctypes.byref(mid)))

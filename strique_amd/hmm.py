@@ -35,6 +35,7 @@ class Graph(object):
     def __init__(self):
         self.names, self.kinds, self.params = [], [], []
         self.edges = []                       # (src, dst, probability)
+        self.layout = {}                      # optional: state -> (slot, lane) placement hint for the GPU kernel
         self.start = self.add_state("start", SILENT)
         self.end = self.add_state("end", SILENT)
 
@@ -170,6 +171,21 @@ class FlankedRepeatModel(object):
         g.add_transition(rep.e2, suf.s2, 1)
         g.add_transition(suf.e1, g.end, 1)
         g.add_transition(suf.e2, g.end, 1)
+        # placement hint for the Viterbi kernel: one slot per column type, lane = profile position, the
+        # repeat unit right behind the prefix (its natural neighbour)
+        # busy states (matches, the repeat unit) in the first two slots, plain inserts in the last two:
+        # the kernel keeps 6 in-edge registers for the former and 3 for the latter
+        lay = {}
+        for p_, st in enumerate(pre.match): lay[st] = (0, p_)
+        for p_, st in enumerate(suf.match): lay[st] = (1, p_)
+        for p_, st in enumerate(pre.insert): lay[st] = (2, p_)
+        for p_, st in enumerate(suf.insert): lay[st] = (3, p_)
+        b0, b1 = len(pre.match), len(suf.match)
+        for q_, st in enumerate(rep.profile.match): lay[st] = (0, b0 + q_)
+        for q_, st in enumerate(rep.profile.insert): lay[st] = (1, b1 + q_)
+        lay[rep.d2] = (0, b0 + len(rep.profile.match)); lay[rep.d1] = (1, b1 + len(rep.profile.insert))
+        if max(l for _, l in lay.values()) < 64:
+            g.layout = lay
         self.graph = g
         self.repeat_offset = rep.repeat_offset
         # visits of the two dummy states count repeat units (STRique.py:374-378)
@@ -205,6 +221,13 @@ class RepeatModModel(object):
             g.add_transition(p.e2, e0, 1)
         g.add_transition(e0, g.end, tp['leave_repeat'])
         g.add_transition(e0, s0, 1 - tp['leave_repeat'])
+        lay = {}
+        lane = 0
+        for group in (base.match, base.insert, mod.match, mod.insert, [s0, e0]):
+            for st in group:
+                lay[st] = (0, lane); lane += 1
+        if lane <= 64:
+            g.layout = lay
         self.graph = g
         self.hub_states = (s0, e0)
         # tag 2 = hub states s0/e0 (group separators of mod_repeats, STRique.py:496), 1 = modified branch
@@ -219,6 +242,7 @@ BakedHMM = namedtuple("BakedHMM", [
     "count_inc",                            # 1 for states whose visits are counted
     "tag",                                  # 1 for states whose name contains `tag_substring`
     "names", "orig_index",
+    "hint_slot", "hint_lane",               # placement hints (-1 = none), see strq_model_create
 ])
 
 
@@ -336,6 +360,10 @@ def bake(g, count_states=(), tag_substring=None, tag2_states=()):
         count_inc[new[s]] = 1
     tag = np.array([2 if old in tag2_states else (1 if (tag_substring and tag_substring in g.names[old]) else 0)
                     for old in final], np.int32)
+    hint_slot = np.full(m, -1, np.int32); hint_lane = np.full(m, -1, np.int32)
+    if g.layout and all(old in g.layout for old in emitting):
+        for old in emitting:
+            hint_slot[new[old]], hint_lane[new[old]] = g.layout[old]
     return BakedHMM(m, ne, new[g.start], new[g.end], in_ptr, np.array(in_src, np.int32),
                     np.array(in_logp, np.float64), kind, ea, eb, ec, count_inc, tag,
-                    [g.names[i] for i in final], np.array(final, np.int32))
+                    [g.names[i] for i in final], np.array(final, np.int32), hint_slot, hint_lane)
