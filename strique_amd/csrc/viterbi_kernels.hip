@@ -197,11 +197,13 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         }
                         if (!__any(win_any)) break;
                     }
+                    if (!single_stage) {
 #pragma unroll
-                    for (int s = 0; s < SPL; ++s) {
-                        if (own_s[s] >= 0) {
-                            const Cell oc = ldcell(vb, (scell0 + s * 64 + lane) * 8);
-                            if (!(oc.v == y[s]) || oc.c != yc[s]) changed = true;
+                        for (int s = 0; s < SPL; ++s) {
+                            if (own_s[s] >= 0) {
+                                const Cell oc = ldcell(vb, (scell0 + s * 64 + lane) * 8);
+                                if (!(oc.v == y[s]) || oc.c != yc[s]) changed = true;
+                            }
                         }
                     }
                 }
@@ -275,9 +277,11 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         if (BP && tk.bp) tk.bp[(size_t)(t + 1) * n + own_e[s]] = (uint16_t)na[s];
                     }
                 }
+                if (!single_stage) {      // silent cells feed other silent states only in multi-stage models
 #pragma unroll
-                for (int s = 0; s < SPL; ++s)
-                    if (own_s[s] >= 0) stcell(vnxt, scell0 + s * 64 + lane, NEGINF, 0);
+                    for (int s = 0; s < SPL; ++s)
+                        if (own_s[s] >= 0) stcell(vnxt, scell0 + s * 64 + lane, NEGINF, 0);
+                }
                 VIT_FENCE();
                 const uint64_t c1 = __builtin_readcyclecounter();
                 relax_silent(vnxt, false, t + 1);
