@@ -108,7 +108,7 @@ template <int R> struct Lane {
 struct LaneConst {
     int off[6];   // LDS byte offset of the class row minus lo4
     int lo4[6];   // band_lo * 4
-    int hi4[6];   // (band_lo + tw - 1) * 4
+    int hi4[6];   // last stored level * 4
 };
 
 template <int R, int S>
@@ -248,14 +248,15 @@ static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int
 {
     const int row0 = tk.row0 + lane * R;                 // global (0-based) index of the lane's first row
     const int kbase = row0 / S - tk.row0 / S, phase = row0 % S;
-    const int tstride = tk.tw + 1;
+    const int off0 = (int)((uint32_t)tk.band_lo[0] >> 16);
 #pragma unroll
     for (int c = 0; c < Shape<R, S>::C; ++c) {
         int k = kbase + c; if (k > tk.k - 1) k = tk.k - 1;
-        const int lo = tk.band_lo[k];
+        const uint32_t d = (uint32_t)tk.band_lo[k];
+        const int lo = (int)(d & 255u), w1 = (int)((d >> 8) & 255u), off = (int)(d >> 16);
         lc.lo4[c] = lo * 4;
-        lc.hi4[c] = (lo + tk.tw - 1) * 4;
-        lc.off[c] = lds_base + k * tstride * 4 - lo * 4;
+        lc.hi4[c] = (lo + w1) * 4;
+        lc.off[c] = lds_base + (off - off0) * 4 - lo * 4;
     }
 #pragma unroll
     for (int x = 0; x < Shape<R, S>::NMASK; ++x) {
@@ -269,8 +270,10 @@ static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int
 // stage the banded score table of one alignment into this wave's LDS slice
 static __device__ __forceinline__ void stage_table(const AlignTask& tk, float* lds, int lane)
 {
-    const int nfl = tk.k * (tk.tw + 1);
-    for (int i = lane; i < nfl; i += 64) lds[i] = tk.table[i];
+    const uint32_t d0 = (uint32_t)tk.band_lo[0], d1 = (uint32_t)tk.band_lo[tk.k - 1];
+    const int off0 = (int)(d0 >> 16), nfl = (int)(d1 >> 16) + (int)((d1 >> 8) & 255u) + 1 - off0;
+    const float* src = tk.table + off0;
+    for (int i = lane; i < nfl; i += 64) lds[i] = src[i];
 }
 
 template <int R>

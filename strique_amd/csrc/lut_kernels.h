@@ -4,9 +4,9 @@
 #include <stdint.h>
 #include "align_kernels.h"
 
-#define STRQ_LUT_MAX_K 160          // classes per flank that fit the 160 KB LDS build buffer
+#define STRQ_LUT_MAX_K 158          // classes per flank: k x 256 floats + bookkeeping must fit the 160 KB LDS build buffer
 #define STRQ_LUT_LOCAL_HARD 64
-#define STRQ_TABLE_SLOT_FLOATS(k) ((size_t)(k) * 259)
+#define STRQ_TABLE_SLOT_FLOATS(k) ((size_t)(k) * 256)
 
 namespace strq {
 
@@ -14,10 +14,10 @@ struct LutJob {
     const float* level_val;   // 256 level values of the read
     const float* cls_val;     // k class values of the flank
     float* table;             // slot of STRQ_TABLE_SLOT_FLOATS(k) floats
-    int32_t* band_lo;         // k
+    int32_t* band_lo;         // k packed row descriptors (see AlignTask::band_lo)
     int32_t k, pad_;
 };
-struct LutInfo { int32_t tw, n_hard, need, pad_; };
+struct LutInfo { int32_t total, n_hard, need, pad_; };   // total: floats of the ragged table; need: widest row
 struct HardEntry { int32_t job, k, level, index; };
 
 int launch_lut_build(hipStream_t stream, const LutJob* jobs, LutInfo* info, int n_jobs, int max_k,

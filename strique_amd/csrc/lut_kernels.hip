@@ -4,8 +4,10 @@
 // src/score_distance.h:115-122):  s = max(dist_offset - (float)pow((double)|h - v|, 1.2), dist_min)
 // by one evaluation per (k-mer class of the flank, 8-bit level of the read) pair.
 //
-// The table is banded: for class k only a contiguous level range [e_l, e_r] is stored and the DP
-// kernel clamps the level into it with one v_med3_i32.  The range is chosen so that clamping
+// The table is banded and ragged: for class k only a contiguous level range [e_l, e_r] is stored
+// (rows back to back; band_lo[k] packs e_l | (e_r - e_l) << 8 | row offset << 16) and the DP
+// kernel clamps the level into it with one v_med3_i32.  A typical 145-class flank needs ~6400
+// floats, which lets six DP waves share one CU's LDS.  The range is chosen so that clamping
 // cannot change a score: left of e_l (right of e_r) every level scores like e_l (e_r) -- either
 // because they all clip to dist_min, or because they all sit on the plateau that
 // normalize2model's np.clip (scripts/STRique.py:178-179) makes of the lowest / highest levels.
@@ -50,7 +52,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
                  int* __restrict__ hard_count, int hard_cap, AlignParams p)
 {
     extern __shared__ float sc_all[];          // k x 256 scores
-    __shared__ int lo[STRQ_LUT_MAX_K], hi[STRQ_LUT_MAX_K];
+    __shared__ int lo[STRQ_LUT_MAX_K], hi[STRQ_LUT_MAX_K + 1];
     __shared__ int width, n_local, plat_lo, plat_hi;
     __shared__ unsigned short local_hard[STRQ_LUT_LOCAL_HARD][2];
     const LutJob jb = jobs[blockIdx.x];
@@ -78,20 +80,35 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
         }
     }
     __syncthreads();
-    // stored range of class k: [e_l, e_r]
-    auto edge_l = [&](int k) { return hi[k] < lo[k] ? 0 : (lo[k] <= plat_lo ? plat_lo : lo[k] - 1); };
-    auto edge_r = [&](int k) { return hi[k] < lo[k] ? 0 : (hi[k] >= plat_hi ? plat_hi : hi[k] + 1); };
-    for (int k = q; k < jb.k; k += 256) atomicMax(&width, edge_r(k) - edge_l(k) + 1);
+    // stored range of class k: [e_l, e_r]; from here on lo[] holds e_l | e_r << 8 and hi[] the row
+    // offset (ragged rows: class k stores exactly its range, rows back to back)
+    {
+        int el[(STRQ_LUT_MAX_K + 255) / 256], er[(STRQ_LUT_MAX_K + 255) / 256];
+        int x = 0;
+        for (int k = q; k < jb.k; k += 256, ++x) {
+            const bool none = hi[k] < lo[k];
+            el[x] = none ? 0 : (lo[k] <= plat_lo ? plat_lo : lo[k] - 1);
+            er[x] = none ? 0 : (hi[k] >= plat_hi ? plat_hi : hi[k] + 1);
+            atomicMax(&width, er[x] - el[x] + 1);
+        }
+        __syncthreads();
+        x = 0;
+        for (int k = q; k < jb.k; k += 256, ++x) { lo[k] = el[x] | (er[x] << 8); hi[k] = er[x] - el[x] + 1; }
+    }
     __syncthreads();
-    const int need = width;
-    const int tw = need <= 48 ? 48 : (need <= 64 ? 64 : (need <= 128 ? 128 : 258));
-    const int stride = tw + 1;
-    for (int idx = q; idx < jb.k * stride; idx += 256) {
-        const int k = idx / stride, w = idx - k * stride;
+    if (q == 0) {
+        int off = 0;
+        for (int k = 0; k < jb.k; ++k) { const int w = hi[k]; hi[k] = off; off += w; }
+        hi[jb.k] = off;
+    }
+    __syncthreads();
+    auto edge_l = [&](int k) { return lo[k] & 255; };
+    auto edge_r = [&](int k) { return lo[k] >> 8; };
+    const int* roff = hi;
+    for (int k = 0; k < jb.k; ++k) {
         const int el = edge_l(k), er = edge_r(k);
-        int lv = el + w; if (lv > er) lv = er;
-        jb.table[idx] = sc_all[k * 256 + lv];
-        if (w == 0) jb.band_lo[k] = el;
+        if (q >= el && q <= er) jb.table[roff[k] + q - el] = sc_all[k * 256 + q];
+        if (q == 0) jb.band_lo[k] = (int32_t)((uint32_t)el | ((uint32_t)(er - el) << 8) | ((uint32_t)roff[k] << 16));
     }
     if (q == 0) {
         int nh = n_local;
@@ -102,8 +119,9 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
             const int k = local_hard[i][0], lv = local_hard[i][1];
             if (lv < edge_l(k) || lv > edge_r(k)) { nh = -1; break; }
         }
-        info[blockIdx.x].tw = tw;
-        info[blockIdx.x].need = need;
+        info[blockIdx.x].total = roff[jb.k];
+        info[blockIdx.x].need = width;
+        info[blockIdx.x].pad_ = 0;
         info[blockIdx.x].n_hard = nh;
         for (int i = 0; i < nh; ++i) {
             const int k = local_hard[i][0], lv = local_hard[i][1];
@@ -111,7 +129,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
             if (slot < hard_cap) {
                 HardEntry e;
                 e.job = blockIdx.x; e.k = k; e.level = lv;
-                e.index = k * stride + (lv - edge_l(k));
+                e.index = roff[k] + (lv - edge_l(k));
                 hard[slot] = e;
             }
         }

@@ -118,8 +118,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipMemcpyAsync(info.data(), d_info, (size_t)nb * sizeof(LutInfo), hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(&hard_count, d_hard_count, 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
-    STRQ_DBG("lut done nb=%d hard=%d tw0=%d", nb, hard_count, info[0].tw);
+    STRQ_DBG("lut done nb=%d hard=%d floats0=%d", nb, hard_count, info[0].total);
     if (getenv("STRQ_DEBUG")) { int hist[9] = {0}; for (int i = 0; i < nb; ++i) hist[std::min(8, info[i].need / 8)]++; STRQ_DBG("band need histogram (x8 levels): %d %d %d %d %d %d %d %d %d", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]); }
+    if (getenv("STRQ_DEBUG")) { long tot = 0; int mx = 0; for (int i = 0; i < nb; ++i) { tot += info[i].total; mx = std::max(mx, info[i].total); } STRQ_DBG("table floats: mean %.0f max %d (k=%d)", (double)tot / nb, mx, in.k[0]); }
     if (hard_count > hard_cap) { c->err = "too many borderline table entries"; return STRQ_ERR_DEVICE; }
     bool any_rebuild = false;
     for (int i = 0; i < nb; ++i) any_rebuild |= info[i].n_hard < 0;
@@ -144,34 +145,44 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     if (any_rebuild) for (int i = 0; i < nb; ++i) if (info[i].n_hard < 0) {
         // whole table from the host libm, full width
         const int kk = in.k[i];
-        std::vector<float> tab((size_t)kk * 259); std::vector<int32_t> blo(kk, -1);
+        std::vector<float> tab((size_t)kk * 256); std::vector<int32_t> blo(kk);
         float lv[256];
         { const int rc = level_vals_of(in.read[i], lv); if (rc) return rc; }
         for (int x = 0; x < kk; ++x) {
-            float* row = &tab[(size_t)x * 259];
-            row[0] = c->ap.dist_min; row[257] = c->ap.dist_min; row[258] = c->ap.dist_min;
-            for (int q = 0; q < 256; ++q) row[1 + q] = host_cell_score(c->ap, lv[q], h_cls[cls_off[i] + x]);
+            float* row = &tab[(size_t)x * 256];
+            for (int q = 0; q < 256; ++q) row[q] = host_cell_score(c->ap, lv[q], h_cls[cls_off[i] + x]);
+            blo[x] = (int32_t)((255u << 8) | ((uint32_t)(x * 256) << 16));     // levels 0..255, row offset x * 256
         }
         STRQ_HIP(c, hipMemcpy(jobs[i].table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
         STRQ_HIP(c, hipMemcpy(jobs[i].band_lo, blo.data(), (size_t)kk * 4, hipMemcpyHostToDevice));
-        info[i].tw = 258;
+        info[i].total = kk * 256;
     }
     out.n_hard = hard_count;
 
-    // ---- tasks.  Alignments are grouped by (rows per lane, strips, table width), longest first.
+    // ---- tasks.  Alignments are grouped by (rows per lane, strips, waves per CU their table allows),
+    // longest first.
     // Layout of the task array: [last strips of every alignment, in result order][first strips of
     // the two-strip alignments]; results / finalize address the first part.
+    int max_wpb = 10;
+    if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 10) max_wpb = v; }
+    auto waves_for = [&](int floats) { return std::min(max_wpb, (160 * 1024) / (std::max(floats, 1) * 4)); };
     std::map<std::tuple<int, int, int>, std::vector<int>> groups;
-    for (int i = 0; i < nb; ++i) groups[std::make_tuple(in.R[i], in.NS[i], info[i].tw)].push_back(i);
+    for (int i = 0; i < nb; ++i) {
+        const int w = waves_for(info[i].total);
+        if (w < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
+        groups[std::make_tuple(in.R[i], in.NS[i], -w)].push_back(i);
+    }
     out.order.clear(); out.order.reserve(nb);
-    struct Launch { int R, NS, tw, first, count, first_up; };
+    struct Launch { int R, NS, wpb, first, count, first_up, lds_floats; };
     std::vector<Launch> launches;
     int n_up = 0;
     for (auto& g : groups) {
         auto& v = g.second;
         std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return in.n[x] > in.n[y]; });
         const int NS = std::get<1>(g.first);
-        launches.push_back({std::get<0>(g.first), NS, std::get<2>(g.first), (int)out.order.size(), (int)v.size(), nb + n_up});
+        int lds_floats = 0;
+        for (int i : v) lds_floats = std::max(lds_floats, info[i].total);
+        launches.push_back({std::get<0>(g.first), NS, -std::get<2>(g.first), (int)out.order.size(), (int)v.size(), nb + n_up, lds_floats});
         out.order.insert(out.order.end(), v.begin(), v.end());
         if (NS > 1) n_up += (int)v.size();
     }
@@ -181,17 +192,17 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     for (auto& L : launches) {
         for (int x = 0; x < L.count; ++x) {
             const int pos = L.first + x, i = out.order[pos];
-            const int R = in.R[i], M = in.m[i], tstride = info[i].tw + 1;
+            const int R = in.R[i], M = in.m[i];
             const size_t ck_per_strip = (size_t)align_num_ckpts(in.n[i]) * STRQ_CKPT_FIELDS(R) * 64;
             AlignTask base; std::memset(&base, 0, sizeof(base));
             base.levels = in.d_levels + in.read_off[in.read[i]];
             base.rec = c->rec.as<int32_t>() + out.rec_off[i];
-            base.n = in.n[i]; base.tw = info[i].tw; base.m_total = M;
+            base.n = in.n[i]; base.m_total = M;
             auto strip = [&](int row0, int rows, int sidx) {
                 AlignTask t = base;
                 const int k0 = row0 / S, k1 = (row0 + rows - 1) / S;
                 t.row0 = row0; t.m = rows; t.k = k1 - k0 + 1;
-                t.table = jobs[i].table + (size_t)k0 * tstride; t.band_lo = jobs[i].band_lo + k0;
+                t.table = jobs[i].table; t.band_lo = jobs[i].band_lo + k0;
                 t.col0 = c->col0.as<float>() + col0_off[i] + row0;
                 t.ckpt = c->ckpt.as<float>() + ck_off[i] + (size_t)sidx * ck_per_strip;
                 return t;
@@ -211,39 +222,24 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipMemsetAsync(d_res, 0, (size_t)nb * sizeof(AlignResult), st));
     size_t scratch_words = 0;
     for (auto& L : launches) scratch_words = std::max(scratch_words, align_trace_scratch_words_per_wave(L.R));
-    int max_wpb = 10;
-    if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 10) max_wpb = v; }
     STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * max_wpb));
     int qi = 0;
-    auto lds_plan = [&](const AlignTask* t, int count, int tw, int* lds_floats, int* wpb) {
-        int max_kk = 0;
-        for (int x = 0; x < count; ++x) max_kk = std::max(max_kk, t[x].k);
-        *lds_floats = max_kk * (tw + 1);
-        int w = (160 * 1024) / (*lds_floats * 4);
-        if (w > max_wpb) w = max_wpb;
-        *wpb = w;
-    };
     STRQ_HIP(c, hipEventRecord(c->ev[2], st));
     out.n_launches = 0;
     for (int level = 0; level < 2; ++level) {          // first strips, then the strips below them
         for (auto& L : launches) {
             if (level == 1 && L.NS == 1) continue;
-            const AlignTask* ht = level == 0 && L.NS > 1 ? &tasks[L.first_up] : &tasks[L.first];
             const AlignTask* dt = level == 0 && L.NS > 1 ? d_tasks + L.first_up : d_tasks + L.first;
             const int mode = L.NS == 1 ? 0 : (level == 0 ? 2 : 1);
-            int lds_floats, wpb; lds_plan(ht, L.count, L.tw, &lds_floats, &wpb);
-            if (wpb < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
-            STRQ_DBG("forward launch R=%d strips=%d tw=%d level=%d count=%d waves/CU=%d", L.R, L.NS, L.tw, level, L.count, wpb);
-            if (launch_align(st, L.R, S, dt, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, lds_floats, wpb, c->n_cu,
+            STRQ_DBG("forward launch R=%d strips=%d table floats=%d level=%d count=%d waves/CU=%d", L.R, L.NS, L.lds_floats, level, L.count, L.wpb);
+            if (launch_align(st, L.R, S, dt, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, L.wpb, c->n_cu,
                              c->scratch.as<uint64_t>(), 0, mode)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
             ++qi; ++out.n_launches;
         }
     }
     STRQ_HIP(c, hipEventRecord(c->ev[3], st));
     for (auto& L : launches) {
-        int lds_floats, wpb; lds_plan(&tasks[L.first], L.count, L.tw, &lds_floats, &wpb);
-        if (L.NS > 1) { int l2, w2; lds_plan(&tasks[L.first_up], L.count, L.tw, &l2, &w2); lds_floats = std::max(lds_floats, l2); wpb = std::min(wpb, w2); }
-        if (launch_align(st, L.R, S, d_tasks + L.first, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, lds_floats, wpb, c->n_cu,
+        if (launch_align(st, L.R, S, d_tasks + L.first, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, L.wpb, c->n_cu,
                          c->scratch.as<uint64_t>(), 1, 0)) { c->err = "trace launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
     }
