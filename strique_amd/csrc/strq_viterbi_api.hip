@@ -238,8 +238,6 @@ int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const doubl
     STRQ_HIP(c, hipMemcpyAsync(res.data(), d_res, (size_t)n_seq * sizeof(VitResult), hipMemcpyDeviceToHost, st));
     if (paths) STRQ_HIP(c, hipMemcpyAsync(paths, c->vit_path.p, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
-    if (getenv("STRQ_DEBUG")) for (int64_t pos = 0; pos < std::min<int64_t>(n_seq, 4); ++pos)
-        fprintf(stderr, "[strq] viterbi T=%lld outer=%u sweeps=%u emit_kcyc=%u silent_kcyc=%u\n", (long long)(x_off[order[pos] + 1] - x_off[order[pos]]), res[pos].dbg[0], res[pos].dbg[1], res[pos].dbg[2], res[pos].dbg[3]);
     for (int64_t pos = 0; pos < n_seq; ++pos) {
         const int64_t i = order[pos];
         if (logp) logp[i] = res[pos].logp;

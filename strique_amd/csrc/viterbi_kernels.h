@@ -54,13 +54,13 @@ struct VitResult {
     int64_t counted;
     int32_t status;          // 0 ok, 1 no path
     int32_t pad_;
-    uint32_t dbg[4];         // profiling aid: outer iterations, chain sweeps, emitting / silent kilo-cycles
+    uint32_t dbg[4];         // reserved (zero)
 };
 
 // One launch decodes windows of several models as long as they fit the same kernel shape
-// (`shape_of`); `max_states` = largest n_states among them (sizes the LDS buffers).
+// (`shape_of`); `max_cells` = largest n_cells among them (checked against the shape's LDS buffers).
 int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fits
-int launch_viterbi(hipStream_t stream, int shape, int max_states, const VitTask* tasks, VitResult* results,
+int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);
 int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order);   // order by descending T (n <= 8192)
 int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResult* results,

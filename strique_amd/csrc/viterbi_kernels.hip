@@ -26,6 +26,7 @@
 // Back-pointers are written only when the caller wants the state path (modification pass).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "viterbi_kernels.h"
 
 namespace strq {
@@ -69,30 +70,44 @@ static __device__ __forceinline__ int dpp_shr1_i32(int v)
 // and all LDS reads of a time step are issued back to back.  Emitting slots are sorted by in-degree:
 // the first half of the slots gets DE_HI edge registers, the second half DE_LO; silent slots get DS
 // (without their chain edge).  Padding edges read the -inf cell.
+//
+// The two value buffers of a wave sit a compile-time distance apart and the time loop is unrolled
+// by two, so every LDS access is `register pointer + immediate offset` (no per-step address
+// arithmetic); lanes that own no state in a slot write to a cell nobody reads (no exec masking).
+template <int EPL, int SPL> struct VitLds {
+    static constexpr int TRASH = (EPL + SPL) * 64 + 1;     // model cells: (epl + spl) * 64 + the -inf cell
+    static constexpr int BUF = (TRASH + 1) * 16;           // bytes per value buffer
+    // waves per CU: two per SIMD.  (Three fit shape (4,2) at 168 VGPRs and raise the throughput of
+    // large uniform batches by ~8%, but a 4096-read batch is bound by its longest window, whose
+    // per-step latency gets worse -- measured 176 ms vs 164 ms per bench step.)
+    static constexpr int WAVES = (160 * 1024) / (2 * BUF) >= 8 ? 8 : ((160 * 1024) / (2 * BUF) >= 4 ? 4 : 2);
+};
+
 template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__((64 * VitLds<EPL, SPL>::WAVES))
 viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
-               int n_tasks, int* __restrict__ queue, const int* __restrict__ order, int max_states)
+               int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
 {
     extern __shared__ double lds_d[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int NPMAX = max_states;                      // cells per buffer incl. the -inf cell (launcher passes the cell count)
+    constexpr int TRASH = VitLds<EPL, SPL>::TRASH, BUF = VitLds<EPL, SPL>::BUF;
     // one 16-byte cell per state: {double value; int count; int pad} -> one ds_read_b128 per in-edge
-    char* vbase = reinterpret_cast<char*>(lds_d) + (size_t)wave * 2 * NPMAX * 16;
+    char* const vbase = reinterpret_cast<char*>(lds_d) + (size_t)wave * 2 * BUF;
     constexpr int DEMAX = DE_HI > DE_LO ? DE_HI : DE_LO;
     auto de_of = [](int s) constexpr { return s < (EPL + 1) / 2 ? DE_HI : DE_LO; };
     const double NEGINF = -__builtin_inf();
-    struct Cell { double v; int c; int pad; };
-    auto ldcell = [](const char* b, int off8) { return *reinterpret_cast<const Cell*>(b + 2 * off8); };
-    auto stcell = [](char* b, int state, double v, int c) { Cell x; x.v = v; x.c = c; x.pad = 0; *reinterpret_cast<Cell*>(b + 16 * state) = x; };
+    struct alignas(16) Cell { double v; int c; int pad; };
+    auto ldcell = [](const char* p, int boff) { return *reinterpret_cast<const Cell*>(p + boff); };
+    auto stcell = [](char* p, int boff, double v, int c) { Cell x; x.v = v; x.c = c; x.pad = 0; *reinterpret_cast<Cell*>(p + boff) = x; };
     const VitModel* cur_model = nullptr;
-    int n = 0, NP = 0, m_start = 0, m_end = 0, ecell0 = 0, scell0 = 0, dummy = 0, start_state = 0; bool single_stage = false;
+    int n = 0, NP = 0, m_start = 0, m_end = 0, scell0 = 0, dummy = 0, start_state = 0; bool single_stage = false;
     // everything a lane needs about the states it owns lives in registers (reloaded when the model changes)
-    int own_e[EPL], ekind[EPL], einc[EPL], eoff[EPL][DEMAX];
+    int own_e[EPL], einc[EPL]; bool enorm[EPL];
+    const char* esrc[EPL][DEMAX]; char* edst[EPL];
     double ea[EPL], eb[EPL], ec[EPL], elp[EPL][DEMAX];
-    int own_s[SPL], sinc[SPL], soff[SPL][DS], chain_src[SPL];
+    int own_s[SPL], sinc[SPL];
+    const char* ssrc[SPL][DS]; char* sdst[SPL];
     double slp[SPL][DS], clp[SPL];
-    bool has_chain[SPL];
 
     for (;;) {
         const int tq = vit_next_task(queue, lane);
@@ -103,18 +118,22 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             cur_model = tk.model;
             const VitModel& M = *cur_model;
             n = M.n_states; NP = M.n_cells; m_start = M.start_cell; m_end = M.end_cell; single_stage = M.single_stage != 0;
-            ecell0 = 0; scell0 = M.epl * 64; dummy = M.n_cells - 1; start_state = M.start;
+            scell0 = M.epl * 64; dummy = M.n_cells - 1; start_state = M.start;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 const bool on = s < M.epl;
                 own_e[s] = on ? M.own_e[s * 64 + lane] : -1;
-                ekind[s] = on ? M.emis_kind[s * 64 + lane] : 0;
-                ea[s] = on ? M.emis_a[s * 64 + lane] : 0.0; eb[s] = on ? M.emis_b[s * 64 + lane] : 0.0; ec[s] = on ? M.emis_c[s * 64 + lane] : 0.0;
+                const int kind = on ? M.emis_kind[s * 64 + lane] : 0;
+                enorm[s] = kind == 1;
+                // padding states: the uniform test x >= +inf never holds -> emission -inf
+                ea[s] = kind ? M.emis_a[s * 64 + lane] : __builtin_inf(); eb[s] = kind ? M.emis_b[s * 64 + lane] : NEGINF;
+                ec[s] = kind ? M.emis_c[s * 64 + lane] : 0.0;
                 einc[s] = own_e[s] >= 0 ? M.count_inc[own_e[s]] : 0;
+                edst[s] = vbase + 16 * (own_e[s] >= 0 ? s * 64 + lane : TRASH);
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j) {
                     const bool ej = on && j < M.e_deg[s];
-                    eoff[s][j] = (ej ? M.edge_src[(M.e_base[s] + j) * 64 + lane] : dummy) * 8;
+                    esrc[s][j] = vbase + 16 * (ej ? M.edge_src[(M.e_base[s] + j) * 64 + lane] : dummy);
                     elp[s][j] = ej ? M.edge_logp[(M.e_base[s] + j) * 64 + lane] : 0.0;
                 }
             }
@@ -123,33 +142,31 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 const bool on = s < M.spl;
                 own_s[s] = on ? M.own_s[s * 64 + lane] : -1;
                 sinc[s] = own_s[s] >= 0 ? M.count_inc[own_s[s]] : 0;
-                chain_src[s] = on ? M.chain_src[s * 64 + lane] : -1;
-                has_chain[s] = chain_src[s] >= 0;
-                clp[s] = has_chain[s] ? M.chain_logp[s * 64 + lane] : NEGINF;
+                const bool has_chain = on && M.chain_src[s * 64 + lane] >= 0;
+                clp[s] = has_chain ? M.chain_logp[s * 64 + lane] : NEGINF;
+                sdst[s] = vbase + 16 * (own_s[s] >= 0 ? scell0 + s * 64 + lane : TRASH);
 #pragma unroll
                 for (int j = 0; j < DS; ++j) {
                     const bool ej = on && j < M.s_deg[s];
-                    soff[s][j] = (ej ? M.edge_src[(M.s_base[s] + j) * 64 + lane] : dummy) * 8;
+                    ssrc[s][j] = vbase + 16 * (ej ? M.edge_src[(M.s_base[s] + j) * 64 + lane] : dummy);
                     slp[s][j] = ej ? M.edge_logp[(M.s_base[s] + j) * 64 + lane] : 0.0;
                 }
             }
         }
         const int64_t T = tk.T;
-        char* vcur = vbase; char* vnxt = vbase + (size_t)NP * 16;
-        for (int i = lane; i < NP; i += 64) { stcell(vcur, i, NEGINF, 0); stcell(vnxt, i, NEGINF, 0); }
+        for (int i = lane; i < NP; i += 64) { stcell(vbase, 16 * i, NEGINF, 0); stcell(vbase, BUF + 16 * i, NEGINF, 0); }
         VIT_FENCE();
-        if (lane == 0) stcell(vcur, m_start, 0.0, 0);
+        if (lane == 0) stcell(vbase, 16 * m_start, 0.0, 0);
         VIT_FENCE();
 
-        // Silent states of buffer `vb` (values) / `cb` (carried counts) to their fixed point.
-        // `pin`: keep start at 0 (t = 0).
-        uint32_t n_outer = 0, n_sweep = 0; uint64_t cyc_e = 0, cyc_s = 0;
-        auto relax_silent = [&](char* vb, bool pin, int64_t trow) {
+        // Silent states of the buffer at byte offset OFF to their fixed point.  PIN: keep start at 0 (t = 0).
+        auto relax_silent = [&](auto pin_c, auto off_c, int64_t trow) {
+            constexpr bool PIN = decltype(pin_c)::value;
+            constexpr int OFF = decltype(off_c)::value;
             double y[SPL], base_prev[SPL]; int yc[SPL], arg[SPL];
 #pragma unroll
             for (int s = 0; s < SPL; ++s) { y[s] = NEGINF; yc[s] = 0; arg[s] = dummy; base_prev[s] = __builtin_nan(""); }
             for (int outer = 0;; ++outer) {
-                ++n_outer;
                 // (A) best non-chain in-edge of every silent state: emitting predecessors (final for
                 //     this time step) and silent predecessors that are not chain neighbours
                 bool base_changed = false;
@@ -159,21 +176,19 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     double best = NEGINF; int bc = 0, a = dummy;
 #pragma unroll
                     for (int j = 0; j < DS; ++j) {
-                        const Cell pc = ldcell(vb, soff[s][j]);
+                        const Cell pc = ldcell(ssrc[s][j], OFF);
                         const double c = pc.v + slp[s][j];
                         const bool gt = c > best;          // strict: the first of equal candidates wins
                         bc = gt ? pc.c : bc;
-                        if (BP) a = gt ? soff[s][j] >> 3 : a;
+                        if (BP) a = gt ? (int)(ssrc[s][j] - vbase) >> 4 : a;
                         best = __builtin_fmax(best, c);
                     }
-                    if (pin && own_s[s] == start_state) { best = 0.0; bc = -sinc[s]; a = dummy; }
-                    if (own_s[s] < 0) { best = NEGINF; bc = 0; a = dummy; }
+                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = -sinc[s]; a = dummy; }
                     base[s] = best; basec[s] = bc + sinc[s]; basea[s] = a;
                     if (!(best == base_prev[s]) && !(best != best)) base_changed = true;
-                    if (outer == 0) base_changed = true;
                 }
                 bool changed = false;
-                if (__any(base_changed)) {
+                if (single_stage || outer == 0 || __any(base_changed)) {
                     // (B) chains.  Within a time step every quantity only grows, so the sweep continues
                     //     from the current values; a local candidate that ties with a chain token wins
                     //     (it precedes the chain edge in evaluation order).
@@ -183,7 +198,6 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         base_prev[s] = base[s];
                     }
                     for (;;) {
-                        ++n_sweep;
                         bool win_any = false;
 #pragma unroll
                         for (int s = 0; s < SPL; ++s) {
@@ -201,7 +215,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #pragma unroll
                         for (int s = 0; s < SPL; ++s) {
                             if (own_s[s] >= 0) {
-                                const Cell oc = ldcell(vb, (scell0 + s * 64 + lane) * 8);
+                                const Cell oc = ldcell(sdst[s], OFF);
                                 if (!(oc.v == y[s]) || oc.c != yc[s]) changed = true;
                             }
                         }
@@ -210,8 +224,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 if (!single_stage && !__any(changed)) break;
                 VIT_FENCE();
 #pragma unroll
-                for (int s = 0; s < SPL; ++s)
-                    if (own_s[s] >= 0) stcell(vb, scell0 + s * 64 + lane, y[s], yc[s]);
+                for (int s = 0; s < SPL; ++s) stcell(sdst[s], OFF, y[s], yc[s]);
                 VIT_FENCE();
                 if (single_stage) break;     // nothing downstream of the chains inside this time step
             }
@@ -222,7 +235,43 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             }
         };
 
-        relax_silent(vcur, true, 0);
+        // one observation: emitting states from the buffer at RD into the buffer at WR, then its silent states
+        auto step = [&](auto rd_c, double x, int64_t t) {
+            constexpr int RD = decltype(rd_c)::value, WR = RD ? 0 : BUF;
+            double nv[EPL]; int nc[EPL], na[EPL];
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {
+                double best = NEGINF; int bc = 0, a = dummy;
+#pragma unroll
+                for (int j = 0; j < DEMAX; ++j) {
+                    if (j < de_of(s)) {     // compile-time
+                        const Cell pc = ldcell(esrc[s][j], RD);
+                        const double c = pc.v + elp[s][j];
+                        const bool gt = c > best;
+                        bc = gt ? pc.c : bc;
+                        if (BP) a = gt ? (int)(esrc[s][j] - vbase) >> 4 : a;
+                        best = __builtin_fmax(best, c);
+                    }
+                }
+                const double d = x - ea[s];
+                const double en = ec[s] - (d * d) * eb[s];
+                const double eu = (x >= ea[s] && x <= eb[s]) ? ec[s] : NEGINF;
+                nv[s] = best + (enorm[s] ? en : eu); nc[s] = bc + einc[s]; na[s] = a;
+            }
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {
+                stcell(edst[s], WR, nv[s], nc[s]);
+                if (BP) { if (own_e[s] >= 0 && tk.bp) tk.bp[(size_t)(t + 1) * n + own_e[s]] = (uint16_t)na[s]; }
+            }
+            if (!single_stage) {      // silent cells feed other silent states only in multi-stage models
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) stcell(sdst[s], WR, NEGINF, 0);
+            }
+            VIT_FENCE();
+            relax_silent(std::false_type{}, std::integral_constant<int, WR>{}, t + 1);
+        };
+
+        relax_silent(std::true_type{}, std::integral_constant<int, 0>{}, 0);
 
         double xchunk = 0.0;
         for (int64_t t0 = 0; t0 < T; t0 += 64) {
@@ -245,55 +294,17 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 xchunk = xv;
             }
             const int send = (int)((T - t0) < 64 ? (T - t0) : 64);
-            for (int s0 = 0; s0 < send; ++s0) {
-                const double x = readlane_f64(xchunk, s0);
-                const int64_t t = t0 + s0;
-                const uint64_t c0 = __builtin_readcyclecounter();
-                double nv[EPL]; int nc[EPL], na[EPL];
-#pragma unroll
-                for (int s = 0; s < EPL; ++s) {
-                    double best = NEGINF; int bc = 0, a = dummy;
-#pragma unroll
-                    for (int j = 0; j < DEMAX; ++j) {
-                        if (j < de_of(s)) {     // compile-time
-                            const Cell pc = ldcell(vcur, eoff[s][j]);
-                            const double c = pc.v + elp[s][j];
-                            const bool gt = c > best;
-                            bc = gt ? pc.c : bc;
-                            if (BP) a = gt ? eoff[s][j] >> 3 : a;
-                            best = __builtin_fmax(best, c);
-                        }
-                    }
-                    double em;
-                    if (ekind[s] == 1) { const double d = x - ea[s]; em = ec[s] - (d * d) * eb[s]; }
-                    else if (ekind[s] == 2) em = (x >= ea[s] && x <= eb[s]) ? ec[s] : NEGINF;
-                    else em = NEGINF;
-                    nv[s] = best + em; nc[s] = bc + einc[s]; na[s] = a;
-                }
-#pragma unroll
-                for (int s = 0; s < EPL; ++s) {
-                    if (own_e[s] >= 0) {
-                        stcell(vnxt, ecell0 + s * 64 + lane, nv[s], nc[s]);
-                        if (BP && tk.bp) tk.bp[(size_t)(t + 1) * n + own_e[s]] = (uint16_t)na[s];
-                    }
-                }
-                if (!single_stage) {      // silent cells feed other silent states only in multi-stage models
-#pragma unroll
-                    for (int s = 0; s < SPL; ++s)
-                        if (own_s[s] >= 0) stcell(vnxt, scell0 + s * 64 + lane, NEGINF, 0);
-                }
-                VIT_FENCE();
-                const uint64_t c1 = __builtin_readcyclecounter();
-                relax_silent(vnxt, false, t + 1);
-                cyc_e += c1 - c0; cyc_s += __builtin_readcyclecounter() - c1;
-                char* tv = vcur; vcur = vnxt; vnxt = tv;
+            // chunks start at even t, so the buffer roles alternate A->B, B->A inside every pair
+            for (int s0 = 0; s0 < send; s0 += 2) {
+                step(std::integral_constant<int, 0>{}, readlane_f64(xchunk, s0), t0 + s0);
+                if (s0 + 1 < send) step(std::integral_constant<int, BUF>{}, readlane_f64(xchunk, s0 + 1), t0 + s0 + 1);
             }
         }
-        const Cell fin = ldcell(vcur, m_end * 8);
+        const Cell fin = ldcell(vbase + 16 * m_end, (T & 1) ? BUF : 0);
         const double lp = fin.v;
         const int cnt = fin.c;
         VitResult r; r.logp = lp; r.counted = cnt; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
-        r.dbg[0] = n_outer; r.dbg[1] = n_sweep; r.dbg[2] = (uint32_t)(cyc_e >> 10); r.dbg[3] = (uint32_t)(cyc_s >> 10);
+        r.dbg[0] = r.dbg[1] = r.dbg[2] = r.dbg[3] = 0;
         results[ti] = r;     // every lane stores the same value
         VIT_FENCE();
     }
@@ -369,39 +380,36 @@ int vit_shape_of(const VitModel& mh)
     return -1;
 }
 
-int launch_viterbi(hipStream_t stream, int shape, int max_states, const VitTask* tasks, VitResult* results,
+template <int E_, int S_, int H_, int L_, int D_>
+static int vit_launch_shape(hipStream_t stream, int max_cells, const VitTask* tasks, VitResult* results, int n_tasks,
+                            int* queue, int n_cu, int want_bp, const int* order)
+{
+    if (max_cells > VitLds<E_, S_>::TRASH) return 3;
+    // per wave: two buffers of 16-byte {value, count} cells; waves of a block are independent
+    const int nw = VitLds<E_, S_>::WAVES;
+    const size_t lds = (size_t)nw * 2 * VitLds<E_, S_>::BUF;
+    const dim3 grid(n_cu), block(64 * nw);
+    if (want_bp) {
+        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, true>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);
+    } else {
+        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, false>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
 {
-    const int NP = max_states;      // = largest n_cells of the models in this launch
-    // per wave: two buffers of 16-byte {value, count} cells; waves of a block are independent
-    int nw = 8;
-    while (nw > 1 && (size_t)nw * 2 * NP * 16 > 160 * 1024) nw >>= 1;
-    const size_t lds = (size_t)nw * 2 * NP * 16;
-    if (lds > 160 * 1024) return 3;
-    int blocks_per_cu = (int)((160 * 1024) / lds);
-    if (blocks_per_cu * nw > 8) blocks_per_cu = 8 / nw;        // 2 waves per SIMD (register budget)
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-    const dim3 grid(n_cu * blocks_per_cu), block(64 * nw);
-#define VIT_LAUNCH(E_, S_, H_, L_, D_)                                                                      \
-    do {                                                                                                    \
-        if (want_bp) {                                                                                      \
-            (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, true>), grid, block, lds, stream, tasks, results, n_tasks, queue, order, max_states); \
-        } else {                                                                                            \
-            (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, false>), grid, block, lds, stream, tasks, results, n_tasks, queue, order, max_states); \
-        }                                                                                                   \
-    } while (0)
     switch (shape) {
-        case 0: VIT_LAUNCH(4, 2, 6, 3, 3); break;
-        case 1: VIT_LAUNCH(1, 1, 8, 8, 4); break;
-        case 2: VIT_LAUNCH(2, 2, 8, 8, 4); break;
-        case 3: VIT_LAUNCH(4, 4, 8, 8, 8); break;
-        case 4: VIT_LAUNCH(8, 4, 8, 8, 8); break;
+        case 0: return vit_launch_shape<4, 2, 6, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
+        case 1: return vit_launch_shape<1, 1, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
+        case 2: return vit_launch_shape<2, 2, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
+        case 3: return vit_launch_shape<4, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
+        case 4: return vit_launch_shape<8, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
         default: return 2;
     }
-#undef VIT_LAUNCH
-    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResult* results,

@@ -1,5 +1,5 @@
 import sys, os, json, time, numpy as np
-R=os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0,R)
+R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R)
 from strique_amd.pore_model import pore_model
 from strique_amd import hmm, ffi
 t=np.load(os.path.join(R,'tests/golden/pore_tables.npz'))
