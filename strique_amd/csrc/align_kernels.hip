@@ -351,7 +351,7 @@ struct Forward {
     const uint64_t (&pm)[Shape<R, S>::NMASK];
     const int lane, rM;
     Lane<R> st;
-    float best; int bestj;
+    float best, bestA; int bestt;
     int qq;
     Bnd4 bcur;
 
@@ -401,8 +401,12 @@ struct Forward {
                 } else {
                     dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, rM, &candA, &candB);
                 }
-                if (candA > best) { best = candA; bestj = jA; }
-                if (okB && candB > best) { best = candB; bestj = jB; }
+                // leftmost maximum of the last row: remember the step of the last strict improvement and
+                // column A's value there (column A is left of column B; decoded after the loop)
+                const float cb = okB ? candB : candA;
+                const float nb = __builtin_fmaxf(__builtin_fmaxf(best, candA), cb);
+                if (nb > best) { bestt = t; bestA = candA; }
+                best = nb;
             }
         }
     }
@@ -419,7 +423,7 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
     const int lM = (tk.m - 1) / R, rM = (tk.m - 1) % R;
     Forward<R, S, LH, LV, MODE, RM_LAST> f{tk, p, ldsb, lc, pm, lane, rM};
     init_lane<R>(tk, lane, f.st);
-    f.best = tk.col0[tk.m]; f.bestj = 0; f.qq = 0;
+    f.best = tk.col0[tk.m]; f.bestA = 0.0f; f.bestt = -1; f.qq = 0;
     __builtin_amdgcn_s_waitcnt(0);   // LDS table written by this wave is visible to it
 
     const int nsteps = (tk.n + 1) / 2 + 63;
@@ -449,8 +453,10 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
         if constexpr (HAS_IN) f.bcur = bnext;
     }
     if constexpr (!HAS_OUT) {
+        int bestj = 0;      // no improvement over column 0
+        if (f.bestt >= 0) bestj = 2 * (f.bestt - lane) - (f.bestA == f.best ? 1 : 0);
         const float b = __shfl(f.best, lM, 64);
-        const int bj = __shfl(f.bestj, lM, 64);
+        const int bj = __shfl(bestj, lM, 64);
         res->best = b; res->j_end = bj;   // every lane stores the same value
     }
 }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for profiles/ on a GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+# Three separate passes, as MI355X_MICROARCH.md prescribes: kernel trace + stats, then one PMC
+# counter per pass (never combined with a trace domain).  Raw output lands in gpurun_out/prof_<tag>/;
+# tools/summarize_profiles.py turns it into the committed profiles/<tag>_*.{md,csv,json}.
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_${TAG}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH_KT="bench.py --steps 2 --warmup 1 --reads 4096 --no-cpu-baseline --check 0"
+BENCH_PMC="bench.py --steps 1 --warmup 0 --reads 1024 --no-cpu-baseline --check 0"
+
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o "$TAG" -- python3 $BENCH_KT > "$OUT/bench_kt.log" 2>&1
+echo "kernel-trace pass rc=$?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o "$TAG" -- python3 $BENCH_PMC > "$OUT/bench_fetch.log" 2>&1
+echo "FETCH_SIZE pass rc=$?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o "$TAG" -- python3 $BENCH_PMC > "$OUT/bench_write.log" 2>&1
+echo "WRITE_SIZE pass rc=$?"
+# the kernel trace itself is large; keep stats + counters only
+rm -f "$OUT"/kt/*_kernel_trace.csv "$OUT"/kt/*.db
+tail -1 "$OUT/bench_kt.log" | cut -c1-400
+ls -la "$OUT"/*

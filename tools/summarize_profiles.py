@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of tools/collect_profiles.sh into the committed evidence:
+
+    profiles/<tag>_kernel_stats.csv / .md   per-kernel time (rocprofv3 --kernel-trace --stats)
+    profiles/<tag>_pmc.md                   FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes)
+    profiles/hbm_traffic.json               bytes per alignment of the forward DP (read by bench.py)
+
+usage: python tools/summarize_profiles.py r01 [reads_in_pmc_run=1024]
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import OrderedDict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("void ", "").strip()
+
+
+def one(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    if not hits:
+        raise SystemExit("missing " + pattern)
+    return hits[-1]
+
+
+def counters(path, counter):
+    """kernel -> [values] in dispatch order."""
+    per = OrderedDict()
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            per.setdefault(short(row["Kernel_Name"]), []).append(float(row["Counter_Value"]))
+    return per
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    pmc_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+
+    stats = one(os.path.join(src, "kt", "**", "*kernel_stats.csv"))
+    shutil.copy(stats, os.path.join(out, tag + "_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(stats)))
+    bench_line = ""
+    log = os.path.join(src, "bench_kt.log")
+    if os.path.exists(log):
+        for ln in open(log):
+            if ln.startswith("{") and '"metric"' in ln:
+                bench_line = ln.strip()
+    with open(os.path.join(out, tag + "_kernel_stats.md"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats (%s)\n\n" % tag)
+        f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s/kt -o %s -- "
+                "python3 bench.py --steps 2 --warmup 1 --reads 4096 --no-cpu-baseline --check 0`\n"
+                "(3 passes over 4096 reads of 50 kb: 1 warm-up + 2 timed).  Raw table: `%s_kernel_stats.csv`.\n\n" % (tag, tag, tag))
+        f.write("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n")
+        for r in rows:
+            f.write("| %s | %s | %.3f | %.1f | %s |\n" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
+                                                        float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+        if bench_line:
+            b = json.loads(bench_line)
+            f.write("\nbench.py line of the same (profiled) run: value %.1f %s, forward DP avg launch %.2f ms "
+                    "(HIP events inside bench.py), stages %s\n" % (b["value"], b["unit"], b["roofline"]["avg_launch_ms"],
+                                                                  json.dumps(b.get("stage_ms_per_step"))))
+
+    fetch = counters(one(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv")), "FETCH_SIZE")
+    write = counters(one(os.path.join(src, "pmc_write", "**", "*counter_collection.csv")), "WRITE_SIZE")
+    with open(os.path.join(out, tag + "_pmc.md"), "w") as f:
+        f.write("# HBM traffic per kernel, rocprofv3 PMC (%s)\n\n" % tag)
+        f.write("Two separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, no trace domain) of\n"
+                "`python3 bench.py --steps 1 --warmup 0 --reads %d --no-cpu-baseline --check 0` (%d reads of 50 kb = %d alignments).\n"
+                "Counter unit: KB.  On gfx950 FETCH_SIZE under-counts wide coalesced streams by 2x (MI355X_MICROARCH.md, HBM\n"
+                "section): the x2 column applies that correction as an upper bound; WRITE_SIZE is used as reported.\n"
+                "Values are per-dispatch averages.\n\n" % (pmc_reads, pmc_reads, 2 * pmc_reads))
+        f.write("| kernel | dispatches | FETCH_SIZE KB | x2 | WRITE_SIZE KB | bytes/launch (x2 + write) |\n|---|---|---|---|---|---|\n")
+        for k in fetch:
+            fv = sum(fetch[k]) / len(fetch[k])
+            wv = sum(write.get(k, [0.0])) / max(1, len(write.get(k, [0.0])))
+            f.write("| %s | %d | %.1f | %.1f | %.1f | %.3e |\n" % (k, len(fetch[k]), fv, 2 * fv, wv, (2 * fv + wv) * 1024))
+    fk = [k for k in fetch if "align_forward_kernel" in k]
+    if fk:
+        k = fk[0]
+        n_launch = len(fetch[k])
+        fv = sum(fetch[k]) / n_launch
+        wv = sum(write[k]) / len(write[k])
+        n_align = 2 * pmc_reads / n_launch
+        info = {
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 "
+                      "--reads %d --no-cpu-baseline --check 0; see profiles/%s_pmc.md" % (pmc_reads, tag),
+            "kernel": k, "alignments_per_launch": n_align,
+            "FETCH_SIZE_KB": fv, "WRITE_SIZE_KB": wv,
+            "bytes_per_launch_raw": (fv + wv) * 1024, "bytes_per_launch_fetch_x2": (2 * fv + wv) * 1024,
+            "align_forward_kernel_bytes_per_alignment": (2 * fv + wv) * 1024 / n_align,
+            "note": "FETCH_SIZE counted x2 as MI355X_MICROARCH.md prescribes for gfx950 (upper bound); WRITE_SIZE uncorrected. "
+                    "Writes are the wavefront checkpoints (one per 512 steps).",
+        }
+        json.dump(info, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+        print(json.dumps(info, indent=1))
+
+
+if __name__ == "__main__":
+    main()
