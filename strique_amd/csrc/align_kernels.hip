@@ -352,14 +352,35 @@ struct Forward {
     const int lane, rM;
     Lane<R> st;
     float best, bestA; int bestt;
-    int qq;
+    int qq;                                   // packed levels (x4) of the two columns of the step about to run
+    float scA[Shape<R, S>::C], scB[Shape<R, S>::C];   // their class scores, fetched one step ahead
     Bnd4 bcur;
 
-    // PRED: lanes may be idle (before their first / after their last column)
-    template <bool PRED, bool KEEP>
-    __device__ __forceinline__ void step(int t, int s, int qcur)
+    // levels of the next step enter at lane 0 (entry `snext` of the chunk register `qsrc`); its scores
+    // are read from LDS now and consumed one step later, so the LDS latency hides behind the DP arithmetic
+    __device__ __forceinline__ void advance(int qsrc, int snext, int& qn, float (&nA)[Shape<R, S>::C], float (&nB)[Shape<R, S>::C])
     {
-        qq = dpp_shr1_i(qq, __builtin_amdgcn_readlane(qcur, s));
+        qn = dpp_shr1_i(qq, __builtin_amdgcn_readlane(qsrc, snext));
+        fetch_scores<R, S>(ldsb, lc, qn & 0xffff, nA);
+        fetch_scores<R, S>(ldsb, lc, (int)((unsigned)qn >> 16), nB);
+    }
+    __device__ __forceinline__ void prime(int qcur)
+    {
+        qq = 0;
+        int qn; float nA[Shape<R, S>::C], nB[Shape<R, S>::C];
+        advance(qcur, 0, qn, nA, nB);
+        qq = qn;
+#pragma unroll
+        for (int c = 0; c < Shape<R, S>::C; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
+    }
+
+    // PRED: lanes may be idle (before their first / after their last column).
+    // s: position of this step inside its 64-step chunk; (qsrc, snext): where the next step's levels come from.
+    template <bool PRED, bool KEEP>
+    __device__ __forceinline__ void step(int t, int s, int qsrc, int snext)
+    {
+        int qn; float nA[Shape<R, S>::C], nB[Shape<R, S>::C];
+        advance(qsrc, snext, qn, nA, nB);
         float fA = 0.0f, fB = 0.0f, fVA = STRQ_NINF, fVB = STRQ_NINF;
         if constexpr (HAS_IN) {
             fA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.sA), s));
@@ -377,9 +398,7 @@ struct Forward {
         bool act = true;
         if constexpr (PRED) act = (jA >= 1) && (jA <= tk.n);
         if (act) {
-            float scA[Shape<R, S>::C], scB[Shape<R, S>::C], rsA[R], rsB[R];
-            fetch_scores<R, S>(ldsb, lc, qq & 0xffff, scA);
-            fetch_scores<R, S>(ldsb, lc, (int)((unsigned)qq >> 16), scB);
+            float rsA[R], rsB[R];
             expand_scores<R, S>(scA, pm, rsA);
             expand_scores<R, S>(scB, pm, rsB);
             bool okB = true;
@@ -409,6 +428,9 @@ struct Forward {
                 best = nb;
             }
         }
+        qq = qn;
+#pragma unroll
+        for (int c = 0; c < Shape<R, S>::C; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
     }
 };
 
@@ -423,11 +445,12 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
     const int lM = (tk.m - 1) / R, rM = (tk.m - 1) % R;
     Forward<R, S, LH, LV, MODE, RM_LAST> f{tk, p, ldsb, lc, pm, lane, rM};
     init_lane<R>(tk, lane, f.st);
-    f.best = tk.col0[tk.m]; f.bestA = 0.0f; f.bestt = -1; f.qq = 0;
+    f.best = tk.col0[tk.m]; f.bestA = 0.0f; f.bestt = -1;
     __builtin_amdgcn_s_waitcnt(0);   // LDS table written by this wave is visible to it
 
     const int nsteps = (tk.n + 1) / 2 + 63;
     int qcur = load_chunk(tk, 0, lane);
+    f.prime(qcur);
     Bnd4 bnext{0.0f, STRQ_NINF, 0.0f, STRQ_NINF};
     if constexpr (HAS_IN) f.bcur = load_bnd(tk, 0, lane); else f.bcur = bnext;
     for (int t0 = 0; t0 < nsteps; t0 += 64) {
@@ -438,13 +461,14 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
         const bool ckpt_here = ((t0 + 64) % STRQ_CKPT_STEPS) == 0 && (t0 + 64) < nsteps;
         const int send = nsteps - t0 < 64 ? nsteps - t0 : 64;
         if (full) {
-            for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, s, qcur);
-            if (ckpt_here) f.template step<false, true>(t0 + 64, 63, qcur);
-            else f.template step<false, false>(t0 + 64, 63, qcur);
+            for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, s, qcur, s + 1);
+            if (ckpt_here) f.template step<false, true>(t0 + 64, 63, qnext, 0);
+            else f.template step<false, false>(t0 + 64, 63, qnext, 0);
         } else {
             for (int s = 0; s < send; ++s) {
-                if (ckpt_here && s == 63) f.template step<true, true>(t0 + s + 1, s, qcur);
-                else f.template step<true, false>(t0 + s + 1, s, qcur);
+                const int qsrc = s == 63 ? qnext : qcur, snext = (s + 1) & 63;
+                if (ckpt_here && s == 63) f.template step<true, true>(t0 + s + 1, s, qsrc, snext);
+                else f.template step<true, false>(t0 + s + 1, s, qsrc, snext);
             }
         }
         if (ckpt_here)
