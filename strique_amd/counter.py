@@ -11,6 +11,8 @@ output tuple.
 """
 from collections import namedtuple
 
+import warnings
+
 import numpy as np
 
 from . import ffi
@@ -89,10 +91,13 @@ class repeatCounter(object):
     # -------------------------------------------------------------------------------------
     def _host_stats(self, raw):
         """Order statistics numpy provides for float64 signals (see include/strique_hip.h)."""
+        if len(raw) == 0:
+            return [np.nan] * 6          # the library reports such a read as status 1 (n = 0 row)
         p = np.concatenate([[0.0], raw, [0.0]])
         flt = np.sort(np.stack([p[:-2], p[1:-1], p[2:]]), axis=0)[1]          # medfilt(raw, 3)
-        med = np.median(flt); mad = self.pm.MAD(flt)
-        with np.errstate(all='ignore'):
+        with np.errstate(all='ignore'), warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # empty tails of very short reads: NaN, flagged by the library
+            med = np.median(flt); mad = self.pm.MAD(flt)
             c1, h1, _, _ = self.pm.minmax_coefficients(flt)
             r1, rh, _, _ = self.pm.minmax_coefficients(raw) if self.pm is not self.pm_mod else (0.0, 1.0, 0, 0)
         return [med, mad, c1, h1, r1, rh]

@@ -17,6 +17,7 @@ Fixtures written (all small):
     config.json            parse_config() of the bundled tsv + json        (STRique.py:836-868)
     sam.json               SAM decode + target intersection of data/*.sam  (STRique.py:648-679)
     bundled_read.npz       raw int16 signal + read id of data/c9orf72.fast5
+    c9orf72.fast5 / .sam   the bundled data files themselves (data, copied byte for byte)
     hmm_topology.json      states / edges emitted by the reference's HMM classes run against a
                            recording stand-in for pomegranate              (STRique.py:201-500)
 """
@@ -230,6 +231,12 @@ def main():
     from strique_amd import fast5
     rid, sig = fast5.read_raw(os.path.join(REF, "data", "c9orf72.fast5"))[0]
     np.savez_compressed(os.path.join(OUT, "bundled_read.npz"), signal=sig, read_id=np.array(rid))
+    # ---- the bundled data files themselves (inputs of the documented `count` run,
+    #      docs/installation/test.md:8-16): byte-for-byte copies, so that the HDF5 reader, the
+    #      index command and the SAM router are exercised on the real file formats
+    import shutil
+    for name in ("c9orf72.fast5", "c9orf72.sam"):
+        shutil.copyfile(os.path.join(REF, "data", name), os.path.join(OUT, name))
     print("fixtures written to", OUT)
 
 

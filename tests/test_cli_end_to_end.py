@@ -1,0 +1,110 @@
+"""The documented `count` run of the reference on its bundled files (docs/installation/test.md:8-16):
+
+    python3 scripts/STRique.py index data/ > data/reads.fofn
+    cat data/c9orf72.sam | python3 scripts/STRique.py count data/reads.fofn models/r9_4_450bps.model
+        configs/repeat_config.tsv --config configs/STRique.json
+
+`tests/golden/c9orf72.fast5` / `.sam` are byte-for-byte copies of the reference's data files
+(tests/golden/make_golden.py); the model, repeat table and JSON config are written back into the
+reference's file formats from the golden values recorded there.
+"""
+import io
+import json
+import os
+import shutil
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+READ_ID = "ce47b364-ed6e-4409-808a-1041c0b5aac2"
+DOCS_ROW = dict(count=735, score_prefix=6.3155927807600545, score_suffix=6.031860427335506,
+                log_p=-119860.52066647023, offset=1633, ticks=40758)
+
+
+@pytest.fixture()
+def workdir(tmp_path, tables, cfg):
+    data = tmp_path / "data"
+    data.mkdir()
+    shutil.copyfile(os.path.join(GOLDEN, "c9orf72.fast5"), data / "c9orf72.fast5")
+    shutil.copyfile(os.path.join(GOLDEN, "c9orf72.sam"), data / "c9orf72.sam")
+    for key, name in (("base", "r9_4_450bps.model"), ("mod", "r9_4_450bps_mCpG.model")):
+        with open(tmp_path / name, "w") as fp:
+            for k, m, s in zip(tables[key + "_kmer"], tables[key + "_mean"], tables[key + "_stdv"]):
+                k = k.decode() if isinstance(k, bytes) else str(k)
+                fp.write("%s\t%s\t%s\t1\n" % (k, repr(float(m)), repr(float(s))))
+    with open(tmp_path / "repeat_config.tsv", "w") as fp:
+        fp.write("chr\tbegin\tend\tname\trepeat\tprefix\tsuffix\n")
+        for name, (chrom, b, e, repeat, prefix, suffix) in cfg["repeat"].items():
+            fp.write("\t".join([chrom, str(b), str(e), name, repeat, prefix, suffix]) + "\n")
+    with open(tmp_path / "STRique.json", "w") as fp:
+        json.dump({"align": cfg["align"], "HMM": cfg["HMM"]}, fp)
+    return tmp_path
+
+
+def _index(workdir):
+    from strique_amd import cli
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        cli.main(["index", str(workdir / "data")])
+    return buf.getvalue()
+
+
+def test_index_and_raw_reader_on_the_bundled_fast5(workdir):
+    """`index` output format (fast5Index.py:53,163-179) and the HDF5 subset reader on the real file
+    (superblock v0, deflate, two chunks) against the committed raw-signal fixture."""
+    from strique_amd import cli, fast5
+    text = _index(workdir)
+    assert text == "c9orf72.fast5\t%s\n" % READ_ID
+    fofn = workdir / "data" / "reads.fofn"
+    fofn.write_text(text)
+    raw = cli.Fast5Index(str(fofn)).get_raw(READ_ID)
+    want = np.load(os.path.join(GOLDEN, "bundled_read.npz"))["signal"]
+    assert raw.dtype == np.int16 and np.array_equal(raw, want)
+    assert cli.Fast5Index(str(fofn)).get_raw("no-such-read") is None
+    (rid, sig), = fast5.read_raw(str(workdir / "data" / "c9orf72.fast5"))
+    assert rid == READ_ID and len(sig) == 284184 and int(sig.min()) == -4096 and int(sig.max()) == 3008
+
+
+def test_sam_router_on_the_bundled_alignment(workdir, cfg):
+    """FLAG / POS / CIGAR-derived span and clips of the real record, and the locus it selects."""
+    from strique_amd import cli
+    want = json.load(open(os.path.join(GOLDEN, "sam.json")))["records"][0]
+    loci = {}
+    for name, (chrom, b, e, *_r) in cfg["repeat"].items():
+        loci.setdefault(chrom, []).append((name, b, e))
+    recs = [cli.decode_sam(l) for l in open(workdir / "data" / "c9orf72.sam") if not l.startswith("@")]
+    assert len(recs) == 1
+    sr = recs[0]
+    got = dict(QNAME=sr.QNAME, FLAG=sr.FLAG, RNAME=sr.RNAME, POS=sr.POS, TLEN=sr.TLEN, CLIP_BEGIN=sr.CLIP_BEGIN,
+               CLIP_END=sr.CLIP_END, targets=cli.intersect_targets(sr, loci))
+    assert got == {k: want[k] for k in got}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_mod", [False, True])
+def test_count_command_end_to_end(workdir, with_mod):
+    from strique_amd import cli
+    fofn = workdir / "data" / "reads.fofn"
+    fofn.write_text(_index(workdir))
+    out = workdir / "out.tsv"
+    argv = ["count", str(fofn), str(workdir / "r9_4_450bps.model"), str(workdir / "repeat_config.tsv"),
+            "--config", str(workdir / "STRique.json"), "--algn", str(workdir / "data" / "c9orf72.sam"), "--out", str(out)]
+    if with_mod:
+        argv += ["--mod_model", str(workdir / "r9_4_450bps_mCpG.model")]
+    cli.main(argv)
+    lines = out.read_text().splitlines()
+    assert lines[0].split("\t") == ["ID", "target", "strand", "count", "score_prefix", "score_suffix", "log_p", "offset", "ticks", "mod"]
+    assert len(lines) == 2
+    rid, target, strand, count, sp, ss, lp, offset, ticks, mod = lines[1].split("\t")
+    assert (rid, target, strand) == (READ_ID, "c9orf72", "-")
+    assert int(offset) == DOCS_ROW["offset"] and int(ticks) == DOCS_ROW["ticks"]     # geometry: exact
+    assert abs(int(count) - DOCS_ROW["count"]) <= 2
+    assert abs(float(sp) / DOCS_ROW["score_prefix"] - 1) < 0.01 and abs(float(ss) / DOCS_ROW["score_suffix"] - 1) < 0.01
+    assert abs(float(lp) / DOCS_ROW["log_p"] - 1) < 0.02
+    if with_mod:
+        assert set(mod) <= set("01") and abs(len(mod) - int(count)) <= 3
+    else:
+        assert mod == "-"

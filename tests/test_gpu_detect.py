@@ -126,3 +126,25 @@ def test_modification_pass(pm, pm_mod, cfg, orc, opm):
             want, _ = orc.detect(sig, tc, opm, params, pm_mod=pm_mod)
             assert tuple(g) == tuple(want), (g, want)
             assert set(g[6]) <= set("01") and abs(len(g[6]) - g[0]) <= 3
+
+
+def test_empty_batch_and_tiny_reads(gpu_counter, orc, opm, pm, cfg):
+    """Empty batch, empty read, reads far shorter than the flank or the morphology window: nothing
+    crashes, such reads come back as the reference's failed-gate row (n = 0, mod '-'), and the real
+    reads that share the batch are untouched (bit-equal to the oracle)."""
+    assert gpu_counter.detect_batch([]) == []
+    rng = np.random.default_rng(8)
+    good = _read(pm, cfg, "c9orf72", "-", 3500, 9, 91)
+    tiny = [rng.integers(300, 900, n).astype(np.int16) for n in (0, 1, 2, 3, 7, 8, 9, 20, 869, 870, 871)]
+    items = [("c9orf72", t, "+") for t in tiny[:6]] + [("c9orf72", good, "-")] + [("fmr1", t, "-") for t in tiny[6:]]
+    got = gpu_counter.detect_batch(items)
+    assert len(got) == len(items)
+    for (name, sig, strand), g in zip(items, got):
+        if sig is good:
+            want, _ = orc.detect(good, oracle_tc(gpu_counter, "c9orf72", "-"), opm, orc.align_params(cfg["align"]))
+            assert tuple(g[:6]) == tuple(want[:6]) and g[0] == 9
+        else:
+            assert g[0] == 0 and g[6] == "-", (len(sig), g)
+    # float64 input path as well
+    got = gpu_counter.detect_batch([("c9orf72", np.zeros(0), "+"), ("c9orf72", np.array([80.0, 90.0, 100.0]), "+")])
+    assert [g[0] for g in got] == [0, 0]
