@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=4096, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=4096, help="reads per GPU per step (16 per CU: the forward DP launch ends without a ragged tail)")
     ap.add_argument("--read-nt", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=2, help="reads verified against the CPU oracle (LUT variant)")

@@ -532,8 +532,13 @@ int strq_batch_run(strq_ctx* c)
     while (r0 < B.n_reads) {
         int64_t r1 = r0; size_t ck = 0; int64_t samples = 0;
         bool mod_batch = false;
-        for (int64_t r = r0; r < B.n_reads && r < r0 + 4096; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
-        const int64_t cap = mod_batch ? 512 : 4096;      // back-pointer memory bounds the modification pass
+        // Sub-batch size: 16 reads (32 alignments) per CU.  The forward DP keeps six waves per CU, two
+        // alone on their SIMD (60.6 ms per 375 k-sample alignment) and four sharing one (73 ms): after
+        // 365 ms both groups have just finished a task (6 x 60.6 = 5 x 73), 32 in total, so the launch
+        // ends without a ragged tail (measured: 4096 reads 365 ms, 4608 reads 437 ms on 256 CUs).
+        const int64_t full = std::min<int64_t>(16 * (int64_t)c->n_cu, 8192);      // 8192: task limit of vit_sort_kernel
+        for (int64_t r = r0; r < B.n_reads && r < r0 + full; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
+        const int64_t cap = mod_batch ? 512 : full;      // back-pointer memory bounds the modification pass
         while (r1 < B.n_reads && r1 - r0 < cap) {
             const Target& t = d->targets[B.target[r1]];
             const int n = (int)(B.off[r1 + 1] - B.off[r1]);
