@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -537,8 +538,10 @@ int strq_batch_run(strq_ctx* c)
         // 365 ms both groups have just finished a task (6 x 60.6 = 5 x 73), 32 in total, so the launch
         // ends without a ragged tail (measured: 4096 reads 365 ms, 4608 reads 437 ms on 256 CUs).
         const int64_t full = std::min<int64_t>(16 * (int64_t)c->n_cu, 8192);      // 8192: task limit of vit_sort_kernel
+        int64_t full_env = 0;
+        if (const char* e = getenv("STRQ_SUBBATCH_READS")) full_env = atoll(e);      // testing: force small sub-batches
         for (int64_t r = r0; r < B.n_reads && r < r0 + full; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
-        const int64_t cap = mod_batch ? 512 : full;      // back-pointer memory bounds the modification pass
+        const int64_t cap = full_env > 0 ? std::min(full_env, full) : (mod_batch ? 512 : full);      // back-pointer memory bounds the modification pass
         while (r1 < B.n_reads && r1 - r0 < cap) {
             const Target& t = d->targets[B.target[r1]];
             const int n = (int)(B.off[r1 + 1] - B.off[r1]);

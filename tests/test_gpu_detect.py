@@ -148,3 +148,17 @@ def test_empty_batch_and_tiny_reads(gpu_counter, orc, opm, pm, cfg):
     # float64 input path as well
     got = gpu_counter.detect_batch([("c9orf72", np.zeros(0), "+"), ("c9orf72", np.array([80.0, 90.0, 100.0]), "+")])
     assert [g[0] for g in got] == [0, 0]
+
+
+def test_sub_batches_give_the_same_results(gpu_counter, pm, cfg, monkeypatch):
+    """A batch larger than one sub-batch is processed in pieces (strq_batch_run); the pieces must not
+    see each other: results equal those of the one-piece run, in input order."""
+    rng = np.random.default_rng(21)
+    items = []
+    for k in range(11):
+        name = ["c9orf72", "fmr1"][k % 2]; strand = "+-"[(k // 2) % 2]
+        items.append((name, _read(pm, cfg, name, strand, int(rng.integers(2500, 6000)), int(rng.integers(4, 60)), 400 + k), strand))
+    whole = gpu_counter.detect_batch(items)
+    monkeypatch.setenv("STRQ_SUBBATCH_READS", "3")
+    pieces = gpu_counter.detect_batch(items)
+    assert pieces == whole

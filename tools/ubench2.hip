@@ -15,6 +15,9 @@ template<int MODE> __global__ void k_rate(float* out, long long* cyc, int iters,
     else if (MODE==3){
       a0=fmaxf(fmaxf(a2,a3),a0+e); a1=fmaxf(fmaxf(a4,a5),a1+e); a0=fmaxf(fmaxf(a6,a7),a0+e); a1=fmaxf(fmaxf(a2,a3),a1+e);
       a0=fmaxf(fmaxf(a2,a3),a0+e); a1=fmaxf(fmaxf(a4,a5),a1+e); a0=fmaxf(fmaxf(a6,a7),a0+e); a1=fmaxf(fmaxf(a2,a3),a1+e);}
+    else if (MODE==4){
+      a0=fmaxf(fmaxf(a4,a5),a0+e); a1=fmaxf(fmaxf(a6,a7),a1+e); a2=fmaxf(fmaxf(a4,a5),a2+e); a3=fmaxf(fmaxf(a6,a7),a3+e);
+      a0=fmaxf(fmaxf(a4,a5),a0+e); a1=fmaxf(fmaxf(a6,a7),a1+e); a2=fmaxf(fmaxf(a4,a5),a2+e); a3=fmaxf(fmaxf(a6,a7),a3+e);}
   }
   long long c1 = __builtin_readcyclecounter();
   long long w1 = wall_clock64();
@@ -35,5 +38,5 @@ template<int MODE> void run(const char* name, int wps){
   hipFree(d); hipFree(dc);
 }
 int main(){
-  for (int w: {1,2,3,4,8}) { run<0>("16 indep v_add",w); run<1>("16 dep v_add",w); run<2>("8x dep(add,max3)",w); run<3>("2 chains(add,max3)",w); }
+  for (int w: {1,2,3,4,8}) { run<0>("16 indep v_add",w); run<1>("16 dep v_add",w); run<2>("8x dep(add,max3)",w); run<3>("2 chains(add,max3)",w); run<4>("4 chains(add,max3)",w); }
 }
