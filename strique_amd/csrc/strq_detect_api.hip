@@ -107,6 +107,8 @@ struct Batch {
     std::vector<int32_t> target;
     std::vector<double> host_stats;      // 6 per read (float64 input only)
     DevBuf raw;                          // all reads, resident
+    const char* host_src = nullptr;      // strq_detect_batch: caller's buffer, uploaded sub-batch by sub-batch
+    int64_t uploaded = 0;                // reads whose samples are in `raw`
     std::vector<strq_result> results;
     std::vector<std::string> mod;        // modification pattern per read ('-' if none)
     float t_cond = 0, t_lut = 0, t_fwd = 0, t_trace = 0, t_vit = 0, t_total = 0;
@@ -122,6 +124,7 @@ struct DetectState {
     DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
+    hipStream_t copy_stream = nullptr;   // host -> HBM uploads that overlap the kernels of the previous sub-batch
 };
 
 static DetectState* dstate(strq_ctx* c)
@@ -137,6 +140,7 @@ void detect_state_free(strq_ctx* c)
     for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx, &d->order,
                       &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern}) b->release();
     if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
+    if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     delete d;
     c->detect = nullptr;
 }
@@ -254,7 +258,25 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     return STRQ_OK;
 }
 
-static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
+// Samples of reads [B.uploaded, upto) from the caller's buffer into `raw`, on the copy stream.  The
+// host blocks here (pageable memory is staged by the runtime) while the kernels already queued on
+// the compute stream keep running: that is the overlap.
+static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
+{
+    Batch& B = d->batch;
+    if (!B.host_src || upto <= B.uploaded) return STRQ_OK;
+    if (!d->copy_stream) STRQ_HIP(c, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    const size_t esz = B.dtype == 0 ? 2 : 8;
+    const size_t b0 = (size_t)B.off[B.uploaded] * esz, b1 = (size_t)B.off[upto] * esz;
+    if (b1 > b0) {
+        STRQ_HIP(c, hipMemcpyAsync(B.raw.as<char>() + b0, B.host_src + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
+        STRQ_HIP(c, hipStreamSynchronize(d->copy_stream));
+    }
+    B.uploaded = upto;
+    return STRQ_OK;
+}
+
+static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, int64_t next_r1)
 {
     Batch& B = d->batch;
     hipStream_t st = c->stream;
@@ -413,6 +435,8 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1)
     STRQ_HIP(c, hipMemcpyAsync(geom.data(), d->geom.p, (size_t)nr * sizeof(ReadGeom), hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(vres.data(), d->vres.p, (size_t)nr * sizeof(VitResult), hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(rc_out.data(), d_rc, (size_t)nr * sizeof(ReadCond), hipMemcpyDeviceToHost, st));
+    // everything of this sub-batch is queued: fetch the next sub-batch's samples while it runs
+    { const int urc = upload_reads(c, d, next_r1); if (urc) return urc; }
     STRQ_HIP(c, hipStreamSynchronize(st));
     for (int i = 0; i < nr; ++i) {
         strq_result& o = B.results[r0 + i];
@@ -494,8 +518,8 @@ int strq_batch_fetch_mod(strq_ctx* c, char* pool, int64_t pool_cap, int64_t* off
     return STRQ_OK;
 }
 
-int strq_batch_upload(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
-                      const int32_t* target_id, const double* host_stats)
+static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
+                         const int32_t* target_id, const double* host_stats, bool lazy)
 {
     if (!c) return STRQ_ERR_ARG;
     DetectState* d = dstate(c);
@@ -514,12 +538,22 @@ int strq_batch_upload(strq_ctx* c, int64_t n_reads, const void* signals, int32_t
     if (dtype == 1) B.host_stats.assign(host_stats, host_stats + n_reads * 6);
     const size_t bytes = (size_t)(n_reads ? B.off[n_reads] : 0) * (dtype == 0 ? 2 : 8);
     STRQ_HIP(c, B.raw.reserve(bytes + 64));
-    if (bytes) STRQ_HIP(c, hipMemcpyAsync(B.raw.p, signals, bytes, hipMemcpyHostToDevice, c->stream));
-    STRQ_HIP(c, hipStreamSynchronize(c->stream));
+    B.host_src = static_cast<const char*>(signals); B.uploaded = 0;
+    if (!lazy) {
+        const int rc = upload_reads(c, d, n_reads);      // resident batch: everything now
+        if (rc) return rc;
+        B.host_src = nullptr;
+    }
     B.results.assign((size_t)n_reads, strq_result());
     B.mod.assign((size_t)n_reads, std::string("-"));
     if (!d->ev_ok) { for (auto& e : d->ev) STRQ_HIP(c, hipEventCreate(&e)); d->ev_ok = true; }
     return STRQ_OK;
+}
+
+int strq_batch_upload(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
+                      const int32_t* target_id, const double* host_stats)
+{
+    return batch_prepare(c, n_reads, signals, dtype, offsets, target_id, host_stats, false);
 }
 
 int strq_batch_run(strq_ctx* c)
@@ -529,6 +563,8 @@ int strq_batch_run(strq_ctx* c)
     Batch& B = d->batch;
     STRQ_HIP(c, hipSetDevice(c->device));
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
+    // partition into sub-batches first, so that the upload of piece k + 1 can overlap the kernels of piece k
+    std::vector<int64_t> cuts(1, 0);
     int64_t r0 = 0;
     while (r0 < B.n_reads) {
         int64_t r1 = r0; size_t ck = 0; int64_t samples = 0;
@@ -549,10 +585,16 @@ int strq_batch_run(strq_ctx* c)
             if (r1 > r0 && (ck + need > c->max_ws_bytes || samples + n > ((int64_t)3 << 30))) break;
             ck += need; samples += n; ++r1;
         }
-        const int rc = run_sub_batch(c, d, r0, r1);
-        if (rc) return rc;
+        cuts.push_back(r1);
         r0 = r1;
     }
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        int rc = upload_reads(c, d, cuts[k + 1]);          // no-op for a resident batch or when already prefetched
+        if (rc) return rc;
+        rc = run_sub_batch(c, d, cuts[k], cuts[k + 1], k + 2 < cuts.size() ? cuts[k + 2] : cuts[k + 1]);
+        if (rc) return rc;
+    }
+    B.host_src = nullptr;      // the caller's buffer is not referenced after the call
     std::fill(c->timing, c->timing + 8, 0.0f);
     c->timing[0] = B.t_lut; c->timing[1] = B.t_fwd; c->timing[2] = B.t_trace; c->timing[5] = B.t_cond; c->timing[6] = B.t_vit;
     c->timing[3] = B.t_lut + B.t_fwd + B.t_trace + B.t_cond + B.t_vit; c->timing[4] = (float)B.n_hard; c->timing[7] = (float)B.n_fwd_launches;
@@ -570,9 +612,11 @@ int strq_batch_fetch(strq_ctx* c, strq_result* out)
 int strq_detect_batch(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
                       const int32_t* target_id, const double* host_stats, strq_result* out)
 {
-    int rc = strq_batch_upload(c, n_reads, signals, dtype, offsets, target_id, host_stats);
+    // signals stay in the caller's buffer and are uploaded one sub-batch ahead of the kernels
+    int rc = batch_prepare(c, n_reads, signals, dtype, offsets, target_id, host_stats, true);
     if (rc) return rc;
     rc = strq_batch_run(c);
+    dstate(c)->batch.host_src = nullptr;
     if (rc) return rc;
     return strq_batch_fetch(c, out);
 }

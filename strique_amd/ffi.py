@@ -197,9 +197,22 @@ class Context(object):
         return out
 
     def detect_batch(self, signals, offsets, target_ids, host_stats=None):
-        self.batch_upload(signals, offsets, target_ids, host_stats)
-        self.batch_run()
-        return self.batch_fetch()
+        """strq_detect_batch: signals stay in this (host) buffer and are uploaded one sub-batch ahead of
+        the kernels.  Use batch_upload / batch_run / batch_fetch to keep a batch resident in HBM."""
+        signals = np.ascontiguousarray(signals)
+        if signals.dtype == np.int16:
+            dtype = 0
+        elif signals.dtype == np.float64:
+            dtype = 1
+        else:
+            raise ValueError("signals must be int16 or float64")
+        offsets = _c(offsets, np.int64); target_ids = _c(target_ids, np.int32)
+        hs = None if host_stats is None else _c(host_stats, np.float64)
+        self._n_batch = len(target_ids)
+        out = np.zeros(self._n_batch, dtype=RESULT_DTYPE)
+        self._check(self._lib.strq_detect_batch(self._h, ctypes.c_int64(len(target_ids)), _ptr(signals), ctypes.c_int32(dtype),
+                                                _ptr(offsets), _ptr(target_ids), _ptr(hs), _ptr(out)))
+        return out
 
     def debug_conditioning(self, read, n):
         levels = np.zeros(n, np.uint8); lval = np.zeros(256, np.float32); sc = np.zeros(10)
