@@ -52,18 +52,27 @@ static __device__ __forceinline__ double readlane_f64(double v, int l)
 
 #define VIT_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
-// wave_shr:1 -- lane l receives lane l-1 (lane 0 receives -inf / 0)
+// wave_shr:1 -- lane l receives lane l-1; lane 0 receives +0.0 / 0 (bound_ctrl).  The chain sweeps add the
+// chain log-probability afterwards, which is -inf for every lane without a chain predecessor (lane 0
+// never has one), so the filler value cannot survive.
 static __device__ __forceinline__ double dpp_shr1_f64(double v)
 {
     const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint64_t ninf = 0xFFF0000000000000ull;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)ninf, (int)(uint32_t)u, 0x138, 0xF, 0xF, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(ninf >> 32), (int)(uint32_t)(u >> 32), 0x138, 0xF, 0xF, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, 0x138, 0xF, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), 0x138, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 static __device__ __forceinline__ int dpp_shr1_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
+}
+// max of two non-NaN doubles in one instruction (__builtin_fmax makes the compiler canonicalise a
+// loop-carried operand first: a second v_max_f64 per sweep)
+static __device__ __forceinline__ double max_f64_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // In-edges per state held in registers: compile-time bounds so that the gather loops are branch free
@@ -97,7 +106,12 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     auto de_of = [](int s) constexpr { return s < (EPL + 1) / 2 ? DE_HI : DE_LO; };
     const double NEGINF = -__builtin_inf();
     struct alignas(16) Cell { double v; int c; int pad; };
-    auto ldcell = [](const char* p, int boff) { return *reinterpret_cast<const Cell*>(p + boff); };
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    auto ldcell = [](const char* p, int boff) {      // one ds_read_b128
+        const v4u q = *reinterpret_cast<const v4u*>(p + boff);
+        Cell x; x.v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x); x.c = (int)q.z; x.pad = 0;
+        return x;
+    };
     auto stcell = [](char* p, int boff, double v, int c) { Cell x; x.v = v; x.c = c; x.pad = 0; *reinterpret_cast<Cell*>(p + boff) = x; };
     const VitModel* cur_model = nullptr;
     int n = 0, NP = 0, m_start = 0, m_end = 0, scell0 = 0, dummy = 0, start_state = 0; bool single_stage = false;
@@ -204,7 +218,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                             const double tin = dpp_shr1_f64(y[s]) + clp[s];
                             const int cin = dpp_shr1_i32(yc[s]) + sinc[s];
                             const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
-                            y[s] = __builtin_fmax(y[s], tin);
+                            y[s] = max_f64_raw(y[s], tin);
                             yc[s] = win ? cin : yc[s];
                             if (BP) arg[s] = win ? scell0 + s * 64 + lane - 1 : arg[s];     // the chain predecessor's cell
                             win_any |= win;

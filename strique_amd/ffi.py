@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstrique_hip.so")
+LIB_PATH = os.environ.get("STRQ_LIB") or os.path.join(_HERE, "lib", "libstrique_hip.so")      # STRQ_LIB: A/B testing of builds
 
 STRQ_OK, STRQ_ERR_ARG, STRQ_ERR_DEVICE, STRQ_ERR_UNSUPPORTED, STRQ_ERR_NOMEM = 0, 1, 2, 3, 4
 
