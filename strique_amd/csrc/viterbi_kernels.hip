@@ -112,7 +112,11 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         Cell x; x.v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x); x.c = (int)q.z; x.pad = 0;
         return x;
     };
-    auto stcell = [](char* p, int boff, double v, int c) { Cell x; x.v = v; x.c = c; x.pad = 0; *reinterpret_cast<Cell*>(p + boff) = x; };
+    auto stcell = [](char* p, int boff, double v, int c) {      // one ds_write_b128
+        const uint64_t u = __builtin_bit_cast(uint64_t, v);
+        v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = (unsigned)c; q.w = 0u;
+        *reinterpret_cast<v4u*>(p + boff) = q;
+    };
     const VitModel* cur_model = nullptr;
     int n = 0, NP = 0, m_start = 0, m_end = 0, scell0 = 0, dummy = 0, start_state = 0; bool single_stage = false;
     // everything a lane needs about the states it owns lives in registers (reloaded when the model changes)
@@ -256,10 +260,14 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 double best = NEGINF; int bc = 0, a = dummy;
+                Cell pcs[DEMAX];          // all reads of the slot in flight before the first use
+#pragma unroll
+                for (int j = 0; j < DEMAX; ++j)
+                    if (j < de_of(s)) pcs[j] = ldcell(esrc[s][j], RD);
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j) {
                     if (j < de_of(s)) {     // compile-time
-                        const Cell pc = ldcell(esrc[s][j], RD);
+                        const Cell pc = pcs[j];
                         const double c = pc.v + elp[s][j];
                         const bool gt = c > best;
                         bc = gt ? pc.c : bc;
