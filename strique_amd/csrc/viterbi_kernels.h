@@ -59,6 +59,7 @@ struct VitResult {
 
 // One launch decodes windows of several models as long as they fit the same kernel shape
 // (`shape_of`); `max_cells` = largest n_cells among them (checked against the shape's LDS buffers).
+#define VIT_SHAPE_SS 16                            // flag in the shape id: single-stage model
 int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fits
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);

@@ -92,7 +92,9 @@ template <int EPL, int SPL> struct VitLds {
     static constexpr int WAVES = (160 * 1024) / (2 * BUF) >= 8 ? 8 : ((160 * 1024) / (2 * BUF) >= 4 ? 4 : 2);
 };
 
-template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP>
+// SS: every model of the launch is single-stage (no silent state has a silent predecessor outside
+// its chain) -- the silent phase is then straight-line code: gather, chain sweeps, store.
+template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP, bool SS>
 __global__ void __launch_bounds__((64 * VitLds<EPL, SPL>::WAVES))
 viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
                int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
@@ -118,7 +120,8 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         *reinterpret_cast<v4u*>(p + boff) = q;
     };
     const VitModel* cur_model = nullptr;
-    int n = 0, NP = 0, m_start = 0, m_end = 0, scell0 = 0, dummy = 0, start_state = 0; bool single_stage = false;
+    int n = 0, NP = 0, m_start = 0, m_end = 0, scell0 = 0, dummy = 0, start_state = 0;
+    constexpr bool single_stage = SS;
     // everything a lane needs about the states it owns lives in registers (reloaded when the model changes)
     int own_e[EPL], einc[EPL]; bool enorm[EPL];
     const char* esrc[EPL][DEMAX]; char* edst[EPL];
@@ -135,7 +138,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         if (tk.model != cur_model) {
             cur_model = tk.model;
             const VitModel& M = *cur_model;
-            n = M.n_states; NP = M.n_cells; m_start = M.start_cell; m_end = M.end_cell; single_stage = M.single_stage != 0;
+            n = M.n_states; NP = M.n_cells; m_start = M.start_cell; m_end = M.end_cell;
             scell0 = M.epl * 64; dummy = M.n_cells - 1; start_state = M.start;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
@@ -181,6 +184,52 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         auto relax_silent = [&](auto pin_c, auto off_c, int64_t trow) {
             constexpr bool PIN = decltype(pin_c)::value;
             constexpr int OFF = decltype(off_c)::value;
+            if constexpr (SS) {
+                double y[SPL]; int yc[SPL], arg[SPL];
+                Cell spc[SPL][DS];
+#pragma unroll
+                for (int s = 0; s < SPL; ++s)
+#pragma unroll
+                    for (int j = 0; j < DS; ++j) spc[s][j] = ldcell(ssrc[s][j], OFF);
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) {
+                    double best = NEGINF; int bc = 0, a = dummy;
+#pragma unroll
+                    for (int j = 0; j < DS; ++j) {
+                        const Cell pc = spc[s][j];
+                        const double c = pc.v + slp[s][j];
+                        const bool gt = c > best;          // strict: the first of equal candidates wins
+                        bc = gt ? pc.c : bc;
+                        if (BP) a = gt ? (int)(ssrc[s][j] - vbase) >> 4 : a;
+                        best = __builtin_fmax(best, c);
+                    }
+                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = -sinc[s]; a = dummy; }
+                    y[s] = best; yc[s] = bc + sinc[s]; arg[s] = a;
+                }
+                for (;;) {
+                    bool win_any = false;
+#pragma unroll
+                    for (int s = 0; s < SPL; ++s) {
+                        const double tin = dpp_shr1_f64(y[s]) + clp[s];
+                        const int cin = dpp_shr1_i32(yc[s]) + sinc[s];
+                        const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
+                        y[s] = max_f64_raw(y[s], tin);
+                        yc[s] = win ? cin : yc[s];
+                        if (BP) arg[s] = win ? scell0 + s * 64 + lane - 1 : arg[s];     // the chain predecessor's cell
+                        win_any |= win;
+                    }
+                    if (!__any(win_any)) break;
+                }
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) stcell(sdst[s], OFF, y[s], yc[s]);
+                VIT_FENCE();
+                if (BP) {
+#pragma unroll
+                    for (int s = 0; s < SPL; ++s)
+                        if (own_s[s] >= 0 && tk.bp) tk.bp[(size_t)trow * n + own_s[s]] = (uint16_t)arg[s];
+                }
+                return;
+            }
             double y[SPL], base_prev[SPL]; int yc[SPL], arg[SPL];
 #pragma unroll
             for (int s = 0; s < SPL; ++s) { y[s] = NEGINF; yc[s] = 0; arg[s] = dummy; base_prev[s] = __builtin_nan(""); }
@@ -388,7 +437,7 @@ __global__ void vit_traceback_kernel(const VitTask* __restrict__ tasks,
 }
 
 // kernel shapes: (EPL, SPL, DE_HI, DE_LO, DS)
-int vit_shape_of(const VitModel& mh)
+static int vit_shape_base(const VitModel& mh)
 {
     const int e = mh.epl, s = mh.spl;
     int hi = 0, lo = 0, ds = 0;
@@ -402,34 +451,43 @@ int vit_shape_of(const VitModel& mh)
     return -1;
 }
 
+int vit_shape_of(const VitModel& mh)
+{
+    const int b = vit_shape_base(mh);
+    return b < 0 ? b : (b | (mh.single_stage ? VIT_SHAPE_SS : 0));
+}
+
 template <int E_, int S_, int H_, int L_, int D_>
 static int vit_launch_shape(hipStream_t stream, int max_cells, const VitTask* tasks, VitResult* results, int n_tasks,
-                            int* queue, int n_cu, int want_bp, const int* order)
+                            int* queue, int n_cu, int want_bp, int single_stage, const int* order)
 {
     if (max_cells > VitLds<E_, S_>::TRASH) return 3;
     // per wave: two buffers of 16-byte {value, count} cells; waves of a block are independent
     const int nw = VitLds<E_, S_>::WAVES;
     const size_t lds = (size_t)nw * 2 * VitLds<E_, S_>::BUF;
     const dim3 grid(n_cu), block(64 * nw);
-    if (want_bp) {
-        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, true>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);
-    } else {
-        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, false>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);
-    }
+#define VIT_GO(BP_, SS_)                                                                                                  \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);       \
+    } while (0)
+    if (want_bp) { if (single_stage) VIT_GO(true, true); else VIT_GO(true, false); }
+    else { if (single_stage) VIT_GO(false, true); else VIT_GO(false, false); }
+#undef VIT_GO
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// `shape` as returned by vit_shape_of: kernel shape | VIT_SHAPE_SS for single-stage models
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
 {
-    switch (shape) {
-        case 0: return vit_launch_shape<4, 2, 6, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
-        case 1: return vit_launch_shape<1, 1, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
-        case 2: return vit_launch_shape<2, 2, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
-        case 3: return vit_launch_shape<4, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
-        case 4: return vit_launch_shape<8, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
+    const int ss = (shape & VIT_SHAPE_SS) ? 1 : 0;
+    switch (shape & ~VIT_SHAPE_SS) {
+        case 0: return vit_launch_shape<4, 2, 6, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
+        case 1: return vit_launch_shape<1, 1, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
+        case 2: return vit_launch_shape<2, 2, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
+        case 3: return vit_launch_shape<4, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
+        case 4: return vit_launch_shape<8, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         default: return 2;
     }
 }
