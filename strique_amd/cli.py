@@ -166,6 +166,7 @@ def count(argv):
     parser.add_argument("--log_level", default='warning', choices=LEVELS, help="Log level")
     parser.add_argument("--batch", type=int, default=2048, help="Reads per GPU batch")
     parser.add_argument("--device", type=int, default=0, help="HIP device")
+    parser.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend when launched with torchrun (default: nccl = RCCL)")
     args = parser.parse_args(argv)
     log = Log(args.log_level)
     config = parse_config(args.repeat, args.config, log)
@@ -174,37 +175,76 @@ def count(argv):
             log("Main: %s does not exist." % what, 'error'); raise SystemExit(1)
     if args.mod_model and not os.path.isfile(args.mod_model):
         log("Main: Modification pore model file does not exist.", 'error'); raise SystemExit(1)
+    from . import dist as sdist
+    rank, world, local = sdist.env_rank_world()
+    if world > 1:
+        # one process per GPU (torchrun): ranks take the accepted (read, target) pairs round-robin, rank 0
+        # gathers the rows once at the end (RCCL / gloo object gather) and writes them in input order
+        if not args.algn:
+            log("Main: --algn FILE is required when running on several GPUs (stdin cannot be shared).", 'error'); raise SystemExit(1)
+        sdist.init_process_group(backend=args.backend)
     from .counter import repeatCounter
     counter = repeatCounter(args.model, mod_model_file=args.mod_model, align_config=config['align'],
-                            HMM_config=config['HMM'], device=args.device)
+                            HMM_config=config['HMM'], device=local if world > 1 else args.device)
     loci = defaultdict(list)
     for name, (chrom, begin, end, repeat, prefix, suffix) in config['repeat'].items():
         counter.add_target(name, repeat, prefix, suffix)
         loci[chrom].append((name, begin, end))
     f5 = Fast5Index(args.f5Index)
-    out = open(args.out, 'w') if args.out else sys.stdout
-    print('\t'.join(HEADER), file=out)
+    stream = open(args.algn) if args.algn else sys.stdin
+    out = (open(args.out, 'w') if args.out else sys.stdout) if rank == 0 else None
+    rows = run_count(stream, loci, f5.get_raw, counter, log, args.batch, rank, world, out if world == 1 else None)
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(rows, gathered, dst=0)
+        if rank == 0:
+            write_rows(out, sorted(r for part in gathered for r in part))
+        dist.barrier()
+        dist.destroy_process_group()
+    if args.out and out is not None:
+        out.close()
+
+
+def write_rows(out, rows, header=True):
+    if header:
+        print('\t'.join(HEADER), file=out)
+    for _, row in rows:
+        print(row, file=out)
+    out.flush()
+
+
+def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, out=None):
+    """Route the SAM records of `stream` to their targets, run this rank's share through
+    `counter.detect_batch` and return [(sequence number, TSV row)].  With `out` given (single
+    process) rows are also written as soon as their batch is done, header first."""
+    if out is not None:
+        print('\t'.join(HEADER), file=out)
+    rows = []
 
     def flush(batch):
         if not batch:
             return
         try:
-            results = counter.detect_batch([(t, raw, s) for _, t, s, raw in batch])
+            results = counter.detect_batch([(t, raw, s) for _, _, t, s, raw in batch])
         except Exception as e:                                    # a bad batch never kills the run
             log("Detector: batch failed (%s), retrying read by read" % e, 'warning')
             results = []
-            for _, t, s, raw in batch:
+            for _, _, t, s, raw in batch:
                 try:
                     results.append(counter.detect(t, raw, s))
                 except Exception as e1:
                     log("Detector: read failed: %s" % e1, 'warning'); results.append(None)
-        for (qname, target, strand, _), res in zip(batch, results):
+        done = []
+        for (seq, qname, target, strand, _), res in zip(batch, results):
             if res is not None:
-                print('\t'.join(str(x) for x in (qname, target, strand) + tuple(res)), file=out)
-        out.flush()
+                done.append((seq, '\t'.join(str(x) for x in (qname, target, strand) + tuple(res))))
+        rows.extend(done)
+        if out is not None:
+            write_rows(out, done, header=False)
 
     batch = []
-    stream = open(args.algn) if args.algn else sys.stdin
+    seq = 0
     for line in stream:
         if line.startswith('@'):
             continue
@@ -215,19 +255,22 @@ def count(argv):
         targets = intersect_targets(sr, loci)
         if not targets:
             log("Detector: No target for %s" % sr.QNAME, 'debug'); continue
+        mine = [(seq + i, t) for i, t in enumerate(targets) if (seq + i) % world == rank]
+        seq += len(targets)
+        if not mine:
+            continue
         try:
-            raw = f5.get_raw(sr.QNAME)
+            raw = get_raw(sr.QNAME)
         except Exception as e:
             log("Detector: cannot read %s: %s" % (sr.QNAME, e), 'warning'); raw = None
         if raw is None:
             log("Detector: No fast5 for ID %s" % sr.QNAME, 'warning'); continue
-        for t in targets:
-            batch.append((sr.QNAME, t, strand, raw))
-        if len(batch) >= args.batch:
+        for sq, t in mine:
+            batch.append((sq, sr.QNAME, t, strand, raw))
+        if len(batch) >= batch_size:
             flush(batch); batch = []
     flush(batch)
-    if args.out:
-        out.close()
+    return rows
 
 
 def index(argv):

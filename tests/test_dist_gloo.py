@@ -38,3 +38,57 @@ def test_two_rank_gather(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+CLI_WORKER = r'''
+import io, json, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from strique_amd import cli, dist as sdist
+rank, world, local = sdist.init_process_group(backend="gloo")
+cfg = json.load(open(os.path.join(%r, "tests", "golden", "config.json")))
+loci = {}
+for name, (chrom, b, e, *_r) in cfg["repeat"].items():
+    loci.setdefault(chrom, []).append((name, b, e))
+lines = ["@HD\tVN:1.0"]
+for i in range(37):
+    chrom, pos = ("chr9", 27570000) if i %% 3 else ("chrX", 146990000)
+    if i %% 7 == 6:
+        chrom = "chr1"                                   # no locus: skipped by every rank alike
+    lines.append("\t".join(["read%%d" %% i, "16" if i %% 2 else "0", chrom, str(pos), "60", "5S8000M3S", "*", "0", "0", "ACGT", "*"]))
+
+class FakeCounter(object):                               # stands in for the GPU engine: rows depend on the inputs only
+    def detect_batch(self, items):
+        return [(len(raw) %% 97, 1.5, 2.5, -3.0 * len(t), int(raw[0]), 7, "-") for t, raw, s in items]
+
+def get_raw(qname):
+    i = int(qname[4:])
+    return None if i == 11 else np.arange(100 + i, 300 + 2 * i)     # read11 has no fast5
+
+log = cli.Log("error")
+mine = cli.run_count(iter(lines), loci, get_raw, FakeCounter(), log, 5, rank, world)
+import torch.distributed as dist
+gathered = [None] * world if rank == 0 else None
+dist.gather_object(mine, gathered, dst=0)
+if rank == 0:
+    buf = io.StringIO(); cli.write_rows(buf, sorted(r for part in gathered for r in part))
+    one = io.StringIO(); cli.run_count(iter(lines), loci, get_raw, FakeCounter(), log, 5, 0, 1, one)
+    assert buf.getvalue() == one.getvalue(), (buf.getvalue(), one.getvalue())
+    assert len(buf.getvalue().splitlines()) == 1 + 31                  # 37 records - 5 off-target - 1 without fast5
+    assert len(mine) in (15, 16)                                       # round-robin share
+    print("CLI_SHARD_OK")
+dist.barrier(); dist.destroy_process_group()
+''' % (ROOT, ROOT)
+
+
+def test_count_rows_shard_and_merge(tmp_path):
+    """`count` under torchrun: ranks take the accepted (read, target) pairs round-robin and rank 0 merges
+    the rows into input order -- identical to the single-process output."""
+    script = tmp_path / "cli_worker.py"
+    script.write_text(CLI_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "CLI_SHARD_OK" in outs[0]
