@@ -3,61 +3,82 @@
 //   rep  = nrm[prefix_begin:suffix_end][ 'repeat' in state ]      samples decoded into repeat states
 //   path = modHMM.viterbi(clip(rep, model_min, model_max))
 //   one character per run of non-hub states: '1' if its first state is in the modified branch
-// Two small streaming kernels around the Viterbi kernels; one thread per read (the per-read work is
-// a sequential compaction over the window).
+// Two streaming kernels around the Viterbi kernels, one wave64 per read: 64 samples per iteration,
+// kept elements compacted with a ballot + lane prefix count (coalesced reads and writes).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mod_kernels.h"
 
 namespace strq {
 
-__global__ void mod_compact_kernel(const ModTask* __restrict__ tasks, int n, int64_t* __restrict__ out_len)
+static __device__ __forceinline__ int lane_prefix(uint64_t mask)      // set bits below this lane
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__global__ void __launch_bounds__(256)
+mod_compact_kernel(const ModTask* __restrict__ tasks, int n, int64_t* __restrict__ out_len)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const ModTask tk = tasks[i];
     int64_t k = 0;
     if (tk.path && tk.T > 0) {
-        for (int64_t t = 0; t < tk.T; ++t) {
-            if (tk.tag[tk.path[t]] != 1) continue;
-            double v = tk.is_f64 ? reinterpret_cast<const double*>(tk.raw)[t] : (double)reinterpret_cast<const int16_t*>(tk.raw)[t];
-            v = (v - tk.c1) / tk.h1;
-            v = v * tk.h2 + tk.c2;
-            v = v < tk.clip_lo ? tk.clip_lo : v;  v = v > tk.clip_hi ? tk.clip_hi : v;     // normalize2model clip
-            v = v < tk.mod_lo ? tk.mod_lo : v;    v = v > tk.mod_hi ? tk.mod_hi : v;       // mod_repeats clip
-            tk.out[k++] = v;
+        for (int64_t t0 = 0; t0 < tk.T; t0 += 64) {
+            const int64_t t = t0 + lane;
+            bool keep = false; double v = 0.0;
+            if (t < tk.T) {
+                keep = tk.tag[tk.path[t]] == 1;
+                v = tk.is_f64 ? reinterpret_cast<const double*>(tk.raw)[t] : (double)reinterpret_cast<const int16_t*>(tk.raw)[t];
+                v = (v - tk.c1) / tk.h1;
+                v = v * tk.h2 + tk.c2;
+                v = v < tk.clip_lo ? tk.clip_lo : v;  v = v > tk.clip_hi ? tk.clip_hi : v;     // normalize2model clip
+                v = v < tk.mod_lo ? tk.mod_lo : v;    v = v > tk.mod_hi ? tk.mod_hi : v;       // mod_repeats clip
+            }
+            const uint64_t m = __ballot(keep);
+            if (keep) tk.out[k + lane_prefix(m)] = v;
+            k += __popcll(m);
         }
     }
-    out_len[i] = k;
+    if (lane == 0) out_len[i] = k;
 }
 
-__global__ void mod_pattern_kernel(const PatTask* __restrict__ tasks, int n, int64_t* __restrict__ out_len)
+__global__ void __launch_bounds__(256)
+mod_pattern_kernel(const PatTask* __restrict__ tasks, int n, int64_t* __restrict__ out_len)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const PatTask tk = tasks[i];
+    if (!tk.ok) { if (lane == 0) { if (tk.out) tk.out[0] = '-'; out_len[i] = tk.out ? 1 : 0; } return; }
     int64_t k = 0;
-    if (!tk.ok) { if (tk.out) tk.out[k++] = '-'; out_len[i] = k; return; }
-    bool prev_hub = true;
-    for (int64_t t = 0; t < tk.T; ++t) {
-        const int tg = tk.tag[tk.path[t]];
-        const bool hub = tg == 2;
-        if (!hub && prev_hub) tk.out[k++] = tg == 1 ? '1' : '0';
-        prev_hub = hub;
+    uint64_t carry = 1;                 // "previous state was a hub" for the first sample
+    for (int64_t t0 = 0; t0 < tk.T; t0 += 64) {
+        const int64_t t = t0 + lane;
+        int tg = 2;                     // past the end: treated as hub, starts nothing
+        if (t < tk.T) tg = tk.tag[tk.path[t]];
+        const uint64_t hubs = __ballot(tg == 2);
+        const uint64_t prev = (hubs << 1) | carry;             // bit l = sample l-1 was a hub
+        const bool start = t < tk.T && tg != 2 && ((prev >> lane) & 1);
+        const uint64_t m = __ballot(start);
+        if (start) tk.out[k + lane_prefix(m)] = tg == 1 ? '1' : '0';
+        k += __popcll(m);
+        carry = hubs >> 63;
     }
-    out_len[i] = k;
+    if (lane == 0) out_len[i] = k;
 }
 
 int launch_mod_compact(hipStream_t s, const ModTask* tasks, int n, int64_t* out_len)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mod_compact_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tasks, n, out_len);
+    hipLaunchKernelGGL(mod_compact_kernel, dim3((n + 3) / 4), dim3(256), 0, s, tasks, n, out_len);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int launch_mod_pattern(hipStream_t s, const PatTask* tasks, int n, int64_t* out_len)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mod_pattern_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tasks, n, out_len);
+    hipLaunchKernelGGL(mod_pattern_kernel, dim3((n + 3) / 4), dim3(256), 0, s, tasks, n, out_len);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -413,26 +413,58 @@ int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order)
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// one thread per task: follow the back-pointers from (T, end) and write the emitting state of
-// every observation (first version: latency-bound, used by the modification pass and the parity API)
-__global__ void vit_traceback_kernel(const VitTask* __restrict__ tasks,
-                                     const VitResult* __restrict__ results, int32_t* const* __restrict__ paths, int n_tasks)
+// One wave per task: follow the back-pointers from (T, end) and write the emitting state of every
+// observation.  The walk is a serial pointer chase, so the rows it is about to visit are staged
+// through LDS in blocks (coalesced dword loads) and every hop costs two LDS reads instead of a
+// dependent global load; all lanes walk in lock-step (broadcast reads), the finished stretch of the
+// path is written back coalesced.
+#define VIT_TB_ROWS_U16 6144      // LDS staging per wave: back-pointer rows
+#define VIT_TB_CELLS 1024         // cell -> state map
+#define VIT_TB_MAXROWS 256
+__global__ void __launch_bounds__(256)
+vit_traceback_kernel(const VitTask* __restrict__ tasks, const VitResult* __restrict__ results,
+                     int32_t* const* __restrict__ paths, int n_tasks)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t rows_all[4][VIT_TB_ROWS_U16 / 2 + 2];
+    __shared__ uint16_t cs_all[4][VIT_TB_CELLS];
+    __shared__ int32_t pb_all[4][VIT_TB_MAXROWS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
     if (i >= n_tasks) return;
     const VitTask& tk = tasks[i];
     const VitModel& M = *tk.model;
     if (results[i].status != 0 || !tk.bp || !paths[i]) return;
+    const int n = M.n_states, ne = M.n_emit, start = M.start, ncell = M.n_cells;
+    if (n > VIT_TB_ROWS_U16 || ncell > VIT_TB_CELLS) return;      // cannot happen with the compiled kernel shapes
+    uint32_t* rows32 = rows_all[wave]; const uint16_t* rows = reinterpret_cast<const uint16_t*>(rows32);
+    uint16_t* cs = cs_all[wave]; int32_t* pb = pb_all[wave];
+    for (int c = lane; c < ncell; c += 64) { const int st = M.cell_state[c]; cs[c] = (uint16_t)(st < 0 ? 0xFFFF : st); }
+    int RB = (VIT_TB_ROWS_U16 - 2) / n; if (RB > VIT_TB_MAXROWS) RB = VIT_TB_MAXROWS;
+    int32_t* path = paths[i];
     int64_t t = tk.T; int l = M.end;
-    const int n = M.n_states, ne = M.n_emit;
-    int guard = 0;
-    while (!(t == 0 && l == M.start)) {
-        const int pcell = tk.bp[(size_t)t * n + l];
-        const int prev = M.cell_state[pcell];     // back-pointers name LDS cells
-        if (prev < 0 || prev >= n) break;
-        if (l < ne) { paths[i][t - 1] = l; --t; guard = 0; }
-        else if (++guard > n) break;
-        l = prev;
+    int guard = 0; bool bad = false;
+    while (!(t == 0 && l == start) && !bad) {
+        const int64_t tb = t - RB + 1 > 0 ? t - RB + 1 : 0;          // stage rows tb .. t
+        const int nrow = (int)(t - tb + 1);
+        const uintptr_t A = reinterpret_cast<uintptr_t>(tk.bp + (size_t)tb * n);
+        const uintptr_t A4 = A & ~(uintptr_t)3;
+        const int shift = (int)((A - A4) >> 1);
+        const int ndw = (nrow * n + shift + 1) / 2;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (int x = lane; x < ndw; x += 64) rows32[x] = reinterpret_cast<const uint32_t*>(A4)[x];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int64_t t_hi = t;                                       // path entries tb-1 .. t_hi-1 may be produced here
+        while (t >= tb && !(t == 0 && l == start)) {
+            const int pcell = rows[(int)(t - tb) * n + l + shift];
+            const int prev = pcell < ncell ? cs[pcell] : 0xFFFF;
+            if (prev == 0xFFFF || prev >= n) { bad = true; break; }
+            if (l < ne) { if (lane == 0) pb[(int)(t - tb)] = l; --t; guard = 0; }      // path[t-1] <- l, kept at slot (t-1) - (tb-1)
+            else if (++guard > n) { bad = true; break; }
+            l = prev;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // entries for observations t .. t_hi-1 (0-based path index = time - 1 -> slot time - tb)
+        for (int64_t tt = t + 1 + lane; tt <= t_hi; tt += 64) path[tt - 1] = pb[(int)(tt - tb)];
     }
 }
 
@@ -496,7 +528,7 @@ int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResu
                          int32_t* const* paths, int n_tasks)
 {
     if (n_tasks <= 0) return 0;
-    hipLaunchKernelGGL(vit_traceback_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, stream, tasks, results, paths, n_tasks);
+    hipLaunchKernelGGL(vit_traceback_kernel, dim3((n_tasks + 3) / 4), dim3(256), 0, stream, tasks, results, paths, n_tasks);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
