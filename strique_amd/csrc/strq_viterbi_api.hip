@@ -127,6 +127,8 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     for (int s = 0; s < spl2; ++s) for (int lane = 0; lane < 64; ++lane) if (own_s[s * 64 + lane] >= 0) fill(own_s[s * 64 + lane], m.s_base[s], lane);
     std::vector<int32_t> kind((size_t)epl * 64, 0); std::vector<double> a((size_t)epl * 64, 0.0), b(a), cc(a);
     for (int i = 0; i < epl * 64; ++i) if (own_e[i] >= 0) { const int e = own_e[i]; kind[i] = emis_kind[e]; a[i] = emis_a[e]; b[i] = emis_b[e]; cc[i] = emis_c[e]; }
+    m.uni_lo_max = -INFINITY; m.uni_hi_min = INFINITY;
+    for (int e = 0; e < ne; ++e) if (emis_kind[e] == 2) { m.uni_lo_max = std::max(m.uni_lo_max, emis_a[e]); m.uni_hi_min = std::min(m.uni_hi_min, emis_b[e]); }
     std::vector<int32_t> inc((size_t)n_states + 1, 0);
     if (count_inc) std::copy(count_inc, count_inc + n_states, inc.begin());
     std::vector<int32_t> tagv((size_t)n_states + 1, 0);

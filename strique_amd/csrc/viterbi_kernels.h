@@ -36,6 +36,7 @@ struct VitModel {
     const double* emis_c;             // -log(sigma sqrt(2pi)) | -log(hi - lo)
     const int32_t* count_inc;         // n_states + 1, by state
     const int32_t* state_tag;         // n_states + 1, by state
+    double uni_lo_max, uni_hi_min;    // tightest bounds of the uniform emissions: observations inside them need no range test
 };
 
 enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };

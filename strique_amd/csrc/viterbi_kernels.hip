@@ -126,6 +126,8 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     int own_e[EPL], einc[EPL]; bool enorm[EPL];
     const char* esrc[EPL][DEMAX]; char* edst[EPL];
     double ea[EPL], eb[EPL], ec[EPL], elp[EPL][DEMAX];
+    double ebf[EPL], ecf[EPL];     // branch-free emission: ecf - (x - ea)^2 * ebf  (uniform: ebf = 0; padding: ecf = -inf)
+    double uni_lo_max = 0.0, uni_hi_min = 0.0;
     int own_s[SPL], sinc[SPL];
     const char* ssrc[SPL][DS]; char* sdst[SPL];
     double slp[SPL][DS], clp[SPL];
@@ -140,15 +142,17 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             const VitModel& M = *cur_model;
             n = M.n_states; NP = M.n_cells; m_start = M.start_cell; m_end = M.end_cell;
             scell0 = M.epl * 64; dummy = M.n_cells - 1; start_state = M.start;
+            uni_lo_max = M.uni_lo_max; uni_hi_min = M.uni_hi_min;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 const bool on = s < M.epl;
                 own_e[s] = on ? M.own_e[s * 64 + lane] : -1;
                 const int kind = on ? M.emis_kind[s * 64 + lane] : 0;
                 enorm[s] = kind == 1;
-                // padding states: the uniform test x >= +inf never holds -> emission -inf
-                ea[s] = kind ? M.emis_a[s * 64 + lane] : __builtin_inf(); eb[s] = kind ? M.emis_b[s * 64 + lane] : NEGINF;
+                // padding states: the uniform test x <= -inf never holds -> emission -inf
+                ea[s] = kind ? M.emis_a[s * 64 + lane] : 0.0; eb[s] = kind ? M.emis_b[s * 64 + lane] : NEGINF;
                 ec[s] = kind ? M.emis_c[s * 64 + lane] : 0.0;
+                ebf[s] = kind == 1 ? eb[s] : 0.0; ecf[s] = kind ? ec[s] : NEGINF;
                 einc[s] = own_e[s] >= 0 ? M.count_inc[own_e[s]] : 0;
                 edst[s] = vbase + 16 * (own_e[s] >= 0 ? s * 64 + lane : TRASH);
 #pragma unroll
@@ -175,6 +179,8 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             }
         }
         const int64_t T = tk.T;
+        // clipped observations (detect pipeline) that cannot leave any uniform emission's support
+        const bool fast_em = tk.src_kind != VIT_SRC_F64 && tk.lo >= uni_lo_max && tk.hi <= uni_hi_min;
         for (int i = lane; i < NP; i += 64) { stcell(vbase, 16 * i, NEGINF, 0); stcell(vbase, BUF + 16 * i, NEGINF, 0); }
         VIT_FENCE();
         if (lane == 0) stcell(vbase, 16 * m_start, 0.0, 0);
@@ -324,10 +330,17 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         best = __builtin_fmax(best, c);
                     }
                 }
-                const double d = x - ea[s];
-                const double en = ec[s] - (d * d) * eb[s];
-                const double eu = (x >= ea[s] && x <= eb[s]) ? ec[s] : NEGINF;
-                nv[s] = best + (enorm[s] ? en : eu); nc[s] = bc + einc[s]; na[s] = a;
+                double em;
+                if (fast_em) {          // every observation of this window lies inside all uniform emissions
+                    const double d = x - ea[s];
+                    em = ecf[s] - (d * d) * ebf[s];
+                } else {
+                    const double d = x - ea[s];
+                    const double en = ec[s] - (d * d) * eb[s];
+                    const double eu = (x >= ea[s] && x <= eb[s]) ? ec[s] : NEGINF;
+                    em = enorm[s] ? en : eu;
+                }
+                nv[s] = best + em; nc[s] = bc + einc[s]; na[s] = a;
             }
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
