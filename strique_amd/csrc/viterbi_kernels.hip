@@ -186,6 +186,24 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         if (lane == 0) stcell(vbase, 16 * m_start, 0.0, 0);
         VIT_FENCE();
 
+        // Best of the first `cnt` candidates into element 0 (value, carried count, source cell).  Pairwise
+        // tournament instead of a serial chain (shorter dependency chains); the right-hand candidate wins
+        // only with a strict '>', so among equal values the lowest index -- the first in-edge -- survives.
+        auto tournament = [&](auto& cv, auto& cc, auto& ca, int cnt) {
+#pragma unroll
+            for (int stride = 1; stride < 8; stride *= 2) {
+#pragma unroll
+                for (int j = 0; j + stride < 8; j += 2 * stride) {
+                    if (j + stride < cnt) {
+                        const bool gt = cv[j + stride] > cv[j];
+                        cc[j] = gt ? cc[j + stride] : cc[j];
+                        if (BP) ca[j] = gt ? ca[j + stride] : ca[j];
+                        cv[j] = __builtin_fmax(cv[j], cv[j + stride]);
+                    }
+                }
+            }
+        };
+
         // Silent states of the buffer at byte offset OFF to their fixed point.  PIN: keep start at 0 (t = 0).
         auto relax_silent = [&](auto pin_c, auto off_c, int64_t trow) {
             constexpr bool PIN = decltype(pin_c)::value;
@@ -199,16 +217,11 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     for (int j = 0; j < DS; ++j) spc[s][j] = ldcell(ssrc[s][j], OFF);
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    double best = NEGINF; int bc = 0, a = dummy;
+                    double cv[DS]; int cc[DS], ca[DS];
 #pragma unroll
-                    for (int j = 0; j < DS; ++j) {
-                        const Cell pc = spc[s][j];
-                        const double c = pc.v + slp[s][j];
-                        const bool gt = c > best;          // strict: the first of equal candidates wins
-                        bc = gt ? pc.c : bc;
-                        if (BP) a = gt ? (int)(ssrc[s][j] - vbase) >> 4 : a;
-                        best = __builtin_fmax(best, c);
-                    }
+                    for (int j = 0; j < DS; ++j) { cv[j] = spc[s][j].v + slp[s][j]; cc[j] = spc[s][j].c; ca[j] = BP ? (int)(ssrc[s][j] - vbase) >> 4 : 0; }
+                    tournament(cv, cc, ca, DS);
+                    double best = cv[0]; int bc = cc[0], a = ca[0];
                     if (PIN && own_s[s] == start_state) { best = 0.0; bc = -sinc[s]; a = dummy; }
                     y[s] = best; yc[s] = bc + sinc[s]; arg[s] = a;
                 }
@@ -314,22 +327,17 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             double nv[EPL]; int nc[EPL], na[EPL];
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
-                double best = NEGINF; int bc = 0, a = dummy;
                 Cell pcs[DEMAX];          // all reads of the slot in flight before the first use
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j)
                     if (j < de_of(s)) pcs[j] = ldcell(esrc[s][j], RD);
+                double cv[DEMAX]; int cc[DEMAX], ca[DEMAX];
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j) {
-                    if (j < de_of(s)) {     // compile-time
-                        const Cell pc = pcs[j];
-                        const double c = pc.v + elp[s][j];
-                        const bool gt = c > best;
-                        bc = gt ? pc.c : bc;
-                        if (BP) a = gt ? (int)(esrc[s][j] - vbase) >> 4 : a;
-                        best = __builtin_fmax(best, c);
-                    }
+                    if (j < de_of(s)) { cv[j] = pcs[j].v + elp[s][j]; cc[j] = pcs[j].c; ca[j] = BP ? (int)(esrc[s][j] - vbase) >> 4 : 0; }
                 }
+                tournament(cv, cc, ca, de_of(s));
+                const double best = cv[0]; const int bc = cc[0], a = ca[0];
                 double em;
                 if (fast_em) {          // every observation of this window lies inside all uniform emissions
                     const double d = x - ea[s];
@@ -387,7 +395,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         const Cell fin = ldcell(vbase + 16 * m_end, (T & 1) ? BUF : 0);
         const double lp = fin.v;
         const int cnt = fin.c;
-        VitResult r; r.logp = lp; r.counted = cnt; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
+        VitResult r; r.logp = lp; r.counted = (lp > NEGINF) ? cnt : 0; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
         r.dbg[0] = r.dbg[1] = r.dbg[2] = r.dbg[3] = 0;
         results[ti] = r;     // every lane stores the same value
         VIT_FENCE();
