@@ -60,8 +60,8 @@ def main():
     with open(os.path.join(out, tag + "_kernel_stats.md"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats (%s)\n\n" % tag)
         f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s/kt -o %s -- "
-                "python3 bench.py --steps 2 --warmup 1 --reads 4096 --no-cpu-baseline --check 0`\n"
-                "(5 passes over 4096 reads of 50 kb: 1 warm-up + 2 timed + the two sub-batches of the host-buffer leg).  Raw table: `%s_kernel_stats.csv`.\n\n" % (tag, tag, tag))
+                "python3 bench.py --steps 2 --warmup 1 --reads 4096 --no-cpu-baseline --no-host-leg --check 0`\n"
+                "(3 passes over 4096 reads of 50 kb: 1 warm-up + 2 timed).  Raw table: `%s_kernel_stats.csv`.\n\n" % (tag, tag, tag))
         f.write("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n")
         for r in rows:
             f.write("| %s | %s | %.3f | %.1f | %s |\n" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
@@ -77,7 +77,7 @@ def main():
     with open(os.path.join(out, tag + "_pmc.md"), "w") as f:
         f.write("# HBM traffic per kernel, rocprofv3 PMC (%s)\n\n" % tag)
         f.write("Two separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, no trace domain) of\n"
-                "`python3 bench.py --steps 1 --warmup 0 --reads %d --no-cpu-baseline --check 0` (%d reads of 50 kb = %d alignments).\n"
+                "`python3 bench.py --steps 1 --warmup 0 --reads %d --no-cpu-baseline --no-host-leg --check 0` (%d reads of 50 kb = %d alignments).\n"
                 "Counter unit: KB.  On gfx950 FETCH_SIZE under-counts wide coalesced streams by 2x (MI355X_MICROARCH.md, HBM\n"
                 "section): the x2 column applies that correction as an upper bound; WRITE_SIZE is used as reported.\n"
                 "Values are per-dispatch averages.\n\n" % (pmc_reads, pmc_reads, 2 * pmc_reads))
@@ -95,7 +95,7 @@ def main():
         n_align = 2 * pmc_reads / n_launch
         info = {
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 "
-                      "--reads %d --no-cpu-baseline --check 0; see profiles/%s_pmc.md" % (pmc_reads, tag),
+                      "--reads %d --no-cpu-baseline --no-host-leg --check 0; see profiles/%s_pmc.md" % (pmc_reads, tag),
             "kernel": k, "alignments_per_launch": n_align,
             "FETCH_SIZE_KB": fv, "WRITE_SIZE_KB": wv,
             "bytes_per_launch_raw": (fv + wv) * 1024, "bytes_per_launch_fetch_x2": (2 * fv + wv) * 1024,
