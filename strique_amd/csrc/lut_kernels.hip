@@ -47,53 +47,62 @@ static __device__ __forceinline__ float cell_score_dev(const AlignParams& p, flo
     return s > p.dist_min ? s : p.dist_min;
 }
 
+// One workgroup per table.  The level values of a read are non-decreasing in the level (they are an
+// affine map of the level, clipped), so for a class the levels that score above dist_min form one
+// contiguous range around the level closest to the class value: the range is found by bisection
+// (~16 pow evaluations per class) and only its entries are evaluated (~44 per class instead of 256).
+// A table whose level values are not monotone is handed to the host (n_hard = -1).
 __global__ void __launch_bounds__(256)
 lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, HardEntry* __restrict__ hard,
                  int* __restrict__ hard_count, int hard_cap, AlignParams p)
 {
-    extern __shared__ float sc_all[];          // k x 256 scores
-    __shared__ int lo[STRQ_LUT_MAX_K], hi[STRQ_LUT_MAX_K + 1];
-    __shared__ int width, n_local, plat_lo, plat_hi;
+    __shared__ float v[256];
+    __shared__ float cls[STRQ_LUT_MAX_K];
+    __shared__ int lo[STRQ_LUT_MAX_K], hi[STRQ_LUT_MAX_K + 1];      // later: e_l | e_r << 8 and the row offsets
+    __shared__ int width, n_local, plat_lo, plat_hi, rebuild;
     __shared__ unsigned short local_hard[STRQ_LUT_LOCAL_HARD][2];
     const LutJob jb = jobs[blockIdx.x];
-    const int q = threadIdx.x;
-    for (int k = q; k < jb.k; k += 256) { lo[k] = 256; hi[k] = -1; }
-    if (q == 0) { width = 0; n_local = 0; plat_lo = 255; plat_hi = 0; }
+    const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
+    v[q] = jb.level_val[q];
+    for (int k = q; k < jb.k; k += 256) cls[k] = jb.cls_val[k];
+    if (q == 0) { width = 0; n_local = 0; plat_lo = 255; plat_hi = 0; rebuild = 0; }
     __syncthreads();
-    const float v = jb.level_val[q];
-    // plateaus: levels 0..plat_lo share the value of level 0, levels plat_hi..255 that of level 255
     {
-        const float v0 = jb.level_val[0], v255 = jb.level_val[255];
-        if (__builtin_bit_cast(uint32_t, v) != __builtin_bit_cast(uint32_t, v0)) atomicMin(&plat_lo, q - 1);
-        if (__builtin_bit_cast(uint32_t, v) != __builtin_bit_cast(uint32_t, v255)) atomicMax(&plat_hi, q + 1);
+        // plateaus: levels 0..plat_lo share the value of level 0, levels plat_hi..255 that of level 255
+        const float v0 = v[0], v255 = v[255], vq = v[q];
+        if (__builtin_bit_cast(uint32_t, vq) != __builtin_bit_cast(uint32_t, v0)) atomicMin(&plat_lo, q - 1);
+        if (__builtin_bit_cast(uint32_t, vq) != __builtin_bit_cast(uint32_t, v255)) atomicMax(&plat_hi, q + 1);
+        if (q > 0 && !(v[q - 1] <= vq)) rebuild = 1;          // not monotone (or NaN): no contiguous bands
     }
     __syncthreads();
+    if (rebuild) { if (q == 0) { info[blockIdx.x].total = 0; info[blockIdx.x].need = 0; info[blockIdx.x].pad_ = 0; info[blockIdx.x].n_hard = -1; } return; }
     const int plat_lo_r = plat_lo, plat_hi_r = plat_hi;
-    for (int k = 0; k < jb.k; ++k) {
-        bool hd;
-        const float s = cell_score_dev(p, v, jb.cls_val[k], &hd);
-        sc_all[k * 256 + q] = s;
-        if (s > p.dist_min) { atomicMin(&lo[k], q); atomicMax(&hi[k], q); }
-        if (hd && q >= plat_lo_r && q <= plat_hi_r) {     // levels inside a plateau duplicate its end level
-            const int slot = atomicAdd(&n_local, 1);
-            if (slot < STRQ_LUT_LOCAL_HARD) { local_hard[slot][0] = (unsigned short)k; local_hard[slot][1] = (unsigned short)q; }
+    auto in_band = [&](int lv, float c) { bool hd; return cell_score_dev(p, v[lv], c, &hd) > p.dist_min; };
+    // ---- band of every class: first / last level scoring above dist_min
+    for (int k = q; k < jb.k; k += 256) {
+        const float c = cls[k];
+        int a = 0, b = 256;                                   // lower bound of c among the level values
+        while (a < b) { const int m = (a + b) >> 1; if (v[m] < c) a = m + 1; else b = m; }
+        int best = a < 256 ? a : 255;
+        if (a > 0 && a < 256) { const float dl = c - v[a - 1], dr = v[a] - c; if (dl <= dr) best = a - 1; }
+        int l = 256, h = -1;
+        bool hd_best;
+        const bool best_in = cell_score_dev(p, v[best], c, &hd_best) > p.dist_min;
+        if (hd_best) rebuild = 1;                             // borderline at the centre of the band: let the host decide
+        if (best_in) {
+            int x = 0, y = best;                              // first level in [0, best] inside the band
+            while (x < y) { const int m = (x + y) >> 1; if (in_band(m, c)) y = m; else x = m + 1; }
+            l = x;
+            x = best; y = 255;                                // last level in [best, 255] inside the band
+            while (x < y) { const int m = (x + y + 1) >> 1; if (in_band(m, c)) x = m; else y = m - 1; }
+            h = x;
         }
-    }
-    __syncthreads();
-    // stored range of class k: [e_l, e_r]; from here on lo[] holds e_l | e_r << 8 and hi[] the row
-    // offset (ragged rows: class k stores exactly its range, rows back to back)
-    {
-        int el[(STRQ_LUT_MAX_K + 255) / 256], er[(STRQ_LUT_MAX_K + 255) / 256];
-        int x = 0;
-        for (int k = q; k < jb.k; k += 256, ++x) {
-            const bool none = hi[k] < lo[k];
-            el[x] = none ? 0 : (lo[k] <= plat_lo ? plat_lo : lo[k] - 1);
-            er[x] = none ? 0 : (hi[k] >= plat_hi ? plat_hi : hi[k] + 1);
-            atomicMax(&width, er[x] - el[x] + 1);
-        }
-        __syncthreads();
-        x = 0;
-        for (int k = q; k < jb.k; k += 256, ++x) { lo[k] = el[x] | (er[x] << 8); hi[k] = er[x] - el[x] + 1; }
+        const bool none = h < l;
+        const int el = none ? 0 : (l <= plat_lo_r ? plat_lo_r : l - 1);
+        const int er = none ? 0 : (h >= plat_hi_r ? plat_hi_r : h + 1);
+        lo[k] = el | (er << 8) | ((!none && l <= plat_lo_r) ? 0 : 1 << 16) | ((!none && h >= plat_hi_r) ? 0 : 1 << 17);   // bits 16/17: the edge entry is a clipped one
+        hi[k] = er - el + 1;
+        atomicMax(&width, er - el + 1);
     }
     __syncthreads();
     if (q == 0) {
@@ -102,23 +111,31 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
         hi[jb.k] = off;
     }
     __syncthreads();
-    auto edge_l = [&](int k) { return lo[k] & 255; };
-    auto edge_r = [&](int k) { return lo[k] >> 8; };
     const int* roff = hi;
-    for (int k = 0; k < jb.k; ++k) {
-        const int el = edge_l(k), er = edge_r(k);
-        if (q >= el && q <= er) jb.table[roff[k] + q - el] = sc_all[k * 256 + q];
-        if (q == 0) jb.band_lo[k] = (int32_t)((uint32_t)el | ((uint32_t)(er - el) << 8) | ((uint32_t)roff[k] << 16));
+    // ---- the stored entries, one wave per class at a time
+    for (int k = wave; k < jb.k; k += 4) {
+        const int d = lo[k], el = d & 255, er = (d >> 8) & 255;
+        const float c = cls[k];
+        for (int lv = el + lane; lv <= er; lv += 64) {
+            bool hd;
+            const float s = cell_score_dev(p, v[lv], c, &hd);
+            jb.table[roff[k] + lv - el] = s;
+            if (hd) {
+                // a borderline value in a clipped edge entry could come out above dist_min on the host: the
+                // band itself would be wrong, so let the host rebuild this table
+                if ((lv == el && (d & (1 << 16))) || (lv == er && (d & (1 << 17)))) rebuild = 1;
+                else {
+                    const int slot = atomicAdd(&n_local, 1);
+                    if (slot < STRQ_LUT_LOCAL_HARD) { local_hard[slot][0] = (unsigned short)k; local_hard[slot][1] = (unsigned short)lv; }
+                }
+            }
+        }
+        if (lane == 0) jb.band_lo[k] = (int32_t)((uint32_t)el | ((uint32_t)(er - el) << 8) | ((uint32_t)roff[k] << 16));
     }
+    __syncthreads();
     if (q == 0) {
         int nh = n_local;
-        if (nh > STRQ_LUT_LOCAL_HARD) nh = -1;    // host rebuilds the whole table
-        // a borderline entry outside the stored band could turn out above dist_min on the host:
-        // the band itself would be wrong, so let the host rebuild this table
-        for (int i = 0; i < nh; ++i) {
-            const int k = local_hard[i][0], lv = local_hard[i][1];
-            if (lv < edge_l(k) || lv > edge_r(k)) { nh = -1; break; }
-        }
+        if (nh > STRQ_LUT_LOCAL_HARD || rebuild) nh = -1;    // host rebuilds the whole table
         info[blockIdx.x].total = roff[jb.k];
         info[blockIdx.x].need = width;
         info[blockIdx.x].pad_ = 0;
@@ -129,7 +146,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
             if (slot < hard_cap) {
                 HardEntry e;
                 e.job = blockIdx.x; e.k = k; e.level = lv;
-                e.index = roff[k] + (lv - edge_l(k));
+                e.index = roff[k] + (lv - (lo[k] & 255));
                 hard[slot] = e;
             }
         }
@@ -147,9 +164,7 @@ int launch_lut_build(hipStream_t stream, const LutJob* jobs, LutInfo* info, int 
                      HardEntry* hard, int* hard_count, int hard_cap, const AlignParams& p)
 {
     if (max_k > STRQ_LUT_MAX_K) return 2;
-    const size_t lds = (size_t)max_k * 256 * 4;
-    (void)hipFuncSetAttribute((const void*)lut_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(lut_build_kernel, dim3(n_jobs), dim3(256), lds, stream, jobs, info, hard, hard_count, hard_cap, p);
+    hipLaunchKernelGGL(lut_build_kernel, dim3(n_jobs), dim3(256), 0, stream, jobs, info, hard, hard_count, hard_cap, p);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
