@@ -134,3 +134,23 @@ def test_two_strip_path(orc, monkeypatch):
             a = lval[lv]
             _same(orc.align_overlap(a, flank, p), ctx2.align_overlap(a, flank))
     ctx2.close()
+
+
+def test_non_monotone_level_values_take_the_host_path(ctx, orc):
+    """The table kernel finds each class's band by bisection, which needs level values that do not
+    decrease with the level; any other level -> value map is handed to the host (full-width tables).
+    Same alignment, levels relabelled by a random permutation: identical results."""
+    rng = np.random.default_rng(17)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    lv, lval, flank = _toy(rng, 2500)
+    perm = rng.permutation(256)                      # new label of old level q is perm[q]
+    lval_p = np.empty_like(lval); lval_p[perm] = lval
+    lv_p = perm[lv].astype(np.uint8)
+    assert np.array_equal(lval_p[lv_p], lval[lv])
+    off = np.array([0, len(lv)]); foff = np.array([0, len(flank)])
+    want = orc.align_overlap(lval[lv], flank, params, want_idx=False)
+    for levels, table in ((lv, lval), (lv_p, lval_p)):
+        sc, je, j0, rec = ctx.align_batch(levels, off, table[None, :], [0], flank, foff)
+        assert np.float32(want[0]).tobytes() == sc[0].tobytes() and want[4] == je[0] and want[5] == j0[0]
+        assert np.array_equal(want[3], rec)
