@@ -15,6 +15,7 @@
 // four sliding min/max passes, LDS-free global atomics for the histograms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "cond_kernels.h"
 
 namespace strq {
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(256)
 quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_all, const ReadCond* __restrict__ rc_all,
                    uint32_t* __restrict__ hist8)
 {
-    __shared__ uint8_t bufA[COND_TILE + 2 * COND_HALO], bufB[COND_TILE + 2 * COND_HALO];
+    __shared__ __attribute__((aligned(16))) uint8_t bufA[COND_TILE + 2 * COND_HALO + 16], bufB[COND_TILE + 2 * COND_HALO + 16];
     __shared__ uint32_t h8[256];
     const ReadCond rc = rc_all[blockIdx.y];
     const int n = rc.n;
@@ -238,6 +239,69 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
     const T* flt = flt_all + rc.off;
     const int lo = t0 - COND_HALO, span = COND_TILE + 2 * COND_HALO;
     h8[threadIdx.x] = 0;
+    uint8_t* levels = levels_all + rc.off;
+    if (lo >= 0 && lo + span <= n) {
+        // ---- interior tile (all but the first and last of a read): no border logic, eight consecutive
+        // samples per thread, the sliding 8-wide min / max of a stage from 16 input bytes in registers
+        // (suffix extrema of bytes 0..7, prefix extrema of bytes 8..15, one combine per output)
+        constexpr int NG = (COND_TILE + 2 * COND_HALO) / 8;      // groups of 8 samples
+        auto quant = [&](int i) -> uint32_t {
+            double z = ((double)flt[i] - rc.med) / rc.mad;
+            z = z * 24.0 + 127.0;
+            z = z < 0.0 ? 0.0 : z;
+            z = z > 255.0 ? 255.0 : z;
+            return (uint32_t)(uint8_t)z;
+        };
+        for (int g = threadIdx.x; g < NG; g += 256) {
+            const int i = lo + 8 * g;
+            const uint32_t w0 = quant(i) | (quant(i + 1) << 8) | (quant(i + 2) << 16) | (quant(i + 3) << 24);
+            const uint32_t w1 = quant(i + 4) | (quant(i + 5) << 8) | (quant(i + 6) << 16) | (quant(i + 7) << 24);
+            reinterpret_cast<uint32_t*>(bufA)[2 * g] = w0; reinterpret_cast<uint32_t*>(bufA)[2 * g + 1] = w1;
+        }
+        __syncthreads();
+        // window of output j of the group: input bytes [j + SH, j + SH + 7] of the 16 bytes starting at 8g - 4
+        auto stage8 = [&](const uint8_t* src, uint8_t* dst, auto sh_c, auto min_c) {
+            constexpr int SH = decltype(sh_c)::value; constexpr bool MIN = decltype(min_c)::value;
+            auto op = [](int a, int b) { return MIN ? (a < b ? a : b) : (a > b ? a : b); };
+            for (int g = threadIdx.x; g < NG; g += 256) {
+                const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+                const int d0 = 2 * g - 1;                         // dword holding byte 8g - 4 (g = 0: never consumed)
+                uint32_t w[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) w[x] = s32[d0 + x < 0 ? 0 : d0 + x];
+                int b[16];
+#pragma unroll
+                for (int x = 0; x < 16; ++x) b[x] = (int)((w[x >> 2] >> (8 * (x & 3))) & 255u);
+                int S[8], P[16];
+                S[7] = b[7];
+#pragma unroll
+                for (int x = 6; x >= 0; --x) S[x] = op(b[x], S[x + 1]);
+                P[8] = b[8];
+#pragma unroll
+                for (int x = 9; x < 16; ++x) P[x] = op(b[x], P[x - 1]);
+                uint32_t o[2] = {0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int a = j + SH;                         // first byte of the window, 0..8
+                    const int v = a == 0 ? S[0] : (a == 8 ? P[15] : op(S[a], P[a + 7]));
+                    o[j >> 2] |= (uint32_t)v << (8 * (j & 3));
+                }
+                reinterpret_cast<uint32_t*>(dst)[2 * g] = o[0]; reinterpret_cast<uint32_t*>(dst)[2 * g + 1] = o[1];
+            }
+            __syncthreads();
+        };
+        // offsets -3..+4 -> bytes [j + 1, j + 8] of the 16; offsets -4..+3 -> bytes [j, j + 7]
+        stage8(bufA, bufB, std::integral_constant<int, 1>{}, std::true_type{});       // erosion   (opening, first stage)
+        stage8(bufB, bufA, std::integral_constant<int, 0>{}, std::false_type{});      // dilation  (opening, second stage)
+        stage8(bufA, bufB, std::integral_constant<int, 1>{}, std::false_type{});      // dilation  (closing, first stage)
+        stage8(bufB, bufA, std::integral_constant<int, 0>{}, std::true_type{});       // erosion   (closing, second stage)
+        for (int x = threadIdx.x; x < COND_TILE; x += 256) {
+            const uint8_t v = bufA[x + COND_HALO]; levels[t0 + x] = v; atomicAdd(&h8[v], 1u);
+        }
+        __syncthreads();
+        if (h8[threadIdx.x]) atomicAdd(&hist8[(size_t)blockIdx.y * 256 + threadIdx.x], h8[threadIdx.x]);
+        return;
+    }
     // stage 0: quantised signal at the real positions of the extended tile
     for (int x = threadIdx.x; x < span; x += 256) {
         const int i = lo + x;
@@ -275,7 +339,6 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
     stage(bufB, bufA, -4, 3, false);     // dilation  (opening, second stage)
     stage(bufA, bufB, -3, 4, false);     // dilation  (closing, first stage)
     stage(bufB, bufA, -4, 3, true);      // erosion   (closing, second stage)
-    uint8_t* levels = levels_all + rc.off;
     for (int x = threadIdx.x; x < COND_TILE; x += 256) {
         const int i = t0 + x;
         if (i < n) { const uint8_t v = bufA[x + COND_HALO]; levels[i] = v; atomicAdd(&h8[v], 1u); }
