@@ -26,12 +26,12 @@ struct ReadCond {
 };
 
 int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, const ReadCond* rc, int n_reads,
-                            int max_n, uint32_t* hist_flt, uint32_t* hist_raw);
+                            int max_n, uint32_t* hist_flt, uint32_t* hist_raw, uint32_t* range4);      // range4: 4 zeroed words per read (occupied bins of flt / raw)
 int launch_medfilt_f64(hipStream_t s, const double* raw, double* flt, const ReadCond* rc, int n_reads, int max_n);
 // which: 0 = filtered int16 histogram (fills med, mad, f_*), 1 = 8-bit histogram (fills m_* and level_val),
 //        2 = raw int16 histogram (fills r_*)
 int launch_hist_stats(hipStream_t s, const uint32_t* hist, int nbins, int bias, ReadCond* rc, int n_reads,
-                      PoreStats ps, int which, float* level_val);
+                      PoreStats ps, int which, float* level_val, const uint32_t* range, int range_stride);   // range: from launch_medfilt_hist_i16, or null
 int launch_quant_morph_i16(hipStream_t s, const int16_t* flt, uint8_t* levels, const ReadCond* rc, int n_reads,
                            int max_n, uint32_t* hist8);
 int launch_quant_morph_f64(hipStream_t s, const double* flt, uint8_t* levels, const ReadCond* rc, int n_reads,

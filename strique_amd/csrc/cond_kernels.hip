@@ -66,13 +66,15 @@ medfilt_kernel(const T* __restrict__ raw_all, T* __restrict__ flt_all, const Rea
 // (nanopore DAC values of a tile span a few thousand counts), and flushes only the non-empty bins
 // with global atomics: ~20x fewer global atomics than one per sample.  Samples outside the window
 // (never seen on real signals) take the global atomic directly, so the result is exact either way.
+#define HSTAT_LDS_BINS 14336      // bins hist_stats_kernel can stage in LDS (56 KB)
 #define HIST_TILE 16384
 #define HIST_WIN 12288
 __global__ void __launch_bounds__(256)
-hist16_kernel(const int16_t* __restrict__ sig_all, const ReadCond* __restrict__ rc_all, uint32_t* __restrict__ hist_all)
+hist16_kernel(const int16_t* __restrict__ sig_all, const ReadCond* __restrict__ rc_all, uint32_t* __restrict__ hist_all,
+              uint32_t* __restrict__ range_all, int range_stride)
 {
     __shared__ uint32_t bins[HIST_WIN];
-    __shared__ int tmin;
+    __shared__ int tmin, tmax;
     const ReadCond rc = rc_all[blockIdx.y];
     const int n = rc.n;
     const int base = blockIdx.x * HIST_TILE;
@@ -80,15 +82,21 @@ hist16_kernel(const int16_t* __restrict__ sig_all, const ReadCond* __restrict__ 
     const int16_t* sig = sig_all + rc.off;
     uint32_t* hist = hist_all + (size_t)blockIdx.y * 65536;
     const int end = base + HIST_TILE < n ? base + HIST_TILE : n;
-    if (threadIdx.x == 0) tmin = 32767;
+    if (threadIdx.x == 0) { tmin = 32767; tmax = -32768; }
     for (int b = threadIdx.x; b < HIST_WIN; b += 256) bins[b] = 0;
     __syncthreads();
-    int mn = 32767;
-    for (int i = base + threadIdx.x; i < end; i += 256) { const int v = sig[i]; mn = v < mn ? v : mn; }
-    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(mn, o, 64); mn = x < mn ? x : mn; }
-    if ((threadIdx.x & 63) == 0) atomicMin(&tmin, mn);
+    int mn = 32767, mx = -32768;
+    for (int i = base + threadIdx.x; i < end; i += 256) { const int v = sig[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(mn, o, 64); mn = x < mn ? x : mn; const int y = __shfl_xor(mx, o, 64); mx = y > mx ? y : mx; }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&tmin, mn); atomicMax(&tmax, mx); }
     __syncthreads();
     const int lo = tmin;
+    if (threadIdx.x == 0 && range_all) {
+        // occupied bin range of the read, both ends as maxima over zero-initialised words: [0] = highest bin,
+        // [1] = 65535 - lowest bin
+        atomicMax(&range_all[(size_t)blockIdx.y * range_stride], (uint32_t)(tmax + 32768));
+        atomicMax(&range_all[(size_t)blockIdx.y * range_stride + 1], (uint32_t)(65535 - (tmin + 32768)));
+    }
     for (int i = base + threadIdx.x; i < end; i += 256) {
         const int v = sig[i], w = v - lo;
         if (w < HIST_WIN) atomicAdd(&bins[w], 1u);
@@ -109,8 +117,10 @@ static __device__ __forceinline__ double np_lerp(double a, double b, double t)
 // normalisation (STRique.py:152-160) and, for the filtered signal, median and MAD.
 __global__ void __launch_bounds__(256)
 hist_stats_kernel(const uint32_t* __restrict__ hist_all, int nbins, int bias, ReadCond* __restrict__ rc_all,
-                  PoreStats ps, int which, float* __restrict__ level_val_all)
+                  PoreStats ps, int which, float* __restrict__ level_val_all,
+                  const uint32_t* __restrict__ range_all, int range_stride)
 {
+    __shared__ uint32_t staged[HSTAT_LDS_BINS];
     __shared__ uint32_t excl[257];
     __shared__ long long ranks[8];
     __shared__ int vals[8];
@@ -120,10 +130,24 @@ hist_stats_kernel(const uint32_t* __restrict__ hist_all, int nbins, int bias, Re
     ReadCond& rc = rc_all[blockIdx.x];
     const uint32_t* hist = hist_all + (size_t)blockIdx.x * nbins;
     const int n = rc.n;
-    const int bpt = nbins / 256, b0 = t * bpt;
     if (n <= 0) { if (t == 0) rc.status = COND_DEGENERATE; return; }
+    // The passes below walk the histogram in bin order, one contiguous chunk per thread.  When the
+    // occupied bin range is known (hist16_kernel) and small -- a nanopore read spans a few thousand DAC
+    // values -- it is staged in LDS with one coalesced sweep and everything else runs on the copy.
+    if (range_all) {
+        const int hi_bin = (int)range_all[(size_t)blockIdx.x * range_stride];
+        const int lo_bin = 65535 - (int)range_all[(size_t)blockIdx.x * range_stride + 1];
+        const int nb = hi_bin - lo_bin + 1;
+        if (nb >= 1 && nb <= HSTAT_LDS_BINS) {
+            for (int b = t; b < nb; b += 256) staged[b] = hist[lo_bin + b];
+            __syncthreads();
+            hist = staged; nbins = nb; bias += lo_bin;
+        }
+    }
+    const int bpt = (nbins + 255) / 256, b0 = t * bpt;
+    auto H = [&](int b) -> uint32_t { return b < nbins ? hist[b] : 0u; };
     uint32_t mysum = 0;
-    for (int b = 0; b < bpt; ++b) mysum += hist[b0 + b];
+    for (int b = 0; b < bpt; ++b) mysum += H(b0 + b);
     excl[t + 1] = mysum;
     if (t == 0) excl[0] = 0;
     __syncthreads();
@@ -136,7 +160,7 @@ hist_stats_kernel(const uint32_t* __restrict__ hist_all, int nbins, int bias, Re
         if (mysum) {
             uint32_t c = mybase;
             for (int b = 0; b < bpt; ++b) {
-                const uint32_t h = hist[b0 + b];
+                const uint32_t h = H(b0 + b);
                 if (h) for (int i = 0; i < k; ++i) if (ranks[i] >= (long long)c && ranks[i] < (long long)c + h) vals[i] = b0 + b + bias;
                 c += h;
             }
@@ -169,7 +193,7 @@ hist_stats_kernel(const uint32_t* __restrict__ hist_all, int nbins, int bias, Re
         unsigned long long cl = 0, ch = 0;
         for (int b = 0; b < bpt; ++b) {
             const double v = (double)(b0 + b + bias);
-            const uint32_t h = hist[b0 + b];
+            const uint32_t h = H(b0 + b);
             if (v < q_lo) cl += h;
             if (v > q_hi) ch += h;
         }
@@ -197,7 +221,7 @@ hist_stats_kernel(const uint32_t* __restrict__ hist_all, int nbins, int bias, Re
         // MAD = mean |x - median|: every term is a multiple of 0.5, the sum is exact in any order
         double s = 0;
         for (int b = 0; b < bpt; ++b) {
-            const uint32_t h = hist[b0 + b];
+            const uint32_t h = H(b0 + b);
             if (h) s += (double)h * fabs((double)(b0 + b + bias) - med);
         }
         red[t] = s;
@@ -350,13 +374,13 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
 static inline dim3 tile_grid(int max_n, int n_reads) { return dim3((max_n + COND_TILE - 1) / COND_TILE, n_reads); }
 
 int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, const ReadCond* rc, int n_reads, int max_n,
-                            uint32_t* hist_flt, uint32_t* hist_raw)
+                            uint32_t* hist_flt, uint32_t* hist_raw, uint32_t* range4)
 {
     if (n_reads <= 0 || max_n <= 0) return 0;
     hipLaunchKernelGGL((medfilt_kernel<int16_t>), tile_grid(max_n, n_reads), dim3(256), 0, s, raw, flt, rc, hist_flt, hist_raw);
     const dim3 hgrid((max_n + HIST_TILE - 1) / HIST_TILE, n_reads);
-    if (hist_flt) hipLaunchKernelGGL(hist16_kernel, hgrid, dim3(256), 0, s, (const int16_t*)flt, rc, hist_flt);
-    if (hist_raw) hipLaunchKernelGGL(hist16_kernel, hgrid, dim3(256), 0, s, raw, rc, hist_raw);
+    if (hist_flt) hipLaunchKernelGGL(hist16_kernel, hgrid, dim3(256), 0, s, (const int16_t*)flt, rc, hist_flt, range4, 4);
+    if (hist_raw) hipLaunchKernelGGL(hist16_kernel, hgrid, dim3(256), 0, s, raw, rc, hist_raw, range4 ? range4 + 2 : nullptr, 4);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int launch_medfilt_f64(hipStream_t s, const double* raw, double* flt, const ReadCond* rc, int n_reads, int max_n)
@@ -366,10 +390,10 @@ int launch_medfilt_f64(hipStream_t s, const double* raw, double* flt, const Read
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int launch_hist_stats(hipStream_t s, const uint32_t* hist, int nbins, int bias, ReadCond* rc, int n_reads, PoreStats ps,
-                      int which, float* level_val)
+                      int which, float* level_val, const uint32_t* range, int range_stride)
 {
     if (n_reads <= 0) return 0;
-    hipLaunchKernelGGL(hist_stats_kernel, dim3(n_reads), dim3(256), 0, s, hist, nbins, bias, rc, ps, which, level_val);
+    hipLaunchKernelGGL(hist_stats_kernel, dim3(n_reads), dim3(256), 0, s, hist, nbins, bias, rc, ps, which, level_val, range, range_stride);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int launch_quant_morph_i16(hipStream_t s, const int16_t* flt, uint8_t* levels, const ReadCond* rc, int n_reads, int max_n, uint32_t* hist8)

@@ -121,7 +121,7 @@ struct DetectState {
     bool have_ps = false;
     std::vector<Target> targets;
     Batch batch;
-    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern;
+    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
     hipStream_t copy_stream = nullptr;   // host -> HBM uploads that overlap the kernels of the previous sub-batch
@@ -138,7 +138,7 @@ void detect_state_free(strq_ctx* c)
     if (!c->detect) return;
     DetectState* d = static_cast<DetectState*>(c->detect);
     for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx, &d->order,
-                      &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern}) b->release();
+                      &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern, &d->hrange}) b->release();
     if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     delete d;
@@ -323,15 +323,18 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
             STRQ_HIP(c, hipMemsetAsync(d->hist_raw.p, 0, (size_t)nr * 65536 * 4, st));
             d_hist_raw = d->hist_raw.as<uint32_t>();
         }
-        bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), d->flt.as<int16_t>(), d_rc, nr, max_n, d->hist16.as<uint32_t>(), d_hist_raw);
-        bad |= launch_hist_stats(st, d->hist16.as<uint32_t>(), 65536, -32768, d_rc, nr, d->ps, 0, nullptr);
-        if (any_mod) bad |= launch_hist_stats(st, d_hist_raw, 65536, -32768, d_rc, nr, d->ps, 2, nullptr);
+        STRQ_HIP(c, d->hrange.reserve((size_t)nr * 16));
+        STRQ_HIP(c, hipMemsetAsync(d->hrange.p, 0, (size_t)nr * 16, st));
+        uint32_t* d_range = d->hrange.as<uint32_t>();
+        bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), d->flt.as<int16_t>(), d_rc, nr, max_n, d->hist16.as<uint32_t>(), d_hist_raw, d_range);
+        bad |= launch_hist_stats(st, d->hist16.as<uint32_t>(), 65536, -32768, d_rc, nr, d->ps, 0, nullptr, d_range, 4);
+        if (any_mod) bad |= launch_hist_stats(st, d_hist_raw, 65536, -32768, d_rc, nr, d->ps, 2, nullptr, d_range + 2, 4);
         bad |= launch_quant_morph_i16(st, d->flt.as<int16_t>(), c->levels.as<uint8_t>(), d_rc, nr, max_n, d->hist8.as<uint32_t>());
     } else {
         bad |= launch_medfilt_f64(st, reinterpret_cast<const double*>(raw), d->flt.as<double>(), d_rc, nr, max_n);
         bad |= launch_quant_morph_f64(st, d->flt.as<double>(), c->levels.as<uint8_t>(), d_rc, nr, max_n, d->hist8.as<uint32_t>());
     }
-    bad |= launch_hist_stats(st, d->hist8.as<uint32_t>(), 256, 0, d_rc, nr, d->ps, 1, c->level_val.as<float>());
+    bad |= launch_hist_stats(st, d->hist8.as<uint32_t>(), 256, 0, d_rc, nr, d->ps, 1, c->level_val.as<float>(), nullptr, 0);
     if (bad) { c->err = "conditioning launch failed"; return STRQ_ERR_DEVICE; }
     STRQ_HIP(c, hipEventRecord(d->ev[1], st));
 
