@@ -58,13 +58,23 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
 {
     const int nb = in.nb, S = in.samples;
     hipStream_t st = c->stream;
-    size_t cls_tot = 0, col0_tot = 0, rec_tot = 0, tab_tot = 0, ck_floats = 0, bnd_floats = 0;
-    std::vector<size_t> cls_off(nb), col0_off(nb), tab_off(nb), ck_off(nb), bnd_off(nb);
+    size_t cls_tot = 0, col0_tot = 0, rec_tot = 0, tab_tot = 0, ck_floats = 0, bnd_floats = 0, desc_tot = 0;
+    // cls_off / col0_off: flank class values and column 0 of the DP are shared by all alignments of
+    // the same flank / flank length (a batch has a handful of distinct ones); desc_off: per-alignment
+    // band descriptors
+    std::vector<size_t> cls_off(nb), col0_off(nb), tab_off(nb), ck_off(nb), bnd_off(nb), desc_off(nb);
+    std::map<const float*, size_t> cls_of_flank; std::map<int, size_t> col0_of_m;
+    std::vector<int> cls_first, col0_first;        // first alignment that uses each shared array
     out.rec_off.assign(nb, 0);
     int max_k = 0;
     for (int i = 0; i < nb; ++i) {
-        cls_off[i] = cls_tot; cls_tot += in.k[i];
-        col0_off[i] = col0_tot; col0_tot += in.m[i] + 1;
+        auto fc = cls_of_flank.find(in.flank[i]);
+        if (fc == cls_of_flank.end()) { fc = cls_of_flank.emplace(in.flank[i], cls_tot).first; cls_tot += in.k[i]; cls_first.push_back(i); }
+        cls_off[i] = fc->second;
+        auto f0 = col0_of_m.find(in.m[i]);
+        if (f0 == col0_of_m.end()) { f0 = col0_of_m.emplace(in.m[i], col0_tot).first; col0_tot += in.m[i] + 1; col0_first.push_back(i); }
+        col0_off[i] = f0->second;
+        desc_off[i] = desc_tot; desc_tot += in.k[i];
         out.rec_off[i] = rec_tot; rec_tot += in.m[i];
         tab_off[i] = tab_tot; tab_tot += STRQ_TABLE_SLOT_FLOATS(in.k[i]);
         ck_off[i] = ck_floats; ck_floats += (size_t)in.NS[i] * align_num_ckpts(in.n[i]) * STRQ_CKPT_FIELDS(in.R[i]) * 64;
@@ -73,14 +83,14 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     }
     out.rec_total = rec_tot;
     std::vector<float> h_cls(cls_tot), h_col0(col0_tot);
-    for (int i = 0; i < nb; ++i) {
+    for (int i : cls_first) {
         const float* f = in.flank[i];
         for (int kk = 0; kk < in.k[i]; ++kk) h_cls[cls_off[i] + kk] = f[(size_t)kk * S];
-        host_col0(c->ap, in.m[i], &h_col0[col0_off[i]]);
     }
+    for (int i : col0_first) host_col0(c->ap, in.m[i], &h_col0[col0_off[i]]);
     STRQ_HIP(c, c->flank_cls.reserve(cls_tot * 4));
     STRQ_HIP(c, c->col0.reserve(col0_tot * 4));
-    STRQ_HIP(c, c->band_lo.reserve(cls_tot * 4));
+    STRQ_HIP(c, c->band_lo.reserve(desc_tot * 4));
     STRQ_HIP(c, c->tables.reserve(tab_tot * 4));
     STRQ_HIP(c, c->ckpt.reserve(ck_floats * 4 + 256));
     STRQ_HIP(c, c->bnd.reserve(bnd_floats * 4 + 256));
@@ -103,7 +113,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         jobs[i].level_val = in.d_level_val + (size_t)in.read[i] * 256;
         jobs[i].cls_val = c->flank_cls.as<float>() + cls_off[i];
         jobs[i].table = c->tables.as<float>() + tab_off[i];
-        jobs[i].band_lo = c->band_lo.as<int32_t>() + cls_off[i];
+        jobs[i].band_lo = c->band_lo.as<int32_t>() + desc_off[i];
         jobs[i].k = in.k[i]; jobs[i].pad_ = 0;
     }
     STRQ_HIP(c, hipMemcpyAsync(d_jobs, jobs.data(), (size_t)nb * sizeof(LutJob), hipMemcpyHostToDevice, st));
