@@ -606,14 +606,25 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
                 qcur = qnext; bcur = bnext;
             }
             __threadfence();   // the walker below reads words written by other lanes of this wave
-            // walk back while the current cell lies inside this strip and this block
+            // walk back while the current cell lies inside this strip and this block.  The walk is a serial
+            // chase through the trace words, so they are fetched 64 at a time: the words of the walker's lane
+            // position for the next 32 steps x 2 columns sit one per lane and every hop is a v_readlane.
+            int pf_l = -1, pf_hi = 0, pf_lo = 0, pf_word = -1; uint64_t pf = 0;
             while (ci > tk.row0 && cj > 0) {
                 const int il = ci - tk.row0;
                 const int l = (il - 1) / R, r = (il - 1) % R;
                 const int t = l + (cj + 1) / 2;
                 if (t <= tb) break;
                 const int colsel = (cj & 1) ? 0 : 1;
-                const uint64_t w = scratch[(size_t)(t - tb - 1) * STEP_WORDS + (colsel * W + r / 16) * 64 + l];
+                if (l != pf_l || r / 16 != pf_word || t > pf_hi || t <= pf_lo) {
+                    pf_l = l; pf_word = r / 16; pf_hi = t; pf_lo = t - 32 > tb ? t - 32 : tb;
+                    const int st = t - (lane >> 1), cs = lane & 1;
+                    pf = st > pf_lo ? scratch[(size_t)(st - tb - 1) * STEP_WORDS + (cs * W + pf_word) * 64 + l] : 0;
+                }
+                const int src = ((pf_hi - t) << 1) | colsel;
+                const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pf, src);
+                const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pf >> 32), src);
+                const uint64_t w = ((uint64_t)whi << 32) | wlo;
                 const uint32_t code = (uint32_t)(w >> (4 * (r % 16))) & 15u;
                 if (state == 0) {
                     const uint32_t d = code & 3u;
