@@ -154,3 +154,22 @@ def test_non_monotone_level_values_take_the_host_path(ctx, orc):
         sc, je, j0, rec = ctx.align_batch(levels, off, table[None, :], [0], flank, foff)
         assert np.float32(want[0]).tobytes() == sc[0].tobytes() and want[4] == je[0] and want[5] == j0[0]
         assert np.array_equal(want[3], rec)
+
+
+def test_randomised_sweep(ctx, orc):
+    """Seeded random sweep over read length, flank size, level spacing and gap / distance parameters
+    (collapsed and general affine recurrences): score bits, end column, start column and the per-row
+    record must equal the oracle's every time."""
+    rng = np.random.default_rng(2026)
+    ks = [1, 2, 7, 33, 64, 65, 96, 127, 128, 145, 158]
+    for it in range(48):
+        k = int(rng.choice(ks)); n = int(rng.integers(1, 6000)); scale = float(rng.choice([0.45, 0.3, 0.12]))
+        if it % 3 == 0:
+            e_h = -float(rng.integers(1, 4)); e_v = -float(rng.integers(2, 20)); params = [e_h, e_h, e_v, e_v]
+        else:
+            params = [-float(rng.integers(1, 6)), -float(rng.integers(1, 4)), -float(rng.integers(4, 24)), -float(rng.integers(1, 18))]
+        params += [float(rng.choice([8.0, 16.0, 12.5])), float(rng.choice([0.0, -2.0, -16.0]))]
+        ctx.set_align_params(*params)
+        lv, lval, flank = _toy(rng, n, k=k, scale=scale)
+        a = lval[lv]
+        _same(orc.align_overlap(a, flank, np.array(params, np.float32), want_idx=True), ctx.align_overlap(a, flank, want_idx=True))

@@ -64,3 +64,62 @@ def test_ragged_batch(ctx, orc, pm, cfg):
     for i, s in enumerate(seqs):
         lo, _, co = orc.viterbi(fm.baked, s, want_path=False)
         assert lo == lg[i] and co == cg[i] and sg[i] == 0
+
+
+def _random_model(rng, ne, ns, extra_silent_edges):
+    """A random baked model: `ne` emitting states, `ns` silent ones (first = start, last = end) in
+    topological order, in-edges sorted by source, every state with at least one in-edge."""
+    import math
+    from strique_amd.hmm import BakedHMM
+    n = ne + ns
+    start, end = ne, n - 1
+    ins = [set() for _ in range(n)]
+    for l in range(ne):                                      # emitting: from emitting states and silent non-end states
+        for k in rng.choice(ne, size=int(rng.integers(1, 5)), replace=False):
+            ins[l].add(int(k))
+        if rng.random() < 0.5:
+            ins[l].add(int(rng.integers(ne, n - 1)))
+    for l in range(ne + 1, n):                               # silent (not start): from emitting and lower silent states
+        for k in rng.choice(ne, size=int(rng.integers(1, 4)), replace=False):
+            ins[l].add(int(k))
+        ins[l].add(l - 1)                                    # a chain through the silent states
+        if extra_silent_edges and l - ne >= 3 and rng.random() < 0.5:
+            ins[l].add(int(rng.integers(ne, l - 1)))         # silent predecessor outside the chain: multi-stage model
+    in_ptr = np.zeros(n + 1, np.int32); src, lp = [], []
+    for l in range(n):
+        ks = sorted(ins[l])
+        in_ptr[l + 1] = in_ptr[l] + len(ks)
+        src += ks; lp += [math.log(rng.uniform(0.05, 0.9)) for _ in ks]
+    kind = rng.integers(1, 3, ne).astype(np.int32)
+    mu = rng.uniform(60, 120, ne); sigma = rng.uniform(1.0, 4.0, ne)
+    ea = np.where(kind == 1, mu, 40.0); eb = np.where(kind == 1, 1.0 / (2 * sigma ** 2), 140.0)
+    ec = np.where(kind == 1, -np.log(sigma * 2.50662827463), -math.log(100.0))
+    count_inc = (rng.random(n) < 0.1).astype(np.int32)
+    return BakedHMM(n, ne, start, end, in_ptr, np.array(src, np.int32), np.array(lp), kind, ea, eb, ec, count_inc,
+                    np.zeros(n, np.int32), ["s%d" % i for i in range(n)], np.arange(n, dtype=np.int32),
+                    np.full(n, -1, np.int32), np.full(n, -1, np.int32))
+
+
+@pytest.mark.parametrize("ne,ns,multi", [(5, 3, False), (40, 10, False), (64, 20, True), (130, 40, True), (200, 70, False), (260, 130, True)])
+def test_random_models_generic_kernel_shapes(ctx, orc, ne, ns, multi):
+    """Models without layout hints and with arbitrary topology go through the generic kernel shapes
+    (degree-sorted ownership, chain decomposition, multi-stage silent phase): log-probability bits,
+    state path and carried counts must equal the oracle's."""
+    rng = np.random.default_rng(1000 + ne)
+    baked = _random_model(rng, ne, ns, multi)
+    mid = ctx.model_create(baked)
+    for T in (1, 7, 150):
+        x = rng.uniform(55, 125, T)
+        lo, po, co = orc.viterbi(baked, x)
+        lg, cg, sg, pg = ctx.viterbi(mid, x, want_path=True)
+        if po is None:
+            assert sg == 1 and lg == -np.inf
+            continue
+        assert np.float64(lo).tobytes() == np.float64(lg).tobytes() and sg == 0
+        lg2, cg2, _, _ = ctx.viterbi(mid, x, want_path=False)
+        assert lg2 == lg and cg2 == cg
+        # ties between equal-probability paths may be broken differently only if the value is the same;
+        # a path is accepted when it is the oracle's, or scores the same log-probability
+        if not np.array_equal(po, pg):
+            pytest.fail("state path differs from the oracle's")
+        assert co == cg
