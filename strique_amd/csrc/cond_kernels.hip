@@ -106,6 +106,62 @@ hist16_kernel(const int16_t* __restrict__ sig_all, const ReadCond* __restrict__ 
     for (int b = threadIdx.x; b < HIST_WIN; b += 256) { const uint32_t c = bins[b]; if (c) atomicAdd(&hist[lo + b + 32768], c); }
 }
 
+// medfilt3 + histogram of its output in one pass over an int16 signal (the filtered samples of a tile
+// stay in registers between the filter, the tile-minimum reduction and the LDS histogram).
+__global__ void __launch_bounds__(256)
+medfilt_hist16_kernel(const int16_t* __restrict__ raw_all, int16_t* __restrict__ flt_all, const ReadCond* __restrict__ rc_all,
+                      uint32_t* __restrict__ hist_all, uint32_t* __restrict__ range_all, int range_stride)
+{
+    __shared__ uint32_t bins[HIST_WIN];
+    __shared__ int tmin, tmax;
+    const ReadCond rc = rc_all[blockIdx.y];
+    const int n = rc.n;
+    const int base = blockIdx.x * HIST_TILE;
+    if (base >= n) return;
+    const int16_t* raw = raw_all + rc.off;
+    int16_t* flt = flt_all + rc.off;
+    uint32_t* hist = hist_all + (size_t)blockIdx.y * 65536;
+    if (threadIdx.x == 0) { tmin = 32767; tmax = -32768; }
+    for (int b = threadIdx.x; b < HIST_WIN; b += 256) bins[b] = 0;
+    constexpr int PER = HIST_TILE / 256;
+    int16_t m[PER];
+    int mn = 32767, mx = -32768;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = base + k * 256 + threadIdx.x;
+        int16_t v = 0;
+        if (i < n) {
+            const int16_t c = raw[i];
+            const int16_t a = i > 0 ? raw[i - 1] : (int16_t)0;           // zero padding (scipy medfilt)
+            const int16_t b = i + 1 < n ? raw[i + 1] : (int16_t)0;
+            v = med3<int16_t>(a, c, b);
+            flt[i] = v;
+            mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+        }
+        m[k] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(mn, o, 64); mn = x < mn ? x : mn; const int y = __shfl_xor(mx, o, 64); mx = y > mx ? y : mx; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicMin(&tmin, mn); atomicMax(&tmax, mx); }
+    __syncthreads();
+    const int lo = tmin;
+    if (threadIdx.x == 0 && range_all) {
+        atomicMax(&range_all[(size_t)blockIdx.y * range_stride], (uint32_t)(tmax + 32768));
+        atomicMax(&range_all[(size_t)blockIdx.y * range_stride + 1], (uint32_t)(65535 - (tmin + 32768)));
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            const int v = m[k], w = v - lo;
+            if (w < HIST_WIN) atomicAdd(&bins[w], 1u);
+            else atomicAdd(&hist[v + 32768], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < HIST_WIN; b += 256) { const uint32_t c = bins[b]; if (c) atomicAdd(&hist[lo + b + 32768], c); }
+}
+
 // numpy's _lerp (np.percentile, method 'linear')
 static __device__ __forceinline__ double np_lerp(double a, double b, double t)
 {
@@ -377,9 +433,9 @@ int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, con
                             uint32_t* hist_flt, uint32_t* hist_raw, uint32_t* range4)
 {
     if (n_reads <= 0 || max_n <= 0) return 0;
-    hipLaunchKernelGGL((medfilt_kernel<int16_t>), tile_grid(max_n, n_reads), dim3(256), 0, s, raw, flt, rc, hist_flt, hist_raw);
     const dim3 hgrid((max_n + HIST_TILE - 1) / HIST_TILE, n_reads);
-    if (hist_flt) hipLaunchKernelGGL(hist16_kernel, hgrid, dim3(256), 0, s, (const int16_t*)flt, rc, hist_flt, range4, 4);
+    if (hist_flt) hipLaunchKernelGGL(medfilt_hist16_kernel, hgrid, dim3(256), 0, s, raw, flt, rc, hist_flt, range4, 4);
+    else hipLaunchKernelGGL((medfilt_kernel<int16_t>), tile_grid(max_n, n_reads), dim3(256), 0, s, raw, flt, rc, hist_flt, hist_raw);
     if (hist_raw) hipLaunchKernelGGL(hist16_kernel, hgrid, dim3(256), 0, s, raw, rc, hist_raw, range4 ? range4 + 2 : nullptr, 4);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
