@@ -17,7 +17,7 @@ struct AlignParams {   // reference: scripts/STRique.py:507-523 -> src/align_raw
 // read-only description of one strip of one alignment (flank x read)
 struct AlignTask {
     const uint8_t* levels;   // n levels of the read (column j <-> levels[j-1])
-    const float* table;      // ragged banded score table of the whole flank (row offsets in band_lo)
+    const float* table;      // ragged banded score table of the whole flank (row offsets in band_lo; equal classes share a row)
     const int32_t* band_lo;  // k classes of this strip: first level | (levels - 1) << 8 | row offset << 16
     const float* col0;       // m+1: S[row0 + i][0] (column 0 is not free)
     float* ckpt;             // wavefront checkpoints of the forward pass (per strip)
@@ -25,7 +25,7 @@ struct AlignTask {
     const float* bnd_in;     // {S, V} of row `row0` for columns 1..n (from the strip above) or null
     float* bnd_out;          // {S, V} of this strip's last row for the strip below, or null
     const AlignTask* up;     // task of the strip above (trace pass), or null
-    int32_t n, m, k, pad_;   // columns; rows / classes of this strip
+    int32_t n, m, k, tsize;  // columns; rows / classes of this strip; floats of the whole score table
     int32_t row0, m_total;   // rows above this strip; rows of the whole flank
 };
 

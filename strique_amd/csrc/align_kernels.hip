@@ -248,7 +248,7 @@ static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int
 {
     const int row0 = tk.row0 + lane * R;                 // global (0-based) index of the lane's first row
     const int kbase = row0 / S - tk.row0 / S, phase = row0 % S;
-    const int off0 = (int)((uint32_t)tk.band_lo[0] >> 16);
+    const int off0 = 0;
 #pragma unroll
     for (int c = 0; c < Shape<R, S>::C; ++c) {
         int k = kbase + c; if (k > tk.k - 1) k = tk.k - 1;
@@ -270,10 +270,8 @@ static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int
 // stage the banded score table of one alignment into this wave's LDS slice
 static __device__ __forceinline__ void stage_table(const AlignTask& tk, float* lds, int lane)
 {
-    const uint32_t d0 = (uint32_t)tk.band_lo[0], d1 = (uint32_t)tk.band_lo[tk.k - 1];
-    const int off0 = (int)(d0 >> 16), nfl = (int)(d1 >> 16) + (int)((d1 >> 8) & 255u) + 1 - off0;
-    const float* src = tk.table + off0;
-    for (int i = lane; i < nfl; i += 64) lds[i] = src[i];
+    // the whole table (rows of equal classes are shared, so a strip's rows are not contiguous)
+    for (int i = lane; i < tk.tsize; i += 64) lds[i] = tk.table[i];
 }
 
 template <int R>

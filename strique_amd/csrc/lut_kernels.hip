@@ -60,6 +60,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
     __shared__ float cls[STRQ_LUT_MAX_K];
     __shared__ int lo[STRQ_LUT_MAX_K], hi[STRQ_LUT_MAX_K + 1];      // later: e_l | e_r << 8 and the row offsets
     __shared__ int width, n_local, plat_lo, plat_hi, rebuild;
+    __shared__ unsigned char dup[STRQ_LUT_MAX_K];
     __shared__ unsigned short local_hard[STRQ_LUT_LOCAL_HARD][2];
     const LutJob jb = jobs[blockIdx.x];
     const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
@@ -105,9 +106,21 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
         atomicMax(&width, er - el + 1);
     }
     __syncthreads();
+    // classes with the same value (a k-mer that occurs more than once in the flank: 27 of the 145 of
+    // the C9orf72 prefix) share one row: dup[k] = first class with the same bits
+    for (int k = q; k < jb.k; k += 256) {
+        int first = k;
+        const uint32_t bits = __builtin_bit_cast(uint32_t, cls[k]);
+        for (int j = 0; j < k; ++j) if (__builtin_bit_cast(uint32_t, cls[j]) == bits) { first = j; break; }
+        dup[k] = (unsigned char)first;
+    }
+    __syncthreads();
     if (q == 0) {
         int off = 0;
-        for (int k = 0; k < jb.k; ++k) { const int w = hi[k]; hi[k] = off; off += w; }
+        for (int k = 0; k < jb.k; ++k) {
+            if (dup[k] == k) { const int w = hi[k]; hi[k] = off; off += w; }
+            else hi[k] = hi[dup[k]];
+        }
         hi[jb.k] = off;
     }
     __syncthreads();
@@ -116,6 +129,10 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
     for (int k = wave; k < jb.k; k += 4) {
         const int d = lo[k], el = d & 255, er = (d >> 8) & 255;
         const float c = cls[k];
+        if (dup[k] != k) {           // row already written for the first occurrence
+            if (lane == 0) jb.band_lo[k] = (int32_t)((uint32_t)el | ((uint32_t)(er - el) << 8) | ((uint32_t)roff[k] << 16));
+            continue;
+        }
         for (int lv = el + lane; lv <= er; lv += 64) {
             bool hd;
             const float s = cell_score_dev(p, v[lv], c, &hd);

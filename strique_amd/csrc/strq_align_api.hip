@@ -182,6 +182,22 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         if (w < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
         groups[std::make_tuple(in.R[i], in.NS[i], -w)].push_back(i);
     }
+    // Every launch ends with a ragged tail (alignments take ~60 ms each), so a group that would not
+    // keep its waves busy for a few rounds joins the next group with fewer waves per CU (larger LDS
+    // slices); groups are ordered by descending waves per CU within (R, strips).
+    {
+        int min_rounds = 4;
+        if (const char* e = getenv("STRQ_MIN_ROUNDS")) min_rounds = atoi(e);
+        for (auto it = groups.begin(); it != groups.end();) {
+            auto nx = std::next(it);
+            const int w = -std::get<2>(it->first);
+            const bool same_kind = nx != groups.end() && std::get<0>(nx->first) == std::get<0>(it->first) && std::get<1>(nx->first) == std::get<1>(it->first);
+            if (same_kind && (long)it->second.size() < (long)min_rounds * w * c->n_cu) {
+                nx->second.insert(nx->second.end(), it->second.begin(), it->second.end());
+                it = groups.erase(it);
+            } else ++it;
+        }
+    }
     out.order.clear(); out.order.reserve(nb);
     struct Launch { int R, NS, wpb, first, count, first_up, lds_floats; };
     std::vector<Launch> launches;
@@ -207,7 +223,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             AlignTask base; std::memset(&base, 0, sizeof(base));
             base.levels = in.d_levels + in.read_off[in.read[i]];
             base.rec = c->rec.as<int32_t>() + out.rec_off[i];
-            base.n = in.n[i]; base.m_total = M;
+            base.n = in.n[i]; base.m_total = M; base.tsize = info[i].total;
             auto strip = [&](int row0, int rows, int sidx) {
                 AlignTask t = base;
                 const int k0 = row0 / S, k1 = (row0 + rows - 1) / S;

@@ -580,7 +580,7 @@ int strq_batch_run(strq_ctx* c)
         int64_t full_env = 0;
         if (const char* e = getenv("STRQ_SUBBATCH_READS")) full_env = atoll(e);      // testing: force small sub-batches
         for (int64_t r = r0; r < B.n_reads && r < r0 + full; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
-        const int64_t cap = full_env > 0 ? std::min(full_env, full) : (mod_batch ? std::min<int64_t>(1024, full) : full);      // back-pointer memory (~60 MB per 50 kb read) bounds the modification pass
+        const int64_t cap = full_env > 0 ? std::min<int64_t>(full_env, 8192) : (mod_batch ? std::min<int64_t>(1024, full) : full);      // back-pointer memory (~60 MB per 50 kb read) bounds the modification pass
         while (r1 < B.n_reads && r1 - r0 < cap) {
             const Target& t = d->targets[B.target[r1]];
             const int n = (int)(B.off[r1 + 1] - B.off[r1]);
