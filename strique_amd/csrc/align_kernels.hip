@@ -484,7 +484,7 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
 }
 
 template <int R, int S, bool LH, bool LV, int MODE>
-__global__ void __launch_bounds__(640, 2)
+__global__ void __launch_bounds__(512)
 align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
                      int* __restrict__ queue, AlignParams p, int lds_floats_per_wave)
 {
@@ -510,7 +510,7 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
 // walk back, and emit one record per flank row.
 // ------------------------------------------------------------------------------------------
 template <int R, int S>
-__global__ void __launch_bounds__(640, 2)
+__global__ void __launch_bounds__(512)      // at most 8 waves per CU (one workgroup): the full 256-VGPR budget, no spills
 align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
                    int* __restrict__ queue, AlignParams p, int lds_floats_per_wave,
                    uint64_t* __restrict__ scratch_all)

@@ -173,8 +173,8 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // longest first.
     // Layout of the task array: [last strips of every alignment, in result order][first strips of
     // the two-strip alignments]; results / finalize address the first part.
-    int max_wpb = 10;
-    if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 10) max_wpb = v; }
+    int max_wpb = 8;      // workgroups of at most 512 threads (launch bounds of the kernels)
+    if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_wpb = v; }
     auto waves_for = [&](int floats) { return std::min(max_wpb, (160 * 1024) / (std::max(floats, 1) * 4)); };
     std::map<std::tuple<int, int, int>, std::vector<int>> groups;
     for (int i = 0; i < nb; ++i) {
