@@ -47,6 +47,5 @@ int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, Align
                  int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
                  int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode);
 size_t align_trace_scratch_words_per_wave(int R);
-int align_set_debug_buffer(int* host_pinned);   // debug only
 
 }  // namespace strq

@@ -5,12 +5,13 @@
 //           Score<float,Distance>::score + gap accessors (src/score_distance.h:115-122,140-226),
 //           i.e. the SeqAn2 globalAlignment(AlignConfig<true,false,false,true>, AffineGaps) call.
 //
-// Mapping (persistent waves pulling tasks from a queue):
-//   * the flank rows are cut into strips of 64*R rows; a strip is one task of one wave64, and the
-//     strips of an alignment run in consecutive launches, the bottom row (S, V) of a strip being
-//     streamed through HBM to the next one (8 B per column).  Two strips per flank halve the score
-//     table each wave keeps in LDS, so two waves share a SIMD -- a single wave can issue only one
-//     VALU instruction per ~4 cycles on this chip;
+// Mapping (persistent waves pulling tasks, longest read first, from an atomic queue):
+//   * one wave64 per alignment; a flank of up to 64*R rows is one strip (R <= 15 rows per lane, the
+//     normal case: 870 rows = 58 lanes x 15).  Taller flanks are cut into two strips that run in
+//     consecutive launches, the bottom row (S, V) of the upper strip being streamed through HBM to
+//     the lower one (8 B per column) -- measured no faster than one strip, so only used when needed;
+//   * waves per CU are limited by LDS (one score table of 20-26 KB per wave: six waves); a wave alone
+//     on its SIMD issues one VALU instruction per ~5 cycles, two waves sharing a SIMD ~6 each;
 //   * lane l owns rows [l*R, l*R+R) of its strip in registers (R rows per lane);
 //   * the wave marches an anti-diagonal wavefront, two DP columns per lane per step (two
 //     independent dependency chains -> ILP 2 inside one wave): at step t lane l computes
@@ -18,7 +19,8 @@
 //     l-1 and the packed levels of the two columns, each one DPP wave_shr:1;
 //   * per-cell scores come from a per-alignment banded table staged in LDS
 //     (row = k-mer class of the flank, column = 8-bit level of the read sample): the
-//     pow(|h-v|,1.2) of the reference never runs in the DP loop;
+//     pow(|h-v|,1.2) of the reference never runs in the DP loop; the table reads of a step are
+//     issued one step ahead, so their latency hides behind the arithmetic;
 //   * no per-cell trace is written by the forward pass.  It stores the wavefront registers
 //     every STRQ_CKPT_STEPS steps; the trace pass re-runs only the blocks of steps the optimal
 //     path crosses, with the full affine tie-break semantics, and walks a 4-bit trace back.
@@ -34,10 +36,6 @@
 namespace strq {
 
 #define STRQ_NINF (-3.4028234663852886e38f / 2)
-
-// debug progress markers (host-pinned buffer; null in production)
-__device__ int* g_strq_dbg = nullptr;
-#define STRQ_MARK(slot, val) do { int* d_ = g_strq_dbg; if (d_) { __hip_atomic_store(d_ + (slot), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
 
 // tie rules -- keep identical to oracle/align_oracle.c
 #define STRQ_TIE_EXT(ext, opn)  ((ext) >= (opn))
@@ -682,11 +680,6 @@ static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult*
 }
 
 #define STRQ_SHAPES(X) X(6, 6) X(7, 6) X(8, 6) X(12, 6) X(15, 6)
-
-int align_set_debug_buffer(int* p)
-{
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_strq_dbg), &p, sizeof(p)) == hipSuccess ? 0 : 1;
-}
 
 // Rows per lane R and number of strips for a flank of m rows.
 int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
