@@ -11,8 +11,8 @@
 // remaining scalar arithmetic repeats numpy's operations one rounding at a time
 // (-ffp-contract=off), so the results are bit-identical to the CPU oracle (oracle/strique_oracle.py).
 //
-// These kernels are HBM-bound byte/short streaming: coalesced 2-byte loads, LDS tiles for the
-// four sliding min/max passes, LDS-free global atomics for the histograms.
+// These kernels are byte/short streaming: coalesced 2-byte loads, LDS tiles for the four sliding
+// min/max passes, histograms accumulated in an LDS window per tile and flushed bin by bin.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
