@@ -17,6 +17,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+# per-file additions: the Viterbi kernel is a web of dependent float64 chains, where the max-ILP
+# scheduling strategy of the AMDGPU backend measures 2 % faster (the flank DP measures 1.5 % slower with it)
+EXTRA_FLAGS = {"viterbi_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -41,7 +46,7 @@ def build_lib(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
