@@ -103,6 +103,17 @@ class Fast5Index(object):
         with open(index_file) as fp:
             self.index = {rid: path for path, rid in (line.split('\t') for line in fp.read().split('\n') if line)}
         self.dir = os.path.dirname(index_file)
+        self._open = {}                  # path -> H5File, the few most recently used (bulk files hold thousands of reads)
+
+    def _file(self, path):
+        from . import fast5
+        f = self._open.pop(path, None)
+        if f is None:
+            f = fast5.H5File(path)
+            while len(self._open) >= 4:
+                self._open.pop(next(iter(self._open)))
+        self._open[path] = f             # most recently used last
+        return f
 
     def get_raw(self, read_id):
         from . import fast5
@@ -110,11 +121,11 @@ class Fast5Index(object):
             return None
         parts = re.split(r'(\.fast5|\.tar)/', self.index[read_id])
         if len(parts) == 1:
-            f = fast5.H5File(os.path.join(self.dir, parts[0]))
+            f = self._file(os.path.join(self.dir, parts[0]))
             grp = "/Raw/Reads/" + f.listdir("/Raw/Reads")[0]
             return f.dataset(grp + "/Signal")
         if parts[1] == '.fast5':
-            f = fast5.H5File(os.path.join(self.dir, parts[0] + '.fast5'))
+            f = self._file(os.path.join(self.dir, parts[0] + '.fast5'))
             return f.dataset("/%s/Raw/Signal" % parts[2].strip('/'))
         with tarfile.open(os.path.join(self.dir, parts[0] + '.tar')) as tar:
             data = tar.extractfile(tar.getmember(parts[2])).read()

@@ -6,6 +6,7 @@ local heaps), version-1 object headers with continuation blocks, chunked int16 d
 deflate (and optional shuffle) filter, contiguous datasets, and the string / integer attributes that
 carry `read_id`.  HDF5 features outside that subset raise NotImplementedError.
 """
+import mmap
 import struct
 import zlib
 
@@ -20,8 +21,12 @@ class H5File(object):
         if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
             self.buf = bytes(path_or_bytes)
         else:
+            # bulk fast5 files hold thousands of reads in hundreds of MB: map, do not read
             with open(path_or_bytes, "rb") as fp:
-                self.buf = fp.read()
+                try:
+                    self.buf = mmap.mmap(fp.fileno(), 0, access=mmap.ACCESS_READ)
+                except (ValueError, OSError):          # empty file, or a file system without mmap
+                    self.buf = fp.read()
         b = self.buf
         if b[:8] != _SIG:
             raise ValueError("not an HDF5 file")
@@ -74,7 +79,9 @@ class H5File(object):
             raise ValueError("bad local heap")
         data_addr, = struct.unpack_from("<Q", b, heap_addr + 24)
         p = data_addr + off
-        e = b.index(b"\x00", p)
+        e = b.find(b"\x00", p)
+        if e < 0:
+            raise ValueError("unterminated heap string")
         return b[p:e].decode()
 
     def _group_entries(self, ohdr):
