@@ -108,3 +108,35 @@ def test_count_command_end_to_end(workdir, with_mod):
         assert set(mod) <= set("01") and abs(len(mod) - int(count)) <= 3
     else:
         assert mod == "-"
+
+
+@pytest.mark.gpu
+def test_count_on_a_multi_read_fast5_with_mixed_targets(workdir, pm, cfg):
+    """`index` + `count` on a bulk (multi-read) fast5 written by tests/h5write.py and a SAM with one
+    record per read over both bundled loci and both strands: one row per record, in input order, target
+    and strand from the SAM record, planted repeat count recovered."""
+    import h5write
+    from strique_amd import cli, synth
+    table = synth.KmerTable(pm)
+    plan = [("c9orf72", "+", 14), ("fmr1", "-", 33), ("c9orf72", "-", 57), ("fmr1", "+", 8), ("c9orf72", "+", 90)]
+    reads, sam = [], ["@HD\tVN:1.0"]
+    for i, (name, strand, nrep) in enumerate(plan):
+        chrom, b, e, repeat, prefix, suffix = cfg["repeat"][name]
+        sig, st = synth.make_read(table, 7, i, 6000 + 500 * i, (repeat, prefix, suffix), nrep, strand=strand)
+        rid = "%08d-0000-4000-8000-%012d" % (i, i)
+        reads.append((rid, sig))
+        sam.append("\t".join([rid, "16" if strand == "-" else "0", chrom, str(b - 3000), "60", "12S6000M5S", "*", "0", "0", "ACGT", "*"]))
+    sam.append("\t".join(["unmapped-elsewhere", "0", "chr1", "1000", "60", "100M", "*", "0", "0", "ACGT", "*"]))
+    bulk = workdir / "bulk"; bulk.mkdir()
+    (bulk / "batch_0.fast5").write_bytes(h5write.multi_read_fast5(reads))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        cli.main(["index", str(bulk)])
+    (bulk / "reads.fofn").write_text(buf.getvalue())
+    (workdir / "aln.sam").write_text("\n".join(sam) + "\n")
+    out = workdir / "multi.tsv"
+    cli.main(["count", str(bulk / "reads.fofn"), str(workdir / "r9_4_450bps.model"), str(workdir / "repeat_config.tsv"),
+              "--config", str(workdir / "STRique.json"), "--algn", str(workdir / "aln.sam"), "--out", str(out), "--batch", "3"])
+    rows = [l.split("\t") for l in out.read_text().splitlines()[1:]]
+    assert [(r[0], r[1], r[2]) for r in rows] == [(rid, name, strand) for (rid, _), (name, strand, _) in zip(reads, plan)]
+    assert [int(r[3]) for r in rows] == [n for _, _, n in plan]

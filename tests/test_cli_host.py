@@ -46,3 +46,36 @@ def test_parse_config_roundtrip(tmp_path, cfg):
     js.write_text(json.dumps({"align": {}}))
     with pytest.raises(SystemExit):
         cli.parse_config(str(tsv), str(js))
+
+
+def test_fast5_layouts_written_by_hand(tmp_path):
+    """Multi-read fast5 (/read_<id>/Raw/Signal), single-read files inside a tar archive, and the index
+    lines / raw lookups for both (STRique_lib/fast5Index.py:53,163-179,220-233): files written byte by
+    byte by tests/h5write.py."""
+    import io
+    import tarfile
+    import numpy as np
+    import h5write
+    from strique_amd import cli, fast5
+    rng = np.random.default_rng(3)
+    reads = [("%08x-aaaa-bbbb-cccc-%012x" % (i, i * 7919), rng.integers(-3000, 3000, 50 + 13 * i).astype(np.int16)) for i in range(9)]
+    (tmp_path / "batch").mkdir()
+    bulk = tmp_path / "batch" / "bulk_0.fast5"
+    bulk.write_bytes(h5write.multi_read_fast5(reads[:6]))
+    got = dict(fast5.read_raw(str(bulk)))
+    assert set(got) == {r for r, _ in reads[:6]} and all(np.array_equal(got[r], s) for r, s in reads[:6])
+    with tarfile.open(tmp_path / "batch" / "singles.tar", "w") as tar:
+        for k, (rid, sig) in enumerate(reads[6:]):
+            blob = h5write.single_read_fast5(rid, sig, read_number=100 + k)
+            info = tarfile.TarInfo("sub/read_%d.fast5" % k); info.size = len(blob)
+            tar.addfile(info, io.BytesIO(blob))
+    lines = list(cli.Fast5Index.index_records(str(tmp_path / "batch")))
+    assert sorted(l.split("\t")[1] for l in lines) == sorted(r for r, _ in reads)
+    assert any(l.startswith("bulk_0.fast5/read_") for l in lines) and any(l.startswith("singles.tar/sub/read_") for l in lines)
+    fofn = tmp_path / "batch" / "reads.fofn"
+    fofn.write_text("\n".join(lines) + "\n")
+    idx = cli.Fast5Index(str(fofn))
+    for rid, sig in reads:
+        raw = idx.get_raw(rid)
+        assert raw is not None and raw.dtype == np.int16 and np.array_equal(raw, sig), rid
+    assert len(idx._open) <= 4
