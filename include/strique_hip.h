@@ -63,7 +63,7 @@ int strq_get_align_params(const strq_ctx* ctx, float params[6]);
  *   j_end,j0   DP columns where the path ends / leaves the free top row (nullable)
  * Supported here: `a` with at most 256 distinct float32 values and `b` made of runs of 6 equal
  * samples (what repeatCounter.detect always passes: an 8-bit morphology signal and
- * generate_signal(..., samples=6), scripts/STRique.py:592-601,562-565), m <= 1536.
+ * generate_signal(..., samples=6), scripts/STRique.py:592-601,562-565), m <= 948 (158 k-mer classes).
  * Anything else returns STRQ_ERR_UNSUPPORTED.
  */
 int strq_align_overlap(strq_ctx* ctx, const float* a, int64_t n, const float* b, int64_t m,
