@@ -18,6 +18,7 @@ struct AlignParams {   // reference: scripts/STRique.py:507-523 -> src/align_raw
 struct AlignTask {
     const uint8_t* levels;   // n levels of the read (column j <-> levels[j-1])
     const float* table;      // ragged banded score table of the whole flank (row offsets in band_lo; equal classes share a row)
+    const uint8_t* table3;   // the same table as 24-bit fixed point (units of 2^-20), 3 bytes per entry, or null
     const int32_t* band_lo;  // k classes of this strip: first level | (levels - 1) << 8 | row offset << 16
     const float* col0;       // m+1: S[row0 + i][0] (column 0 is not free)
     float* ckpt;             // wavefront checkpoints of the forward pass (per strip)
@@ -43,9 +44,10 @@ static inline int align_num_ckpts(int n) { return (align_num_steps(n) - 1) / STR
 int align_plan(int m, int samples, int* rows_per_lane, int* n_strips);
 // phase 0 = forward, 1 = trace.  `queue`: one zero-initialised int per launch.
 // mode (forward only): bit 0 = strip has an input boundary, bit 1 = strip has an output boundary.
+// packed: the tasks carry 3-byte tables (table3); lds_floats_per_wave is the LDS slice of a wave in dwords.
 int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* results,
                  int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
-                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode);
+                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode, int packed);
 size_t align_trace_scratch_words_per_wave(int R);
 
 }  // namespace strq

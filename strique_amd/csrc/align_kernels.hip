@@ -107,16 +107,30 @@ struct LaneConst {
     int off[6];   // LDS byte offset of the class row minus lo4
     int lo4[6];   // band_lo * 4
     int hi4[6];   // last stored level * 4
+    int off2[6];  // packed tables: LDS byte offset of the class row in the low-byte plane minus lo (lo4 / hi4 / off are then in level / 16-bit units)
 };
 
-template <int R, int S>
+// PK: the table holds 24-bit fixed-point scores (units of 2^-20; the table kernel packs a table only
+// when every entry is exactly representable) and the whole DP runs in those units: scaling by a
+// power of two commutes with every float32 rounding, so the results are the same bits with a shifted
+// exponent.  Three bytes per entry in two planes -- the high 16 bits, then the low 8 bits -- so that
+// every LDS access is naturally aligned (unaligned 32-bit LDS reads measure 3x slower on gfx950).
+#define STRQ_PK_SCALE 1048576.0f
+template <int R, int S, bool PK>
 static __device__ __forceinline__ void fetch_scores(const char* lds, const LaneConst& lc, int q4,
                                                     float (&sc)[Shape<R, S>::C])
 {
 #pragma unroll
     for (int c = 0; c < Shape<R, S>::C; ++c) {
-        const int t = med3i(q4, lc.lo4[c], lc.hi4[c]) + lc.off[c];
-        sc[c] = *reinterpret_cast<const float*>(lds + t);
+        if constexpr (PK) {
+            const int ci = med3i(q4, lc.lo4[c], lc.hi4[c]);                      // clamped level
+            const uint32_t h = *reinterpret_cast<const uint16_t*>(lds + (ci << 1) + lc.off[c]);
+            const uint32_t l = *reinterpret_cast<const uint8_t*>(lds + ci + lc.off2[c]);
+            sc[c] = (float)((h << 8) | l);
+        } else {
+            const int t = med3i(q4, lc.lo4[c], lc.hi4[c]) + lc.off[c];
+            sc[c] = *reinterpret_cast<const float*>(lds + t);
+        }
     }
 }
 
@@ -240,7 +254,7 @@ static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[
     if (candA) { *candA = pick_row<R>(SA, rM); *candB = pick_row<R>(SB, rM); }   // last flank row in an interior register
 }
 
-template <int R, int S>
+template <int R, int S, bool PK>
 static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int lane, int lds_base,
                                                         LaneConst& lc, uint64_t (&pm)[Shape<R, S>::NMASK])
 {
@@ -252,9 +266,16 @@ static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int
         int k = kbase + c; if (k > tk.k - 1) k = tk.k - 1;
         const uint32_t d = (uint32_t)tk.band_lo[k];
         const int lo = (int)(d & 255u), w1 = (int)((d >> 8) & 255u), off = (int)(d >> 16);
-        lc.lo4[c] = lo * 4;
-        lc.hi4[c] = (lo + w1) * 4;
-        lc.off[c] = lds_base + (off - off0) * 4 - lo * 4;
+        if constexpr (PK) {
+            lc.lo4[c] = lo; lc.hi4[c] = lo + w1;
+            lc.off[c] = lds_base + (off - lo) * 2;
+            lc.off2[c] = lds_base + ((2 * tk.tsize + 3) & ~3) + off - lo;
+        } else {
+            lc.lo4[c] = lo * 4;
+            lc.hi4[c] = (lo + w1) * 4;
+            lc.off[c] = lds_base + (off - off0) * 4 - lo * 4;
+            lc.off2[c] = 0;
+        }
     }
 #pragma unroll
     for (int x = 0; x < Shape<R, S>::NMASK; ++x) {
@@ -266,34 +287,45 @@ static __device__ __forceinline__ void load_lane_consts(const AlignTask& tk, int
 }
 
 // stage the banded score table of one alignment into this wave's LDS slice
+template <bool PK>
 static __device__ __forceinline__ void stage_table(const AlignTask& tk, float* lds, int lane)
 {
     // the whole table (rows of equal classes are shared, so a strip's rows are not contiguous)
-    for (int i = lane; i < tk.tsize; i += 64) lds[i] = tk.table[i];
+    if constexpr (PK) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tk.table3);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+        const int nd = (((2 * tk.tsize + 3) & ~3) + tk.tsize + 3) / 4;      // 16-bit plane (padded to a dword), 8-bit plane
+        for (int i = lane; i < nd; i += 64) dst[i] = src[i];
+    } else {
+        for (int i = lane; i < tk.tsize; i += 64) lds[i] = tk.table[i];
+    }
 }
 
-template <int R>
+template <int R, bool PK>
 static __device__ __forceinline__ void init_lane(const AlignTask& tk, int lane, Lane<R>& st)
 {
+    constexpr float SC = PK ? STRQ_PK_SCALE : 1.0f;
     const int row0 = lane * R;   // DP row of register r is row0 + r + 1
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int i = row0 + r + 1; if (i > tk.m) i = tk.m;
-        st.S[r] = tk.col0[i];
+        st.S[r] = tk.col0[i] * SC;
         st.H[r] = STRQ_NINF;
     }
-    { int i = row0 + R; if (i > tk.m) i = tk.m; st.SbotA = st.VbotA = st.VbotB = tk.col0[i]; }  // V[i][0] == S[i][0]
-    { int i = row0;     if (i > tk.m) i = tk.m; st.upS = tk.col0[i]; }    // S[row0][0]; col0[0] == 0
+    { int i = row0 + R; if (i > tk.m) i = tk.m; st.SbotA = st.VbotA = st.VbotB = tk.col0[i] * SC; }  // V[i][0] == S[i][0]
+    { int i = row0;     if (i > tk.m) i = tk.m; st.upS = tk.col0[i] * SC; }    // S[row0][0]; col0[0] == 0
 }
 
 // packed levels (x4) of columns 2*(64*chunk+lane)+1 and +2
+template <bool PK>
 static __device__ __forceinline__ int load_chunk(const AlignTask& tk, int chunk, int lane)
 {
+    constexpr int U = PK ? 1 : 4;
     const int idx = (chunk * 64 + lane) * 2;
     int a = 0, b = 0;
     if (idx < tk.n) a = tk.levels[idx];
     if (idx + 1 < tk.n) b = tk.levels[idx + 1];
-    return (a << 2) | (b << 18);
+    return (a * U) | ((b * U) << 16);
 }
 
 // boundary {S, V} of the row above the strip for columns 2*(64*chunk+lane)+1 and +2
@@ -337,7 +369,7 @@ static __device__ __forceinline__ void load_ckpt(const float* c, int lane, Lane<
 // ------------------------------------------------------------------------------------------
 // MODE: which boundaries the strip has.  bit 0: input from the strip above (else the free top row),
 //       bit 1: output to the strip below (else this strip holds the last flank row and tracks the best).
-template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST>
+template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK>
 struct Forward {
     static constexpr bool HAS_IN = (MODE & 1) != 0, HAS_OUT = (MODE & 2) != 0;
     const AlignTask& tk;
@@ -357,8 +389,8 @@ struct Forward {
     __device__ __forceinline__ void advance(int qsrc, int snext, int& qn, float (&nA)[Shape<R, S>::C], float (&nB)[Shape<R, S>::C])
     {
         qn = dpp_shr1_i(qq, __builtin_amdgcn_readlane(qsrc, snext));
-        fetch_scores<R, S>(ldsb, lc, qn & 0xffff, nA);
-        fetch_scores<R, S>(ldsb, lc, (int)((unsigned)qn >> 16), nB);
+        fetch_scores<R, S, PK>(ldsb, lc, qn & 0xffff, nA);
+        fetch_scores<R, S, PK>(ldsb, lc, (int)((unsigned)qn >> 16), nB);
     }
     __device__ __forceinline__ void prime(int qcur)
     {
@@ -430,27 +462,27 @@ struct Forward {
     }
 };
 
-template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST>
+template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK>
 static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignResult* res, const AlignParams& p,
                                                    float* lds, int lds_base, const char* ldsb, int lane)
 {
     constexpr bool HAS_IN = (MODE & 1) != 0, HAS_OUT = (MODE & 2) != 0;
-    stage_table(tk, lds, lane);
+    stage_table<PK>(tk, lds, lane);
     LaneConst lc; uint64_t pm[Shape<R, S>::NMASK];
-    load_lane_consts<R, S>(tk, lane, lds_base, lc, pm);
+    load_lane_consts<R, S, PK>(tk, lane, lds_base, lc, pm);
     const int lM = (tk.m - 1) / R, rM = (tk.m - 1) % R;
-    Forward<R, S, LH, LV, MODE, RM_LAST> f{tk, p, ldsb, lc, pm, lane, rM};
-    init_lane<R>(tk, lane, f.st);
-    f.best = tk.col0[tk.m]; f.bestA = 0.0f; f.bestt = -1;
+    Forward<R, S, LH, LV, MODE, RM_LAST, PK> f{tk, p, ldsb, lc, pm, lane, rM};
+    init_lane<R, PK>(tk, lane, f.st);
+    f.best = tk.col0[tk.m] * (PK ? STRQ_PK_SCALE : 1.0f); f.bestA = 0.0f; f.bestt = -1;
     __builtin_amdgcn_s_waitcnt(0);   // LDS table written by this wave is visible to it
 
     const int nsteps = (tk.n + 1) / 2 + 63;
-    int qcur = load_chunk(tk, 0, lane);
+    int qcur = load_chunk<PK>(tk, 0, lane);
     f.prime(qcur);
     Bnd4 bnext{0.0f, STRQ_NINF, 0.0f, STRQ_NINF};
     if constexpr (HAS_IN) f.bcur = load_bnd(tk, 0, lane); else f.bcur = bnext;
     for (int t0 = 0; t0 < nsteps; t0 += 64) {
-        const int qnext = load_chunk(tk, t0 / 64 + 1, lane);   // prefetch next 128 columns
+        const int qnext = load_chunk<PK>(tk, t0 / 64 + 1, lane);   // prefetch next 128 columns
         if constexpr (HAS_IN) bnext = load_bnd(tk, t0 / 64 + 1, lane);
         // every lane busy with two valid columns for all 64 steps?
         const bool full = (t0 >= 63) && (2 * (t0 + 64) <= tk.n);
@@ -477,11 +509,11 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
         if (f.bestt >= 0) bestj = 2 * (f.bestt - lane) - (f.bestA == f.best ? 1 : 0);
         const float b = __shfl(f.best, lM, 64);
         const int bj = __shfl(bestj, lM, 64);
-        res->best = b; res->j_end = bj;   // every lane stores the same value
+        res->best = b * (PK ? 1.0f / STRQ_PK_SCALE : 1.0f); res->j_end = bj;   // every lane stores the same value
     }
 }
 
-template <int R, int S, bool LH, bool LV, int MODE>
+template <int R, int S, bool LH, bool LV, int MODE, bool PK>
 __global__ void __launch_bounds__(512)
 align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
                      int* __restrict__ queue, AlignParams p, int lds_floats_per_wave)
@@ -495,10 +527,10 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
         const int ti = next_task(queue, lane);
         if (ti >= n_tasks) break;
         const AlignTask& tk = tasks[ti];
-        if constexpr ((MODE & 2) != 0) forward_one<R, S, LH, LV, MODE, true>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+        if constexpr ((MODE & 2) != 0) forward_one<R, S, LH, LV, MODE, true, PK>(tk, results + ti, p, lds, lds_base, ldsb, lane);
         else {
-            if ((tk.m - 1) % R == R - 1) forward_one<R, S, LH, LV, MODE, true>(tk, results + ti, p, lds, lds_base, ldsb, lane);
-            else forward_one<R, S, LH, LV, MODE, false>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+            if ((tk.m - 1) % R == R - 1) forward_one<R, S, LH, LV, MODE, true, PK>(tk, results + ti, p, lds, lds_base, ldsb, lane);
+            else forward_one<R, S, LH, LV, MODE, false, PK>(tk, results + ti, p, lds, lds_base, ldsb, lane);
         }
     }
 }
@@ -507,7 +539,7 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
 // trace pass: re-run the blocks of steps the optimal path crosses, keep 4 bits per cell,
 // walk back, and emit one record per flank row.
 // ------------------------------------------------------------------------------------------
-template <int R, int S>
+template <int R, int S, bool PK>
 __global__ void __launch_bounds__(512)      // at most 8 waves per CU (one workgroup): the full 256-VGPR budget, no spills
 align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
                    int* __restrict__ queue, AlignParams p, int lds_floats_per_wave,
@@ -535,8 +567,8 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
             while (ci <= cur->row0) cur = uniform_ptr(cur->up);       // the strip that holds row ci
             if (cur != staged) {
                 __builtin_amdgcn_s_waitcnt(0);
-                stage_table(*cur, lds, lane);
-                load_lane_consts<R, S>(*cur, lane, lds_base, lc, pm);
+                stage_table<PK>(*cur, lds, lane);
+                load_lane_consts<R, S, PK>(*cur, lane, lds_base, lc, pm);
                 __builtin_amdgcn_s_waitcnt(0);
                 staged = cur;
             }
@@ -553,7 +585,7 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
             const int blk = (tcur - 1) / STRQ_CKPT_STEPS;
             const int tb = blk * STRQ_CKPT_STEPS;          // state after step tb is the restart point
             Lane<R> st;
-            if (blk == 0) init_lane<R>(tk, lane, st);
+            if (blk == 0) init_lane<R, PK>(tk, lane, st);
             else load_ckpt<R>(tk.ckpt + (size_t)(blk - 1) * (STRQ_CKPT_FIELDS(R) * 64), lane, st);
             // packed levels of the two columns this lane finished at step tb
             int qq = 0;
@@ -562,13 +594,13 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
                 int a = 0, b = 0;
                 if (jA >= 1 && jA <= tk.n) a = tk.levels[jA - 1];
                 if (jB >= 1 && jB <= tk.n) b = tk.levels[jB - 1];
-                qq = (a << 2) | (b << 18);
+                qq = (a * (PK ? 1 : 4)) | ((b * (PK ? 1 : 4)) << 16);
             }
-            int qcur = load_chunk(tk, tb / 64, lane);
+            int qcur = load_chunk<PK>(tk, tb / 64, lane);
             Bnd4 bcur{0.0f, STRQ_NINF, 0.0f, STRQ_NINF}, bnext = bcur;
             if (has_in) bcur = load_bnd(tk, tb / 64, lane);
             for (int t0 = tb; t0 < tcur; t0 += 64) {
-                const int qnext = load_chunk(tk, t0 / 64 + 1, lane);
+                const int qnext = load_chunk<PK>(tk, t0 / 64 + 1, lane);
                 if (has_in) bnext = load_bnd(tk, t0 / 64 + 1, lane);
                 const int send = tcur - t0 < 64 ? tcur - t0 : 64;
                 for (int s = 0; s < send; ++s) {
@@ -586,8 +618,8 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
                     TraceWords w; w.a[0] = w.a[1] = w.b[0] = w.b[1] = 0;
                     if (jA >= 1 && jA <= tk.n) {
                         float scA[Shape<R, S>::C], scB[Shape<R, S>::C], rsA[R], rsB[R];
-                        fetch_scores<R, S>(ldsb, lc, qq & 0xffff, scA);
-                        fetch_scores<R, S>(ldsb, lc, (int)((unsigned)qq >> 16), scB);
+                        fetch_scores<R, S, PK>(ldsb, lc, qq & 0xffff, scA);
+                        fetch_scores<R, S, PK>(ldsb, lc, (int)((unsigned)qq >> 16), scB);
                         expand_scores<R, S>(scA, pmu, rsA);
                         expand_scores<R, S>(scB, pmu, rsB);
                         dp_step2<R, false, false, true, true>(st, rsA, rsB, upA, upB, upVA, upVB, p, &w, 0, nullptr, nullptr);
@@ -646,16 +678,16 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
 template <int R, int S>
 static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult* results, int n_tasks,
                         int* queue, const AlignParams& p, int lds_floats_per_wave, int waves_per_block,
-                        int n_blocks, uint64_t* scratch, int phase, int mode)
+                        int n_blocks, uint64_t* scratch, int phase, int mode, int packed)
 {
     const size_t lds_bytes = (size_t)lds_floats_per_wave * 4 * waves_per_block;
     const dim3 grid(n_blocks), block(64 * waves_per_block);
     const bool lh = p.open_h == p.ext_h, lv = p.open_v == p.ext_v;
 #define STRQ_FWD1(LH_, LV_, MODE_)                                                                      \
     do {                                                                                                \
-        (void)hipFuncSetAttribute((const void*)align_forward_kernel<R, S, LH_, LV_, MODE_>,             \
+        (void)hipFuncSetAttribute((const void*)align_forward_kernel<R, S, LH_, LV_, MODE_, false>,      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);          \
-        hipLaunchKernelGGL((align_forward_kernel<R, S, LH_, LV_, MODE_>), grid, block, lds_bytes, stream,\
+        hipLaunchKernelGGL((align_forward_kernel<R, S, LH_, LV_, MODE_, false>), grid, block, lds_bytes, stream,\
                            tasks, results, n_tasks, queue, p, lds_floats_per_wave);                     \
     } while (0)
 #define STRQ_FWD(LH_, LV_)                                                                              \
@@ -663,15 +695,31 @@ static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult*
         if (mode == 0) STRQ_FWD1(LH_, LV_, 0); else if (mode == 1) STRQ_FWD1(LH_, LV_, 1);              \
         else if (mode == 2) STRQ_FWD1(LH_, LV_, 2); else STRQ_FWD1(LH_, LV_, 3);                        \
     } while (0)
-    if (phase == 0) {
+    if (packed && !(lh && lv && mode == 0)) return 2;      // packed tables: collapsed single-strip kernels only
+    if (phase == 0 && packed) {
+        // gap parameters in table units (2^-20): exact, a power-of-two scaling
+        AlignParams ps = p;
+        ps.open_h *= STRQ_PK_SCALE; ps.ext_h *= STRQ_PK_SCALE; ps.open_v *= STRQ_PK_SCALE; ps.ext_v *= STRQ_PK_SCALE;
+        (void)hipFuncSetAttribute((const void*)align_forward_kernel<R, S, true, true, 0, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((align_forward_kernel<R, S, true, true, 0, true>), grid, block, lds_bytes, stream,
+                           tasks, results, n_tasks, queue, ps, lds_floats_per_wave);
+    } else if (phase == 0) {
         if (lh && lv) STRQ_FWD(true, true);
         else if (lh) STRQ_FWD(true, false);
         else if (lv) STRQ_FWD(false, true);
         else STRQ_FWD(false, false);
-    } else {
-        (void)hipFuncSetAttribute((const void*)align_trace_kernel<R, S>,
+    } else if (packed) {
+        AlignParams ps = p;
+        ps.open_h *= STRQ_PK_SCALE; ps.ext_h *= STRQ_PK_SCALE; ps.open_v *= STRQ_PK_SCALE; ps.ext_v *= STRQ_PK_SCALE;
+        (void)hipFuncSetAttribute((const void*)align_trace_kernel<R, S, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL((align_trace_kernel<R, S>), grid, block, lds_bytes, stream, tasks, results,
+        hipLaunchKernelGGL((align_trace_kernel<R, S, true>), grid, block, lds_bytes, stream, tasks, results,
+                           n_tasks, queue, ps, lds_floats_per_wave, scratch);
+    } else {
+        (void)hipFuncSetAttribute((const void*)align_trace_kernel<R, S, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((align_trace_kernel<R, S, false>), grid, block, lds_bytes, stream, tasks, results,
                            n_tasks, queue, p, lds_floats_per_wave, scratch);
     }
 #undef STRQ_FWD
@@ -706,12 +754,12 @@ size_t align_trace_scratch_words_per_wave(int R)
 
 int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* results,
                  int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
-                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode)
+                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode, int packed)
 {
 #define STRQ_CASE(R_, S_)                                                                               \
     if (R == R_ && S == S_)                                                                             \
         return launch_shape<R_, S_>(stream, tasks, results, n_tasks, queue, p, lds_floats_per_wave,     \
-                                    waves_per_block, n_blocks, scratch, phase, mode);
+                                    waves_per_block, n_blocks, scratch, phase, mode, packed);
     STRQ_SHAPES(STRQ_CASE)
 #undef STRQ_CASE
     return 2;

@@ -14,10 +14,11 @@ struct LutJob {
     const float* level_val;   // 256 level values of the read
     const float* cls_val;     // k class values of the flank
     float* table;             // slot of STRQ_TABLE_SLOT_FLOATS(k) floats
+    uint8_t* table3;          // slot of 3 * STRQ_TABLE_SLOT_FLOATS(k) + 8 bytes: the same entries as 24-bit fixed point (16-bit plane, 8-bit plane)
     int32_t* band_lo;         // k packed row descriptors (see AlignTask::band_lo)
     int32_t k, pad_;
 };
-struct LutInfo { int32_t total, n_hard, need, pad_; };   // total: floats of the ragged table; need: widest row
+struct LutInfo { int32_t total, n_hard, need, packed; };   // total: entries of the ragged table; need: widest row; packed: table3 is exact
 struct HardEntry { int32_t job, k, level, index; };
 
 int launch_lut_build(hipStream_t stream, const LutJob* jobs, LutInfo* info, int n_jobs, int max_k,

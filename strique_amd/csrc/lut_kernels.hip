@@ -59,14 +59,14 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
     __shared__ float v[256];
     __shared__ float cls[STRQ_LUT_MAX_K];
     __shared__ int lo[STRQ_LUT_MAX_K], hi[STRQ_LUT_MAX_K + 1];      // later: e_l | e_r << 8 and the row offsets
-    __shared__ int width, n_local, plat_lo, plat_hi, rebuild;
+    __shared__ int width, n_local, plat_lo, plat_hi, rebuild, unpackable;
     __shared__ unsigned char dup[STRQ_LUT_MAX_K];
     __shared__ unsigned short local_hard[STRQ_LUT_LOCAL_HARD][2];
     const LutJob jb = jobs[blockIdx.x];
     const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
     v[q] = jb.level_val[q];
     for (int k = q; k < jb.k; k += 256) cls[k] = jb.cls_val[k];
-    if (q == 0) { width = 0; n_local = 0; plat_lo = 255; plat_hi = 0; rebuild = 0; }
+    if (q == 0) { width = 0; n_local = 0; plat_lo = 255; plat_hi = 0; rebuild = 0; unpackable = 0; }
     __syncthreads();
     {
         // plateaus: levels 0..plat_lo share the value of level 0, levels plat_hi..255 that of level 255
@@ -76,7 +76,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
         if (q > 0 && !(v[q - 1] <= vq)) rebuild = 1;          // not monotone (or NaN): no contiguous bands
     }
     __syncthreads();
-    if (rebuild) { if (q == 0) { info[blockIdx.x].total = 0; info[blockIdx.x].need = 0; info[blockIdx.x].pad_ = 0; info[blockIdx.x].n_hard = -1; } return; }
+    if (rebuild) { if (q == 0) { info[blockIdx.x].total = 0; info[blockIdx.x].need = 0; info[blockIdx.x].packed = 0; info[blockIdx.x].n_hard = -1; } return; }
     const int plat_lo_r = plat_lo, plat_hi_r = plat_hi;
     auto in_band = [&](int lv, float c) { bool hd; return cell_score_dev(p, v[lv], c, &hd) > p.dist_min; };
     // ---- band of every class: first / last level scoring above dist_min
@@ -137,6 +137,15 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
             bool hd;
             const float s = cell_score_dev(p, v[lv], c, &hd);
             jb.table[roff[k] + lv - el] = s;
+            {   // 24-bit fixed point in units of 2^-20, when that is the same number
+                const float r = s * 1048576.0f;
+                const uint32_t u = r >= 0.0f && r < 16777216.0f ? (uint32_t)r : 0u;
+                if (!((float)u == r) || !(r < 16777216.0f) || __builtin_bit_cast(uint32_t, r) == 0x80000000u) unpackable = 1;
+                // two planes: the high 16 bits of every entry, then (dword aligned) the low 8 bits
+                const int e = roff[k] + lv - el, total = roff[jb.k];
+                reinterpret_cast<uint16_t*>(jb.table3)[e] = (uint16_t)(u >> 8);
+                jb.table3[((2 * total + 3) & ~3) + e] = (uint8_t)u;
+            }
             if (hd) {
                 // a borderline value in a clipped edge entry could come out above dist_min on the host: the
                 // band itself would be wrong, so let the host rebuild this table
@@ -155,7 +164,7 @@ lut_build_kernel(const LutJob* __restrict__ jobs, LutInfo* __restrict__ info, Ha
         if (nh > STRQ_LUT_LOCAL_HARD || rebuild) nh = -1;    // host rebuilds the whole table
         info[blockIdx.x].total = roff[jb.k];
         info[blockIdx.x].need = width;
-        info[blockIdx.x].pad_ = 0;
+        info[blockIdx.x].packed = (nh == 0 && !unpackable) ? 1 : 0;      // patched or rebuilt tables stay float32
         info[blockIdx.x].n_hard = nh;
         for (int i = 0; i < nh; ++i) {
             const int k = local_hard[i][0], lv = local_hard[i][1];

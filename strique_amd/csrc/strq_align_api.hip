@@ -92,6 +92,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, c->col0.reserve(col0_tot * 4));
     STRQ_HIP(c, c->band_lo.reserve(desc_tot * 4));
     STRQ_HIP(c, c->tables.reserve(tab_tot * 4));
+    STRQ_HIP(c, c->tables3.reserve(tab_tot * 3 + (size_t)nb * 8 + 64));
     STRQ_HIP(c, c->ckpt.reserve(ck_floats * 4 + 256));
     STRQ_HIP(c, c->bnd.reserve(bnd_floats * 4 + 256));
     STRQ_HIP(c, c->rec.reserve(rec_tot * 4 + 256));
@@ -113,6 +114,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         jobs[i].level_val = in.d_level_val + (size_t)in.read[i] * 256;
         jobs[i].cls_val = c->flank_cls.as<float>() + cls_off[i];
         jobs[i].table = c->tables.as<float>() + tab_off[i];
+        jobs[i].table3 = c->tables3.as<uint8_t>() + tab_off[i] * 3 + (size_t)i * 8 - (tab_off[i] * 3 + (size_t)i * 8) % 4;      // 4-byte aligned slot
         jobs[i].band_lo = c->band_lo.as<int32_t>() + desc_off[i];
         jobs[i].k = in.k[i]; jobs[i].pad_ = 0;
     }
@@ -175,12 +177,19 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // the two-strip alignments]; results / finalize address the first part.
     int max_wpb = 8;      // workgroups of at most 512 threads (launch bounds of the kernels)
     if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_wpb = v; }
-    auto waves_for = [&](int floats) { return std::min(max_wpb, (160 * 1024) / (std::max(floats, 1) * 4)); };
-    std::map<std::tuple<int, int, int>, std::vector<int>> groups;
+    auto waves_for = [&](int dwords) { return std::min(max_wpb, (160 * 1024) / (std::max(dwords, 1) * 4)); };
+    // 24-bit tables (lut_kernels.hip) are used by the collapsed single-strip kernels when every entry of
+    // the table is exact in that format; they are 3/4 of the size, which buys the seventh and eighth wave
+    const bool pack_ok = c->ap.open_h == c->ap.ext_h && c->ap.open_v == c->ap.ext_v && !getenv("STRQ_NO_PACK");
+    auto packed_dwords = [](int entries) { return (((2 * entries + 3) & ~3) + entries + 3) / 4; };
+    std::vector<char> packed(nb, 0);
+    // key: rows per lane, strips, -waves per CU, 0 = packed / 1 = float32 (packed first among equals)
+    std::map<std::tuple<int, int, int, int>, std::vector<int>> groups;
     for (int i = 0; i < nb; ++i) {
-        const int w = waves_for(info[i].total);
+        packed[i] = pack_ok && in.NS[i] == 1 && info[i].packed && info[i].n_hard == 0;
+        const int w = waves_for(packed[i] ? packed_dwords(info[i].total) : info[i].total);
         if (w < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
-        groups[std::make_tuple(in.R[i], in.NS[i], -w)].push_back(i);
+        groups[std::make_tuple(in.R[i], in.NS[i], -w, packed[i] ? 0 : 1)].push_back(i);
     }
     // Every launch ends with a ragged tail (alignments take ~60 ms each), so a group that would not
     // keep its waves busy for a few rounds joins the next group with fewer waves per CU (larger LDS
@@ -191,7 +200,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         for (auto it = groups.begin(); it != groups.end();) {
             auto nx = std::next(it);
             const int w = -std::get<2>(it->first);
-            const bool same_kind = nx != groups.end() && std::get<0>(nx->first) == std::get<0>(it->first) && std::get<1>(nx->first) == std::get<1>(it->first);
+            // a packed alignment also has its float32 table, so it can join a float32 launch -- not the other way round
+            const bool same_kind = nx != groups.end() && std::get<0>(nx->first) == std::get<0>(it->first) && std::get<1>(nx->first) == std::get<1>(it->first)
+                                   && !(std::get<3>(it->first) == 1 && std::get<3>(nx->first) == 0);
             if (same_kind && (long)it->second.size() < (long)min_rounds * w * c->n_cu) {
                 nx->second.insert(nx->second.end(), it->second.begin(), it->second.end());
                 it = groups.erase(it);
@@ -199,16 +210,19 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         }
     }
     out.order.clear(); out.order.reserve(nb);
-    struct Launch { int R, NS, wpb, first, count, first_up, lds_floats; };
+    struct Launch { int R, NS, wpb, first, count, first_up, lds_floats, packed; };
     std::vector<Launch> launches;
     int n_up = 0;
     for (auto& g : groups) {
         auto& v = g.second;
         std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return in.n[x] > in.n[y]; });
         const int NS = std::get<1>(g.first);
-        int lds_floats = 0;
-        for (int i : v) lds_floats = std::max(lds_floats, info[i].total);
-        launches.push_back({std::get<0>(g.first), NS, -std::get<2>(g.first), (int)out.order.size(), (int)v.size(), nb + n_up, lds_floats});
+        const int pk = std::get<3>(g.first) == 0;
+        int lds_floats = 0;      // LDS slice of a wave in dwords
+        for (int i : v) lds_floats = std::max(lds_floats, pk ? packed_dwords(info[i].total) : info[i].total);
+        const int wpb = std::min(-std::get<2>(g.first), waves_for(lds_floats));       // members that joined from a smaller-slice group
+        if (wpb < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
+        launches.push_back({std::get<0>(g.first), NS, wpb, (int)out.order.size(), (int)v.size(), nb + n_up, lds_floats, pk});
         out.order.insert(out.order.end(), v.begin(), v.end());
         if (NS > 1) n_up += (int)v.size();
     }
@@ -228,7 +242,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 AlignTask t = base;
                 const int k0 = row0 / S, k1 = (row0 + rows - 1) / S;
                 t.row0 = row0; t.m = rows; t.k = k1 - k0 + 1;
-                t.table = jobs[i].table; t.band_lo = jobs[i].band_lo + k0;
+                t.table = jobs[i].table; t.table3 = jobs[i].table3; t.band_lo = jobs[i].band_lo + k0;
                 t.col0 = c->col0.as<float>() + col0_off[i] + row0;
                 t.ckpt = c->ckpt.as<float>() + ck_off[i] + (size_t)sidx * ck_per_strip;
                 return t;
@@ -257,16 +271,16 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             if (level == 1 && L.NS == 1) continue;
             const AlignTask* dt = level == 0 && L.NS > 1 ? d_tasks + L.first_up : d_tasks + L.first;
             const int mode = L.NS == 1 ? 0 : (level == 0 ? 2 : 1);
-            STRQ_DBG("forward launch R=%d strips=%d table floats=%d level=%d count=%d waves/CU=%d", L.R, L.NS, L.lds_floats, level, L.count, L.wpb);
+            STRQ_DBG("forward launch R=%d strips=%d slice dwords=%d packed=%d level=%d count=%d waves/CU=%d", L.R, L.NS, L.lds_floats, L.packed, level, L.count, L.wpb);
             if (launch_align(st, L.R, S, dt, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, L.wpb, c->n_cu,
-                             c->scratch.as<uint64_t>(), 0, mode)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
+                             c->scratch.as<uint64_t>(), 0, mode, L.packed)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
             ++qi; ++out.n_launches;
         }
     }
     STRQ_HIP(c, hipEventRecord(c->ev[3], st));
     for (auto& L : launches) {
         if (launch_align(st, L.R, S, d_tasks + L.first, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, L.wpb, c->n_cu,
-                         c->scratch.as<uint64_t>(), 1, 0)) { c->err = "trace launch failed"; return STRQ_ERR_DEVICE; }
+                         c->scratch.as<uint64_t>(), 1, 0, L.packed)) { c->err = "trace launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
     }
     STRQ_HIP(c, hipEventRecord(c->ev[4], st));
@@ -394,7 +408,7 @@ void strq_ctx_destroy(strq_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     detect_state_free(c);
-    for (DevBuf* b : {&c->levels, &c->level_val, &c->flank_cls, &c->tables, &c->band_lo, &c->col0, &c->ckpt,
+    for (DevBuf* b : {&c->levels, &c->level_val, &c->flank_cls, &c->tables, &c->tables3, &c->band_lo, &c->col0, &c->ckpt,
                       &c->rec, &c->tasks, &c->results, &c->queue, &c->scratch, &c->lutinfo, &c->hard, &c->misc,
                       &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd})
         b->release();

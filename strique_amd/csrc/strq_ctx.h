@@ -64,7 +64,7 @@ struct strq_ctx {
     std::string err;
     float timing[8] = {};
     // workspace
-    strq::DevBuf levels, level_val, flank_cls, tables, band_lo, col0, ckpt, rec, tasks, results,
+    strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd;
     std::vector<strq::HostModel*> models;
     void* detect = nullptr;                   // DetectState (strq_detect_api.hip)
