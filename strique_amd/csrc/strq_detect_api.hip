@@ -572,10 +572,11 @@ int strq_batch_run(strq_ctx* c)
     while (r0 < B.n_reads) {
         int64_t r1 = r0; size_t ck = 0; int64_t samples = 0;
         bool mod_batch = false;
-        // Sub-batch size: 16 reads (32 alignments) per CU.  The forward DP keeps six waves per CU, two
-        // alone on their SIMD (60.6 ms per 375 k-sample alignment) and four sharing one (73 ms): after
-        // 365 ms both groups have just finished a task (6 x 60.6 = 5 x 73), 32 in total, so the launch
-        // ends without a ragged tail (measured: 4096 reads 365 ms, 4608 reads 437 ms on 256 CUs).
+        // Sub-batch size: 16 reads (32 alignments) per CU.  The alignments of a batch are about equally
+        // long, so the forward DP proceeds in rounds: 32 per CU is four full rounds of the eight waves the
+        // 24-bit tables allow (and, with six float32 waves -- two alone on their SIMD at 60.6 ms per
+        // alignment, four sharing one at 73 ms -- 6 x 60.6 = 5 x 73 ends without a ragged tail as well;
+        // 4608 reads measured 437 ms against 365 ms for 4096).
         const int64_t full = std::min<int64_t>(16 * (int64_t)c->n_cu, 8192);      // 8192: task limit of vit_sort_kernel
         int64_t full_env = 0;
         if (const char* e = getenv("STRQ_SUBBATCH_READS")) full_env = atoll(e);      // testing: force small sub-batches
