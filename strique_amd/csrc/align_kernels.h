@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define STRQ_CKPT_STEPS 512                  // wavefront checkpoint spacing in steps (multiple of 64)
+#define STRQ_CKPT_STEPS 256                  // wavefront checkpoint spacing in steps (multiple of 64)
 #define STRQ_COLS_PER_STEP 2                 // a lane computes two DP columns per step (ILP 2)
 #define STRQ_CKPT_FIELDS(R) (2 * (R) + 6)    // S[R], H[R], SbotA, VbotA, VbotB, upS, pad, pad
 #define STRQ_TRACE_WORDS(R) (((R) + 15) / 16)

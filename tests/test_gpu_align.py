@@ -31,7 +31,7 @@ def _same(o, g):
         assert np.array_equal(o[1], g[1]) and np.array_equal(o[2], g[2])
 
 
-@pytest.mark.parametrize("n", [1, 2, 10, 63, 127, 128, 129, 1000, 1023, 1024, 1025, 2049, 20001])
+@pytest.mark.parametrize("n", [1, 2, 10, 63, 127, 128, 129, 511, 512, 513, 1000, 1023, 1024, 1025, 2049, 20001])
 def test_align_overlap_lengths(ctx, orc, n):
     """Includes reads shorter than the flank (vertical run at column 0), the 64-step wavefront
     boundaries and the 1024-column checkpoint boundaries."""

@@ -101,7 +101,7 @@ def main():
             "bytes_per_launch_raw": (fv + wv) * 1024, "bytes_per_launch_fetch_x2": (2 * fv + wv) * 1024,
             "align_forward_kernel_bytes_per_alignment": (2 * fv + wv) * 1024 / n_align,
             "note": "FETCH_SIZE counted x2 as MI355X_MICROARCH.md prescribes for gfx950 (upper bound); WRITE_SIZE uncorrected. "
-                    "Writes are the wavefront checkpoints (one per 512 steps).",
+                    "Writes are the wavefront checkpoints (one per 256 steps).",
         }
         json.dump(info, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
         print(json.dumps(info, indent=1))
