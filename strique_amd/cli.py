@@ -15,7 +15,8 @@ import re
 import sys
 import tarfile
 import tempfile
-from collections import defaultdict
+import threading
+from collections import defaultdict, deque
 
 HEADER = ['ID', 'target', 'strand', 'count', 'score_prefix', 'score_suffix', 'log_p', 'offset', 'ticks', 'mod']
 LEVELS = ['error', 'warning', 'info', 'debug']
@@ -104,16 +105,18 @@ class Fast5Index(object):
             self.index = {rid: path for path, rid in (line.split('\t') for line in fp.read().split('\n') if line)}
         self.dir = os.path.dirname(index_file)
         self._open = {}                  # path -> H5File, the few most recently used (bulk files hold thousands of reads)
+        self._lock = threading.Lock()
 
     def _file(self, path):
         from . import fast5
-        f = self._open.pop(path, None)
-        if f is None:
-            f = fast5.H5File(path)
-            while len(self._open) >= 4:
-                self._open.pop(next(iter(self._open)))
-        self._open[path] = f             # most recently used last
-        return f
+        with self._lock:                 # get_raw may be called from the reader threads of `count`
+            f = self._open.pop(path, None)
+            if f is None:
+                f = fast5.H5File(path)
+                while len(self._open) >= 4:
+                    self._open.pop(next(iter(self._open)))
+            self._open[path] = f         # most recently used last
+            return f
 
     def get_raw(self, read_id):
         from . import fast5
@@ -173,7 +176,7 @@ def count(argv):
     parser.add_argument("--algn", default=None, help="Alignment in sam format, if not given read from stdin")
     parser.add_argument("--mod_model", default=None, help="Base modification pore model")
     parser.add_argument("--config", help="Config file with HMM transition probabilities")
-    parser.add_argument("--t", type=int, default=1, help="Accepted for compatibility: the GPU batch replaces the worker processes")
+    parser.add_argument("--t", type=int, default=1, help="Reader threads that fetch and inflate raw signals ahead of the GPU batches (the reference's worker-process count)")
     parser.add_argument("--log_level", default='warning', choices=LEVELS, help="Log level")
     parser.add_argument("--batch", type=int, default=2048, help="Reads per GPU batch")
     parser.add_argument("--device", type=int, default=0, help="HIP device")
@@ -204,7 +207,8 @@ def count(argv):
     f5 = Fast5Index(args.f5Index)
     stream = open(args.algn) if args.algn else sys.stdin
     out = (open(args.out, 'w') if args.out else sys.stdout) if rank == 0 else None
-    rows = run_count(stream, loci, f5.get_raw, counter, log, args.batch, rank, world, out if world == 1 else None)
+    readers = args.t if args.t > 1 else min(8, os.cpu_count() or 1)
+    rows = run_count(stream, loci, f5.get_raw, counter, log, args.batch, rank, world, out if world == 1 else None, readers=readers)
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world if rank == 0 else None
@@ -225,10 +229,13 @@ def write_rows(out, rows, header=True):
     out.flush()
 
 
-def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, out=None):
+def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, out=None, readers=0):
     """Route the SAM records of `stream` to their targets, run this rank's share through
     `counter.detect_batch` and return [(sequence number, TSV row)].  With `out` given (single
-    process) rows are also written as soon as their batch is done, header first."""
+    process) rows are also written as soon as their batch is done, header first.
+    `readers` > 0: raw signals are fetched by that many threads ahead of the GPU batches (inflating
+    the deflate chunks of a fast5 releases the GIL and is what bounds a `count` run on real files);
+    the order of the rows does not change."""
     if out is not None:
         print('\t'.join(HEADER), file=out)
     rows = []
@@ -254,8 +261,35 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
         if out is not None:
             write_rows(out, done, header=False)
 
+    def fetch(qname):
+        try:
+            return get_raw(qname)
+        except Exception as e:
+            log("Detector: cannot read %s: %s" % (qname, e), 'warning')
+            return None
+
+    pool = None
+    if readers > 0:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=readers)
+    pending = deque()                      # (qname, strand, [(seq, target)], raw or future), in input order
     batch = []
+
+    def drain(keep):
+        nonlocal batch
+        while len(pending) > keep:
+            qname, strand, mine, raw = pending.popleft()
+            if pool is not None:
+                raw = raw.result()
+            if raw is None:
+                log("Detector: No fast5 for ID %s" % qname, 'warning'); continue
+            for sq, t in mine:
+                batch.append((sq, qname, t, strand, raw))
+            if len(batch) >= batch_size:
+                flush(batch); batch = []
+
     seq = 0
+    lookahead = max(1, 2 * batch_size) if pool is not None else 0
     for line in stream:
         if line.startswith('@'):
             continue
@@ -270,17 +304,12 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
         seq += len(targets)
         if not mine:
             continue
-        try:
-            raw = get_raw(sr.QNAME)
-        except Exception as e:
-            log("Detector: cannot read %s: %s" % (sr.QNAME, e), 'warning'); raw = None
-        if raw is None:
-            log("Detector: No fast5 for ID %s" % sr.QNAME, 'warning'); continue
-        for sq, t in mine:
-            batch.append((sq, sr.QNAME, t, strand, raw))
-        if len(batch) >= batch_size:
-            flush(batch); batch = []
+        pending.append((sr.QNAME, strand, mine, pool.submit(fetch, sr.QNAME) if pool is not None else fetch(sr.QNAME)))
+        drain(lookahead)
+    drain(0)
     flush(batch)
+    if pool is not None:
+        pool.shutdown()
     return rows
 
 

@@ -79,3 +79,36 @@ def test_fast5_layouts_written_by_hand(tmp_path):
         raw = idx.get_raw(rid)
         assert raw is not None and raw.dtype == np.int16 and np.array_equal(raw, sig), rid
     assert len(idx._open) <= 4
+
+
+def test_reader_threads_keep_the_row_order(cfg):
+    """`count` fetches raw signals with a thread pool ahead of the GPU batches; rows must come out exactly
+    as without it (input order, failed reads skipped)."""
+    import io
+    import time
+    import numpy as np
+    from strique_amd import cli
+    loci = {}
+    for name, (chrom, b, e, *_r) in cfg["repeat"].items():
+        loci.setdefault(chrom, []).append((name, b, e))
+    lines = ["\t".join(["read%d" % i, "16" if i % 2 else "0", "chr9" if i % 3 else "chrX", str(27570000 if i % 3 else 146990000),
+                        "60", "8000M", "*", "0", "0", "ACGT", "*"]) for i in range(40)]
+
+    class FakeCounter(object):
+        def detect_batch(self, items):
+            return [(len(raw) % 89, 1.0, 2.0, -1.0 * len(t), int(raw[0]), 3, "-") for t, raw, s in items]
+
+    def get_raw(qname):
+        i = int(qname[4:])
+        time.sleep(0.002 * ((i * 7) % 5))                 # finish out of order
+        if i == 13:
+            raise IOError("broken file")
+        return None if i == 21 else np.arange(50 + i, 400 + 3 * i)
+
+    log = cli.Log("error")
+    outs = []
+    for readers in (0, 4):
+        buf = io.StringIO()
+        cli.run_count(iter(lines), loci, get_raw, FakeCounter(), log, 7, 0, 1, buf, readers=readers)
+        outs.append(buf.getvalue())
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == 1 + 38
