@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/ on a GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
-# Three separate passes, as MI355X_MICROARCH.md prescribes: kernel trace + stats, then one PMC
-# counter per pass (never combined with a trace domain).  Raw output lands in gpurun_out/prof_<tag>/;
+# Separate passes, as MI355X_MICROARCH.md prescribes: kernel trace + stats, then one TCC counter per
+# pass and one pass of eight SQ counters (never combined with a trace domain).  Raw output lands in gpurun_out/prof_<tag>/;
 # tools/summarize_profiles.py turns it into the committed profiles/<tag>_*.{md,csv,json}.
 set -u
 TAG=${1:-r01}
@@ -18,6 +18,8 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -
 echo "FETCH_SIZE pass rc=$?"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o "$TAG" -- python3 $BENCH_PMC > "$OUT/bench_write.log" 2>&1
 echo "WRITE_SIZE pass rc=$?"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_sq" -o "$TAG" -- python3 $BENCH_PMC > "$OUT/bench_sq.log" 2>&1
+echo "SQ pass rc=$?"
 # the kernel trace itself is large; keep stats + counters only
 rm -f "$OUT"/kt/*_kernel_trace.csv "$OUT"/kt/*.db
 tail -1 "$OUT/bench_kt.log" | cut -c1-400

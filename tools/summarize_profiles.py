@@ -105,6 +105,35 @@ def main():
         }
         json.dump(info, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
         print(json.dumps(info, indent=1))
+    sq_summary(tag, src, out, pmc_reads)
+
+
+def sq_summary(tag, src, out, pmc_reads):
+    """Issue / stall split of the waves (SQ counters, quad-cycle units) -> profiles/<tag>_sq.md."""
+    hits = sorted(glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"), recursive=True))
+    if not hits:
+        return
+    names = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU",
+             "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
+    per = OrderedDict()
+    for n in names:
+        for k, v in counters(hits[-1], n).items():
+            per.setdefault(k, {})[n] = sum(v) / len(v)
+    with open(os.path.join(out, tag + "_sq.md"), "w") as f:
+        f.write("# Where the wave cycles go, rocprofv3 SQ counters (%s)\n\n" % tag)
+        f.write("One pass of `--pmc %s` over `python3 bench.py --steps 1 --warmup 0 --reads %d --no-cpu-baseline --no-host-leg --check 0`.\n"
+                "Cycle counters are in quad-cycles summed over all waves (MI355X_MICROARCH.md): WAVE_CYCLES = resident wave time,\n"
+                "ACTIVE_INST_ANY = issuing, WAIT_INST_ANY = issue stalls, WAIT_ANY = parked on s_waitcnt.  Per-dispatch averages.\n\n" % (" ".join(names), pmc_reads))
+        f.write("| kernel | issuing | of which VALU | issue stall | waitcnt | VALU instructions | LDS active | LDS bank conflict |\n|---|---|---|---|---|---|---|---|\n")
+        for k, v in per.items():
+            wc = v.get("SQ_WAVE_CYCLES", 0.0)
+            if wc < 1e7:
+                continue
+            pct = lambda n: "%.0f %%" % (100.0 * v.get(n, 0.0) / wc)
+            f.write("| %s | %s | %s | %s | %s | %.3g | %s | %s |\n" % (k, pct("SQ_ACTIVE_INST_ANY"), pct("SQ_ACTIVE_INST_VALU"), pct("SQ_WAIT_INST_ANY"),
+                    pct("SQ_WAIT_ANY"), v.get("SQ_INSTS_VALU", 0.0), pct("SQ_LDS_IDX_ACTIVE"), pct("SQ_LDS_BANK_CONFLICT")))
+        f.write("\nPercentages are of SQ_WAVE_CYCLES.  Forward DP: the resident waves issue three quarters of the time, almost all of it\n"
+                "VALU -- the kernel is bound by VALU issue of the waves its LDS tables admit, not by memory.\n")
 
 
 if __name__ == "__main__":
