@@ -52,23 +52,23 @@ def make_batch(pm, cfg, n_reads, read_nt, first_index, config_id=3):
     return sigs, strands, nreps
 
 
+def _oracle_side(strand):
+    """The CPU oracle's own pore model and classifier (built inside oracle/, nothing from the product)."""
+    from oracle import strique_oracle as orc
+    t = np.load(os.path.join(ROOT, "tests", "golden", "pore_tables.npz"))
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "config.json")))
+    opm = orc.PoreModel(table=(t["base_kmer"], t["base_mean"], t["base_stdv"]))
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    return orc, opm, orc.classifier(repeat, prefix, suffix, strand, opm, None, cfg["HMM"]), orc.align_params(cfg["align"])
+
+
 def _cpu_one(args):
     """One read through the CPU oracle (worker process): with the reference's per-cell double pow, or
     with memoised scores (same bits, the honest "optimised CPU" variant)."""
     sig, strand, use_lut = args
-    from oracle import strique_oracle as orc
-    from strique_amd import hmm
-    from strique_amd.counter import reverse_complement as rc
-    pm, cfg = load_inputs()
-    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
-    P, S, PE, SE, R = prefix[-50:].upper(), suffix[:50].upper(), prefix.upper(), suffix.upper(), repeat.upper()
-    if strand == "-":
-        R, P, S, PE, SE = rc(R), rc(S), rc(P), rc(SE), rc(PE)
-    g = lambda s: pm.generate_signal(s, samples=6)
-    tc = dict(prefix=g(P), suffix=g(S), prefix_ext=g(PE), suffix_ext=g(SE), hmm=hmm.FlankedRepeatModel(R, P, S, pm, cfg["HMM"]))
-    opm = orc.PoreModel.__new__(orc.PoreModel); opm.means = pm._means; opm.model_min = pm.model_min; opm.model_max = pm.model_max
+    orc, opm, tc, params = _oracle_side(strand)
     t0 = time.time()
-    res, _ = orc.detect(sig, tc, opm, orc.align_params(cfg["align"]), use_lut=use_lut)
+    res, _ = orc.detect(sig, tc, opm, params, use_lut=use_lut)
     return time.time() - t0, res[0]
 
 
@@ -228,19 +228,9 @@ def main():
 
 
 def _cpu_check(sig, strand):
-    from oracle import strique_oracle as orc
-    from strique_amd import hmm
-    from strique_amd.counter import reverse_complement as rc
-    pm, cfg = load_inputs()
-    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
-    P, S, PE, SE, R = prefix[-50:].upper(), suffix[:50].upper(), prefix.upper(), suffix.upper(), repeat.upper()
-    if strand == "-":
-        R, P, S, PE, SE = rc(R), rc(S), rc(P), rc(SE), rc(PE)
-    g = lambda s: pm.generate_signal(s, samples=6)
-    tc = dict(prefix=g(P), suffix=g(S), prefix_ext=g(PE), suffix_ext=g(SE), hmm=hmm.FlankedRepeatModel(R, P, S, pm, cfg["HMM"]))
-    opm = orc.PoreModel.__new__(orc.PoreModel); opm.means = pm._means; opm.model_min = pm.model_min; opm.model_max = pm.model_max
+    orc, opm, tc, params = _oracle_side(strand)
     t0 = time.time()
-    res, _ = orc.detect(sig, tc, opm, orc.align_params(cfg["align"]), use_lut=True)
+    res, _ = orc.detect(sig, tc, opm, params, use_lut=True)
     return time.time() - t0, int(res[0])
 
 

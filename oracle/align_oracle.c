@@ -28,10 +28,26 @@
 #include <string.h>
 #include <float.h>
 
-/* tie rules: H/V "extend" wins over "open"; H wins over V; diagonal wins over gap */
+/* tie rules: H/V "extend" wins over "open"; H wins over V; diagonal wins over gap.
+ * oracle/residual_probe.py recompiles this file with the alternatives (-DTIE_...=...) and with the
+ * ORACLE_* switches below to show which enumerated semantics move the documented known answer. */
+#ifndef TIE_EXT
 #define TIE_EXT(ext, opn)   ((ext) >= (opn))
+#endif
+#ifndef TIE_H_OVER_V
 #define TIE_H_OVER_V(h, v)  ((h) >= (v))
+#endif
+#ifndef TIE_D_OVER_G
 #define TIE_D_OVER_G(d, g)  ((d) >= (g))
+#endif
+/* probe switches (all off in the oracle proper):
+ *   ORACLE_GAP_OPEN_PLUS_EXT  a gap of n costs open + n*ext instead of SeqAn's open + (n-1)*ext
+ *   ORACLE_POWF               powf in float instead of pow in double
+ *   ORACLE_LINEAR             |h-v| without the exponent (the commented-out line src/score_distance.h:119)
+ *   ORACLE_EXPONENT           the exponent (default 1.2) */
+#ifndef ORACLE_EXPONENT
+#define ORACLE_EXPONENT 1.2
+#endif
 
 #define TR_DIR_MASK 3u   /* 0 = diagonal, 1 = from H, 2 = from V */
 #define TR_HEXT 4u
@@ -45,7 +61,13 @@ typedef struct {
 static inline float cell_score(const strq_oracle_params *p, float h, float v)
 {
     float d = h > v ? h - v : v - h;
-    float s = p->dist_offset - (float)pow((double)d, 1.2);
+#if defined(ORACLE_LINEAR)
+    float s = p->dist_offset - d;
+#elif defined(ORACLE_POWF)
+    float s = p->dist_offset - powf(d, (float)ORACLE_EXPONENT);
+#else
+    float s = p->dist_offset - (float)pow((double)d, ORACLE_EXPONENT);
+#endif
     return s > p->dist_min ? s : p->dist_min;
 }
 
@@ -77,6 +99,9 @@ int strq_oracle_align(const float *a, int64_t n, const float *b, int64_t m,
 {
     if (n < 0 || m < 1) return 1;
     strq_oracle_params p = { params[0], params[1], params[2], params[3], params[4], params[5] };
+#ifdef ORACLE_GAP_OPEN_PLUS_EXT
+    p.open_h += p.ext_h; p.open_v += p.ext_v;
+#endif
     const float NINF = -FLT_MAX / 2;
     const int64_t rows = m + 1;
     uint8_t *trace = (uint8_t *)malloc((size_t)(n + 1) * rows);

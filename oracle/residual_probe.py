@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY (CPU).  Residual probe for the one real-data known answer.
+
+The reference documents one output row (docs/installation/test.md:15-16) for its bundled read:
+    count 735  score_prefix 6.3155927807600545  score_suffix 6.031860427335506
+    log_p -119860.52066647023  offset 1633  ticks 40758
+The oracle reproduces offset / ticks exactly but gives count 733 and floats ~1 % off.  SeqAn 2
+(alignment), pomegranate 0.10.0 (bake / viterbi) and scikit-image 0.14 (morphology) are not in
+/root/reference and cannot be installed here, so their semantics in oracle/ are recalled
+(SURVEY.md Appendix A).  This script re-runs the oracle on that read with every enumerated
+alternative of those semantics, one at a time, and prints what each does to the row -- either
+one of them reproduces the documented row (then it is adopted), or the committed table shows that
+none of them does.
+
+    python -m oracle.residual_probe [--out profiles/r02_residual_probe.md] [--only NAME ...]
+
+Input: tests/golden/bundled_read.npz (the raw int16 samples of data/c9orf72.fast5, a data fixture),
+tests/golden/pore_tables.npz, tests/golden/config.json.  Nothing under strique_amd/ is imported.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from oracle import hmm_oracle as ho            # noqa: E402
+from oracle import strique_oracle as orc       # noqa: E402
+
+DOCS = dict(count=735, score_prefix=6.3155927807600545, score_suffix=6.031860427335506,
+            log_p=-119860.52066647023, offset=1633, ticks=40758)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+# ---------------------------------------------------------------------------------------------
+# variant plumbing
+# ---------------------------------------------------------------------------------------------
+_LIBS = {}
+
+
+def variant_lib(defines):
+    """liboracle compiled with extra -D switches (oracle/align_oracle.c), cached per switch set."""
+    key = tuple(sorted(defines))
+    if key not in _LIBS:
+        d = tempfile.mkdtemp(prefix="strq_probe_")
+        so = os.path.join(d, "liboracle_variant.so")
+        srcs = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith(".c")]
+        cmd = ["gcc", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared", "-o", so] + \
+              ["-D" + x for x in key] + srcs + ["-lm"]
+        subprocess.check_call(cmd)
+        lib = ctypes.CDLL(so)
+        lib.strq_oracle_cell_score.restype = ctypes.c_float
+        _LIBS[key] = lib
+    return _LIBS[key]
+
+
+def window(x, lo, hi, fn, border="reflect"):
+    n = len(x)
+    pad = max(-lo, hi, 0)
+    idx = np.arange(-pad, n + pad)
+    if border == "reflect":
+        idx = np.mod(idx, 2 * n); idx = np.where(idx >= n, 2 * n - 1 - idx, idx)
+    else:                                   # 'edge'
+        idx = np.clip(idx, 0, n - 1)
+    xp = x[idx]
+    out = None
+    for off in range(lo, hi + 1):
+        seg = xp[pad + off: pad + off + n]
+        out = seg.copy() if out is None else fn(out, seg)
+    return out
+
+
+def open_close(u8, first=(-3, 4), second=(-4, 3), border="reflect"):
+    o = window(window(u8, first[0], first[1], np.minimum, border), second[0], second[1], np.maximum, border)
+    return window(window(o, first[0], first[1], np.maximum, border), second[0], second[1], np.minimum, border)
+
+
+def normalize(pm, sig, mode="minmax", percentiles=(1, 99), clip=True):
+    sig = np.asarray(sig, np.float64)
+    if mode == "minmax":
+        if clip:
+            return pm.normalize_minmax(sig, percentiles)
+        save = (pm.model_min, pm.model_max)
+        pm.model_min, pm.model_max = -1e300, 1e300
+        try:
+            return pm.normalize_minmax(sig, percentiles)
+        finally:
+            pm.model_min, pm.model_max = save
+    med = np.median(sig); mad = np.mean(np.abs(sig - med))
+    mmed = np.median(pm.means); mmad = np.mean(np.abs(pm.means - mmed))
+    out = (sig - med) / mad * mmad + mmed
+    if clip:
+        np.clip(out, pm.model_min + .5, pm.model_max - .5, out=out)
+    return out
+
+
+def run(raw, pm, cfg, v):
+    """detect() of the bundled read ('-' strand, c9orf72) under variant dict `v`."""
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    samples = v.get("samples", 6)
+    tc = orc.classifier(repeat, prefix, suffix, "-", pm, None, dict(cfg["HMM"], **v.get("hmm_cfg", {})), samples=samples)
+    if "prepare" in v:
+        pe, se, r = prefix.upper(), suffix.upper(), repeat.upper()
+        r_, p_, s_ = orc.revcomp(r), orc.revcomp(se[:50]), orc.revcomp(pe[-50:])
+        net, _, _ = ho.flanked_net(r_, p_, s_, pm, dict(cfg["HMM"], **v.get("hmm_cfg", {})))
+        if v.get("in_edge_by_index"):
+            pass
+        tc["hmm"] = ho.prepare(net, **v["prepare"])
+    params = orc.align_params(dict(cfg["align"], **v.get("align_cfg", {})))
+    # ---- conditioning (STRique.py:590-597) with the variant's switches
+    k = v.get("medfilt", 3)
+    if k == 3:
+        flt = orc.medfilt3(raw)
+    elif k == 1:
+        flt = raw.copy()
+    else:
+        import scipy.signal
+        flt = scipy.signal.medfilt(raw, k)
+    med = np.median(flt)
+    scale = np.median(np.abs(flt - med)) if v.get("true_mad") else orc.mad(flt)
+    z = (flt - med) / scale * v.get("gain", 24) + 127
+    z = np.clip(np.round(z) if v.get("round_u8") else z, 0, 255).astype(np.uint8)
+    if v.get("morph", True):
+        u8 = open_close(z, v.get("first", (-3, 4)), v.get("second", (-4, 3)), v.get("border", "reflect"))
+    else:
+        u8 = z
+    pct = v.get("percentiles", (1, 99))
+    morph = normalize(pm, u8.astype(np.float64), v.get("morph_mode", "minmax"), pct, v.get("clip", True))
+    fltn = normalize(pm, flt.astype(np.float64), v.get("flt_mode", "minmax"), pct, v.get("clip", True))
+    if v.get("align_on_flt"):
+        morph = fltn
+    if v.get("hmm_on_morph"):
+        fltn = morph
+    # ---- alignment + HMM through the (variant) C library
+    saved = orc._LIB
+    orc.lib()
+    if v.get("defines"):
+        orc._LIB = variant_lib(v["defines"])
+    try:
+        tp = len(tc["prefix_ext"]) - len(tc["prefix"]); ts = len(tc["suffix_ext"]) - len(tc["suffix"])
+        sp, pb, pe_ = orc.detect_range(morph, tc["prefix_ext"], params, pre_trim=tp)
+        ss, sb, se_ = orc.detect_range(morph, tc["suffix_ext"], params, post_trim=ts)
+        n, lp = 0, 0.0
+        if pb < se_ and sp > 0 and ss > 0:
+            lp, path, counted = orc.viterbi(tc["hmm"], fltn[pb:se_])
+            n = counted + tc["count_bias"] if path is not None else 0
+    finally:
+        orc._LIB = saved
+    return dict(count=int(n), score_prefix=float(sp), score_suffix=float(ss), log_p=float(lp),
+                offset=int(pe_), ticks=int(max(sb - pe_, 0)))
+
+
+def variants():
+    V = [("baseline (oracle as committed)", {})]
+    # --- SeqAn boundary
+    V += [("tie: gap-open wins over gap-extend", dict(defines=["TIE_EXT(e,o)=((e)>(o))"])),
+          ("tie: V wins over H", dict(defines=["TIE_H_OVER_V(h,v)=((h)>(v))"])),
+          ("tie: gap wins over diagonal", dict(defines=["TIE_D_OVER_G(d,g)=((d)>(g))"])),
+          ("gap of n costs open + n*ext", dict(defines=["ORACLE_GAP_OPEN_PLUS_EXT"])),
+          ("powf(float) instead of pow(double)", dict(defines=["ORACLE_POWF"])),
+          ("|d| without exponent (score_distance.h:119, commented out)", dict(defines=["ORACLE_LINEAR"])),
+          ("exponent 1.25", dict(defines=["ORACLE_EXPONENT=1.25"])),
+          ("exponent 1.1", dict(defines=["ORACLE_EXPONENT=1.1"])),
+          ("align_raw default parameters (config not applied)", dict(align_cfg=dict(gap_open_h=-2, gap_open_v=-2, gap_extension_h=-8, gap_extension_v=-8, dist_offset=8, dist_min=-16))),
+          ("dist_min -1 instead of 0", dict(align_cfg=dict(dist_min=-1.0))),
+          ("gap_open_h -2", dict(align_cfg=dict(gap_open_h=-2.0)))]
+    # --- normalisation
+    for pc in ((5, 95), (2, 98), (0.5, 99.5), (10, 90)):
+        V.append(("percentiles %s" % (pc,), dict(percentiles=pc)))
+    V += [("morph signal normalised in 'median' mode", dict(morph_mode="median")),
+          ("filtered signal normalised in 'median' mode", dict(flt_mode="median")),
+          ("both in 'median' mode", dict(morph_mode="median", flt_mode="median")),
+          ("no clip to [model_min+.5, model_max-.5]", dict(clip=False)),
+          ("MAD = median |x - median| (true MAD)", dict(true_mad=True)),
+          ("z*24+127 rounded instead of truncated", dict(round_u8=True)),
+          ("gain 32 instead of 24", dict(gain=32)),
+          ("no median filter", dict(medfilt=1)),
+          ("median filter width 5", dict(medfilt=5))]
+    # --- scikit-image morphology
+    V += [("morphology: both stages window [-3,+4]", dict(first=(-3, 4), second=(-3, 4))),
+          ("morphology: both stages window [-4,+3]", dict(first=(-4, 3), second=(-4, 3))),
+          ("morphology: stages swapped ([-4,+3] then [-3,+4])", dict(first=(-4, 3), second=(-3, 4))),
+          ("morphology: symmetric width 9 [-4,+4]", dict(first=(-4, 4), second=(-4, 4))),
+          ("morphology: width 7 [-3,+3]", dict(first=(-3, 3), second=(-3, 3))),
+          ("morphology: 'edge' border (pad_for_eccentric_selems)", dict(border="edge")),
+          ("no morphology", dict(morph=False)),
+          ("alignment on the filtered signal instead of the morphology signal", dict(align_on_flt=True)),
+          ("HMM on the morphology signal", dict(hmm_on_morph=True))]
+    # --- pomegranate boundary
+    V += [("bake: no out-edge renormalisation", dict(prepare=dict(renormalise=False))),
+          ("bake: renormalise whenever the sum differs at all (no round(.,8))", dict(prepare=dict(round_digits=None))),
+          ("Normal log-pdf constant as -0.5*log(2*pi*sigma^2)", dict(prepare=dict(normal_form="textbook"))),
+          ("rep_std_scale 1.05", dict(hmm_cfg=dict(rep_std_scale=1.05))),
+          ("rep_std_scale 1.1", dict(hmm_cfg=dict(rep_std_scale=1.1))),
+          ("rep_std_scale 1.5 (repeatModHMM's default, STRique.py:450)", dict(hmm_cfg=dict(rep_std_scale=1.5))),
+          ("rep_std_offset 0.1", dict(hmm_cfg=dict(rep_std_offset=0.1))),
+          ("seq_std_scale 1.5", dict(hmm_cfg=dict(seq_std_scale=1.5))),
+          ("e1_ratio 0.5", dict(hmm_cfg=dict(e1_ratio=0.5))),
+          ("flank templates with samples=10 (generate_signal default)", dict(samples=10))]
+    return V
+
+
+def fmt_row(name, r, secs):
+    d = lambda k: r[k] - DOCS[k]
+    rel = lambda k: 100.0 * (r[k] / DOCS[k] - 1.0)
+    hit = all(r[k] == DOCS[k] for k in DOCS)
+    return "| %s | %d (%+d) | %.10f (%+.3f %%) | %.10f (%+.3f %%) | %.4f (%+.3f %%) | %d (%+d) | %d (%+d) | %s | %.0f |" % (
+        name, r["count"], d("count"), r["score_prefix"], rel("score_prefix"), r["score_suffix"], rel("score_suffix"),
+        r["log_p"], rel("log_p"), r["offset"], d("offset"), r["ticks"], d("ticks"), "**YES**" if hit else "no", secs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--only", nargs="*", default=None, help="substring filters on the variant name")
+    ap.add_argument("--mod-model", action="store_true", help="also run every variant with the mCpG table as base model")
+    a = ap.parse_args()
+    z = np.load(os.path.join(GOLDEN, "bundled_read.npz"))
+    raw = z["signal"]
+    t = np.load(os.path.join(GOLDEN, "pore_tables.npz"))
+    pm = orc.PoreModel(table=(t["base_kmer"], t["base_mean"], t["base_stdv"]))
+    pmm = orc.PoreModel(table=(t["mod_kmer"], t["mod_mean"], t["mod_stdv"]))
+    cfg = json.load(open(os.path.join(GOLDEN, "config.json")))
+    lines = ["# Residual probe: the bundled read under every enumerated alternative semantic",
+             "",
+             "Generated by `python -m oracle.residual_probe` (CPU, oracle only).  Target row "
+             "(`docs/installation/test.md:15-16` of the reference): count %(count)d, score_prefix %(score_prefix).16g, "
+             "score_suffix %(score_suffix).16g, log_p %(log_p).16g, offset %(offset)d, ticks %(ticks)d." % DOCS,
+             "Each line changes ONE semantic of the committed oracle; values are followed by their difference "
+             "from the documented row.",
+             "",
+             "| variant | count | score_prefix | score_suffix | log_p | offset | ticks | reproduces the row | s |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    hits = []
+    todo = variants()
+    if a.mod_model:
+        todo += [(n + " + mCpG table as the base model", dict(v, _pm="mod")) for n, v in variants()[:1]]
+    for name, v in todo:
+        if a.only and not any(s in name for s in a.only):
+            continue
+        t0 = time.time()
+        try:
+            r = run(raw, pmm if v.get("_pm") == "mod" else pm, cfg, v)
+            row = fmt_row(name, r, time.time() - t0)
+            if all(r[k] == DOCS[k] for k in DOCS):
+                hits.append(name)
+        except Exception as ex:          # a variant that cannot run is part of the record
+            row = "| %s | failed: %s | | | | | | no | |" % (name, str(ex).replace("|", "/")[:80])
+        print(row, flush=True)
+        lines.append(row)
+    lines += ["", "Variants reproducing the documented row exactly: %s." % (", ".join(hits) if hits else "**none**"), "",
+              "## Reading",
+              "",
+              "* The optimal alignment score does not depend on tie-breaks (first block: identical rows), and offset / ticks",
+              "  are exact under every variant that keeps the conditioning, so the documented geometry pins the",
+              "  conditioning windows (A.3: a different window placement moves `offset` by 2) and the 1/99 percentiles.",
+              "* No single gap convention, `pow` form or exponent moves both flank scores onto the documented values",
+              "  (open + n*ext: -0.18 % / +0.16 %; none hits both).",
+              "* The count becomes 735 as soon as the repeat-state emissions are slightly wider (rep_std_scale >= 1.1 or",
+              "  rep_std_offset >= 0.1), and the documented log_p lies between rep_std_scale 1.05 and 1.1 -- not at a",
+              "  configured value: consistent with a row produced from a slightly different k-mer table / config revision",
+              "  (release notes v0.3.0: 'Update pore models'; the docs call the row 'similar to'), not with a different",
+              "  DP, bake or Viterbi rule.  With the bundled mCpG table as base model the scores move by +0.2 % / +1.0 %,",
+              "  i.e. a table revision is enough to produce shifts of this size with unchanged geometry.",
+              "* Result: none of the enumerated semantics reproduces the row; the oracle stays as committed and the",
+              "  residual (count -2, scores +0.7 % / +0.9 %, log_p 1.4 %) is stated in DESIGN.md.", ""]
+    if a.out:
+        with open(a.out, "w") as fp:
+            fp.write("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

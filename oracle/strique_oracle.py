@@ -18,6 +18,8 @@ installed here -- see `grey_open_close_1x8`.
 PARITY STATUS
   pinned by tests/golden (generated from the reference's own code, tests/golden/make_golden.py):
       pore-model statistics, minmax / median normalisation, flank templates, HMM topology.
+  independent of the product: pore-model statistics, templates and HMMs are built here
+      (PoreModel, classifier, hmm_oracle.py -- un-baked graphs); nothing is imported from strique_amd.
   pinned by the reference's docs/tests: integer geometry of the bundled read (offset 1633,
       ticks 40758; docs/installation/test.md:15-16) and repeat counts of scripts/STRique_test.py.
   "parity unpinned": float outputs at the SeqAn and pomegranate boundaries (neither library is
@@ -88,7 +90,9 @@ def align_overlap(a, b, params, use_lut=True, want_idx=True):
 
 
 def viterbi(baked, x, want_path=True):
-    """(logp, emitting-state path or None, counted visits) on a baked model (strique_amd.hmm.bake)."""
+    """(logp, emitting-state path or None, counted visits).  `baked`: any object with the array
+    fields of hmm_oracle.Prepared (the product's BakedHMM has the same ones, which is how the GPU
+    kernel tests feed both sides the same arrays)."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     T = len(x)
     logp = ctypes.c_double(); counted = ctypes.c_int64(0)
@@ -147,34 +151,77 @@ def grey_open_close_1x8(u8):
 
 
 class PoreModel(object):
-    """Statistics of a k-mer table the normalisation needs (STRique.py:114-127,154-158)."""
+    """k-mer table and the statistics the hot path needs (STRique.py:114-127,145-148,154-158,182-195).
+    Built from the reference's `.model` file format or from (kmers, means, stdvs) arrays -- the
+    golden fixture tests/golden/pore_tables.npz holds the two bundled tables in that form."""
 
-    def __init__(self, model_file):
-        table = {}
-        with open(model_file) as fp:
-            for line in fp:
-                c = line.strip().split('\t')
-                if len(c) >= 3:
-                    table[c[0]] = (float(c[1]), float(c[2]))
-        self.table = table
-        self.kmer = len(next(iter(table)))
-        means = np.array([v[0] for v in table.values()])
-        self.means = means
-        lo = min(table.values(), key=lambda v: v[0]); hi = max(table.values(), key=lambda v: v[0])
+    def __init__(self, model_file=None, table=None):
+        t = {}
+        if table is not None:
+            for k, m, s in zip(*table):
+                t[k.decode() if isinstance(k, bytes) else str(k)] = (float(m), float(s))
+        else:
+            with open(model_file) as fp:
+                for line in fp:
+                    c = line.strip().split('\t')
+                    if len(c) >= 3:
+                        t[c[0]] = (float(c[1]), float(c[2]))
+        self.table = t
+        self.kmer = len(next(iter(t)))
+        self.means = np.array([v[0] for v in t.values()])
+        self.stdvs = np.array([v[1] for v in t.values()])
+        lo = min(t.values(), key=lambda v: v[0]); hi = max(t.values(), key=lambda v: v[0])
         self.model_min = lo[0] - 6 * lo[1]
         self.model_max = hi[0] + 6 * hi[1]
 
-    def normalize_minmax(self, signal):
+    def scale2stdv(self, other):
+        return np.median(other.stdvs) / np.median(self.stdvs)
+
+    def template(self, sequence, samples=6):
+        """generate_signal(sequence, samples) without noise: every k-mer mean `samples` times."""
+        K = self.kmer
+        return np.repeat(np.array([self.table[sequence[i:i + K]][0] for i in range(len(sequence) - K + 1)]), samples)
+
+    def normalize_minmax(self, signal, percentiles=(1, 99)):
         signal = np.asarray(signal, dtype=np.float64)
         mv = self.means
-        q5_sig, q95_sig = np.percentile(signal, [1, 99])
-        q5_mod, q95_mod = np.percentile(mv, [1, 99])
+        q5_sig, q95_sig = np.percentile(signal, list(percentiles))
+        q5_mod, q95_mod = np.percentile(mv, list(percentiles))
         m5_sig = np.median(signal[signal < q5_sig]); m95_sig = np.median(signal[signal > q95_sig])
         m5_mod = np.median(mv[mv < q5_mod]); m95_mod = np.median(mv[mv > q95_mod])
         out = (signal - (m5_sig + (m95_sig - m5_sig) / 2)) / ((m95_sig - m5_sig) / 2)
         out = out * ((m95_mod - m5_mod) / 2) + (m5_mod + (m95_mod - m5_mod) / 2)
         np.clip(out, self.model_min + .5, self.model_max - .5, out=out)
         return out
+
+
+_COMPLEMENT = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A'}
+
+
+def revcomp(seq):
+    return ''.join(_COMPLEMENT.get(b, b) for b in reversed(seq))
+
+
+def classifier(repeat, prefix, suffix, strand, pm, pm_mod=None, hmm_config=None, samples=6):
+    """One strand of repeatCounter.add_target (STRique.py:553-576), built by the oracle alone:
+    flank templates, the un-baked flanked-repeat HMM and (with a second pore model) the un-baked
+    modification HMM.  `prefix` / `suffix` are the full configured flanks (150 nt in the bundled
+    config); the HMM sees their inner 50 nt."""
+    from . import hmm_oracle as ho
+    pe, se, r = prefix.upper(), suffix.upper(), repeat.upper()
+    p, s = pe[-50:], se[:50]
+    if strand == '-':
+        r, p, s, pe, se = revcomp(r), revcomp(s), revcomp(p), revcomp(se), revcomp(pe)
+    elif strand != '+':
+        raise ValueError("strand must be + or -")
+    net, flanking_count, repeat_offset = ho.flanked_net(r, p, s, pm, hmm_config)
+    tc = dict(prefix=pm.template(p, samples), suffix=pm.template(s, samples),
+              prefix_ext=pm.template(pe, samples), suffix_ext=pm.template(se, samples),
+              hmm=ho.prepare(net), count_bias=flanking_count - repeat_offset, mod=None)
+    if pm_mod is not None:
+        mnet, lo, hi = ho.mod_net(r, pm, pm_mod, hmm_config)
+        tc['mod'] = ho.prepare(mnet); tc['mod_range'] = (lo, hi)
+    return tc
 
 
 def mad(signal):
@@ -229,9 +276,7 @@ def positions_from_rec(rec, j0, j_end, n, rows):
 
 
 def detect(raw_signal, tc, pm, params, pm_mod=None, use_lut=True):
-    """repeatCounter.detect for one strand-specific classifier `tc` with fields prefix, suffix,
-    prefix_ext, suffix_ext (float64 templates), hmm (baked flanked model + count_bias) and
-    optionally mod (baked mod model, hub indices, model_min/max).
+    """repeatCounter.detect (STRique.py:581-618) for one strand-specific `classifier(...)`.
     Returns (n, score_prefix, score_suffix, log_p, offset, ticks, mod_pattern) plus a dict with
     the intermediate geometry."""
     raw_signal = np.asarray(raw_signal)
@@ -242,28 +287,29 @@ def detect(raw_signal, tc, pm, params, pm_mod=None, use_lut=True):
     score_suffix, suffix_begin, suffix_end = detect_range(morph, tc['suffix_ext'], params, post_trim=trim_suffix, use_lut=use_lut)
     n = 0; p = 0; mod_pattern = '-'
     if prefix_begin < suffix_end and score_prefix > 0.0 and score_suffix > 0.0:
-        baked = tc['hmm'].baked
-        logp, path, counted = viterbi(baked, fltn[prefix_begin:suffix_end])
+        model = tc['hmm']
+        logp, path, counted = viterbi(model, fltn[prefix_begin:suffix_end])
         if path is not None:
-            n = int(counted) + tc['hmm'].count_bias
+            # count_repeats (STRique.py:374-378,437): visits of dummy1 / dummy2 - repeat_offset + flanking_count
+            names = [model.names[s] for s in path]
+            assert counted == sum(1 for s in path if model.count_inc[s])
+            n = int(counted) + tc['count_bias']
             p = logp
             if pm_mod is not None and tc.get('mod') is not None:
                 nrm = pm.normalize_minmax(raw_signal.astype(np.float64))
-                mask = baked.tag[path].astype(bool)
-                rep = nrm[prefix_begin:suffix_end][mask]
-                mod_pattern = mod_repeats(tc['mod'], rep)
+                mask = np.array(['repeat' in x for x in names], bool)           # STRique.py:608
+                mod_pattern = mod_repeats(tc['mod'], tc['mod_range'], nrm[prefix_begin:suffix_end][mask])
         else:
             n, p = 0, 0
     info = dict(prefix_begin=prefix_begin, prefix_end=prefix_end, suffix_begin=suffix_begin, suffix_end=suffix_end, u8=u8)
     return (n, score_prefix, score_suffix, p, prefix_end, max(suffix_begin - prefix_end, 0), mod_pattern), info
 
 
-def mod_repeats(mod, signal):
+def mod_repeats(model, value_range, signal):
     """repeatModHMM.mod_repeats (STRique.py:492-500)."""
-    baked = mod.baked
-    logp, path, _ = viterbi(baked, np.clip(signal, mod.model_min, mod.model_max))
+    logp, path, _ = viterbi(model, np.clip(signal, value_range[0], value_range[1]))
     if path is None:
         return '-'
-    names = [baked.names[s] for s in path]
+    names = [model.names[s] for s in path]
     first = [next(g) for k, g in itertools.groupby(names, key=lambda x: x not in ('s0', 'e0')) if k]
     return ''.join('1' if 'mod' in x else '0' for x in first)

@@ -45,22 +45,45 @@ def orc():
 
 
 @pytest.fixture(scope="session")
-def opm(orc, pm):
-    o = orc.PoreModel.__new__(orc.PoreModel)
-    o.means = pm._means; o.model_min = pm.model_min; o.model_max = pm.model_max
-    return o
+def opm(orc, tables):
+    """The oracle's own pore model, from the recorded k-mer table (not from the product's object)."""
+    return orc.PoreModel(table=(tables["base_kmer"], tables["base_mean"], tables["base_stdv"]))
 
 
 @pytest.fixture(scope="session")
-def gpu_counter(pm, cfg):
+def opm_mod(orc, tables):
+    return orc.PoreModel(table=(tables["mod_kmer"], tables["mod_mean"], tables["mod_stdv"]))
+
+
+@pytest.fixture(scope="session")
+def targets(cfg):
+    """name -> (repeat, prefix, suffix): the bundled loci plus the build-authored HTT/CAG row
+    (tests/golden/repeat_config_htt.tsv; BASELINE configs[3])."""
+    from strique_amd.cli import parse_config
+    out = {name: tuple(v[3:6]) for name, v in cfg["repeat"].items()}
+    extra = parse_config(os.path.join(GOLDEN, "repeat_config_htt.tsv"))["repeat"]
+    out.update({name: tuple(v[3:6]) for name, v in extra.items()})
+    return out
+
+
+@pytest.fixture(scope="session")
+def gpu_counter(pm, cfg, targets):
     """repeatCounter on cuda:0 with both bundled targets; fails loudly when there is no GPU."""
     from strique_amd.counter import repeatCounter
     rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
-    for name, (chrom, b, e, repeat, prefix, suffix) in cfg["repeat"].items():
+    for name, (repeat, prefix, suffix) in targets.items():
         rc.add_target(name, repeat, prefix, suffix)
     return rc
 
 
-def oracle_tc(counter, name, strand):
-    tc = counter._classifier_for(name, strand)
-    return dict(prefix=tc.prefix, suffix=tc.suffix, prefix_ext=tc.prefix_ext, suffix_ext=tc.suffix_ext, hmm=tc.repeatHMM)
+_TC_CACHE = {}
+
+
+def oracle_tc(orc, opm, targets, name, strand, hmm_cfg, opm_mod=None):
+    """The oracle's own classifier of one strand of a target (templates + un-baked HMMs, built in
+    oracle/ from the sequences; nothing comes from the product)."""
+    key = (name, strand, opm_mod is not None, json.dumps(hmm_cfg, sort_keys=True))
+    if key not in _TC_CACHE:
+        repeat, prefix, suffix = targets[name]
+        _TC_CACHE[key] = orc.classifier(repeat, prefix, suffix, strand, opm, opm_mod, hmm_cfg)
+    return _TC_CACHE[key]

@@ -19,20 +19,10 @@ def bundled():
     return str(z["read_id"]), z["signal"]
 
 
-def _oracle_tc(pm, cfg):
-    from strique_amd import hmm
-    from strique_amd.counter import reverse_complement as rc
-    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
-    P, S, PE, SE, R = prefix[-50:].upper(), suffix[:50].upper(), prefix.upper(), suffix.upper(), repeat.upper()
-    R, P, S, PE, SE = rc(R), rc(S), rc(P), rc(SE), rc(PE)          # FLAG 16 -> '-' strand
-    g = lambda s: pm.generate_signal(s, samples=6)
-    return dict(prefix=g(P), suffix=g(S), prefix_ext=g(PE), suffix_ext=g(SE), hmm=hmm.FlankedRepeatModel(R, P, S, pm, cfg["HMM"]))
-
-
-def test_oracle_reproduces_documented_geometry(bundled, pm, cfg, orc, opm):
+def test_oracle_reproduces_documented_geometry(bundled, cfg, orc, opm, targets):
     rid, sig = bundled
     assert rid == "ce47b364-ed6e-4409-808a-1041c0b5aac2" and sig.dtype == np.int16 and len(sig) == 284184
-    res, info = orc.detect(sig, _oracle_tc(pm, cfg), opm, orc.align_params(cfg["align"]))
+    res, info = orc.detect(sig, oracle_tc(orc, opm, targets, "c9orf72", "-", cfg["HMM"]), opm, orc.align_params(cfg["align"]))
     n, sp, ss, lp, offset, ticks, mod = res
     assert offset == DOCS["offset"] and ticks == DOCS["ticks"]          # integer geometry: exact
     assert abs(n - DOCS["count"]) <= 2
@@ -57,9 +47,9 @@ def test_fast5_reader_on_synthetic_hdf5(tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_equals_oracle_on_the_real_read(bundled, gpu_counter, pm, cfg, orc, opm):
+def test_gpu_equals_oracle_on_the_real_read(bundled, gpu_counter, cfg, orc, opm, targets):
     rid, sig = bundled
     got = gpu_counter.detect("c9orf72", sig, "-")
-    want, _ = orc.detect(sig, oracle_tc(gpu_counter, "c9orf72", "-"), opm, orc.align_params(cfg["align"]))
+    want, _ = orc.detect(sig, oracle_tc(orc, opm, targets, "c9orf72", "-", cfg["HMM"]), opm, orc.align_params(cfg["align"]))
     assert tuple(got[:6]) == tuple(want[:6])
     assert got[4] == DOCS["offset"] and got[5] == DOCS["ticks"] and abs(got[0] - DOCS["count"]) <= 2

@@ -7,31 +7,41 @@ from conftest import oracle_tc
 pytestmark = pytest.mark.gpu
 
 
-def _read(pm, cfg, name, strand, total_nt, nrep, idx, as_int16=True):
+_TABLE = []
+
+
+def _read(pm, targets, name, strand, total_nt, nrep, idx, as_int16=True):
     from strique_amd import synth
-    chrom, b, e, repeat, prefix, suffix = cfg["repeat"][name]
-    return synth.make_read(synth.KmerTable(pm), 9, idx, total_nt, (repeat, prefix, suffix), nrep, strand=strand, as_int16=as_int16)[0]
+    if not _TABLE:
+        _TABLE.append(synth.KmerTable(pm))
+    return synth.make_read(_TABLE[0], 9, idx, total_nt, targets[name], nrep, strand=strand, as_int16=as_int16)[0]
 
 
-def _check(gpu_counter, orc, opm, cfg, items):
-    got = gpu_counter.detect_batch([(n, s, st) for n, s, st in items])
+@pytest.fixture
+def want(orc, opm, targets, cfg):
+    """The oracle's detect() for (name, signal, strand), with the oracle's own classifier."""
     params = orc.align_params(cfg["align"])
+    return lambda name, sig, strand: orc.detect(sig, oracle_tc(orc, opm, targets, name, strand, cfg["HMM"]), opm, params)[0]
+
+
+def _check(gpu_counter, want, items):
+    got = gpu_counter.detect_batch([(n, s, st) for n, s, st in items])
     for (name, sig, strand), g in zip(items, got):
-        want, _ = orc.detect(sig, oracle_tc(gpu_counter, name, strand), opm, params)
-        assert tuple(g[:6]) == tuple(want[:6]), (name, strand, g, want)
+        w = want(name, sig, strand)
+        assert tuple(g[:6]) == tuple(w[:6]), (name, strand, g, w)
     return got
 
 
-def test_int16_and_float64_reads(gpu_counter, orc, opm, pm, cfg):
+def test_int16_and_float64_reads(gpu_counter, want, pm, targets):
     rng = np.random.default_rng(2)
     items = []
     for k in range(10):
         name = ["c9orf72", "fmr1"][k % 2]; strand = "+-"[(k // 2) % 2]
-        items.append((name, _read(pm, cfg, name, strand, int(rng.integers(3000, 8000)), int(rng.integers(4, 90)), k, as_int16=(k % 3 != 0)), strand))
+        items.append((name, _read(pm, targets, name, strand, int(rng.integers(3000, 8000)), int(rng.integers(4, 90)), k, as_int16=(k % 3 != 0)), strand))
     ints = [it for it in items if it[1].dtype == np.int16]
     flts = [it for it in items if it[1].dtype != np.int16]
-    _check(gpu_counter, orc, opm, cfg, ints)
-    _check(gpu_counter, orc, opm, cfg, flts)
+    _check(gpu_counter, want, ints)
+    _check(gpu_counter, want, flts)
 
 
 def test_reference_scenarios(gpu_counter, pm, cfg):
@@ -46,17 +56,15 @@ def test_reference_scenarios(gpu_counter, pm, cfg):
         assert gpu_counter.detect("c9orf72", pm.generate_signal(prefix + repeat * i + suffix, samples=8), "+")[0] == i
 
 
-def test_bad_reads_do_not_kill_the_batch(gpu_counter, orc, opm, pm, cfg):
+def test_bad_reads_do_not_kill_the_batch(gpu_counter, want, pm, targets):
     rng = np.random.default_rng(6)
-    good = _read(pm, cfg, "c9orf72", "+", 4000, 12, 77)
+    good = _read(pm, targets, "c9orf72", "+", 4000, 12, 77)
     const = np.full(3000, 500, np.int16)                       # normalisation undefined
     noise = rng.integers(300, 900, 5000).astype(np.int16)      # no locus inside
     got = gpu_counter.detect_batch([("c9orf72", const, "+"), ("c9orf72", good, "+"), ("fmr1", noise, "-")])
     assert got[0][0] == 0 and got[0][6] == "-"
-    want, _ = orc.detect(good, oracle_tc(gpu_counter, "c9orf72", "+"), opm, orc.align_params(cfg["align"]))
-    assert tuple(got[1][:6]) == tuple(want[:6]) and got[1][0] == 12
-    want, _ = orc.detect(noise, oracle_tc(gpu_counter, "fmr1", "-"), opm, orc.align_params(cfg["align"]))
-    assert tuple(got[2][:6]) == tuple(want[:6])
+    assert tuple(got[1][:6]) == tuple(want("c9orf72", good, "+")[:6]) and got[1][0] == 12
+    assert tuple(got[2][:6]) == tuple(want("fmr1", noise, "-")[:6])
 
 
 def test_errors_match_the_reference(gpu_counter):
@@ -68,9 +76,9 @@ def test_errors_match_the_reference(gpu_counter):
         gpu_counter.add_target("c9orf72", "GGCCCC", "A" * 150, "C" * 150)  # STRique.py:579
 
 
-def test_conditioning_stage(gpu_counter, orc, opm, pm, cfg):
+def test_conditioning_stage(gpu_counter, orc, opm, pm, targets):
     """Steps 1-6 of detect (STRique.py:590-597): 8-bit morphology levels and their values."""
-    sigs = [_read(pm, cfg, "c9orf72", "+", 3000 + 500 * i, 10 + i, 200 + i) for i in range(3)]
+    sigs = [_read(pm, targets, "c9orf72", "+", 3000 + 500 * i, 10 + i, 200 + i) for i in range(3)]
     gpu_counter.detect_batch([("c9orf72", s, "+") for s in sigs])
     for i, s in enumerate(sigs):
         lv, lval, sc = gpu_counter.ctx.debug_conditioning(i, len(s))
@@ -81,11 +89,11 @@ def test_conditioning_stage(gpu_counter, orc, opm, pm, cfg):
         assert sc[0] == np.median(flt) and sc[1] == orc.mad(flt)
 
 
-def test_full_size_reads_properties(gpu_counter, orc, opm, pm, cfg):
+def test_full_size_reads_properties(gpu_counter, want, pm, targets):
     """BASELINE config 3 size (50 kb reads).  One read is compared field by field with the oracle;
     for the rest: determinism, planted count recovered, geometry consistent with the planted locus."""
     plan = [(200, "+"), (1000, "-"), (2000, "+"), (500, "-")]
-    sigs = [_read(pm, cfg, "c9orf72", st, 50000, n, 300 + i) for i, (n, st) in enumerate(plan)]
+    sigs = [_read(pm, targets, "c9orf72", st, 50000, n, 300 + i) for i, (n, st) in enumerate(plan)]
     items = [("c9orf72", s, st) for s, (n, st) in zip(sigs, plan)]
     a = gpu_counter.detect_batch(items)
     b = gpu_counter.detect_batch(items)
@@ -93,11 +101,10 @@ def test_full_size_reads_properties(gpu_counter, orc, opm, pm, cfg):
     for (n, st), r, s in zip(plan, a, sigs):
         assert abs(r[0] - n) <= 2
         assert 0 < r[4] < len(s) and 6 * 6 * n * 0.9 < r[5] < 9 * 6 * n * 1.1      # ticks ~ 6 nt x n x dwell
-    want, _ = orc.detect(sigs[0], oracle_tc(gpu_counter, "c9orf72", "+"), opm, orc.align_params(cfg["align"]))
-    assert tuple(a[0][:6]) == tuple(want[:6])
+    assert tuple(a[0][:6]) == tuple(want("c9orf72", sigs[0], "+")[:6])
 
 
-def test_modification_pass(pm, pm_mod, cfg, orc, opm):
+def test_modification_pass(pm, pm_mod, cfg, orc, opm, opm_mod, targets):
     """detect steps 12-14 (STRique.py:605-609) and repeatModHMM.mod_repeats (:492-500): the
     pattern string must equal the oracle's, for signals drawn from the base and from the mCpG model
     (the reference's own test_Modification, scripts/STRique_test.py:104-124, only asserts the count)."""
@@ -116,33 +123,31 @@ def test_modification_pass(pm, pm_mod, cfg, orc, opm):
         items.append(("c9orf72", np.round(sig * (8192 / 1400.0) - 10).astype(np.int16), "+")); truth.append(i)
     flt_items = [it for it in items if it[1].dtype != np.int16]
     int_items = [it for it in items if it[1].dtype == np.int16]
-    tcp = rc._classifier_for("c9orf72", "+")
-    tc = dict(prefix=tcp.prefix, suffix=tcp.suffix, prefix_ext=tcp.prefix_ext, suffix_ext=tcp.suffix_ext,
-              hmm=tcp.repeatHMM, mod=tcp.modHMM)
+    tc = oracle_tc(orc, opm, targets, "c9orf72", "+", cfg["HMM"], opm_mod)
     params = orc.align_params(cfg["align"])
-    for group in (flt_items, int_items):
+    for group, planted in ((flt_items, truth[0::2]), (int_items, truth[1::2])):
         got = rc.detect_batch(group)
-        for (name, sig, strand), g in zip(group, got):
-            want, _ = orc.detect(sig, tc, opm, params, pm_mod=pm_mod)
+        for (name, sig, strand), g, n_true in zip(group, got, planted):
+            want, _ = orc.detect(sig, tc, opm, params, pm_mod=opm_mod)
             assert tuple(g) == tuple(want), (g, want)
             assert set(g[6]) <= set("01") and abs(len(g[6]) - g[0]) <= 3
+            assert abs(g[0] - n_true) <= 1, (g[0], n_true)
 
 
-def test_empty_batch_and_tiny_reads(gpu_counter, orc, opm, pm, cfg):
+def test_empty_batch_and_tiny_reads(gpu_counter, want, pm, targets):
     """Empty batch, empty read, reads far shorter than the flank or the morphology window: nothing
     crashes, such reads come back as the reference's failed-gate row (n = 0, mod '-'), and the real
     reads that share the batch are untouched (bit-equal to the oracle)."""
     assert gpu_counter.detect_batch([]) == []
     rng = np.random.default_rng(8)
-    good = _read(pm, cfg, "c9orf72", "-", 3500, 9, 91)
+    good = _read(pm, targets, "c9orf72", "-", 3500, 9, 91)
     tiny = [rng.integers(300, 900, n).astype(np.int16) for n in (0, 1, 2, 3, 7, 8, 9, 20, 869, 870, 871)]
     items = [("c9orf72", t, "+") for t in tiny[:6]] + [("c9orf72", good, "-")] + [("fmr1", t, "-") for t in tiny[6:]]
     got = gpu_counter.detect_batch(items)
     assert len(got) == len(items)
     for (name, sig, strand), g in zip(items, got):
         if sig is good:
-            want, _ = orc.detect(good, oracle_tc(gpu_counter, "c9orf72", "-"), opm, orc.align_params(cfg["align"]))
-            assert tuple(g[:6]) == tuple(want[:6]) and g[0] == 9
+            assert tuple(g[:6]) == tuple(want("c9orf72", good, "-")[:6]) and g[0] == 9
         else:
             assert g[0] == 0 and g[6] == "-", (len(sig), g)
     # float64 input path as well
@@ -150,14 +155,14 @@ def test_empty_batch_and_tiny_reads(gpu_counter, orc, opm, pm, cfg):
     assert [g[0] for g in got] == [0, 0]
 
 
-def test_sub_batches_give_the_same_results(gpu_counter, pm, cfg, monkeypatch):
+def test_sub_batches_give_the_same_results(gpu_counter, pm, targets, monkeypatch):
     """A batch larger than one sub-batch is processed in pieces (strq_batch_run); the pieces must not
     see each other: results equal those of the one-piece run, in input order."""
     rng = np.random.default_rng(21)
     items = []
     for k in range(11):
         name = ["c9orf72", "fmr1"][k % 2]; strand = "+-"[(k // 2) % 2]
-        items.append((name, _read(pm, cfg, name, strand, int(rng.integers(2500, 6000)), int(rng.integers(4, 60)), 400 + k), strand))
+        items.append((name, _read(pm, targets, name, strand, int(rng.integers(2500, 6000)), int(rng.integers(4, 60)), 400 + k), strand))
     whole = gpu_counter.detect_batch(items)
     monkeypatch.setenv("STRQ_SUBBATCH_READS", "3")
     pieces = gpu_counter.detect_batch(items)

@@ -90,14 +90,8 @@ def test_morphology_matches_ndimage(orc):
 @pytest.mark.parametrize("repeat,locus,counts", [("GGCCCC", "c9orf72", (100, 200)), ("GCG", "fmr1", (100, 300))])
 def test_reference_unit_test_scenarios(pm, cfg, orc, opm, repeat, locus, counts):
     """scripts/STRique_test.py:47-82: noise-free signals, 8 samples per k-mer, n must equal i."""
-    from strique_amd import hmm
     chrom, b, e, _, prefix, suffix = cfg["repeat"][locus]
-    if repeat == "GCG":   # the reference's interpolation test uses these flanks (STRique_test.py:70-72)
-        prefix = prefix[1:] if False else prefix
-    g = lambda s: pm.generate_signal(s, samples=6)
-    p, s = prefix[-50:].upper(), suffix[:50].upper()
-    tc = dict(prefix=g(p), suffix=g(s), prefix_ext=g(prefix.upper()), suffix_ext=g(suffix.upper()),
-              hmm=hmm.FlankedRepeatModel(repeat, p, s, pm, None))
+    tc = orc.classifier(repeat, prefix, suffix, "+", opm, None, None)
     rng = np.random.default_rng(3)
     backbone = "".join(rng.choice(list("ACTG"), 2000))
     params = orc.align_params(None)
@@ -109,12 +103,8 @@ def test_reference_unit_test_scenarios(pm, cfg, orc, opm, repeat, locus, counts)
 
 def test_normalization_scenario_without_backbone(pm, cfg, orc, opm):
     """scripts/STRique_test.py:86-100."""
-    from strique_amd import hmm
     chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
-    g = lambda s: pm.generate_signal(s, samples=6)
-    p, s = prefix[-50:].upper(), suffix[:50].upper()
-    tc = dict(prefix=g(p), suffix=g(s), prefix_ext=g(prefix.upper()), suffix_ext=g(suffix.upper()),
-              hmm=hmm.FlankedRepeatModel(repeat, p, s, pm, None))
+    tc = orc.classifier(repeat, prefix, suffix, "+", opm, None, None)
     for i in (10, 50, 90):
         res, _ = orc.detect(pm.generate_signal(prefix + repeat * i + suffix, samples=8), tc, opm, orc.align_params(None))
         assert res[0] == i
