@@ -167,3 +167,56 @@ def test_sub_batches_give_the_same_results(gpu_counter, pm, targets, monkeypatch
     monkeypatch.setenv("STRQ_SUBBATCH_READS", "3")
     pieces = gpu_counter.detect_batch(items)
     assert pieces == whole
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs, each met by the oracle at least once at its own size
+# ---------------------------------------------------------------------------------------------
+def test_config1_ten_kb_thirty_repeats(gpu_counter, want, pm, targets):
+    """configs[1]: 10 kb reads, 30 x GGGGCC (C9orf72), both strands."""
+    items = [("c9orf72", _read(pm, targets, "c9orf72", st, 10000, 30, 500 + i), st) for i, st in enumerate("+-")]
+    got = _check(gpu_counter, want, items)
+    assert [g[0] for g in got] == [30, 30]
+
+
+def test_config3_three_targets_mixed(gpu_counter, want, pm, targets):
+    """configs[3]: C9orf72 / FMR1(CGG) / HTT(CAG) targets from repeat_config.tsv mixed in one batch,
+    both strands, n ~ U{30..1000} scaled to short reads; every field equals the oracle's."""
+    rng = np.random.default_rng(33)
+    items = []
+    for k in range(12):
+        name = ["c9orf72", "fmr1", "htt"][k % 3]; strand = "+-"[(k // 3) % 2]
+        unit = len(targets[name][0])
+        nt = int(rng.integers(4000, 8000))
+        nrep = int(rng.integers(30, (nt - 2400) // unit))
+        items.append((name, _read(pm, targets, name, strand, nt, nrep, 600 + k), strand))
+    got = _check(gpu_counter, want, items)
+    assert all(g[0] > 0 for g in got)
+
+
+@pytest.mark.parametrize("name,nrep", [("c9orf72", 1000), ("fmr1", 1000), ("htt", 700)])
+def test_config3_full_size_read_per_target(gpu_counter, want, pm, targets, name, nrep):
+    """configs[2]/[3] at full size: one 50 kb read per target against the oracle, field by field."""
+    strand = "-" if name == "fmr1" else "+"
+    sig = _read(pm, targets, name, strand, 50000, nrep, 700 + len(name))
+    got = _check(gpu_counter, want, [(name, sig, strand)])
+    assert abs(got[0][0] - nrep) <= 2
+
+
+def test_config4_modification_pass_full_size(pm, pm_mod, cfg, orc, opm, opm_mod, targets):
+    """configs[4]: a 50 kb int16 read drawn from the mCpG model through the dual-HMM pass; the whole
+    tuple, including the per-unit modification string, equals the oracle's."""
+    from strique_amd import synth
+    from strique_amd.counter import repeatCounter
+    rc = repeatCounter(pm, mod_model_file=pm_mod, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    rc.add_target("c9orf72", *targets["c9orf72"])
+    sig_mod = synth.make_read(synth.KmerTable(pm_mod), 5, 1, 50000, targets["c9orf72"], 800, strand="+")[0]
+    sig_base = synth.make_read(synth.KmerTable(pm), 5, 2, 50000, targets["c9orf72"], 300, strand="-")[0]
+    got = rc.detect_batch([("c9orf72", sig_mod, "+"), ("c9orf72", sig_base, "-")])
+    params = orc.align_params(cfg["align"])
+    for g, sig, strand, planted in zip(got, (sig_mod, sig_base), "+-", (800, 300)):
+        w, _ = orc.detect(sig, oracle_tc(orc, opm, targets, "c9orf72", strand, cfg["HMM"], opm_mod), opm, params, pm_mod=opm_mod)
+        assert tuple(g) == tuple(w)
+        assert abs(g[0] - planted) <= 2 and abs(len(g[6]) - g[0]) <= 3
+    # the mCpG read is called mostly modified, the base read mostly unmodified
+    assert got[0][6].count("1") > 0.8 * len(got[0][6]) and got[1][6].count("0") > 0.8 * len(got[1][6])
