@@ -28,6 +28,7 @@ struct AlignTask {
     const AlignTask* up;     // task of the strip above (trace pass), or null
     int32_t n, m, k, tsize;  // columns; rows / classes of this strip; floats of the whole score table
     int32_t row0, m_total;   // rows above this strip; rows of the whole flank
+    int32_t col_off, n_full; // column segment: DP column 0 of this task is column col_off of the read; columns of the whole read
 };
 
 struct AlignResult {
@@ -42,12 +43,30 @@ static inline int align_num_ckpts(int n) { return (align_num_steps(n) - 1) / STR
 
 // rows per lane and number of strips for a flank of m rows; 0 if no compiled shape fits
 int align_plan(int m, int samples, int* rows_per_lane, int* n_strips);
+// Column segments (several waves per alignment, one score table per workgroup).
+// A read of n columns is cut into `segs` pieces; piece k owns the columns (o_k, o_k+1] and starts its DP
+// cold (the column-0 rule) `overlap` columns to the left of o_k.  With dist_min >= 0 and negative
+// horizontal gap scores every path that scores >= 0 spans at most `overlap` columns, so every last-row
+// value >= 0 inside the owned range -- and every cell of the optimal path that ends there -- is computed
+// exactly; the best of the pieces (leftmost on ties) is the best of the read.
+// Returns 0 when the parameters do not allow it (then segs must be 1).
+int align_segment_overlap(const AlignParams& p, int m);
+// forward pass of `n_groups` alignments of `segs` tasks each (tasks[g * segs + k]; n == 0: unused piece);
+// one workgroup of `segs` waves per table, `tables_per_cu` workgroups per CU.  LH = LV = true, one strip.
+int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* seg_results,
+                          int n_groups, int segs, int* queue, const AlignParams& p, int lds_dwords,
+                          int tables_per_cu, int n_cu, int packed);
+// per alignment: best piece -> results[a] (j_end in read columns), pick[a] = index of its task
+int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const AlignResult* seg_results, int n_align,
+                         int segs, AlignResult* results, int32_t* pick);
 // phase 0 = forward, 1 = trace.  `queue`: one zero-initialised int per launch.
+// trace: task of alignment ti is tasks[pick[ti]] (pick may be null: identity), result slot is results[ti].
 // mode (forward only): bit 0 = strip has an input boundary, bit 1 = strip has an output boundary.
 // packed: the tasks carry 3-byte tables (table3); lds_floats_per_wave is the LDS slice of a wave in dwords.
 int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* results,
                  int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
-                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode, int packed);
+                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode, int packed,
+                 const int32_t* pick = nullptr);
 size_t align_trace_scratch_words_per_wave(int R);
 
 }  // namespace strq

@@ -462,12 +462,12 @@ struct Forward {
     }
 };
 
-template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK>
+template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK, bool STAGE = true>
 static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignResult* res, const AlignParams& p,
                                                    float* lds, int lds_base, const char* ldsb, int lane)
 {
     constexpr bool HAS_IN = (MODE & 1) != 0, HAS_OUT = (MODE & 2) != 0;
-    stage_table<PK>(tk, lds, lane);
+    if constexpr (STAGE) stage_table<PK>(tk, lds, lane);
     LaneConst lc; uint64_t pm[Shape<R, S>::NMASK];
     load_lane_consts<R, S, PK>(tk, lane, lds_base, lc, pm);
     const int lM = (tk.m - 1) / R, rM = (tk.m - 1) % R;
@@ -535,6 +535,65 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
     }
 }
 
+// Column segments: a workgroup of SEG waves shares ONE score table in LDS and each wave runs the forward
+// pass of one piece of the read (AlignTask::col_off; the pieces of alignment g are tasks[g * SEG + w]).
+// More waves per CU at the same LDS footprint is what the issue-latency-bound DP needs; WPE (waves per
+// SIMD) caps the registers the compiler may use so that all of them are resident.
+template <int R, int S, bool PK, int SEG, int WPE>
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * SEG, 64 * SEG), amdgpu_waves_per_eu(WPE, WPE)))
+align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_groups,
+                         int* __restrict__ queue, AlignParams p)
+{
+    extern __shared__ float lds_all[];
+    __shared__ int next_group;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char* ldsb = reinterpret_cast<const char*>(lds_all);
+    const int lds_base = 0;                    // table offsets are relative to lds_all
+    for (;;) {
+        __syncthreads();                       // every wave is done with the previous table
+        if (threadIdx.x == 0) next_group = atomicAdd(queue, 1);
+        __syncthreads();
+        const int gi = __builtin_amdgcn_readfirstlane(next_group);
+        if (gi >= n_groups) break;
+        {
+            const AlignTask& t0 = tasks[(size_t)gi * SEG];      // all pieces share the table of the alignment
+            if constexpr (PK) {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(t0.table3);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(lds_all);
+                const int nd = (((2 * t0.tsize + 3) & ~3) + t0.tsize + 3) / 4;
+                for (int i = threadIdx.x; i < nd; i += 64 * SEG) dst[i] = src[i];
+            } else {
+                for (int i = threadIdx.x; i < t0.tsize; i += 64 * SEG) lds_all[i] = t0.table[i];
+            }
+        }
+        __syncthreads();
+        const int ti = gi * SEG + wave;
+        const AlignTask& tk = tasks[ti];
+        if (tk.n <= 0) continue;               // unused piece of a short read (wave-uniform)
+        if ((tk.m - 1) % R == R - 1) forward_one<R, S, true, true, 0, true, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+        else forward_one<R, S, true, true, 0, false, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+    }
+}
+
+__global__ void align_combine_kernel(const AlignTask* __restrict__ tasks, const AlignResult* __restrict__ seg, int n_align,
+                                     int segs, AlignResult* __restrict__ out, int32_t* __restrict__ pick)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_align) return;
+    int best_k = 0;
+    float best = seg[(size_t)a * segs].best;
+    for (int k = 1; k < segs; ++k) {
+        const size_t t = (size_t)a * segs + k;
+        if (tasks[t].n <= 0) continue;
+        if (seg[t].best > best) { best = seg[t].best; best_k = k; }      // strict: the leftmost piece wins ties
+    }
+    const size_t t = (size_t)a * segs + best_k;
+    AlignResult r = seg[t];
+    r.j_end += tasks[t].col_off;
+    out[a] = r;
+    pick[a] = (int32_t)t;
+}
+
 // ------------------------------------------------------------------------------------------
 // trace pass: re-run the blocks of steps the optimal path crosses, keep 4 bits per cell,
 // walk back, and emit one record per flank row.
@@ -543,7 +602,7 @@ template <int R, int S, bool PK>
 __global__ void __launch_bounds__(512)      // at most 8 waves per CU (one workgroup): the full 256-VGPR budget, no spills
 align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_tasks,
                    int* __restrict__ queue, AlignParams p, int lds_floats_per_wave,
-                   uint64_t* __restrict__ scratch_all)
+                   uint64_t* __restrict__ scratch_all, const int32_t* __restrict__ pick)
 {
     extern __shared__ float lds_all[];
     constexpr int W = STRQ_TRACE_WORDS(R);
@@ -557,12 +616,13 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
     for (;;) {
         const int ti = next_task(queue, lane);
         if (ti >= n_tasks) break;
-        const AlignTask* cur = &tasks[ti];             // the strip that holds the last flank row
+        const AlignTask* cur = &tasks[pick ? __builtin_amdgcn_readfirstlane(pick[ti]) : ti];   // the strip (and column segment) that holds the end of the path
         const AlignTask* staged = nullptr;
         int32_t* rec = cur->rec;
+        const int col_off = __builtin_amdgcn_readfirstlane(cur->col_off);      // read column of the segment's column 0
         LaneConst lc; uint64_t pm[Shape<R, S>::NMASK];
 
-        int ci = cur->m_total, cj = __builtin_amdgcn_readfirstlane(results[ti].j_end), state = 0;     // walker position (wave-uniform)
+        int ci = cur->m_total, cj = __builtin_amdgcn_readfirstlane(results[ti].j_end) - col_off, state = 0;     // walker position (wave-uniform), segment columns
         while (ci > 0 && cj > 0) {
             while (ci <= cur->row0) cur = uniform_ptr(cur->up);       // the strip that holds row ci
             if (cur != staged) {
@@ -656,19 +716,20 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
                 const uint32_t code = (uint32_t)(w >> (4 * (r % 16))) & 15u;
                 if (state == 0) {
                     const uint32_t d = code & 3u;
-                    if (d == 0) { rec[ci - 1] = cj << 1; --ci; --cj; }
+                    if (d == 0) { rec[ci - 1] = (cj + col_off) << 1; --ci; --cj; }
                     else state = (int)d;
                 } else if (state == 1) {
                     --cj; if (!(code & 4u)) state = 0;
                 } else {
-                    rec[ci - 1] = (cj << 1) | 1;
+                    rec[ci - 1] = ((cj + col_off) << 1) | 1;
                     --ci; if (!(code & 8u)) state = 0;
                 }
             }
         }
-        // column 0 is not free: whatever is left of the flank is a vertical run before a[0]
-        for (int i = ci - lane; i > 0; i -= 64) rec[i - 1] = 1;
-        results[ti].j0 = cj;
+        // column 0 is not free: whatever is left of the flank is a vertical run before a[0] (in a later
+        // column segment: before the segment's first sample -- a path the full DP has as well)
+        for (int i = ci - lane; i > 0; i -= 64) rec[i - 1] = (col_off << 1) | 1;
+        results[ti].j0 = cj + col_off;
     }
 }
 
@@ -678,7 +739,7 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
 template <int R, int S>
 static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult* results, int n_tasks,
                         int* queue, const AlignParams& p, int lds_floats_per_wave, int waves_per_block,
-                        int n_blocks, uint64_t* scratch, int phase, int mode, int packed)
+                        int n_blocks, uint64_t* scratch, int phase, int mode, int packed, const int32_t* pick)
 {
     const size_t lds_bytes = (size_t)lds_floats_per_wave * 4 * waves_per_block;
     const dim3 grid(n_blocks), block(64 * waves_per_block);
@@ -715,12 +776,12 @@ static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult*
         (void)hipFuncSetAttribute((const void*)align_trace_kernel<R, S, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL((align_trace_kernel<R, S, true>), grid, block, lds_bytes, stream, tasks, results,
-                           n_tasks, queue, ps, lds_floats_per_wave, scratch);
+                           n_tasks, queue, ps, lds_floats_per_wave, scratch, pick);
     } else {
         (void)hipFuncSetAttribute((const void*)align_trace_kernel<R, S, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL((align_trace_kernel<R, S, false>), grid, block, lds_bytes, stream, tasks, results,
-                           n_tasks, queue, p, lds_floats_per_wave, scratch);
+                           n_tasks, queue, p, lds_floats_per_wave, scratch, pick);
     }
 #undef STRQ_FWD
 #undef STRQ_FWD1
@@ -754,15 +815,75 @@ size_t align_trace_scratch_words_per_wave(int R)
 
 int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* results,
                  int n_tasks, int* queue, const AlignParams& p, int lds_floats_per_wave,
-                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode, int packed)
+                 int waves_per_block, int n_blocks, uint64_t* scratch, int phase, int mode, int packed,
+                 const int32_t* pick)
 {
 #define STRQ_CASE(R_, S_)                                                                               \
     if (R == R_ && S == S_)                                                                             \
         return launch_shape<R_, S_>(stream, tasks, results, n_tasks, queue, p, lds_floats_per_wave,     \
-                                    waves_per_block, n_blocks, scratch, phase, mode, packed);
+                                    waves_per_block, n_blocks, scratch, phase, mode, packed, pick);
     STRQ_SHAPES(STRQ_CASE)
 #undef STRQ_CASE
     return 2;
+}
+
+int align_segment_overlap(const AlignParams& p, int m)
+{
+    // horizontal steps cost at least c_h each, a diagonal step gains at most dist_offset, vertical steps
+    // cost: a path that scores >= 0 has h * c_h <= m * dist_offset horizontal steps, i.e. spans at most
+    // m + h columns.  1 % + 64 columns cover the float32 rounding of the running sums (<= 2^-11 relative
+    // per addition on values below 2^14 * dist_offset / 16).
+    if (!(p.dist_min >= 0.0f) || !(p.open_h < 0.0f) || !(p.ext_h < 0.0f) || !(p.dist_offset > 0.0f)) return 0;
+    if (!(p.open_v <= 0.0f) || !(p.ext_v <= 0.0f)) return 0;
+    const double c_h = -(double)(p.open_h > p.ext_h ? p.open_h : p.ext_h);
+    const double h = (double)m * (double)p.dist_offset / c_h;
+    const double L = (double)m + h * 1.01 + 64.0;
+    if (!(L < 1e8)) return 0;
+    return (int)L + 1;
+}
+
+template <int R, int S, bool PK, int SEG, int WPE>
+static int launch_seg1(hipStream_t stream, const AlignTask* tasks, AlignResult* seg_results, int n_groups, int* queue,
+                       const AlignParams& p, int lds_dwords, int n_blocks)
+{
+    const size_t lds_bytes = (size_t)lds_dwords * 4;
+    (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
+                       tasks, seg_results, n_groups, queue, p);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// compiled (segments, waves per SIMD) pairs
+#define STRQ_SEG_CONFIGS(X, R_, S_, PK_) X(R_, S_, PK_, 1, 2) X(R_, S_, PK_, 2, 3) X(R_, S_, PK_, 2, 4) X(R_, S_, PK_, 3, 3) X(R_, S_, PK_, 4, 4) X(R_, S_, PK_, 3, 4) X(R_, S_, PK_, 4, 3)
+
+int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* seg_results,
+                          int n_groups, int segs, int* queue, const AlignParams& p, int lds_dwords,
+                          int tables_per_cu, int n_cu, int packed)
+{
+    if (!(p.open_h == p.ext_h && p.open_v == p.ext_v)) return 2;
+    AlignParams ps = p;
+    if (packed) { ps.open_h *= STRQ_PK_SCALE; ps.ext_h *= STRQ_PK_SCALE; ps.open_v *= STRQ_PK_SCALE; ps.ext_v *= STRQ_PK_SCALE; }
+    const int waves = tables_per_cu * segs;
+    int wpe = (waves + 3) / 4; if (wpe < 2) wpe = 2;
+    if (segs == 1) wpe = 2;
+    const int n_blocks = tables_per_cu * n_cu;
+#define STRQ_SEGCASE(R_, S_, PK_, SEG_, WPE_)                                                             \
+    if (R == R_ && S == S_ && (packed != 0) == PK_ && segs == SEG_ && wpe == WPE_)                        \
+        return launch_seg1<R_, S_, PK_, SEG_, WPE_>(stream, tasks, seg_results, n_groups, queue, ps, lds_dwords, n_blocks);
+#define STRQ_SEGSHAPE(R_, S_) STRQ_SEG_CONFIGS(STRQ_SEGCASE, R_, S_, true) STRQ_SEG_CONFIGS(STRQ_SEGCASE, R_, S_, false)
+    STRQ_SHAPES(STRQ_SEGSHAPE)
+#undef STRQ_SEGSHAPE
+#undef STRQ_SEGCASE
+    return 2;
+}
+
+int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const AlignResult* seg_results, int n_align,
+                         int segs, AlignResult* results, int32_t* pick)
+{
+    if (n_align <= 0) return 0;
+    hipLaunchKernelGGL(align_combine_kernel, dim3((n_align + 255) / 256), dim3(256), 0, stream, tasks, seg_results, n_align, segs, results, pick);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 }  // namespace strq

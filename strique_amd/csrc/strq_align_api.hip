@@ -58,11 +58,11 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
 {
     const int nb = in.nb, S = in.samples;
     hipStream_t st = c->stream;
-    size_t cls_tot = 0, col0_tot = 0, rec_tot = 0, tab_tot = 0, ck_floats = 0, bnd_floats = 0, desc_tot = 0;
+    size_t cls_tot = 0, col0_tot = 0, rec_tot = 0, tab_tot = 0, bnd_floats = 0, desc_tot = 0;
     // cls_off / col0_off: flank class values and column 0 of the DP are shared by all alignments of
     // the same flank / flank length (a batch has a handful of distinct ones); desc_off: per-alignment
     // band descriptors
-    std::vector<size_t> cls_off(nb), col0_off(nb), tab_off(nb), ck_off(nb), bnd_off(nb), desc_off(nb);
+    std::vector<size_t> cls_off(nb), col0_off(nb), tab_off(nb), bnd_off(nb), desc_off(nb);
     std::map<const float*, size_t> cls_of_flank; std::map<int, size_t> col0_of_m;
     std::vector<int> cls_first, col0_first;        // first alignment that uses each shared array
     out.rec_off.assign(nb, 0);
@@ -77,7 +77,6 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         desc_off[i] = desc_tot; desc_tot += in.k[i];
         out.rec_off[i] = rec_tot; rec_tot += in.m[i];
         tab_off[i] = tab_tot; tab_tot += STRQ_TABLE_SLOT_FLOATS(in.k[i]);
-        ck_off[i] = ck_floats; ck_floats += (size_t)in.NS[i] * align_num_ckpts(in.n[i]) * STRQ_CKPT_FIELDS(in.R[i]) * 64;
         bnd_off[i] = bnd_floats; if (in.NS[i] > 1) bnd_floats += (size_t)(in.NS[i] - 1) * 2 * ((size_t)in.n[i] + 2);
         max_k = std::max(max_k, in.k[i]);
     }
@@ -93,11 +92,8 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, c->band_lo.reserve(desc_tot * 4));
     STRQ_HIP(c, c->tables.reserve(tab_tot * 4));
     STRQ_HIP(c, c->tables3.reserve(tab_tot * 3 + (size_t)nb * 8 + 64));
-    STRQ_HIP(c, c->ckpt.reserve(ck_floats * 4 + 256));
     STRQ_HIP(c, c->bnd.reserve(bnd_floats * 4 + 256));
     STRQ_HIP(c, c->rec.reserve(rec_tot * 4 + 256));
-    STRQ_HIP(c, c->tasks.reserve((size_t)nb * 2 * sizeof(AlignTask)));
-    STRQ_HIP(c, c->results.reserve((size_t)nb * sizeof(AlignResult)));
     STRQ_HIP(c, c->lutinfo.reserve((size_t)nb * (sizeof(LutJob) + sizeof(LutInfo))));
     const int hard_cap = 1 << 16;
     STRQ_HIP(c, c->hard.reserve((size_t)hard_cap * (sizeof(HardEntry) + 4) + 64));
@@ -171,29 +167,70 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     }
     out.n_hard = hard_count;
 
-    // ---- tasks.  Alignments are grouped by (rows per lane, strips, waves per CU their table allows),
-    // longest first.
-    // Layout of the task array: [last strips of every alignment, in result order][first strips of
-    // the two-strip alignments]; results / finalize address the first part.
-    int max_wpb = 8;      // workgroups of at most 512 threads (launch bounds of the kernels)
-    if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_wpb = v; }
-    auto waves_for = [&](int dwords) { return std::min(max_wpb, (160 * 1024) / (std::max(dwords, 1) * 4)); };
+    // ---- tasks.  Alignments are grouped by (rows per lane, strips, score tables per CU), longest first.
+    // Collapsed single-strip alignments (STRique's parameters) run as column segments: `segs` waves per
+    // alignment share one table (align_kernels.h), so a CU holds tables_per_cu x segs waves.
+    // Layout of the task array: per launch, `segs` consecutive tasks per alignment (in result order);
+    // the first strips of two-strip alignments follow at the end.  seg_results is indexed like the
+    // tasks; results / pick / heads are indexed by alignment position.
+    const bool collapsed = c->ap.open_h == c->ap.ext_h && c->ap.open_v == c->ap.ext_v;
+    int seg_want = 0, max_tables = 8, max_waves = 16;      // seg_want 0: chosen below from the read lengths
+    if (const char* e = getenv("STRQ_SEG")) { const int v = atoi(e); if (v >= 1 && v <= 4) seg_want = v; }
+    if (const char* e = getenv("STRQ_TABLES")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_tables = v; }
+    if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_tables = v; }      // older name
+    if (const char* e = getenv("STRQ_MAX_WAVES")) { const int v = atoi(e); if (v >= 4 && v <= 16) max_waves = v; }
+    bool allow_pack = collapsed && !getenv("STRQ_NO_PACK");
+    if (collapsed) {
+        // Launch geometry.  Measured on MI355X (ms per 8192 alignments per 1000 columns computed, 870-row flanks,
+        // tools/dp_sweep.py): one wave per table 0.94 (24-bit tables, 8 waves per CU) / 1.02 (float32, 6 waves);
+        // two waves per table 0.86 (24-bit, 16 waves) / 0.79 (float32, 12 waves); four waves per table 0.80 /
+        // 0.69 (float32, 16 waves).  Three waves per table place unevenly on the four SIMDs (0.85 and worse).
+        // Every extra wave recomputes `overlap` columns, so short reads prefer fewer pieces.
+        static const double rate[5][2] = {{0, 0}, {1.017, 0.941}, {0.79, 0.862}, {0, 0}, {0.69, 0.80}};
+        double mean_n = 0, mean_l = 0; int cnt = 0; bool all_packable = allow_pack;
+        for (int i = 0; i < nb; ++i) if (in.NS[i] == 1) {
+            mean_n += in.n[i]; mean_l += align_segment_overlap(c->ap, in.m[i]); ++cnt;
+            all_packable = all_packable && info[i].packed && info[i].n_hard == 0;
+        }
+        if (cnt) { mean_n /= cnt; mean_l /= cnt; }
+        double best_cost = 0; int best_s = 1, best_p = all_packable ? 1 : 0;
+        for (int sgs : {1, 2, 4}) {
+            if (seg_want && sgs != seg_want) continue;
+            if (sgs > 1 && (mean_l <= 0 || mean_n < (sgs + 1) * mean_l)) continue;
+            for (int pk = 0; pk < 2; ++pk) {
+                if (pk && !all_packable) continue;
+                const double cost = (mean_n + (sgs - 1) * mean_l) * rate[sgs][pk];
+                if (best_cost == 0 || cost < best_cost) { best_cost = cost; best_s = sgs; best_p = pk; }
+            }
+        }
+        if (seg_want == 3) { best_s = 3; best_p = allow_pack && all_packable && getenv("STRQ_PACK") ? 1 : 0; }
+        seg_want = best_s;
+        if (!getenv("STRQ_PACK")) allow_pack = allow_pack && best_p;      // STRQ_PACK=1: 24-bit tables whenever they are exact
+    } else seg_want = 1;
+    auto tables_for = [&](int dwords, int segs) {
+        int t = std::min(max_tables, (160 * 1024 - 64) / (std::max(dwords, 1) * 4));
+        if (segs > 1) t = std::min(t, max_waves / segs);
+        return t;
+    };
     // 24-bit tables (lut_kernels.hip) are used by the collapsed single-strip kernels when every entry of
-    // the table is exact in that format; they are 3/4 of the size, which buys the seventh and eighth wave
-    const bool pack_ok = c->ap.open_h == c->ap.ext_h && c->ap.open_v == c->ap.ext_v && !getenv("STRQ_NO_PACK");
+    // the table is exact in that format; they are 3/4 of the size
+    const bool pack_ok = allow_pack;
     auto packed_dwords = [](int entries) { return (((2 * entries + 3) & ~3) + entries + 3) / 4; };
-    std::vector<char> packed(nb, 0);
-    // key: rows per lane, strips, -waves per CU, 0 = packed / 1 = float32 (packed first among equals)
+    std::vector<char> packed(nb, 0), segmentable(nb, 0);
+    std::vector<int> overlap(nb, 0);
+    // key: rows per lane, strips, -tables per CU, 0 = packed / 1 = float32 (packed first among equals)
     std::map<std::tuple<int, int, int, int>, std::vector<int>> groups;
     for (int i = 0; i < nb; ++i) {
         packed[i] = pack_ok && in.NS[i] == 1 && info[i].packed && info[i].n_hard == 0;
-        const int w = waves_for(packed[i] ? packed_dwords(info[i].total) : info[i].total);
+        segmentable[i] = collapsed && in.NS[i] == 1;
+        overlap[i] = segmentable[i] ? align_segment_overlap(c->ap, in.m[i]) : 0;
+        const int w = tables_for(packed[i] ? packed_dwords(info[i].total) : info[i].total, segmentable[i] ? seg_want : 1);
         if (w < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
         groups[std::make_tuple(in.R[i], in.NS[i], -w, packed[i] ? 0 : 1)].push_back(i);
     }
-    // Every launch ends with a ragged tail (alignments take ~60 ms each), so a group that would not
-    // keep its waves busy for a few rounds joins the next group with fewer waves per CU (larger LDS
-    // slices); groups are ordered by descending waves per CU within (R, strips).
+    // Every launch ends with a ragged tail (alignments take tens of ms each), so a group that would not
+    // keep its waves busy for a few rounds joins the next group with fewer tables per CU (larger LDS
+    // slices); groups are ordered by descending tables per CU within (R, strips).
     {
         int min_rounds = 4;
         if (const char* e = getenv("STRQ_MIN_ROUNDS")) min_rounds = atoi(e);
@@ -210,81 +247,141 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         }
     }
     out.order.clear(); out.order.reserve(nb);
-    struct Launch { int R, NS, wpb, first, count, first_up, lds_floats, packed; };
+    struct Launch { int R, NS, tables, first, count, first_task, first_up, lds_floats, packed, segs; };
     std::vector<Launch> launches;
-    int n_up = 0;
+    int n_up = 0; size_t n_tasks = 0;
     for (auto& g : groups) {
         auto& v = g.second;
         std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return in.n[x] > in.n[y]; });
         const int NS = std::get<1>(g.first);
         const int pk = std::get<3>(g.first) == 0;
-        int lds_floats = 0;      // LDS slice of a wave in dwords
-        for (int i : v) lds_floats = std::max(lds_floats, pk ? packed_dwords(info[i].total) : info[i].total);
-        const int wpb = std::min(-std::get<2>(g.first), waves_for(lds_floats));       // members that joined from a smaller-slice group
-        if (wpb < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
-        launches.push_back({std::get<0>(g.first), NS, wpb, (int)out.order.size(), (int)v.size(), nb + n_up, lds_floats, pk});
+        int lds_floats = 0;      // LDS slice of a table in dwords
+        bool seg_ok = true;
+        for (int i : v) { lds_floats = std::max(lds_floats, pk ? packed_dwords(info[i].total) : info[i].total); seg_ok &= segmentable[i] != 0; }
+        int segs = seg_ok ? seg_want : 1;
+        // column segments pay `overlap` extra columns per piece: only worth it when the reads are long
+        if (segs > 1) {
+            long tot_n = 0, tot_l = 0;
+            for (int i : v) { tot_n += in.n[i]; tot_l += overlap[i]; }
+            if (tot_l <= 0) segs = 1;
+        }
+        const int tables = std::min(-std::get<2>(g.first), tables_for(lds_floats, segs));       // members that joined from a smaller-slice group
+        if (tables < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
+        launches.push_back({std::get<0>(g.first), NS, tables, (int)out.order.size(), (int)v.size(), (int)n_tasks, 0, lds_floats, pk, segs});
         out.order.insert(out.order.end(), v.begin(), v.end());
+        n_tasks += (size_t)v.size() * segs;
         if (NS > 1) n_up += (int)v.size();
     }
-    std::vector<AlignTask> tasks((size_t)nb + n_up);
+    { size_t up = n_tasks; for (auto& L : launches) if (L.NS > 1) { L.first_up = (int)up; up += L.count; } }
+    // piece boundaries and checkpoint areas
+    struct Piece { int col_off, n; size_t ck; };
+    std::vector<Piece> pieces(n_tasks);
+    std::vector<size_t> ck_up(nb, 0);
+    size_t ck_floats = 0;
+    for (auto& L : launches) {
+        for (int x = 0; x < L.count; ++x) {
+            const int i = out.order[L.first + x];
+            const int n = in.n[i], R = in.R[i], ov = overlap[i];
+            const size_t per_ckpt = (size_t)STRQ_CKPT_FIELDS(R) * 64;
+            int use = L.segs;
+            while (use > 1 && (ov <= 0 || (long)n < (long)(use + 1) * ov)) --use;      // every piece owns >= `overlap` columns
+            const long len = use > 1 ? ((long)n + (long)(use - 1) * ov + use - 1) / use : n;      // columns each piece computes
+            long o = 0;                                                                        // columns owned so far
+            for (int k = 0; k < L.segs; ++k) {
+                Piece& pc = pieces[(size_t)L.first_task + (size_t)x * L.segs + k];
+                if (k >= use) { pc = {0, 0, ck_floats}; continue; }
+                const long start = k == 0 ? 0 : o - ov;
+                long end = k == use - 1 ? n : start + len; if (end > n) end = n;
+                pc.col_off = (int)start; pc.n = (int)(end - start); pc.ck = ck_floats;
+                ck_floats += (size_t)align_num_ckpts(pc.n) * per_ckpt;
+                o = end;
+            }
+            if (L.NS > 1) { ck_up[i] = ck_floats; ck_floats += (size_t)align_num_ckpts(n) * per_ckpt; }
+        }
+    }
+    STRQ_HIP(c, c->ckpt.reserve(ck_floats * 4 + 256));
+    STRQ_HIP(c, c->tasks.reserve((n_tasks + n_up + nb) * sizeof(AlignTask)));
+    STRQ_HIP(c, c->results.reserve((n_tasks + nb) * sizeof(AlignResult) + (size_t)nb * 4 + 64));
+    std::vector<AlignTask> tasks(n_tasks + n_up + nb);      // pieces, upper strips, one head per alignment
     AlignTask* d_tasks = c->tasks.as<AlignTask>();
-    AlignResult* d_res = c->results.as<AlignResult>();
+    AlignTask* d_heads = d_tasks + n_tasks + n_up;
+    AlignResult* d_seg = c->results.as<AlignResult>();
+    AlignResult* d_res = d_seg + n_tasks;
+    int32_t* d_pick = reinterpret_cast<int32_t*>(d_res + nb);
     for (auto& L : launches) {
         for (int x = 0; x < L.count; ++x) {
             const int pos = L.first + x, i = out.order[pos];
             const int R = in.R[i], M = in.m[i];
-            const size_t ck_per_strip = (size_t)align_num_ckpts(in.n[i]) * STRQ_CKPT_FIELDS(R) * 64;
             AlignTask base; std::memset(&base, 0, sizeof(base));
             base.levels = in.d_levels + in.read_off[in.read[i]];
             base.rec = c->rec.as<int32_t>() + out.rec_off[i];
-            base.n = in.n[i]; base.m_total = M; base.tsize = info[i].total;
-            auto strip = [&](int row0, int rows, int sidx) {
+            base.n = in.n[i]; base.n_full = in.n[i]; base.m_total = M; base.tsize = info[i].total;
+            auto strip = [&](int row0, int rows, size_t ck) {
                 AlignTask t = base;
                 const int k0 = row0 / S, k1 = (row0 + rows - 1) / S;
                 t.row0 = row0; t.m = rows; t.k = k1 - k0 + 1;
                 t.table = jobs[i].table; t.table3 = jobs[i].table3; t.band_lo = jobs[i].band_lo + k0;
                 t.col0 = c->col0.as<float>() + col0_off[i] + row0;
-                t.ckpt = c->ckpt.as<float>() + ck_off[i] + (size_t)sidx * ck_per_strip;
+                t.ckpt = c->ckpt.as<float>() + ck;
                 return t;
             };
-            if (L.NS == 1) tasks[pos] = strip(0, M, 0);
-            else {
+            tasks[n_tasks + n_up + pos] = strip(0, M, 0);       // head: what finalize reads (rec, m_total, n)
+            if (L.NS == 1) {
+                for (int k = 0; k < L.segs; ++k) {
+                    const Piece& pc = pieces[(size_t)L.first_task + (size_t)x * L.segs + k];
+                    AlignTask t = strip(0, M, pc.ck);
+                    t.levels += pc.col_off; t.n = pc.n; t.col_off = pc.col_off;
+                    tasks[(size_t)L.first_task + (size_t)x * L.segs + k] = t;
+                }
+            } else {
                 const int rows0 = 64 * R;
-                AlignTask top = strip(0, rows0, 0), bot = strip(rows0, M - rows0, 1);
+                AlignTask top = strip(0, rows0, ck_up[i]), bot = strip(rows0, M - rows0, pieces[(size_t)L.first_task + x].ck);
                 float* bnd = c->bnd.as<float>() + bnd_off[i];
                 top.bnd_out = bnd; bot.bnd_in = bnd;
                 bot.up = d_tasks + L.first_up + x;
-                tasks[pos] = bot; tasks[(size_t)L.first_up + x] = top;
+                tasks[(size_t)L.first_task + x] = bot; tasks[(size_t)L.first_up + x] = top;
             }
         }
     }
     STRQ_HIP(c, hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(AlignTask), hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, hipMemsetAsync(d_res, 0, (size_t)nb * sizeof(AlignResult), st));
+    STRQ_HIP(c, hipMemsetAsync(d_seg, 0, (n_tasks + nb) * sizeof(AlignResult), st));
     size_t scratch_words = 0;
     for (auto& L : launches) scratch_words = std::max(scratch_words, align_trace_scratch_words_per_wave(L.R));
-    STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * max_wpb));
+    const int trace_wpb = 8;
+    STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * trace_wpb));
     int qi = 0;
     STRQ_HIP(c, hipEventRecord(c->ev[2], st));
     out.n_launches = 0;
     for (int level = 0; level < 2; ++level) {          // first strips, then the strips below them
         for (auto& L : launches) {
             if (level == 1 && L.NS == 1) continue;
-            const AlignTask* dt = level == 0 && L.NS > 1 ? d_tasks + L.first_up : d_tasks + L.first;
-            const int mode = L.NS == 1 ? 0 : (level == 0 ? 2 : 1);
-            STRQ_DBG("forward launch R=%d strips=%d slice dwords=%d packed=%d level=%d count=%d waves/CU=%d", L.R, L.NS, L.lds_floats, L.packed, level, L.count, L.wpb);
-            if (launch_align(st, L.R, S, dt, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, L.wpb, c->n_cu,
-                             c->scratch.as<uint64_t>(), 0, mode, L.packed)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
+            STRQ_DBG("forward launch R=%d strips=%d slice dwords=%d packed=%d level=%d count=%d tables/CU=%d segments=%d", L.R, L.NS, L.lds_floats, L.packed, level, L.count, L.tables, L.segs);
+            int rc;
+            if (L.NS == 1 && collapsed) {
+                rc = launch_align_segments(st, L.R, S, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, c->queue.as<int>() + qi,
+                                           c->ap, L.lds_floats, L.tables, c->n_cu, L.packed);
+            } else {
+                const AlignTask* dt = level == 0 && L.NS > 1 ? d_tasks + L.first_up : d_tasks + L.first_task;
+                const int mode = L.NS == 1 ? 0 : (level == 0 ? 2 : 1);
+                rc = launch_align(st, L.R, S, dt, d_seg + L.first_task, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, L.tables, c->n_cu,
+                                  c->scratch.as<uint64_t>(), 0, mode, L.packed);
+            }
+            if (rc) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
             ++qi; ++out.n_launches;
         }
     }
+    for (auto& L : launches)
+        if (launch_align_combine(st, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, d_res + L.first, d_pick + L.first)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
     STRQ_HIP(c, hipEventRecord(c->ev[3], st));
     for (auto& L : launches) {
-        if (launch_align(st, L.R, S, d_tasks + L.first, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, L.wpb, c->n_cu,
-                         c->scratch.as<uint64_t>(), 1, 0, L.packed)) { c->err = "trace launch failed"; return STRQ_ERR_DEVICE; }
+        // the trace pass keeps one table per wave (it re-runs a few blocks of one piece per alignment)
+        const int wpb = std::min(trace_wpb, (160 * 1024) / (std::max(L.lds_floats, 1) * 4));
+        if (launch_align(st, L.R, S, d_tasks + L.first_task, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, wpb, c->n_cu,
+                         c->scratch.as<uint64_t>(), 1, 0, L.packed, d_pick + L.first)) { c->err = "trace launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
     }
     STRQ_HIP(c, hipEventRecord(c->ev[4], st));
-    out.d_tasks = d_tasks; out.d_results = d_res; out.d_rec = c->rec.as<int32_t>();
+    out.d_tasks = d_heads; out.d_results = d_res; out.d_rec = c->rec.as<int32_t>();
     return STRQ_OK;
 }
 
@@ -299,7 +396,8 @@ int align_core_times(strq_ctx* c, float* t_lut, float* t_fwd, float* t_tr)
 
 size_t align_workspace_bytes(int n, int m, int R, int NS)
 {
-    size_t b = (size_t)NS * align_num_ckpts(n) * STRQ_CKPT_FIELDS(R) * 64 * 4;
+    // column segments recompute `overlap` columns per extra piece: a quarter more checkpoints plus a constant covers it
+    size_t b = (size_t)NS * (align_num_ckpts(n) + align_num_ckpts(n) / 4 + 300) * STRQ_CKPT_FIELDS(R) * 64 * 4;
     if (NS > 1) b += (size_t)(NS - 1) * ((size_t)n + 2) * 8;
     (void)m;
     return b;

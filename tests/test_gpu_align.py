@@ -173,3 +173,64 @@ def test_randomised_sweep(ctx, orc):
         lv, lval, flank = _toy(rng, n, k=k, scale=scale)
         a = lval[lv]
         _same(orc.align_overlap(a, flank, np.array(params, np.float32), want_idx=True), ctx.align_overlap(a, flank, want_idx=True))
+
+
+def _overlap(m, params):
+    # align_segment_overlap (align_kernels.hip): longest column span of a path that scores >= 0
+    open_h, ext_h, open_v, ext_v, off, dmin = [float(v) for v in params]
+    return int(m + m * off / -max(open_h, ext_h) * 1.01 + 64.0) + 1
+
+
+@pytest.mark.parametrize("segs", [2, 4])
+@pytest.mark.parametrize("k,n", [(40, 30000), (145, 100000)])
+def test_column_segments_seam_adversarial(ctx, orc, monkeypatch, segs, k, n):
+    """Several waves per alignment (column segments with a cold-started overlap): the flank
+    is planted so that its best path ends exactly on / next to every piece boundary, starts exactly at a
+    piece's cold-start column, lies inside an overlap zone, or occurs twice with identical samples in
+    two different pieces (tie: the leftmost must win).  Score bits, end column, start column and the
+    whole path must equal the single-matrix oracle's."""
+    rng = np.random.default_rng(1000 * segs + k)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    monkeypatch.setenv("STRQ_SEG", str(segs))
+    scale = 0.45
+    cls = rng.uniform(60, 120, k).astype(np.float32)
+    flank = np.repeat(cls, 6)
+    m = len(flank)
+    lval = (40 + scale * np.arange(256)).astype(np.float32)
+    ov = _overlap(m, params)
+    assert n >= (segs + 1) * ov
+    ln = (n + (segs - 1) * ov + segs - 1) // segs
+    own_end = [ln + j * (ln - ov) for j in range(segs - 1)]            # last column owned by piece j
+    cold = [e - ov for e in own_end]                                   # cold-start column of piece j + 1
+    emb = np.repeat(np.clip(np.round((cls - 40) / scale), 0, 255).astype(np.uint8), rng.integers(6, 10, k))
+    w = len(emb)
+
+    def background():
+        return np.repeat(rng.integers(30, 200, n // 5 + 1), rng.integers(3, 10, n // 5 + 1))[:n].astype(np.uint8)
+
+    cases = []
+    for e, c0 in zip(own_end, cold):
+        for end in (e - 1, e, e + 1, e + 2, e + w // 2):               # path ends around the boundary
+            cases.append([end - w])
+        for start in (c0 - 1, c0, c0 + 1, c0 + ov // 2):               # path starts at the cold column / inside the overlap
+            cases.append([start])
+        cases.append([c0 - w - 50, e + 50])                            # identical occurrences left and right of the seam
+        cases.append([e + 50, c0 - w - 50])
+    cases.append([])                                                   # no occurrence at all
+    levels, offs = [], [0]
+    for plant in cases:
+        lv = background()
+        for p in plant:
+            p = max(0, min(n - w, p))
+            lv[p:p + w] = emb
+        levels.append(lv); offs.append(offs[-1] + n)
+    na = len(cases)
+    got = ctx.align_batch(np.concatenate(levels), np.array(offs, np.int64), np.tile(lval, (na, 1)), np.arange(na, dtype=np.int32),
+                          np.tile(flank, na), np.arange(na + 1, dtype=np.int64) * m)
+    assert ctx.last_timing()[7] >= 1
+    for i, lv in enumerate(levels):
+        o = orc.align_overlap(lval[lv], flank, params, want_idx=False)
+        assert np.float32(o[0]).tobytes() == np.float32(got[0][i]).tobytes(), (i, cases[i])
+        assert (o[4], o[5]) == (int(got[1][i]), int(got[2][i])), (i, cases[i])
+        assert np.array_equal(o[3], got[3][i * m:(i + 1) * m]), (i, cases[i])
