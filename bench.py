@@ -12,9 +12,13 @@ signals are uploaded once and stay resident in HBM; the timed region covers ever
 pipeline and the (tiny) result read-back.  Reads shard over ranks (weak scaling: the batch per GPU is
 fixed); with N > 1 every step ends with the gather of the result records to rank 0 (RCCL).
 
-Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (the forward flank DP) with the
-algorithmic bytes of SURVEY.md 8d; `cpu_baseline` times the CPU oracle (the reference's own
-arithmetic: full matrix, one double pow per cell) on the host cores on a bounded sample.
+Rank 0 prints one JSON line.  `roofline` names what binds the dominant kernel (the forward flank DP):
+VALU issue -- wave instructions per second against 1024 SIMDs x 2.4 GHz / 2, with the instruction count
+per wave-step taken from the committed SQ_INSTS_VALU profile (profiles/dp_constants.json) and the
+wave-steps counted by the library in this run; the SURVEY.md 8d algorithmic-bytes figure is kept under
+`roofline.hbm_algorithmic`.  `host_inclusive_reads_per_s` is the same pipeline with the signals starting
+in pageable host RAM.  `cpu_baseline` times the CPU oracle (the reference's own arithmetic: full matrix,
+one double pow per cell) on the host cores on a bounded sample.
 """
 import argparse
 import json
@@ -28,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+N_SIMD = 1024                  # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md): one wave64 VALU instruction per 2 cycles each
+CLOCK_HZ = 2.4e9
 FLANK_ROWS = 870               # (150 - 6 + 1) k-mers x 6 samples per flank
 REPEAT_SWEEP = (200, 500, 1000, 1500, 2000)
 
@@ -72,9 +78,22 @@ def _cpu_one(args):
     return time.time() - t0, res[0]
 
 
-def cpu_baseline(sigs, strands, max_workers=16):
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sigs, strands, max_workers=32):
+    """The CPU oracle (reference arithmetic: full matrix, one double pow per cell, float64 Viterbi) on the
+    host cores, one worker process per core like STRique's --t N, one read per worker."""
     import multiprocessing as mp
-    cores = max(1, min(max_workers, os.cpu_count() or 1, len(sigs)))
+    host_cores = os.cpu_count() or 1
+    cores = max(1, min(max_workers, host_cores, len(sigs)))
     sample = [(s, st, False) for s, st in zip(sigs[:cores], strands[:cores])]
     with mp.get_context("spawn").Pool(cores) as pool:
         pool.map(_cpu_one, [(sigs[0][:20000], strands[0], True)] * cores)      # start the workers, load the oracle
@@ -86,6 +105,10 @@ def cpu_baseline(sigs, strands, max_workers=16):
         wall_lut = time.time() - t0
     per_core = float(np.mean([o[0] for o in out]))
     return {"value": len(sample) / wall, "unit": "reads/s", "cores": cores, "kind": "port",
+            "host_cpu_count": host_cores, "cpu_model": _cpu_model(),
+            "cores_note": "one worker process per logical CPU, capped at %d workers" % max_workers,
+            "per_core_reads_per_s": 1.0 / per_core, "seconds_per_read_per_core": per_core,
+            "whole_host_estimate_reads_per_s": host_cores / per_core,
             "lut_variant": {"value": len(sample) / wall_lut, "unit": "reads/s", "same_counts": [int(o[1]) for o in out_lut] == [int(o[1]) for o in out],
                             "note": "same oracle with scores memoised per (level, class) instead of one pow per cell"},
             "sample": "%d reads of the timed batch (one per worker process, like STRique's --t), full 2x(N+1)x871 "
@@ -103,6 +126,7 @@ def main():
     ap.add_argument("--read-nt", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive strq_detect_batch measurement")
+    ap.add_argument("--host-leg-batches", type=int, default=3, help="sub-batches of the PCIe-inclusive leg")
     ap.add_argument("--check", type=int, default=2, help="reads verified against the CPU oracle (LUT variant)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="testing only: all ranks use HIP device 0 (needs --backend gloo)")
@@ -132,9 +156,11 @@ def main():
     off = np.zeros(len(sigs) + 1, np.int64); off[1:] = np.cumsum([len(s) for s in sigs])
     tids = [counter._classifier_for("c9orf72", s).target_id for s in strands]
     ctx = counter.ctx
+    flat = np.concatenate(sigs)
     t_up = time.time()
-    ctx.batch_upload(np.concatenate(sigs), off, tids)           # host -> HBM, not timed
+    ctx.batch_upload(flat, off, tids)           # host -> HBM, not timed
     t_up = time.time() - t_up
+    del flat
 
     def barrier():
         if dist is not None:
@@ -156,11 +182,12 @@ def main():
         step()
     barrier()
     t0 = time.time()
-    fwd_ms = 0.0; fwd_launches = 0; stage_ms = np.zeros(8)
+    fwd_ms = 0.0; fwd_launches = 0; stage_ms = np.zeros(8); counters = np.zeros(8)
     for _ in range(args.steps):
         res = step()
-        tm = ctx.last_timing()
+        tm = ctx.last_timing(); cn = ctx.last_counters()
         fwd_ms += float(tm[1]); fwd_launches += int(tm[7]); stage_ms += tm
+        counters[:3] += cn[:3]; counters[3:7] = cn[3:7]; counters[7] += cn[7]
     barrier()
     elapsed = time.time() - t0
     if dist is not None:
@@ -180,44 +207,81 @@ def main():
         total_reads = world * args.reads * args.steps
         value = total_reads / elapsed
         n_samples = int(off[-1])
-        # algorithmic bytes of the forward DP: int16 signal once + 1 B of trace per cell
-        bytes_per_step = sum(2 * len(s) + 2 * (FLANK_ROWS + 1) * (len(s) + 1) for s in sigs)
         launches_per_step = max(1, fwd_launches // max(1, args.steps))
         avg_launch_s = (fwd_ms / 1e3) / max(1, fwd_launches)
-        achieved = bytes_per_step / launches_per_step / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # --- what binds the dominant kernel (the forward flank DP): VALU issue.  SURVEY.md 8d: when the
+        # implementation removes the per-cell trace stream, GCUPS / VALU is the binding roofline.
+        prof = _profile_constants()
+        segs, tables, packed, R = int(counters[3]), int(counters[4]), int(counters[5]), int(counters[6])
+        kname = "align_forward_seg_kernel<%d, 6, %s, %d, *>" % (R, "true" if packed else "false", segs)
+        ipstep = prof.get("valu_insts_per_wave_step", {}).get("packed" if packed else "float32")
+        wave_steps_per_launch = counters[0] / max(1, fwd_launches)
+        valu_peak = N_SIMD * CLOCK_HZ / 2.0 / 1e9                     # wave64 VALU instructions per second, all SIMDs (G/s)
         cells = sum(2 * (FLANK_ROWS + 1) * (len(s) + 1) for s in sigs)
+        bytes_per_step = sum(2 * len(s) + 2 * (FLANK_ROWS + 1) * (len(s) + 1) for s in sigs)
+        hbm_alg = bytes_per_step / launches_per_step / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        roof = {"bound": "valu", "unit": "G wave-instructions/s", "peak": valu_peak,
+                "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches_per_step,
+                "waves_per_alignment": segs, "score_tables_per_cu": tables, "waves_per_cu": segs * tables,
+                "wave_steps_per_launch": wave_steps_per_launch,
+                "columns_computed_over_columns_of_the_reads": counters[1] / max(1.0, 2.0 * n_samples * args.steps),
+                "lane_utilisation": FLANK_ROWS / float(64 * R) if R else None,
+                "gcups": cells / (fwd_ms / 1e3 / max(1, args.steps)) / 1e9 if fwd_ms > 0 else None,
+                "traffic": (prof.get("hbm_bytes_per_column", 0.0) * counters[1] / max(1, fwd_launches)) or None,
+                "traffic_source": prof.get("traffic_source"),
+                "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBS,
+                                    "bytes_per_launch": bytes_per_step / launches_per_step,
+                                    "note": "SURVEY.md 8d algorithmic bytes (int16 signal once + the reference's 1 B/cell trace) over the measured "
+                                            "launch time.  These bytes never move here (checkpoint + recompute instead of a per-cell trace), "
+                                            "so this figure is a work rate in the reference's units, not HBM utilisation; it may exceed 1."}}
+        if ipstep and avg_launch_s > 0:
+            roof["valu_insts_per_wave_step"] = ipstep
+            roof["valu_insts_source"] = prof.get("valu_source")
+            roof["achieved"] = ipstep * wave_steps_per_launch / avg_launch_s / 1e9
+            roof["frac"] = roof["achieved"] / valu_peak
+            roof["instr_per_cell"] = ipstep / (2.0 * R)                    # per lane: R rows x 2 columns per step
+            roof["instr_per_cell_floor"] = 4.0                             # 3 v_add_f32 + 1 v_max3_f32
+        else:
+            roof["achieved"] = None; roof["frac"] = None
         out = {
             "metric": "reads/s for STRique 'count' on 50 kb r9.4 signals", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 DP + f64 Viterbi",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "float32 flank DP (dominant), float64 HMM Viterbi and conditioning statistics",
             "data": "synthetic (SURVEY.md 8d recipe, seeded), int16 signals resident in HBM",
             "config": {"workload": "BASELINE configs[2]: %d reads/GPU/step, %d nt (N~%d samples), C9orf72 GGGGCC x {200,500,1000,1500,2000}"
                                    % (args.reads, args.read_nt, n_samples // max(1, len(sigs))),
                        "reads_per_gpu_per_step": args.reads, "read_nt": args.read_nt, "sharding": "reads over ranks, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": _traffic_from_profiles(2 * args.reads / launches_per_step) if args.read_nt == 50000 else None,
-                         "kernel": "align_forward_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_launch": bytes_per_step / launches_per_step,
-                         "gcups": cells / (fwd_ms / 1e3 / max(1, args.steps)) / 1e9 if fwd_ms > 0 else None,
-                         "note": "the forward pass keeps no per-cell trace (checkpoint + recompute), so real HBM traffic is far below the algorithmic bytes; the binding resource is VALU issue, see DESIGN.md"},
+            "resident_reads_per_s": value,
+            "roofline": roof,
             "stage_ms_per_step": {"conditioning": float(stage_ms[5]) / args.steps, "score_tables": float(stage_ms[0]) / args.steps,
                                   "forward_dp": float(stage_ms[1]) / args.steps, "trace": float(stage_ms[2]) / args.steps,
                                   "viterbi": float(stage_ms[6]) / args.steps},
+            "viterbi": {"time_steps_per_step": counters[7] / args.steps,
+                        "us_per_time_step_per_wave_slot": (float(stage_ms[6]) / args.steps * 1e3) / max(1.0, counters[7] / args.steps / (8 * N_SIMD / 4))},
             "host": {"synth_s": t_gen, "upload_s": t_up, "upload_GBs": n_samples * 2 / t_up / 1e9 if t_up > 0 else None},
             "check": checked,
         }
         if not args.no_host_leg:
-            # the boundary's host-buffer entry (strq_detect_batch): two sub-batches, the second one's
-            # upload overlapping the first one's kernels.  Reported beside `value`, never as `value`.
-            big = np.concatenate(sigs + sigs)
-            off2 = np.zeros(2 * len(sigs) + 1, np.int64); off2[1:] = np.cumsum([len(s) for s in sigs] * 2)
+            # SURVEY.md 8d quotes the metric with the signals in host RAM: the boundary's host-buffer entry
+            # (strq_detect_batch) over `host_leg_batches` sub-batches, samples in pageable host memory, uploads of
+            # sub-batch k + 1 overlapping the kernels of sub-batch k.  Reported beside `value`, never as `value`.
+            reps = max(1, args.host_leg_batches)
+            big = np.concatenate(sigs * reps)
+            off2 = np.zeros(reps * len(sigs) + 1, np.int64); off2[1:] = np.cumsum([len(s) for s in sigs] * reps)
+            tids2 = np.array(list(tids) * reps, np.int32)
             t1 = time.time()
-            res2 = ctx.detect_batch(big, off2, list(tids) + list(tids), None)
+            res2 = ctx.detect_batch(big, off2, tids2, None)          # first call: sizes the device buffers for this batch (hipMalloc)
+            dt_cold = time.time() - t1
+            t1 = time.time()
+            res2 = ctx.detect_batch(big, off2, tids2, None)          # steady state of a long-running caller
             dt = time.time() - t1
-            same = bool(np.array_equal(res2["count"][:len(sigs)], res["count"]) and np.array_equal(res2["count"][len(sigs):], res["count"]))
-            out["host_buffers"] = {"reads": 2 * len(sigs), "seconds": dt, "reads_per_s": 2 * len(sigs) / dt, "GB": big.nbytes / 1e9,
+            same = all(bool(np.array_equal(res2["count"][k * len(sigs):(k + 1) * len(sigs)], res["count"])) for k in range(reps))
+            out["host_inclusive_reads_per_s"] = reps * len(sigs) / dt
+            out["host_buffers"] = {"reads": reps * len(sigs), "sub_batches": reps, "seconds": dt, "seconds_first_call_with_allocations": dt_cold, "reads_per_s": reps * len(sigs) / dt, "GB": big.nbytes / 1e9,
                                    "same_counts_as_resident_run": same,
-                                   "note": "PCIe-inclusive: int16 signals start in pageable host memory; upload of sub-batch k+1 overlaps the kernels of sub-batch k"}
+                                   "note": "PCIe-inclusive: int16 signals start in pageable host memory and go through a pinned staging ring; "
+                                           "only the first sub-batch's upload is exposed"}
             del big
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sigs, strands)
@@ -234,16 +298,15 @@ def _cpu_check(sig, strand):
     return time.time() - t0, int(res[0])
 
 
-def _traffic_from_profiles(alignments_per_launch=None):
-    """HBM bytes per forward-DP launch from the committed rocprofv3 PMC passes (profiles/r01_pmc.md):
-    measured bytes per alignment at the same read length x alignments of this launch."""
-    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(p) and alignments_per_launch:
-        try:
-            return json.load(open(p))["align_forward_kernel_bytes_per_alignment"] * alignments_per_launch
-        except Exception:
-            return None
-    return None
+def _profile_constants():
+    """Per-unit constants measured with rocprofv3 counters and committed under profiles/ (the counters
+    cannot be collected inside the timed run): VALU instructions per wave-step of the forward DP
+    (SQ_INSTS_VALU / wave-steps) and HBM bytes per DP column (FETCH_SIZE + WRITE_SIZE)."""
+    p = os.path.join(ROOT, "profiles", "dp_constants.json")
+    try:
+        return json.load(open(p))
+    except Exception:
+        return {}
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 3 */
+int strq_abi_version(void);   /* currently 4 */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -184,6 +184,12 @@ int strq_debug_conditioning(strq_ctx* ctx, int64_t read, uint8_t* levels, int64_
  * [0] table build  [1] forward DP  [2] trace pass  [3] total  [4] table entries re-evaluated on
  * the host  [5] conditioning  [6] Viterbi  [7] number of forward-DP kernel launches.  */
 int strq_last_timing(const strq_ctx* ctx, float ms[8]);
+/* Work counters of the last batched call (what the benchmark's roofline is priced with):
+ * [0] forward-DP wave-steps (one step = two DP columns of every flank row, summed over all waves)
+ * [1] DP columns computed, including the columns column segments recompute   [2] alignments
+ * [3] waves per alignment (column segments) of the last forward launch   [4] score tables per CU
+ * [5] 1 = 24-bit tables, 0 = float32   [6] rows per lane   [7] Viterbi time steps. */
+int strq_last_counters(const strq_ctx* ctx, double out[8]);
 
 #ifdef __cplusplus
 }

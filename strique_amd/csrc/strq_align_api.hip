@@ -351,7 +351,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * trace_wpb));
     int qi = 0;
     STRQ_HIP(c, hipEventRecord(c->ev[2], st));
-    out.n_launches = 0;
+    out.n_launches = 0; out.wave_steps = 0; out.columns = 0;
+    for (size_t t = 0; t < n_tasks + n_up; ++t) if (tasks[t].n > 0) { out.wave_steps += align_num_steps(tasks[t].n); out.columns += tasks[t].n; }
+    if (!launches.empty()) { const Launch& L = launches.back(); out.segs = L.segs; out.tables = L.tables; out.packed = L.packed; out.rows_per_lane = L.R; }
     for (int level = 0; level < 2; ++level) {          // first strips, then the strips below them
         for (auto& L : launches) {
             if (level == 1 && L.NS == 1) continue;
@@ -439,6 +441,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
     STRQ_HIP(c, hipMemcpyAsync(c->level_val.p, in.level_val, (size_t)in.n_reads * 256 * 4, hipMemcpyHostToDevice, st));
     int64_t a0 = 0;
     float t_lut = 0, t_fwd = 0, t_tr = 0, n_hard = 0, n_launch = 0;
+    std::fill(c->counters, c->counters + 8, 0.0);
     while (a0 < NA) {
         int64_t a1 = a0; size_t ck_bytes = 0;
         while (a1 < NA) {
@@ -470,6 +473,8 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
         rc = align_core_times(c, &t_lut, &t_fwd, &t_tr);
         if (rc) return rc;
         n_hard += co.n_hard; n_launch += co.n_launches;
+        c->counters[0] += co.wave_steps; c->counters[1] += co.columns; c->counters[2] += nb;
+        c->counters[3] = co.segs; c->counters[4] = co.tables; c->counters[5] = co.packed; c->counters[6] = co.rows_per_lane;
         a0 = a1;
     }
     c->timing[0] = t_lut; c->timing[1] = t_fwd; c->timing[2] = t_tr; c->timing[3] = t_lut + t_fwd + t_tr; c->timing[4] = n_hard; c->timing[7] = n_launch;
@@ -480,7 +485,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 
 extern "C" {
 
-int strq_abi_version(void) { return 3; }
+int strq_abi_version(void) { return 4; }
 
 int strq_ctx_create(int device_id, strq_ctx** out)
 {
@@ -544,6 +549,13 @@ int strq_last_timing(const strq_ctx* c, float ms[8])
 {
     if (!c || !ms) return STRQ_ERR_ARG;
     std::memcpy(ms, c->timing, sizeof(c->timing));
+    return STRQ_OK;
+}
+
+int strq_last_counters(const strq_ctx* c, double out[8])
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    std::memcpy(out, c->counters, sizeof(c->counters));
     return STRQ_OK;
 }
 

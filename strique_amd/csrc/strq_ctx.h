@@ -45,6 +45,8 @@ struct AlignCoreOut {
     AlignTask* d_tasks = nullptr; AlignResult* d_results = nullptr; int32_t* d_rec = nullptr;
     int n_hard = 0;
     int n_launches = 0;                    // forward-kernel launches
+    double wave_steps = 0, columns = 0;    // forward work of this sub-batch
+    int segs = 1, tables = 0, packed = 0, rows_per_lane = 0;
 };
 
 struct HostModel {
@@ -63,6 +65,7 @@ struct strq_ctx {
     strq::AlignParams ap{-2.0f, -8.0f, -2.0f, -8.0f, 8.0f, -16.0f};   // src/align_raw.h:51-60
     std::string err;
     float timing[8] = {};
+    double counters[8] = {};
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd;

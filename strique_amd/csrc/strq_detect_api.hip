@@ -10,6 +10,8 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
+#include <time.h>
 #include <vector>
 #include "../../include/strique_hip.h"
 #include "strq_ctx.h"
@@ -18,6 +20,9 @@
 #include "mod_kernels.h"
 
 using namespace strq;
+
+#define STRQ_DBG(...) do { if (getenv("STRQ_DEBUG")) { fprintf(stderr, "[strq] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 namespace strq {
 
@@ -125,6 +130,8 @@ struct DetectState {
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
     hipStream_t copy_stream = nullptr;   // host -> HBM uploads that overlap the kernels of the previous sub-batch
+    static constexpr int N_STAGE = 4;    // pinned staging ring of upload_reads
+    void* stage[N_STAGE] = {}; hipEvent_t stage_ev[N_STAGE] = {}; bool stage_busy[N_STAGE] = {};
 };
 
 static DetectState* dstate(strq_ctx* c)
@@ -141,6 +148,7 @@ void detect_state_free(strq_ctx* c)
                       &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern, &d->hrange}) b->release();
     if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
+    for (int i = 0; i < DetectState::N_STAGE; ++i) { if (d->stage[i]) (void)hipHostFree(d->stage[i]); if (d->stage_ev[i]) (void)hipEventDestroy(d->stage_ev[i]); }
     delete d;
     c->detect = nullptr;
 }
@@ -258,9 +266,11 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     return STRQ_OK;
 }
 
-// Samples of reads [B.uploaded, upto) from the caller's buffer into `raw`, on the copy stream.  The
-// host blocks here (pageable memory is staged by the runtime) while the kernels already queued on
-// the compute stream keep running: that is the overlap.
+// Samples of reads [B.uploaded, upto) from the caller's (pageable) buffer into `raw`.  The runtime's own
+// pageable path measures 8.3 GB/s; here the bytes go through a ring of pinned staging buffers: a few host
+// threads copy the next piece into a free slot while the DMA engine drains the previous ones on the copy
+// stream.  The calling thread blocks here while the kernels already queued on the compute stream keep
+// running: that is the overlap of sub-batch k + 1's upload with sub-batch k's kernels.
 static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
 {
     Batch& B = d->batch;
@@ -268,9 +278,40 @@ static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
     if (!d->copy_stream) STRQ_HIP(c, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     const size_t esz = B.dtype == 0 ? 2 : 8;
     const size_t b0 = (size_t)B.off[B.uploaded] * esz, b1 = (size_t)B.off[upto] * esz;
-    if (b1 > b0) {
+    const size_t SLOT = (size_t)32 << 20;
+    int n_threads = 6;
+    if (const char* e = getenv("STRQ_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 0 && v <= 32) n_threads = v; }
+    if (b1 > b0 && n_threads == 0) {          // the runtime's pageable path
         STRQ_HIP(c, hipMemcpyAsync(B.raw.as<char>() + b0, B.host_src + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
         STRQ_HIP(c, hipStreamSynchronize(d->copy_stream));
+    } else if (b1 > b0) {
+        if (!d->stage[0]) {
+            for (int i = 0; i < DetectState::N_STAGE; ++i) {
+                STRQ_HIP(c, hipHostMalloc(&d->stage[i], SLOT, hipHostMallocDefault));
+                STRQ_HIP(c, hipEventCreateWithFlags(&d->stage_ev[i], hipEventDisableTiming));
+                d->stage_busy[i] = false;
+            }
+        }
+        int slot = 0;
+        for (size_t pos = b0; pos < b1; pos += SLOT, slot = (slot + 1) % DetectState::N_STAGE) {
+            const size_t len = std::min(SLOT, b1 - pos);
+            if (d->stage_busy[slot]) { STRQ_HIP(c, hipEventSynchronize(d->stage_ev[slot])); d->stage_busy[slot] = false; }
+            char* dst = static_cast<char*>(d->stage[slot]);
+            const char* src = B.host_src + pos;
+            const size_t part = ((len + n_threads - 1) / n_threads + 4095) & ~(size_t)4095;
+            std::vector<std::thread> th;
+            for (int t = 1; t < n_threads; ++t) {
+                const size_t o = (size_t)t * part;
+                if (o < len) th.emplace_back([=] { std::memcpy(dst + o, src + o, std::min(part, len - o)); });
+            }
+            std::memcpy(dst, src, std::min(part, len));
+            for (auto& t : th) t.join();
+            STRQ_HIP(c, hipMemcpyAsync(B.raw.as<char>() + pos, dst, len, hipMemcpyHostToDevice, d->copy_stream));
+            STRQ_HIP(c, hipEventRecord(d->stage_ev[slot], d->copy_stream));
+            d->stage_busy[slot] = true;
+        }
+        STRQ_HIP(c, hipStreamSynchronize(d->copy_stream));
+        for (int i = 0; i < DetectState::N_STAGE; ++i) d->stage_busy[i] = false;
     }
     B.uploaded = upto;
     return STRQ_OK;
@@ -309,15 +350,12 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     ReadCond* d_rc = d->rc.as<ReadCond>();
     STRQ_HIP(c, hipMemcpyAsync(d_rc, rc.data(), (size_t)nr * sizeof(ReadCond), hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemsetAsync(d->hist8.p, 0, (size_t)nr * 256 * 4, st));
-    STRQ_HIP(c, hipEventRecord(d->ev[0], st));
-    // ---- conditioning (STRique.py:590-597)
     const char* raw = d->batch.raw.as<char>() + (size_t)s0 * esz;
-    int bad = 0;
     bool any_mod = false;
     for (int i = 0; i < nr; ++i) any_mod |= d->targets[B.target[r0 + i]].mod_model_id >= 0;
+    uint32_t* d_hist_raw = nullptr; uint32_t* d_range = nullptr;
     if (B.dtype == 0) {
         STRQ_HIP(c, hipMemsetAsync(d->hist16.p, 0, (size_t)nr * 65536 * 4, st));
-        uint32_t* d_hist_raw = nullptr;
         if (any_mod) {
             STRQ_HIP(c, d->hist_raw.reserve((size_t)nr * 65536 * 4));
             STRQ_HIP(c, hipMemsetAsync(d->hist_raw.p, 0, (size_t)nr * 65536 * 4, st));
@@ -325,43 +363,11 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         }
         STRQ_HIP(c, d->hrange.reserve((size_t)nr * 16));
         STRQ_HIP(c, hipMemsetAsync(d->hrange.p, 0, (size_t)nr * 16, st));
-        uint32_t* d_range = d->hrange.as<uint32_t>();
-        bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), d->flt.as<int16_t>(), d_rc, nr, max_n, d->hist16.as<uint32_t>(), d_hist_raw, d_range);
-        bad |= launch_hist_stats(st, d->hist16.as<uint32_t>(), 65536, -32768, d_rc, nr, d->ps, 0, nullptr, d_range, 4);
-        if (any_mod) bad |= launch_hist_stats(st, d_hist_raw, 65536, -32768, d_rc, nr, d->ps, 2, nullptr, d_range + 2, 4);
-        bad |= launch_quant_morph_i16(st, d->flt.as<int16_t>(), c->levels.as<uint8_t>(), d_rc, nr, max_n, d->hist8.as<uint32_t>());
-    } else {
-        bad |= launch_medfilt_f64(st, reinterpret_cast<const double*>(raw), d->flt.as<double>(), d_rc, nr, max_n);
-        bad |= launch_quant_morph_f64(st, d->flt.as<double>(), c->levels.as<uint8_t>(), d_rc, nr, max_n, d->hist8.as<uint32_t>());
+        d_range = d->hrange.as<uint32_t>();
     }
-    bad |= launch_hist_stats(st, d->hist8.as<uint32_t>(), 256, 0, d_rc, nr, d->ps, 1, c->level_val.as<float>(), nullptr, 0);
-    if (bad) { c->err = "conditioning launch failed"; return STRQ_ERR_DEVICE; }
-    STRQ_HIP(c, hipEventRecord(d->ev[1], st));
-
-    // ---- the two flank alignments of every read
-    const int na = 2 * nr;
-    std::vector<int32_t> a_read(na); std::vector<int> n(na), m(na), k(na), R(na), NS(na); std::vector<const float*> fl(na);
-    std::vector<int32_t> trim(na);
-    int S = 6;
-    for (int i = 0; i < nr; ++i) {
-        const Target& t = d->targets[B.target[r0 + i]];
-        S = t.samples;
-        a_read[2 * i] = a_read[2 * i + 1] = i;
-        n[2 * i] = n[2 * i + 1] = rc[i].n;
-        m[2 * i] = (int)t.prefix_ext.size(); k[2 * i] = t.kp; R[2 * i] = t.Rp; NS[2 * i] = t.NSp; fl[2 * i] = t.prefix_ext.data(); trim[2 * i] = t.trim_prefix;
-        m[2 * i + 1] = (int)t.suffix_ext.size(); k[2 * i + 1] = t.ks; R[2 * i + 1] = t.Rs; NS[2 * i + 1] = t.NSs; fl[2 * i + 1] = t.suffix_ext.data(); trim[2 * i + 1] = t.trim_suffix;
-    }
-    AlignCoreIn ci; AlignCoreOut co;
-    ci.nb = na; ci.samples = S; ci.d_levels = c->levels.as<uint8_t>(); ci.read_off = loff.data(); ci.d_level_val = c->level_val.as<float>();
-    ci.read = a_read.data(); ci.n = n.data(); ci.m = m.data(); ci.k = k.data(); ci.R = R.data(); ci.NS = NS.data(); ci.flank = fl.data();
-    int rcode = align_core(c, ci, co);
-    if (rcode) return rcode;
-    B.n_hard += co.n_hard; B.n_fwd_launches += co.n_launches;
-
-    // ---- positions, gate, Viterbi tasks (grouped by HMM)
-    std::vector<int32_t> task_of(na);
-    for (int pos = 0; pos < na; ++pos) task_of[co.order[pos]] = pos;
-    std::map<int, std::vector<int>> by_shape;      // windows of all models with one kernel shape share a launch
+    // Viterbi tasks are grouped by kernel shape over the whole sub-batch (windows of all models with one
+    // shape share a launch)
+    std::map<int, std::vector<int>> by_shape;
     std::vector<const VitModel*> model_of(nr);
     for (int i = 0; i < nr; ++i) {
         HostModel* hm = c->models[d->targets[B.target[r0 + i]].model_id];
@@ -373,29 +379,92 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     std::vector<int32_t> vit_slot(nr);
     struct VL { int shape, first, count, max_states; };
     std::vector<VL> vls;
-    { int s = 0;
+    { int sl = 0;
       for (auto& g : by_shape) {
         int mx = 0;
         for (int i : g.second) mx = std::max(mx, c->models[d->targets[B.target[r0 + i]].model_id]->h.n_cells);
-        vls.push_back({g.first, s, (int)g.second.size(), mx});
-        for (int i : g.second) vit_slot[i] = s++;
+        vls.push_back({g.first, sl, (int)g.second.size(), mx});
+        for (int i : g.second) vit_slot[i] = sl++;
       } }
-    STRQ_HIP(c, d->idx.reserve((size_t)(na * 2 + nr) * 4 + (size_t)nr * 8 + 64));
-    int32_t* d_task_of = d->idx.as<int32_t>(); int32_t* d_trim = d_task_of + na; int32_t* d_slot = d_trim + na;
-    const VitModel** d_model_of = reinterpret_cast<const VitModel**>(d->idx.as<char>() + (((size_t)(na * 2 + nr) * 4 + 15) & ~(size_t)15));
+    const size_t idx_ints = (size_t)nr * 5;        // task_of (2 per read), trim (2 per read), vit_slot
+    STRQ_HIP(c, d->idx.reserve(idx_ints * 4 + (size_t)nr * 8 + 64));
+    int32_t* d_task_of = d->idx.as<int32_t>(); int32_t* d_trim = d_task_of + 2 * (size_t)nr; int32_t* d_slot = d_trim + 2 * (size_t)nr;
+    const VitModel** d_model_of = reinterpret_cast<const VitModel**>(d->idx.as<char>() + ((idx_ints * 4 + 15) & ~(size_t)15));
     STRQ_HIP(c, hipMemcpyAsync(d_model_of, model_of.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, hipMemcpyAsync(d_task_of, task_of.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, hipMemcpyAsync(d_trim, trim.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(d_slot, vit_slot.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, d->geom.reserve((size_t)nr * sizeof(ReadGeom)));
     STRQ_HIP(c, d->vit.reserve((size_t)nr * sizeof(VitTask)));
     STRQ_HIP(c, d->vres.reserve((size_t)nr * sizeof(VitResult)));
     STRQ_HIP(c, d->order.reserve((size_t)nr * 4 + 64));
-    FinalizeArgs fa;
-    fa.tasks = co.d_tasks; fa.results = co.d_results; fa.task_of = d_task_of; fa.trim = d_trim; fa.vit_slot = d_slot;
-    fa.rc = d_rc; fa.model_of = d_model_of; fa.flt = d->flt.p; fa.is_f64 = B.dtype; fa.ps = d->ps; fa.geom = d->geom.as<ReadGeom>(); fa.vit = d->vit.as<VitTask>(); fa.n_reads = nr;
-    hipLaunchKernelGGL(finalize_kernel, dim3((nr + 127) / 128), dim3(128), 0, st, fa);
-    STRQ_HIP(c, hipGetLastError());
+
+    // Conditioning, the two flank alignments and the positions / gate of the reads, in `parts` pieces: a
+    // sub-batch whose samples are still in the caller's buffer is uploaded piece by piece, each piece's
+    // kernels running under the upload of the next (only the first piece's upload is exposed); a resident
+    // or prefetched sub-batch is one piece.  The Viterbi launches below always cover the whole sub-batch.
+    int parts = 1;
+    if (B.host_src && B.uploaded < r1 && nr >= 1024) { parts = 2; if (const char* e = getenv("STRQ_UPLOAD_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= 16) parts = v; } }
+    for (int part = 0; part < parts; ++part) {
+        const int i0 = (int)((int64_t)nr * part / parts), i1 = (int)((int64_t)nr * (part + 1) / parts), np_ = i1 - i0;
+        if (np_ <= 0) continue;
+        { const int urc = upload_reads(c, d, r0 + i1); if (urc) return urc; }
+        int max_n = 0;
+        for (int i = i0; i < i1; ++i) max_n = std::max(max_n, rc[i].n);
+        if (part == 0) STRQ_HIP(c, hipEventRecord(d->ev[0], st));
+        // ---- conditioning (STRique.py:590-597)
+        int bad = 0;
+        uint8_t* levels = c->levels.as<uint8_t>();
+        float* level_val = c->level_val.as<float>() + (size_t)i0 * 256;
+        uint32_t* hist8 = d->hist8.as<uint32_t>() + (size_t)i0 * 256;
+        if (B.dtype == 0) {
+            uint32_t* h16 = d->hist16.as<uint32_t>() + (size_t)i0 * 65536;
+            uint32_t* hraw = d_hist_raw ? d_hist_raw + (size_t)i0 * 65536 : nullptr;
+            uint32_t* rng = d_range + (size_t)i0 * 4;
+            bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), d->flt.as<int16_t>(), d_rc + i0, np_, max_n, h16, hraw, rng);
+            bad |= launch_hist_stats(st, h16, 65536, -32768, d_rc + i0, np_, d->ps, 0, nullptr, rng, 4);
+            if (any_mod) bad |= launch_hist_stats(st, hraw, 65536, -32768, d_rc + i0, np_, d->ps, 2, nullptr, rng + 2, 4);
+            bad |= launch_quant_morph_i16(st, d->flt.as<int16_t>(), levels, d_rc + i0, np_, max_n, hist8);
+        } else {
+            bad |= launch_medfilt_f64(st, reinterpret_cast<const double*>(raw), d->flt.as<double>(), d_rc + i0, np_, max_n);
+            bad |= launch_quant_morph_f64(st, d->flt.as<double>(), levels, d_rc + i0, np_, max_n, hist8);
+        }
+        bad |= launch_hist_stats(st, hist8, 256, 0, d_rc + i0, np_, d->ps, 1, level_val, nullptr, 0);
+        if (bad) { c->err = "conditioning launch failed"; return STRQ_ERR_DEVICE; }
+        if (part == 0) STRQ_HIP(c, hipEventRecord(d->ev[1], st));
+
+        // ---- the two flank alignments of every read
+        const int na = 2 * np_;
+        std::vector<int32_t> a_read(na); std::vector<int> n(na), m(na), k(na), R(na), NS(na); std::vector<const float*> fl(na);
+        std::vector<int32_t> trim(na);
+        int S = 6;
+        for (int j = 0; j < np_; ++j) {
+            const Target& t = d->targets[B.target[r0 + i0 + j]];
+            S = t.samples;
+            a_read[2 * j] = a_read[2 * j + 1] = j;
+            n[2 * j] = n[2 * j + 1] = rc[i0 + j].n;
+            m[2 * j] = (int)t.prefix_ext.size(); k[2 * j] = t.kp; R[2 * j] = t.Rp; NS[2 * j] = t.NSp; fl[2 * j] = t.prefix_ext.data(); trim[2 * j] = t.trim_prefix;
+            m[2 * j + 1] = (int)t.suffix_ext.size(); k[2 * j + 1] = t.ks; R[2 * j + 1] = t.Rs; NS[2 * j + 1] = t.NSs; fl[2 * j + 1] = t.suffix_ext.data(); trim[2 * j + 1] = t.trim_suffix;
+        }
+        AlignCoreIn ci; AlignCoreOut co;
+        ci.nb = na; ci.samples = S; ci.d_levels = levels; ci.read_off = loff.data() + i0; ci.d_level_val = level_val;
+        ci.read = a_read.data(); ci.n = n.data(); ci.m = m.data(); ci.k = k.data(); ci.R = R.data(); ci.NS = NS.data(); ci.flank = fl.data();
+        const int rcode = align_core(c, ci, co);
+        if (rcode) return rcode;
+        B.n_hard += co.n_hard; B.n_fwd_launches += co.n_launches;
+        c->counters[0] += co.wave_steps; c->counters[1] += co.columns; c->counters[2] += na;
+        c->counters[3] = co.segs; c->counters[4] = co.tables; c->counters[5] = co.packed; c->counters[6] = co.rows_per_lane;
+
+        // ---- positions, gate, Viterbi tasks
+        std::vector<int32_t> task_of(na);
+        for (int pos = 0; pos < na; ++pos) task_of[co.order[pos]] = pos;
+        STRQ_HIP(c, hipMemcpyAsync(d_task_of + 2 * (size_t)i0, task_of.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
+        STRQ_HIP(c, hipMemcpyAsync(d_trim + 2 * (size_t)i0, trim.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
+        FinalizeArgs fa;
+        fa.tasks = co.d_tasks; fa.results = co.d_results; fa.task_of = d_task_of + 2 * (size_t)i0; fa.trim = d_trim + 2 * (size_t)i0; fa.vit_slot = d_slot + i0;
+        fa.rc = d_rc + i0; fa.model_of = d_model_of + i0; fa.flt = d->flt.p; fa.is_f64 = B.dtype; fa.ps = d->ps;
+        fa.geom = d->geom.as<ReadGeom>() + i0; fa.vit = d->vit.as<VitTask>(); fa.n_reads = np_;
+        hipLaunchKernelGGL(finalize_kernel, dim3((np_ + 127) / 128), dim3(128), 0, st, fa);
+        STRQ_HIP(c, hipGetLastError());
+    }
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
     // modification pass needs the state path of the flanked model: size the back-pointer arrays
     std::vector<VitTask> h_vit;
@@ -433,13 +502,15 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         ++qi;
       } }
     STRQ_HIP(c, hipEventRecord(d->ev[3], st));
-    // ---- results
+    // ---- results.  Everything of this sub-batch is queued: fetch the next sub-batch's samples while it runs
+    // (before the read-backs below -- a device-to-host copy into pageable memory blocks the host until the stream
+    // has drained, which would leave the upload exposed).
+    { const double tu = now_s(); const int urc = upload_reads(c, d, next_r1); if (urc) return urc;
+      STRQ_DBG("  prefetch of the next sub-batch %.1f ms", (now_s() - tu) * 1e3); }
     std::vector<ReadGeom> geom(nr); std::vector<VitResult> vres(nr); std::vector<ReadCond> rc_out(nr);
     STRQ_HIP(c, hipMemcpyAsync(geom.data(), d->geom.p, (size_t)nr * sizeof(ReadGeom), hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(vres.data(), d->vres.p, (size_t)nr * sizeof(VitResult), hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(rc_out.data(), d_rc, (size_t)nr * sizeof(ReadCond), hipMemcpyDeviceToHost, st));
-    // everything of this sub-batch is queued: fetch the next sub-batch's samples while it runs
-    { const int urc = upload_reads(c, d, next_r1); if (urc) return urc; }
     STRQ_HIP(c, hipStreamSynchronize(st));
     for (int i = 0; i < nr; ++i) {
         strq_result& o = B.results[r0 + i];
@@ -450,6 +521,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         o.score_prefix = g.score_prefix; o.score_suffix = g.score_suffix;
         o.prefix_begin = g.prefix_begin; o.prefix_end = g.prefix_end; o.suffix_begin = g.suffix_begin; o.suffix_end = g.suffix_end;
         o.offset = g.prefix_end; o.ticks = std::max<int64_t>(g.suffix_begin - g.prefix_end, 0);
+        if (g.gate) c->counters[7] += (double)(g.suffix_end - g.prefix_begin);
         if (g.gate && v.status == 0) {
             o.count = (int32_t)v.counted + d->targets[B.target[r0 + i]].count_bias;
             o.log_p = v.logp;
@@ -462,7 +534,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     float ms;
     STRQ_HIP(c, hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); B.t_cond += ms;
     STRQ_HIP(c, hipEventElapsedTime(&ms, d->ev[2], d->ev[3])); B.t_vit += ms;
-    rcode = align_core_times(c, &B.t_lut, &B.t_fwd, &B.t_trace);
+    const int rcode = align_core_times(c, &B.t_lut, &B.t_fwd, &B.t_trace);      // of the last piece when the sub-batch ran in pieces
     return rcode;
 }
 
@@ -566,6 +638,7 @@ int strq_batch_run(strq_ctx* c)
     Batch& B = d->batch;
     STRQ_HIP(c, hipSetDevice(c->device));
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
+    std::fill(c->counters, c->counters + 8, 0.0);
     // partition into sub-batches first, so that the upload of piece k + 1 can overlap the kernels of piece k
     std::vector<int64_t> cuts(1, 0);
     int64_t r0 = 0;
@@ -593,10 +666,11 @@ int strq_batch_run(strq_ctx* c)
         r0 = r1;
     }
     for (size_t k = 0; k + 1 < cuts.size(); ++k) {
-        int rc = upload_reads(c, d, cuts[k + 1]);          // no-op for a resident batch or when already prefetched
+        const double t1 = now_s();
+        // samples not yet in HBM (first sub-batch of strq_detect_batch) are uploaded piece by piece inside
+        const int rc = run_sub_batch(c, d, cuts[k], cuts[k + 1], k + 2 < cuts.size() ? cuts[k + 2] : cuts[k + 1]);
         if (rc) return rc;
-        rc = run_sub_batch(c, d, cuts[k], cuts[k + 1], k + 2 < cuts.size() ? cuts[k + 2] : cuts[k + 1]);
-        if (rc) return rc;
+        STRQ_DBG("sub-batch %zu: reads %ld..%ld  %.1f ms", k, (long)cuts[k], (long)cuts[k + 1], (now_s() - t1) * 1e3);
     }
     B.host_src = nullptr;      // the caller's buffer is not referenced after the call
     std::fill(c->timing, c->timing + 8, 0.0f);

@@ -116,6 +116,11 @@ class Context(object):
         self._check(self._lib.strq_last_timing(self._h, _ptr(t)))
         return t
 
+    def last_counters(self):
+        t = np.zeros(8, np.float64)
+        self._check(self._lib.strq_last_counters(self._h, _ptr(t)))
+        return t
+
     # ---- HMM ------------------------------------------------------------------------------
     def model_create(self, baked):
         mid = ctypes.c_int32(-1)

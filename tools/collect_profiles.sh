@@ -20,6 +20,11 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -
 echo "WRITE_SIZE pass rc=$?"
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_sq" -o "$TAG" -- python3 $BENCH_PMC > "$OUT/bench_sq.log" 2>&1
 echo "SQ pass rc=$?"
+# the same counters for the one-wave-per-table 24-bit geometry of round 1 (comparison row + the constant for packed tables)
+export STRQ_SEG=1 STRQ_PACK=1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_sq_packed" -o "$TAG" -- python3 $BENCH_PMC > "$OUT/bench_sq_packed.log" 2>&1
+echo "SQ pass (24-bit tables, one wave per table) rc=$?"
+unset STRQ_SEG STRQ_PACK
 # the kernel trace itself is large; keep stats + counters only
 rm -f "$OUT"/kt/*_kernel_trace.csv "$OUT"/kt/*.db
 tail -1 "$OUT/bench_kt.log" | cut -c1-400

@@ -86,7 +86,7 @@ def main():
             fv = sum(fetch[k]) / len(fetch[k])
             wv = sum(write.get(k, [0.0])) / max(1, len(write.get(k, [0.0])))
             f.write("| %s | %d | %.1f | %.1f | %.1f | %.3e |\n" % (k, len(fetch[k]), fv, 2 * fv, wv, (2 * fv + wv) * 1024))
-    fk = [k for k in fetch if "align_forward_kernel" in k]
+    fk = [k for k in fetch if "align_forward" in k]
     if fk:
         k = fk[0]
         n_launch = len(fetch[k])
@@ -105,14 +105,53 @@ def main():
         }
         json.dump(info, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
         print(json.dumps(info, indent=1))
-    sq_summary(tag, src, out, pmc_reads)
+    consts = {}
+    fb = bench_json(os.path.join(src, "bench_fetch.log"))
+    if fk and fb:
+        cols = fb["roofline"]["columns_computed_over_columns_of_the_reads"] * 2.0 * fb["config"]["reads_per_gpu_per_step"] * \
+            float(fb["config"]["workload"].split("N~")[1].split(" ")[0]) / max(1, fb["roofline"]["launches_per_step"])
+        consts["hbm_bytes_per_column"] = info["bytes_per_launch_fetch_x2"] / cols
+        consts["traffic_source"] = "profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 per MI355X_MICROARCH.md)" % tag
+    sq_summary(tag, src, out, pmc_reads, consts)
+    if consts:
+        json.dump(consts, open(os.path.join(out, "dp_constants.json"), "w"), indent=1)
+        print(json.dumps(consts, indent=1))
 
 
-def sq_summary(tag, src, out, pmc_reads):
+def bench_json(log):
+    if not os.path.exists(log):
+        return None
+    for ln in open(log):
+        if ln.startswith("{") and '"metric"' in ln:
+            return json.loads(ln)
+    return None
+
+
+def sq_summary(tag, src, out, pmc_reads, consts):
     """Issue / stall split of the waves (SQ counters, quad-cycle units) -> profiles/<tag>_sq.md."""
     hits = sorted(glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"), recursive=True))
     if not hits:
         return
+    # VALU instructions per wave-step of the forward DP: SQ_INSTS_VALU of the launch / wave-steps the library counted in the same run
+    for sub, log, key in (("pmc_sq", "bench_sq.log", None), ("pmc_sq_packed", "bench_sq_packed.log", "packed")):
+        h = sorted(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True))
+        b = bench_json(os.path.join(src, log))
+        if not h or not b:
+            continue
+        iv = counters(h[-1], "SQ_INSTS_VALU"); wc = counters(h[-1], "SQ_WAVE_CYCLES"); ai = counters(h[-1], "SQ_ACTIVE_INST_VALU")
+        for k in iv:
+            if "align_forward" not in k:
+                continue
+            steps = b["roofline"]["wave_steps_per_launch"]
+            targs = [x.strip() for x in k.split("<", 1)[1].rstrip(">").split(",")]
+            kind = "packed" if (targs[2] if "seg_kernel" in k else targs[-1]) == "true" else "float32"
+            consts.setdefault("valu_insts_per_wave_step", {})[kind] = sum(iv[k]) / len(iv[k]) / steps
+            consts.setdefault("kernels", {})[kind] = k
+            consts.setdefault("issue_utilisation_counters", {})[kind] = {
+                "SQ_INSTS_VALU": sum(iv[k]) / len(iv[k]), "wave_steps": steps,
+                "valu_active_fraction_of_wave_cycles": (sum(ai[k]) / len(ai[k])) / (sum(wc[k]) / len(wc[k])) if k in ai and k in wc else None,
+                "avg_launch_ms_in_counter_run": b["roofline"]["avg_launch_ms"]}
+        consts["valu_source"] = "profiles/%s_sq.md (rocprofv3 --pmc SQ_INSTS_VALU over bench.py --reads %d; wave-steps from strq_last_counters of the same run)" % (tag, pmc_reads)
     names = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU",
              "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
     per = OrderedDict()
@@ -132,8 +171,16 @@ def sq_summary(tag, src, out, pmc_reads):
             pct = lambda n: "%.0f %%" % (100.0 * v.get(n, 0.0) / wc)
             f.write("| %s | %s | %s | %s | %s | %.3g | %s | %s |\n" % (k, pct("SQ_ACTIVE_INST_ANY"), pct("SQ_ACTIVE_INST_VALU"), pct("SQ_WAIT_INST_ANY"),
                     pct("SQ_WAIT_ANY"), v.get("SQ_INSTS_VALU", 0.0), pct("SQ_LDS_IDX_ACTIVE"), pct("SQ_LDS_BANK_CONFLICT")))
-        f.write("\nPercentages are of SQ_WAVE_CYCLES.  Forward DP: the resident waves issue three quarters of the time, almost all of it\n"
-                "VALU -- the kernel is bound by VALU issue of the waves its LDS tables admit, not by memory.\n")
+        f.write("\nPercentages are of SQ_WAVE_CYCLES (time a wave is resident).\n")
+        if consts.get("valu_insts_per_wave_step"):
+            f.write("\nForward DP, VALU instructions per wave-step (SQ_INSTS_VALU / wave-steps counted by the library in the same run): %s.\n"
+                    "One wave-step = 2 DP columns x R rows per lane.  Chip-level issue utilisation = SQ_INSTS_VALU / launch time / "
+                    "(1024 SIMDs x 2.4 GHz / 2) is computed by bench.py from these constants and its own event timing.\n"
+                    % json.dumps(consts["valu_insts_per_wave_step"]))
+            for kind, v in consts.get("issue_utilisation_counters", {}).items():
+                u = v["SQ_INSTS_VALU"] / (v["avg_launch_ms_in_counter_run"] * 1e-3) / (1024 * 2.4e9 / 2)
+                f.write("* %s tables (`%s`): %.4g VALU instructions in a %.2f ms launch (counter run, %d reads) = %.3f of the chip's VALU issue peak.\n"
+                        % (kind, consts["kernels"][kind], v["SQ_INSTS_VALU"], v["avg_launch_ms_in_counter_run"], pmc_reads, u))
 
 
 if __name__ == "__main__":
