@@ -61,10 +61,11 @@ int strq_get_align_params(const strq_ctx* ctx, float params[6]);
  *              diagonal step b[k] is aligned to a[j-1] and for a vertical step j samples of `a`
  *              precede b[k]
  *   j_end,j0   DP columns where the path ends / leaves the free top row (nullable)
- * Supported here: `a` with at most 256 distinct float32 values and `b` made of runs of 6 equal
- * samples (what repeatCounter.detect always passes: an 8-bit morphology signal and
- * generate_signal(..., samples=6), scripts/STRique.py:592-601,562-565), m <= 948 (158 k-mer classes).
- * Anything else returns STRQ_ERR_UNSUPPORTED.
+ * Any float32 inputs are accepted, like the reference (src/pyalign.cpp:59-61).  What
+ * repeatCounter.detect passes -- `a` with at most 256 distinct values (an 8-bit morphology signal) and `b`
+ * made of runs of 6 equal samples, m <= 948 (scripts/STRique.py:592-601,562-565) -- runs on the
+ * LDS-table wavefront kernels; everything else on a generic kernel (one trace byte per cell in HBM like
+ * the reference: (n + 1) x (m + 1) <= 1.7e10, at most 2e9 distinct (a, b) value pairs), same results.
  */
 int strq_align_overlap(strq_ctx* ctx, const float* a, int64_t n, const float* b, int64_t m,
                        float* score, uint64_t* a_idx, uint64_t* b_idx,

@@ -15,6 +15,7 @@
 #include "strq_ctx.h"
 #include "align_kernels.h"
 #include "lut_kernels.h"
+#include "align_generic.h"
 
 using namespace strq;
 
@@ -513,7 +514,7 @@ void strq_ctx_destroy(strq_ctx* c)
     detect_state_free(c);
     for (DevBuf* b : {&c->levels, &c->level_val, &c->flank_cls, &c->tables, &c->tables3, &c->band_lo, &c->col0, &c->ckpt,
                       &c->rec, &c->tasks, &c->results, &c->queue, &c->scratch, &c->lutinfo, &c->hard, &c->misc,
-                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd})
+                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd, &c->gen_codes, &c->gen_table, &c->gen_bnd, &c->gen_trace, &c->gen_hard})
         b->release();
     for (HostModel* m : c->models) if (m) { m->blob.release(); delete m; }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -574,35 +575,138 @@ int strq_align_batch(strq_ctx* c, int64_t n_align, int64_t n_reads, const uint8_
     return run_align_batch(c, in, out);
 }
 
+// align_overlap for inputs the 8-bit / 6-run kernels do not cover: any `a`, any `b` (align_generic.hip)
+static int align_overlap_generic(strq_ctx* c, const float* a, int64_t n, const float* b, int64_t m, float* score,
+                                 std::vector<int32_t>& rec, int64_t* je, int64_t* j0)
+{
+    if (n > ((int64_t)1 << 30) || m > ((int64_t)1 << 24) || (double)(n + 1) * (double)(m + 1) > 1.7e10) {
+        c->err = "align_overlap: (n + 1) x (m + 1) exceeds the 16 GiB trace limit of the generic path"; return STRQ_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = c->stream;
+    // dictionary-encode by bit pattern (so that -0.0 / +0.0 and NaN payloads keep their own rows)
+    auto encode = [](const float* x, int64_t len, std::vector<float>& vals, std::vector<uint32_t>& code) {
+        std::vector<uint32_t> bits((size_t)len);
+        std::memcpy(bits.data(), x, (size_t)len * 4);
+        std::vector<uint32_t> uniq(bits);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        code.resize((size_t)len);
+        for (int64_t i = 0; i < len; ++i) code[(size_t)i] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), bits[(size_t)i]) - uniq.begin());
+        vals.resize(uniq.size());
+        std::memcpy(vals.data(), uniq.data(), uniq.size() * 4);
+    };
+    std::vector<float> va, vb; std::vector<uint32_t> ca, cb;
+    encode(a, n, va, ca); encode(b, m, vb, cb);
+    const size_t na = va.size(), nbv = vb.size();
+    if ((double)na * (double)nbv > 2.0e9) { c->err = "align_overlap: more than 2e9 distinct (a, b) value pairs"; return STRQ_ERR_UNSUPPORTED; }
+    const size_t tab = std::max<size_t>(1, na * nbv);
+    const int hard_cap = 1 << 20;
+    STRQ_HIP(c, c->gen_codes.reserve(((size_t)n + (size_t)m + na + nbv) * 4 + 64));
+    STRQ_HIP(c, c->gen_table.reserve(tab * 4 + 64));
+    STRQ_HIP(c, c->gen_bnd.reserve(((size_t)n + 1) * 16 + ((size_t)m + 1) * 4 + 256));
+    STRQ_HIP(c, c->gen_trace.reserve(((size_t)n + 1) * ((size_t)m + 1) + 64));
+    STRQ_HIP(c, c->gen_hard.reserve((size_t)hard_cap * (sizeof(GenericHard) + 4) + 64));
+    STRQ_HIP(c, c->results.reserve(sizeof(AlignResult) + 64));
+    STRQ_HIP(c, c->queue.reserve(1024));
+    uint32_t* d_ca = c->gen_codes.as<uint32_t>(); uint32_t* d_cb = d_ca + n;
+    float* d_va = reinterpret_cast<float*>(d_cb + m); float* d_vb = d_va + na;
+    float* d_tab = c->gen_table.as<float>();
+    float* d_bnd = c->gen_bnd.as<float>();
+    GenericHard* d_hard = c->gen_hard.as<GenericHard>(); float* d_hvals = reinterpret_cast<float*>(d_hard + hard_cap);
+    int* d_count = c->queue.as<int>();
+    if (n) STRQ_HIP(c, hipMemcpyAsync(d_ca, ca.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemcpyAsync(d_cb, cb.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    if (na) STRQ_HIP(c, hipMemcpyAsync(d_va, va.data(), na * 4, hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemcpyAsync(d_vb, vb.data(), nbv * 4, hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
+    int hard_count = 0;
+    if (na) {
+        if (launch_generic_table(st, d_va, (int)na, d_vb, (int)nbv, d_tab, d_hard, d_count, hard_cap, c->ap)) { c->err = "table launch failed"; return STRQ_ERR_DEVICE; }
+        STRQ_HIP(c, hipMemcpyAsync(&hard_count, d_count, 4, hipMemcpyDeviceToHost, st));
+        STRQ_HIP(c, hipStreamSynchronize(st));
+        if (hard_count > hard_cap) {       // pathological: evaluate the whole table with the host libm
+            std::vector<float> full(tab);
+            for (size_t y = 0; y < nbv; ++y) for (size_t x = 0; x < na; ++x) full[y * na + x] = host_cell_score(c->ap, va[x], vb[y]);
+            STRQ_HIP(c, hipMemcpy(d_tab, full.data(), tab * 4, hipMemcpyHostToDevice));
+        } else if (hard_count > 0) {
+            std::vector<GenericHard> he((size_t)hard_count); std::vector<float> hv((size_t)hard_count);
+            STRQ_HIP(c, hipMemcpy(he.data(), d_hard, (size_t)hard_count * sizeof(GenericHard), hipMemcpyDeviceToHost));
+            for (int i = 0; i < hard_count; ++i) hv[(size_t)i] = host_cell_score(c->ap, va[(size_t)he[(size_t)i].ia], vb[(size_t)he[(size_t)i].ib]);
+            STRQ_HIP(c, hipMemcpyAsync(d_hvals, hv.data(), (size_t)hard_count * 4, hipMemcpyHostToDevice, st));
+            if (launch_generic_patch(st, d_tab, (int)na, d_hard, d_hvals, hard_count)) { c->err = "patch launch failed"; return STRQ_ERR_DEVICE; }
+        }
+    }
+    c->timing[4] = (float)hard_count;
+    std::vector<float> col0((size_t)m + 1);
+    host_col0(c->ap, (int)m, col0.data());
+    GenericAlignArgs ga;
+    ga.code_a = d_ca; ga.code_b = d_cb; ga.table = d_tab;
+    ga.bnd_S[0] = d_bnd; ga.bnd_V[0] = d_bnd + (n + 1); ga.bnd_S[1] = d_bnd + 2 * (n + 1); ga.bnd_V[1] = d_bnd + 3 * (n + 1);
+    float* d_col0 = d_bnd + 4 * (n + 1);
+    STRQ_HIP(c, hipMemcpyAsync(d_col0, col0.data(), ((size_t)m + 1) * 4, hipMemcpyHostToDevice, st));
+    ga.col0 = d_col0; ga.trace = c->gen_trace.as<uint8_t>(); ga.result = c->results.as<AlignResult>();
+    ga.p = c->ap; ga.n = (int32_t)n; ga.m = (int32_t)m; ga.na = (int32_t)na; ga.nb = (int32_t)nbv;
+    if (launch_generic_align(st, ga)) { c->err = "generic align launch failed"; return STRQ_ERR_DEVICE; }
+    AlignResult res;
+    std::vector<uint8_t> trace(((size_t)n + 1) * ((size_t)m + 1));
+    STRQ_HIP(c, hipMemcpyAsync(&res, ga.result, sizeof(res), hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipMemcpyAsync(trace.data(), ga.trace, trace.size(), hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipStreamSynchronize(st));
+    // traceback (the state machine of SURVEY.md A.1; column 0 is not free: what is left of the flank there is vertical)
+    rec.assign((size_t)m, 0);
+    int64_t i = m, j = res.j_end; int state = 0;
+    const size_t W = (size_t)n + 1;
+    while (i > 0 && j > 0) {
+        const uint8_t tr = trace[(size_t)i * W + (size_t)j];
+        if (state == 0) {
+            const unsigned dsel = tr & 3u;
+            if (dsel == 0) { rec[(size_t)i - 1] = (int32_t)(j << 1); --i; --j; }
+            else state = (int)dsel;
+        } else if (state == 1) { --j; if (!(tr & 4u)) state = 0; }
+        else { rec[(size_t)i - 1] = (int32_t)((j << 1) | 1); --i; if (!(tr & 8u)) state = 0; }
+    }
+    for (; i > 0; --i) rec[(size_t)i - 1] = (int32_t)((j << 1) | 1);
+    *score = res.best; *je = res.j_end; *j0 = j;
+    return STRQ_OK;
+}
+
 int strq_align_overlap(strq_ctx* c, const float* a, int64_t n, const float* b, int64_t m, float* score,
                        uint64_t* a_idx, uint64_t* b_idx, int32_t* rec_out, int64_t* j_end_out, int64_t* j0_out)
 {
     if (!c) return STRQ_ERR_ARG;
-    if (!a || !b || n < 0 || m < 1 || !score) { c->err = "bad argument"; return STRQ_ERR_ARG; }
-    // dictionary-encode `a`: levels are the ranks of its distinct values
-    std::vector<float> vals(a, a + n);
-    std::sort(vals.begin(), vals.end());
-    vals.erase(std::unique(vals.begin(), vals.end(), [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; }), vals.end());
-    if (vals.size() > 256) { c->err = "more than 256 distinct values in `a`"; return STRQ_ERR_UNSUPPORTED; }
-    for (float v : vals) if (v != v) { c->err = "NaN in `a`"; return STRQ_ERR_UNSUPPORTED; }
-    std::vector<uint8_t> lv((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        // -0.0 and +0.0 compare equal under '<' but differ bitwise; resolve by exact bit match
-        auto it = std::lower_bound(vals.begin(), vals.end(), a[i]);
-        while (std::memcmp(&*it, &a[i], 4) != 0) ++it;
-        lv[(size_t)i] = (uint8_t)(it - vals.begin());
-    }
-    std::vector<float> lval(256, INFINITY);   // unused levels: score clips to dist_min
-    std::copy(vals.begin(), vals.end(), lval.begin());
-    const int64_t roff[2] = {0, n}, foff[2] = {0, m};
-    const int32_t ar = 0;
+    if ((!a && n > 0) || !b || n < 0 || m < 1 || !score) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+    STRQ_HIP(c, hipSetDevice(c->device));
+    std::fill(c->timing, c->timing + 8, 0.0f);
     std::vector<int32_t> rec((size_t)m);
     int64_t je = 0, j0 = 0;
-    STRQ_HIP(c, hipSetDevice(c->device));
-    BatchIn in{1, 1, lv.data(), roff, lval.data(), &ar, b, foff, 6};
-    BatchOut out{score, &je, &j0, rec.data()};
-    const int rc = run_align_batch(c, in, out);
-    if (rc) return rc;
+    // fast path: what repeatCounter.detect passes -- at most 256 distinct values in `a` (an 8-bit signal) and a
+    // flank made of runs of 6 equal samples that a compiled kernel shape covers
+    std::vector<float> vals(a, a + n);
+    std::sort(vals.begin(), vals.end(), [](float x, float y) { return __builtin_bit_cast(uint32_t, x) < __builtin_bit_cast(uint32_t, y); });
+    vals.erase(std::unique(vals.begin(), vals.end(), [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; }), vals.end());
+    bool fast = vals.size() <= 256 && m % 6 == 0 && !getenv("STRQ_GENERIC_ALIGN");
+    for (float v : vals) if (v != v) fast = false;
+    if (fast) {
+        std::sort(vals.begin(), vals.end());
+        for (size_t x = 1; x < vals.size(); ++x) if (vals[x] == vals[x - 1]) fast = false;      // -0.0 and +0.0 both present
+        int kk, RR, NN;
+        if (fast && align_validate_flank(c, b, m, 6, &kk, &RR, &NN) != STRQ_OK) fast = false;
+    }
+    if (fast) {
+        std::vector<uint8_t> lv((size_t)n);
+        for (int64_t i = 0; i < n; ++i) lv[(size_t)i] = (uint8_t)(std::lower_bound(vals.begin(), vals.end(), a[i]) - vals.begin());
+        std::vector<float> lval(256, INFINITY);   // unused levels: score clips to dist_min
+        std::copy(vals.begin(), vals.end(), lval.begin());
+        const int64_t roff[2] = {0, n}, foff[2] = {0, m};
+        const int32_t ar = 0;
+        BatchIn in{1, 1, lv.data(), roff, lval.data(), &ar, b, foff, 6};
+        BatchOut out{score, &je, &j0, rec.data()};
+        const int rc = run_align_batch(c, in, out);
+        if (rc) return rc;
+    } else {
+        const int rc = align_overlap_generic(c, a, n, b, m, score, rec, &je, &j0);
+        if (rc) return rc;
+    }
     if (rec_out) std::memcpy(rec_out, rec.data(), (size_t)m * 4);
     if (j_end_out) *j_end_out = je;
     if (j0_out) *j0_out = j0;

@@ -68,7 +68,8 @@ struct strq_ctx {
     double counters[8] = {};
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
-        queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd;
+        queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd,
+        gen_codes, gen_table, gen_bnd, gen_trace, gen_hard;      // generic align_overlap path
     std::vector<strq::HostModel*> models;
     void* detect = nullptr;                   // DetectState (strq_detect_api.hip)
     size_t max_ws_bytes = (size_t)96 << 30;   // cap for checkpoint workspace per sub-batch

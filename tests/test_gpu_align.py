@@ -108,15 +108,20 @@ def test_full_size_read(ctx, orc):
     _same(orc.align_overlap(a, flank, params, want_idx=False), ctx.align_overlap(a, flank, want_idx=False))
 
 
-def test_unsupported_inputs(ctx):
+def test_formerly_unsupported_inputs_now_match_the_oracle(ctx, orc):
+    """More than 256 distinct values in `a`, a flank without runs of 6: the generic kernel covers them
+    (reference src/pyalign.cpp:59-61 takes any two float lists); bad arguments still raise."""
     from strique_amd import ffi
     rng = np.random.default_rng(1)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    a = rng.normal(90, 10, 5000); b = np.repeat(rng.uniform(60, 120, 10), 6)
+    _same(orc.align_overlap(a, b, params), ctx.align_overlap(a, b))
+    a = np.ones(100); b = rng.uniform(60, 120, 61)
+    _same(orc.align_overlap(a, b, params), ctx.align_overlap(a, b))
     with pytest.raises(ffi.StriqueHipError) as e:
-        ctx.align_overlap(rng.normal(90, 10, 5000), np.repeat(rng.uniform(60, 120, 10), 6))      # > 256 levels
-    assert e.value.code == ffi.STRQ_ERR_UNSUPPORTED
-    with pytest.raises(ffi.StriqueHipError):
-        ctx.align_overlap(np.ones(100), rng.uniform(60, 120, 60))                                 # no runs of 6
-    assert np.array_equal(ctx.get_align_params(), ctx.get_align_params())
+        ctx.align_overlap(a, np.zeros(0))                      # an empty flank is not an alignment
+    assert e.value.code == ffi.STRQ_ERR_ARG
 
 
 def test_two_strip_path(orc, monkeypatch):
