@@ -18,6 +18,8 @@ import tempfile
 import threading
 from collections import defaultdict, deque
 
+import numpy as np
+
 HEADER = ['ID', 'target', 'strand', 'count', 'score_prefix', 'score_suffix', 'log_p', 'offset', 'ticks', 'mod']
 LEVELS = ['error', 'warning', 'info', 'debug']
 
@@ -59,10 +61,10 @@ def parse_config(repeat_config_file, param_config_file=None, log=None):
 
 
 class SamRecord(object):
-    __slots__ = ('QNAME', 'FLAG', 'RNAME', 'POS', 'TLEN', 'CLIP_BEGIN', 'CLIP_END')
+    __slots__ = ('QNAME', 'FLAG', 'RNAME', 'POS', 'TLEN', 'CLIP_BEGIN', 'CLIP_END', 'QLEN')
 
     def __init__(self):
-        self.QNAME = ''; self.FLAG = 0; self.RNAME = ''; self.POS = 0; self.TLEN = 0; self.CLIP_BEGIN = 0; self.CLIP_END = 0
+        self.QNAME = ''; self.FLAG = 0; self.RNAME = ''; self.POS = 0; self.TLEN = 0; self.CLIP_BEGIN = 0; self.CLIP_END = 0; self.QLEN = 0
 
 
 def decode_cigar(cigar):
@@ -84,6 +86,7 @@ def decode_sam(sam_line):
             sr.TLEN = ops_length(ops, recOps='MDN=X')
             sr.CLIP_BEGIN = sum(n for n, op in ops[:2] if op in 'SH')
             sr.CLIP_END = sum(n for n, op in ops[-2:] if op in 'SH')
+            sr.QLEN = max(ops_length(ops, recOps='MIS=XH'), len(cols[9]) if cols[9] != '*' else 0)      # read length: the cost of its alignments
         except Exception:
             return SamRecord()
     return sr
@@ -181,6 +184,7 @@ def count(argv):
     parser.add_argument("--batch", type=int, default=2048, help="Reads per GPU batch")
     parser.add_argument("--device", type=int, default=0, help="HIP device")
     parser.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend when launched with torchrun (default: nccl = RCCL)")
+    parser.add_argument("--share-device", action="store_true", help="testing: every rank uses --device instead of its LOCAL_RANK")
     args = parser.parse_args(argv)
     log = Log(args.log_level)
     config = parse_config(args.repeat, args.config, log)
@@ -192,33 +196,80 @@ def count(argv):
     from . import dist as sdist
     rank, world, local = sdist.env_rank_world()
     if world > 1:
-        # one process per GPU (torchrun): ranks take the accepted (read, target) pairs round-robin, rank 0
-        # gathers the rows once at the end (RCCL / gloo object gather) and writes them in input order
+        # one process per GPU (torchrun): the accepted (read, target) pairs are dealt to the ranks by read
+        # length (strique_amd.dist.shard_indices), rank 0 gathers fixed-size result records plus the
+        # modification strings once at the end (strique_amd.dist.gather_results) and writes the rows in input order
         if not args.algn:
             log("Main: --algn FILE is required when running on several GPUs (stdin cannot be shared).", 'error'); raise SystemExit(1)
         sdist.init_process_group(backend=args.backend)
     from .counter import repeatCounter
+    device = args.device if (world == 1 or args.share_device) else local
     counter = repeatCounter(args.model, mod_model_file=args.mod_model, align_config=config['align'],
-                            HMM_config=config['HMM'], device=local if world > 1 else args.device)
+                            HMM_config=config['HMM'], device=device)
     loci = defaultdict(list)
     for name, (chrom, begin, end, repeat, prefix, suffix) in config['repeat'].items():
-        counter.add_target(name, repeat, prefix, suffix)
+        try:
+            counter.add_target(name, repeat, prefix, suffix)
+        except ValueError:
+            raise
+        except Exception as e:                # e.g. a flank longer than the compiled kernel shapes cover
+            log("Main: target %s is not supported by the GPU engine (%s); its reads are skipped." % (name, e), 'error')
+            continue
         loci[chrom].append((name, begin, end))
     f5 = Fast5Index(args.f5Index)
     stream = open(args.algn) if args.algn else sys.stdin
     out = (open(args.out, 'w') if args.out else sys.stdout) if rank == 0 else None
-    readers = args.t if args.t > 1 else min(8, os.cpu_count() or 1)
-    rows = run_count(stream, loci, f5.get_raw, counter, log, args.batch, rank, world, out if world == 1 else None, readers=readers)
+    readers = max(1, args.t)
+    stats = {}
+    rows = run_count(stream, loci, f5.get_raw, counter, log, args.batch, rank, world, out if world == 1 else None, readers=readers, stats=stats)
     if world > 1:
         import torch.distributed as dist
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(rows, gathered, dst=0)
+        merged = gather_rows(rows, stats["items"], sdist)
         if rank == 0:
-            write_rows(out, sorted(r for part in gathered for r in part))
+            write_rows(out, merged)
         dist.barrier()
         dist.destroy_process_group()
     if args.out and out is not None:
         out.close()
+    if stats.get("failed"):
+        log("Main: %d read(s) could not be processed (see warnings above)." % stats["failed"], 'error')
+        raise SystemExit(2)
+
+
+ROW_DTYPE = np.dtype([("count", np.int32), ("valid", np.int32), ("score_prefix", np.float64), ("score_suffix", np.float64),
+                      ("log_p", np.float64), ("offset", np.int64), ("ticks", np.int64)])
+
+
+def format_row(qname, target, strand, res):
+    return '\t'.join(str(x) for x in (qname, target, strand) + tuple(res))
+
+
+def gather_rows(rows, items, sdist):
+    """Rows of this rank -> fixed-size records + modification strings -> one gather -> on rank 0 the
+    merged [(sequence number, TSV row)] in input order (None elsewhere).  `items`: every accepted
+    (qname, strand, target) of the input, which each rank derives from the same SAM file."""
+    rec = np.zeros(len(rows), ROW_DTYPE); mods = []; idx = np.zeros(len(rows), np.int64)
+    for k, (seq, res) in enumerate(rows):
+        idx[k] = seq
+        if res is None:
+            mods.append("")
+            continue
+        n, sp, ss, p, offset, ticks, mod = res
+        rec[k] = (n, 1, sp, ss, float(p), offset, ticks)
+        mods.append(mod)
+    full, full_mods = sdist.gather_results(rec, idx, len(items), mods)
+    if full is None:
+        return None
+    merged = []
+    for seq, (qname, strand, target) in enumerate(items):
+        r = full[seq]
+        if not r["valid"]:
+            continue
+        n = int(r["count"]); lp = float(r["log_p"])
+        p = lp if (n or lp != 0) else 0              # the reference prints the integer 0 for a failed gate (STRique.py:602,616)
+        merged.append((seq, format_row(qname, target, strand, (n, float(r["score_prefix"]), float(r["score_suffix"]), p,
+                                                                 int(r["offset"]), int(r["ticks"]), full_mods[seq]))))
+    return merged
 
 
 def write_rows(out, rows, header=True):
@@ -229,34 +280,83 @@ def write_rows(out, rows, header=True):
     out.flush()
 
 
-def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, out=None, readers=0):
+def route(stream, loci, log):
+    """Accepted SAM records of `stream`: (qname, strand, [targets], read length)."""
+    for line in stream:
+        if line.startswith('@'):
+            continue
+        sr = decode_sam(line)
+        if not sr.QNAME:
+            log("Detector: Error parsing alignment \n%s" % line, 'error'); continue
+        targets = intersect_targets(sr, loci)
+        if not targets:
+            log("Detector: No target for %s" % sr.QNAME, 'debug'); continue
+        yield sr.QNAME, ('+' if sr.FLAG & 0x10 == 0 else '-'), targets, sr.QLEN
+
+
+def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, out=None, readers=0, stats=None):
     """Route the SAM records of `stream` to their targets, run this rank's share through
-    `counter.detect_batch` and return [(sequence number, TSV row)].  With `out` given (single
-    process) rows are also written as soon as their batch is done, header first.
+    `counter.detect_batch` and return [(sequence number, result tuple or TSV row)].
+
+    Single process: rows [(seq, TSV row)] are also written to `out` as soon as their batch is done.
+    Several ranks: the records are read first (the SAM carries the read lengths), the accepted
+    (read, target) pairs are dealt to the ranks by descending read length
+    (strique_amd.dist.shard_indices: the DP cost of a read is proportional to its length), and the
+    return value is [(seq, result tuple)] for `gather_rows`.
     `readers` > 0: raw signals are fetched by that many threads ahead of the GPU batches (inflating
     the deflate chunks of a fast5 releases the GIL and is what bounds a `count` run on real files);
     the order of the rows does not change."""
+    from .ffi import StriqueHipError, STRQ_ERR_ARG, STRQ_ERR_UNSUPPORTED
+    if stats is None:
+        stats = {}
+    stats.setdefault("failed", 0)
     if out is not None:
         print('\t'.join(HEADER), file=out)
     rows = []
+    records = route(stream, loci, log)
+    mine_set = None
+    if world > 1:
+        from . import dist as sdist
+        records = list(records)
+        items, cost = [], []
+        for qname, strand, targets, qlen in records:
+            for t in targets:
+                items.append((qname, strand, t)); cost.append(qlen)
+        mine_set = set(int(i) for i in sdist.shard_indices(len(items), rank, world, cost))
+        stats["items"] = items
 
     def flush(batch):
         if not batch:
             return
+        results = None
         try:
             results = counter.detect_batch([(t, raw, s) for _, _, t, s, raw in batch])
+        except StriqueHipError as e:
+            if e.code not in (STRQ_ERR_ARG, STRQ_ERR_UNSUPPORTED):
+                # a device fault or an out-of-memory condition will not go away read by read
+                log("Detector: device error, giving up: %s" % e, 'error')
+                raise SystemExit(3)
+            log("Detector: batch rejected (%s), retrying read by read" % e, 'warning')
         except Exception as e:                                    # a bad batch never kills the run
             log("Detector: batch failed (%s), retrying read by read" % e, 'warning')
+        if results is None:
             results = []
             for _, _, t, s, raw in batch:
                 try:
                     results.append(counter.detect(t, raw, s))
+                except StriqueHipError as e1:
+                    if e1.code not in (STRQ_ERR_ARG, STRQ_ERR_UNSUPPORTED):
+                        log("Detector: device error, giving up: %s" % e1, 'error')
+                        raise SystemExit(3)
+                    log("Detector: read failed: %s" % e1, 'warning'); results.append(None); stats["failed"] += 1
                 except Exception as e1:
-                    log("Detector: read failed: %s" % e1, 'warning'); results.append(None)
+                    log("Detector: read failed: %s" % e1, 'warning'); results.append(None); stats["failed"] += 1
         done = []
         for (seq, qname, target, strand, _), res in zip(batch, results):
-            if res is not None:
-                done.append((seq, '\t'.join(str(x) for x in (qname, target, strand) + tuple(res))))
+            if world > 1:
+                done.append((seq, res))
+            elif res is not None:
+                done.append((seq, format_row(qname, target, strand, res)))
         rows.extend(done)
         if out is not None:
             write_rows(out, done, header=False)
@@ -264,12 +364,15 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
     def fetch(qname):
         try:
             return get_raw(qname)
+        except NotImplementedError as e:          # a storage layout / filter the HDF5 subset reader does not cover
+            log("Detector: cannot read %s: %s" % (qname, e), 'error'); stats["failed"] += 1
+            return None
         except Exception as e:
             log("Detector: cannot read %s: %s" % (qname, e), 'warning')
             return None
 
     pool = None
-    if readers > 0:
+    if readers > 1:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=readers)
     pending = deque()                      # (qname, strand, [(seq, target)], raw or future), in input order
@@ -290,21 +393,12 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
 
     seq = 0
     lookahead = max(1, 2 * batch_size) if pool is not None else 0
-    for line in stream:
-        if line.startswith('@'):
-            continue
-        sr = decode_sam(line)
-        if not sr.QNAME:
-            log("Detector: Error parsing alignment \n%s" % line, 'error'); continue
-        strand = '+' if sr.FLAG & 0x10 == 0 else '-'
-        targets = intersect_targets(sr, loci)
-        if not targets:
-            log("Detector: No target for %s" % sr.QNAME, 'debug'); continue
-        mine = [(seq + i, t) for i, t in enumerate(targets) if (seq + i) % world == rank]
+    for qname, strand, targets, _qlen in records:
+        mine = [(seq + i, t) for i, t in enumerate(targets) if mine_set is None or (seq + i) in mine_set]
         seq += len(targets)
         if not mine:
             continue
-        pending.append((sr.QNAME, strand, mine, pool.submit(fetch, sr.QNAME) if pool is not None else fetch(sr.QNAME)))
+        pending.append((qname, strand, mine, pool.submit(fetch, qname) if pool is not None else fetch(qname)))
         drain(lookahead)
     drain(0)
     flush(batch)

@@ -34,33 +34,72 @@ def init_process_group(backend=None):
     return rank, world, local
 
 
-def gather_records(records, index, n_total, device=None):
-    """records: structured numpy array of this rank's results, index: their global positions.
-    Returns the full array on rank 0 (None elsewhere).  One all_gather of (index, payload)."""
+def gather_results(records, index, n_total, mods=None, device=None):
+    """The one collective of a run, used by `bench.py` and by `count` alike: every rank contributes the
+    fixed-size result records of the items it processed (structured numpy array), their global
+    positions `index` and, optionally, one byte string per record (`mods`: the modification patterns,
+    variable length) in a byte pool.  Three all_gathers of padded tensors (sizes, records + positions,
+    pool); with the "nccl" backend that is RCCL over xGMI, ~100 B per read.
+    Returns (records, mods) for all n_total items on rank 0, (None, None) elsewhere."""
     import torch
     import torch.distributed as dist
+    records = np.ascontiguousarray(records)
+    index = np.asarray(index, np.int64)
+    if mods is not None:
+        blobs = [m.encode() if isinstance(m, str) else bytes(m) for m in mods]
+        lens = np.array([len(b) for b in blobs], np.int64)
+        pool = np.frombuffer(b"".join(blobs), np.uint8)
+    else:
+        lens = np.zeros(len(records), np.int64); pool = np.zeros(0, np.uint8)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         out = np.zeros(n_total, dtype=records.dtype)
         out[index] = records
-        return out
+        out_m = None
+        if mods is not None:
+            out_m = [""] * n_total
+            for i, m in zip(index, mods):
+                out_m[int(i)] = m if isinstance(m, str) else bytes(m).decode()
+        return out, out_m
     world = dist.get_world_size()
     itemsize = records.dtype.itemsize
-    counts = [None] * world
-    dist.all_gather_object(counts, int(len(records)))
-    cap = max(counts)
-    payload = np.zeros((cap, itemsize), np.uint8)
-    payload[:len(records)] = records.view(np.uint8).reshape(len(records), itemsize)
-    idx = np.full(cap, -1, np.int64); idx[:len(records)] = index
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    t_pay = torch.from_numpy(payload).to(dev); t_idx = torch.from_numpy(idx).to(dev)
-    pays = [torch.empty_like(t_pay) for _ in range(world)]; idxs = [torch.empty_like(t_idx) for _ in range(world)]
+    sizes = torch.tensor([len(records), len(pool)], dtype=torch.int64, device=dev)
+    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [t.cpu().numpy() for t in all_sizes]
+    cap = max(1, max(int(t[0]) for t in all_sizes)); pool_cap = max(1, max(int(t[1]) for t in all_sizes))
+    # one row per record: [payload bytes | position (8) | pattern length (8)]
+    row = itemsize + 16
+    payload = np.zeros((cap, row), np.uint8)
+    if len(records):
+        payload[:len(records), :itemsize] = records.view(np.uint8).reshape(len(records), itemsize)
+        payload[:len(records), itemsize:itemsize + 8] = index.view(np.uint8).reshape(-1, 8)
+        payload[:len(records), itemsize + 8:] = lens.view(np.uint8).reshape(-1, 8)
+    pool_pad = np.zeros(pool_cap, np.uint8); pool_pad[:len(pool)] = pool
+    t_pay = torch.from_numpy(payload).to(dev); t_pool = torch.from_numpy(pool_pad).to(dev)
+    pays = [torch.empty_like(t_pay) for _ in range(world)]; pools = [torch.empty_like(t_pool) for _ in range(world)]
     dist.all_gather(pays, t_pay)
-    dist.all_gather(idxs, t_idx)
+    dist.all_gather(pools, t_pool)
     if dist.get_rank() != 0:
-        return None
+        return None, None
     out = np.zeros(n_total, dtype=records.dtype)
+    out_m = [""] * n_total if mods is not None else None
     for r in range(world):
-        k = counts[r]
-        ii = idxs[r][:k].cpu().numpy()
-        out[ii] = pays[r][:k].cpu().numpy().reshape(-1).view(records.dtype)
-    return out
+        k = int(all_sizes[r][0])
+        if not k:
+            continue
+        pr = pays[r][:k].cpu().numpy()
+        ii = np.ascontiguousarray(pr[:, itemsize:itemsize + 8]).view(np.int64).reshape(-1)
+        ll = np.ascontiguousarray(pr[:, itemsize + 8:]).view(np.int64).reshape(-1)
+        out[ii] = np.ascontiguousarray(pr[:, :itemsize]).reshape(-1).view(records.dtype)
+        if out_m is not None:
+            pl = pools[r].cpu().numpy().tobytes()
+            pos = 0
+            for i, ln in zip(ii, ll):
+                out_m[int(i)] = pl[pos:pos + int(ln)].decode(); pos += int(ln)
+    return out, out_m
+
+
+def gather_records(records, index, n_total, device=None):
+    """Records only (no byte strings): see gather_results."""
+    return gather_results(records, index, n_total, None, device)[0]

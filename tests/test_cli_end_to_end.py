@@ -140,3 +140,47 @@ def test_count_on_a_multi_read_fast5_with_mixed_targets(workdir, pm, cfg):
     rows = [l.split("\t") for l in out.read_text().splitlines()[1:]]
     assert [(r[0], r[1], r[2]) for r in rows] == [(rid, name, strand) for (rid, _), (name, strand, _) in zip(reads, plan)]
     assert [int(r[3]) for r in rows] == [n for _, _, n in plan]
+
+
+@pytest.mark.gpu
+def test_two_rank_count_equals_single_rank(workdir, pm, pm_mod, cfg):
+    """SURVEY.md 8e on real kernels: two fresh rank processes (gloo, both on HIP device 0) run `count`
+    with the modification model on 12 mixed reads -- the (read, target) pairs dealt by read length, one
+    gather of records + modification strings -- and rank 0's merged TSV equals the single-process TSV."""
+    import subprocess
+    import sys
+    import h5write
+    from conftest import ROOT
+    from strique_amd import cli, synth
+    table, table_mod = synth.KmerTable(pm), synth.KmerTable(pm_mod)
+    rng = np.random.default_rng(17)
+    reads, sam = [], ["@HD\tVN:1.0"]
+    for i in range(12):
+        name = ["c9orf72", "fmr1"][i % 2]; strand = "+-"[(i // 2) % 2]
+        chrom, b, e, repeat, prefix, suffix = cfg["repeat"][name]
+        nt = int(rng.integers(4000, 9000))
+        sig, _ = synth.make_read(table_mod if i % 3 == 0 else table, 8, i, nt, (repeat, prefix, suffix), int(rng.integers(5, 80)), strand=strand)
+        rid = "%08d-1111-4000-8000-%012d" % (i, i)
+        reads.append((rid, sig))
+        sam.append("\t".join([rid, "16" if strand == "-" else "0", chrom, str(b - 3000), "60", "12S%dM5S" % nt, "*", "0", "0", "*", "*"]))
+    bulk = workdir / "bulk2"; bulk.mkdir()
+    (bulk / "batch_0.fast5").write_bytes(h5write.multi_read_fast5(reads[:7]))
+    (bulk / "batch_1.fast5").write_bytes(h5write.multi_read_fast5(reads[7:]))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        cli.main(["index", str(bulk)])
+    (bulk / "reads.fofn").write_text(buf.getvalue())
+    (workdir / "aln2.sam").write_text("\n".join(sam) + "\n")
+    base = [str(bulk / "reads.fofn"), str(workdir / "r9_4_450bps.model"), str(workdir / "repeat_config.tsv"),
+            "--config", str(workdir / "STRique.json"), "--algn", str(workdir / "aln2.sam"),
+            "--mod_model", str(workdir / "r9_4_450bps_mCpG.model"), "--batch", "4"]
+    one = workdir / "one.tsv"
+    cli.main(["count"] + base + ["--out", str(one)])
+    two = workdir / "two.tsv"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "STRique.py"), "count"] + base + ["--out", str(two), "--backend", "gloo", "--share-device"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert len(one.read_text().splitlines()) == 13
+    assert two.read_text() == one.read_text()

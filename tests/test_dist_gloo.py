@@ -18,12 +18,14 @@ rec = np.zeros(len(mine), dtype=ffi.RESULT_DTYPE)
 rec["count"] = mine * 3 + 1          # stand-in for detect results of my shard
 rec["log_p"] = -1.5 * mine
 full = sdist.gather_records(rec, mine, n, device="cpu")
+full2, mods = sdist.gather_results(rec, mine, n, [("m" + str(i)) * (i %% 4) for i in mine], device="cpu")
 if rank == 0:
     assert full is not None and np.array_equal(full["count"], np.arange(n) * 3 + 1)
     assert np.array_equal(full["log_p"], -1.5 * np.arange(n))
+    assert np.array_equal(full2, full) and mods == [("m" + str(i)) * (i %% 4) for i in range(n)]
     print("GATHER_OK")
 else:
-    assert full is None
+    assert full is None and full2 is None and mods is None
 import torch.distributed as dist
 dist.barrier(); dist.destroy_process_group()
 ''' % ROOT
@@ -59,24 +61,26 @@ for i in range(37):
 
 class FakeCounter(object):                               # stands in for the GPU engine: rows depend on the inputs only
     def detect_batch(self, items):
-        return [(len(raw) %% 97, 1.5, 2.5, -3.0 * len(t), int(raw[0]), 7, "-") for t, raw, s in items]
+        return [(len(raw) %% 97, 1.5, 2.5, -3.0 * len(t), int(raw[0]), 7, "01"[len(raw) %% 2] * (len(raw) %% 5)) for t, raw, s in items]
 
 def get_raw(qname):
     i = int(qname[4:])
     return None if i == 11 else np.arange(100 + i, 300 + 2 * i)     # read11 has no fast5
 
 log = cli.Log("error")
-mine = cli.run_count(iter(lines), loci, get_raw, FakeCounter(), log, 5, rank, world)
+stats = {}
+mine = cli.run_count(iter(lines), loci, get_raw, FakeCounter(), log, 5, rank, world, stats=stats)
 import torch.distributed as dist
-gathered = [None] * world if rank == 0 else None
-dist.gather_object(mine, gathered, dst=0)
+merged = cli.gather_rows(mine, stats["items"], sdist)            # the run's one collective (records + byte pool)
 if rank == 0:
-    buf = io.StringIO(); cli.write_rows(buf, sorted(r for part in gathered for r in part))
+    buf = io.StringIO(); cli.write_rows(buf, merged)
     one = io.StringIO(); cli.run_count(iter(lines), loci, get_raw, FakeCounter(), log, 5, 0, 1, one)
     assert buf.getvalue() == one.getvalue(), (buf.getvalue(), one.getvalue())
     assert len(buf.getvalue().splitlines()) == 1 + 31                  # 37 records - 5 off-target - 1 without fast5
-    assert len(mine) in (15, 16)                                       # round-robin share
+    assert len(mine) in (15, 16)                                       # dealt by read length: equal shares
     print("CLI_SHARD_OK")
+else:
+    assert merged is None
 dist.barrier(); dist.destroy_process_group()
 ''' % (ROOT, ROOT)
 
