@@ -6,7 +6,7 @@
 namespace strq {
 
 struct ModTask {
-    const int32_t* path;     // emitting state of every sample of the window (flanked model), null = skip
+    const int32_t* path;     // emitting state of every sample of the window (flanked model); null = keep every sample
     const int32_t* tag;      // state tags of that model (1 = repeat section)
     const void* raw;         // raw signal at prefix_begin
     double* out;             // compacted, normalised, clipped samples
@@ -19,7 +19,7 @@ struct PatTask {
     const int32_t* tag;      // 2 = hub (s0/e0), 1 = modified branch
     char* out;
     int64_t T;
-    int32_t ok, pad_;
+    const int32_t* status;   // status of the modification-model Viterbi of this read (device): 0 = a path exists
 };
 
 int launch_mod_compact(hipStream_t s, const ModTask* tasks, int n, int64_t* out_len);

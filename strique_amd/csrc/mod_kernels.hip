@@ -24,12 +24,12 @@ mod_compact_kernel(const ModTask* __restrict__ tasks, int n, int64_t* __restrict
     if (i >= n) return;
     const ModTask tk = tasks[i];
     int64_t k = 0;
-    if (tk.path && tk.T > 0) {
+    if (tk.T > 0) {
         for (int64_t t0 = 0; t0 < tk.T; t0 += 64) {
             const int64_t t = t0 + lane;
             bool keep = false; double v = 0.0;
             if (t < tk.T) {
-                keep = tk.tag[tk.path[t]] == 1;
+                keep = tk.path ? tk.tag[tk.path[t]] == 1 : true;      // no path: the task is already the contiguous repeat stretch
                 v = tk.is_f64 ? reinterpret_cast<const double*>(tk.raw)[t] : (double)reinterpret_cast<const int16_t*>(tk.raw)[t];
                 v = (v - tk.c1) / tk.h1;
                 v = v * tk.h2 + tk.c2;
@@ -51,7 +51,7 @@ mod_pattern_kernel(const PatTask* __restrict__ tasks, int n, int64_t* __restrict
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const PatTask tk = tasks[i];
-    if (!tk.ok) { if (lane == 0) { if (tk.out) tk.out[0] = '-'; out_len[i] = tk.out ? 1 : 0; } return; }
+    if (*tk.status != 0) { if (lane == 0) { if (tk.out) tk.out[0] = '-'; out_len[i] = tk.out ? 1 : 0; } return; }
     int64_t k = 0;
     uint64_t carry = 1;                 // "previous state was a hub" for the first sample
     for (int64_t t0 = 0; t0 < tk.T; t0 += 64) {

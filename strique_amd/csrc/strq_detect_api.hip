@@ -154,10 +154,11 @@ void detect_state_free(strq_ctx* c)
 }
 
 // Modification pass for the reads of one sub-batch whose target has a modification model.
+// The flanked-model Viterbi ran in MARK mode (viterbi_kernels.hip): its result carries the first and
+// last sample decoded into the repeat section, which is all detect step 13 (STRique.py:608) needs.
 static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const std::vector<ReadCond>& rc,
                         const std::vector<ReadGeom>& geom, const std::vector<VitResult>& vres,
-                        const std::vector<int32_t>& vit_slot, const std::vector<VitTask>& h_vit,
-                        const std::vector<size_t>& path_off)
+                        const std::vector<int32_t>& vit_slot)
 {
     Batch& B = d->batch;
     hipStream_t st = c->stream;
@@ -166,18 +167,25 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     std::vector<int> who;                      // reads that reach the modification model
     for (int i = 0; i < nr; ++i) {
         const Target& t = d->targets[B.target[r0 + i]];
-        if (t.mod_model_id >= 0 && geom[i].gate && vres[vit_slot[i]].status == 0 && rc[i].status == COND_OK) who.push_back(i);
+        if (t.mod_model_id < 0 || !geom[i].gate || rc[i].status != COND_OK) continue;
+        const VitResult& v = vres[vit_slot[i]];
+        if (v.status == 2) { c->err = "modification pass: repeat window of 2^21 samples or more"; return STRQ_ERR_UNSUPPORTED; }
+        if (v.status == 0) who.push_back(i);
     }
     const int nm = (int)who.size();
     if (!nm) return STRQ_OK;
-    // 1. state paths of the flanked model
-    std::vector<VitTask> tb(nm); std::vector<VitResult> tr(nm); std::vector<int32_t*> tp(nm);
+    // 1. + 2. the samples decoded into repeat states: one contiguous stretch [enter, leave) of the window,
+    //         renormalised from the raw signal and clipped
+    std::vector<int64_t> len(nm), first(nm);
     size_t sig_tot = 0; std::vector<size_t> sig_off(nm);
     for (int k = 0; k < nm; ++k) {
         const int i = who[k];
-        tb[k] = h_vit[vit_slot[i]]; tr[k] = vres[vit_slot[i]];
-        tp[k] = d->path.as<int32_t>() + path_off[i];
-        sig_off[k] = sig_tot; sig_tot += (size_t)tb[k].T;
+        const VitResult& v = vres[vit_slot[i]];
+        const int64_t T = geom[i].suffix_end - geom[i].prefix_begin;
+        const int64_t enter = v.dbg[0], leave = v.dbg[1];
+        first[k] = enter ? enter - 1 : 0;
+        len[k] = enter ? (leave ? leave - 1 : T) - (enter - 1) : 0;
+        sig_off[k] = sig_tot; sig_tot += (size_t)len[k];
     }
     STRQ_HIP(c, d->modtask.reserve((size_t)nm * (sizeof(VitTask) + sizeof(VitResult) + 8 + sizeof(ModTask) + sizeof(PatTask)) + 256));
     VitTask* d_tb = d->modtask.as<VitTask>();
@@ -185,29 +193,21 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     int32_t** d_tp = reinterpret_cast<int32_t**>(d_tr + nm);
     ModTask* d_mt = reinterpret_cast<ModTask*>(d_tp + nm);
     PatTask* d_pt = reinterpret_cast<PatTask*>(d_mt + nm);
-    STRQ_HIP(c, hipMemcpyAsync(d_tb, tb.data(), (size_t)nm * sizeof(VitTask), hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, hipMemcpyAsync(d_tr, tr.data(), (size_t)nm * sizeof(VitResult), hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, hipMemcpyAsync(d_tp, tp.data(), (size_t)nm * 8, hipMemcpyHostToDevice, st));
-    if (launch_vit_traceback(st, d_tb, d_tr, d_tp, nm)) { c->err = "traceback launch failed"; return STRQ_ERR_DEVICE; }
-    // 2. samples decoded into repeat states, renormalised from the raw signal and clipped
     STRQ_HIP(c, d->modsig.reserve(sig_tot * 8 + 64));
     STRQ_HIP(c, d->modlen.reserve((size_t)nm * 16 + 64));
     std::vector<ModTask> mt(nm);
     for (int k = 0; k < nm; ++k) {
         const int i = who[k]; const Target& t = d->targets[B.target[r0 + i]];
         ModTask& m = mt[k];
-        m.path = tp[k]; m.tag = c->models[t.model_id]->h.state_tag;
-        m.raw = d->batch.raw.as<char>() + (size_t)(s0 + rc[i].off + geom[i].prefix_begin) * esz;
-        m.out = d->modsig.as<double>() + sig_off[k]; m.T = tb[k].T; m.is_f64 = B.dtype; m.pad_ = 0;
+        m.path = nullptr; m.tag = nullptr;          // contiguous stretch: every sample is kept
+        m.raw = d->batch.raw.as<char>() + (size_t)(s0 + rc[i].off + geom[i].prefix_begin + first[k]) * esz;
+        m.out = d->modsig.as<double>() + sig_off[k]; m.T = len[k]; m.is_f64 = B.dtype; m.pad_ = 0;
         m.c1 = rc[i].r_c1; m.h1 = rc[i].r_h1; m.h2 = rc[i].h2; m.c2 = rc[i].c2;
         m.clip_lo = d->ps.clip_lo; m.clip_hi = d->ps.clip_hi; m.mod_lo = t.mod_min; m.mod_hi = t.mod_max;
     }
     int64_t* d_len = d->modlen.as<int64_t>();
     STRQ_HIP(c, hipMemcpyAsync(d_mt, mt.data(), (size_t)nm * sizeof(ModTask), hipMemcpyHostToDevice, st));
     if (launch_mod_compact(st, d_mt, nm, d_len)) { c->err = "compaction launch failed"; return STRQ_ERR_DEVICE; }
-    std::vector<int64_t> len(nm);
-    STRQ_HIP(c, hipMemcpyAsync(len.data(), d_len, (size_t)nm * 8, hipMemcpyDeviceToHost, st));
-    STRQ_HIP(c, hipStreamSynchronize(st));
     // 3. Viterbi on the modification model, with state path
     std::map<int, std::vector<int>> by_shape;
     for (int k = 0; k < nm; ++k) {
@@ -222,7 +222,6 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
         HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
         bp2_off[k] = bp2; bp2 += (size_t)(len[k] + 1) * hm->h.n_states; p2_off[k] = p2; p2 += (size_t)len[k] + 1;
     }
-    // the flanked model's back-pointers are no longer needed: reuse the buffers
     STRQ_HIP(c, d->bp.reserve(bp2 * 2 + 64));
     STRQ_HIP(c, d->pattern.reserve(p2 * 5 + (size_t)nm * 8 + 64));
     int32_t* d_path2 = d->pattern.as<int32_t>(); char* d_chars = reinterpret_cast<char*>(d_path2 + p2);
@@ -237,21 +236,23 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
             slot2[k] = sidx; tp2[sidx] = d_path2 + p2_off[k]; mx = std::max(mx, hm->h.n_cells); ++sidx;
         }
         STRQ_HIP(c, hipMemcpyAsync(d_tb + first, vt2.data() + first, (size_t)(sidx - first) * sizeof(VitTask), hipMemcpyHostToDevice, st));
-        if (launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, 1, nullptr)) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
+        int* d_order = nullptr;
+        if (sidx - first <= 8192) {
+            d_order = d->order.as<int>() + first;
+            if (launch_vit_sort(st, d_tb + first, sidx - first, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
+        }
+        if (launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, 1, d_order)) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
       } }
     STRQ_HIP(c, hipMemcpyAsync(d_tp, tp2.data(), (size_t)nm * 8, hipMemcpyHostToDevice, st));
     if (launch_vit_traceback(st, d_tb, d_tr, d_tp, nm)) { c->err = "traceback launch failed"; return STRQ_ERR_DEVICE; }
-    std::vector<VitResult> r2(nm);
-    STRQ_HIP(c, hipMemcpyAsync(r2.data(), d_tr, (size_t)nm * sizeof(VitResult), hipMemcpyDeviceToHost, st));
-    STRQ_HIP(c, hipStreamSynchronize(st));
     // 4. pattern strings
     std::vector<PatTask> pt(nm);
     for (int k = 0; k < nm; ++k) {
         const int sl = slot2[k];
         HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
         pt[sl].path = tp2[sl]; pt[sl].tag = hm->h.state_tag; pt[sl].out = d_chars + p2_off[k]; pt[sl].T = len[k];
-        pt[sl].ok = r2[sl].status == 0 ? 1 : 0; pt[sl].pad_ = 0;
+        pt[sl].status = &d_tr[sl].status;
     }
     STRQ_HIP(c, hipMemcpyAsync(d_pt, pt.data(), (size_t)nm * sizeof(PatTask), hipMemcpyHostToDevice, st));
     if (launch_mod_pattern(st, d_pt, nm, d_len)) { c->err = "pattern launch failed"; return STRQ_ERR_DEVICE; }
@@ -466,28 +467,6 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         STRQ_HIP(c, hipGetLastError());
     }
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
-    // modification pass needs the state path of the flanked model: size the back-pointer arrays
-    std::vector<VitTask> h_vit;
-    std::vector<size_t> bp_off(nr, 0), path_off(nr, 0);
-    if (any_mod) {
-        h_vit.resize(nr);
-        STRQ_HIP(c, hipMemcpyAsync(h_vit.data(), d->vit.p, (size_t)nr * sizeof(VitTask), hipMemcpyDeviceToHost, st));
-        STRQ_HIP(c, hipStreamSynchronize(st));
-        size_t bp_cells = 0, path_cells = 0;
-        for (int i = 0; i < nr; ++i) {
-            const Target& t = d->targets[B.target[r0 + i]];
-            if (t.mod_model_id < 0) continue;
-            const VitTask& vt = h_vit[vit_slot[i]];
-            bp_off[i] = bp_cells; bp_cells += (size_t)(vt.T + 1) * c->models[t.model_id]->h.n_states;
-            path_off[i] = path_cells; path_cells += (size_t)vt.T + 1;
-        }
-        if (bp_cells * 2 > ((size_t)160 << 30)) { c->err = "modification pass: too many reads in one batch"; return STRQ_ERR_NOMEM; }
-        STRQ_HIP(c, d->bp.reserve(bp_cells * 2 + 64));
-        STRQ_HIP(c, d->path.reserve(path_cells * 4 + 64));
-        for (int i = 0; i < nr; ++i)
-            if (d->targets[B.target[r0 + i]].mod_model_id >= 0) h_vit[vit_slot[i]].bp = d->bp.as<uint16_t>() + bp_off[i];
-        STRQ_HIP(c, hipMemcpyAsync(d->vit.p, h_vit.data(), (size_t)nr * sizeof(VitTask), hipMemcpyHostToDevice, st));
-    }
     STRQ_HIP(c, hipEventRecord(d->ev[2], st));
     { int qi = 0;
       for (auto& v : vls) {
@@ -497,7 +476,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
             if (launch_vit_sort(st, d->vit.as<VitTask>() + v.first, v.count, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
         }
         const int rc2 = launch_viterbi(st, v.shape, v.max_states, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
-                                       c->queue.as<int>() + qi, c->n_cu, any_mod ? 1 : 0, d_order);
+                                       c->queue.as<int>() + qi, c->n_cu, any_mod ? 2 : 0, d_order);
         if (rc2) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
       } }
@@ -528,7 +507,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         }
     }
     if (any_mod) {
-        const int rcm = run_mod_pass(c, d, r0, nr, rc_out, geom, vres, vit_slot, h_vit, path_off);
+        const int rcm = run_mod_pass(c, d, r0, nr, rc_out, geom, vres, vit_slot);
         if (rcm) return rcm;
     }
     float ms;
@@ -654,7 +633,8 @@ int strq_batch_run(strq_ctx* c)
         int64_t full_env = 0;
         if (const char* e = getenv("STRQ_SUBBATCH_READS")) full_env = atoll(e);      // testing: force small sub-batches
         for (int64_t r = r0; r < B.n_reads && r < r0 + full; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
-        const int64_t cap = full_env > 0 ? std::min<int64_t>(full_env, 8192) : (mod_batch ? std::min<int64_t>(1024, full) : full);      // back-pointer memory (~60 MB per 50 kb read) bounds the modification pass
+        const int64_t cap = full_env > 0 ? std::min<int64_t>(full_env, 8192) : full;      // (the modification pass keeps back-pointers of the small dual model only: ~3 MB per 50 kb read)
+        (void)mod_batch;
         while (r1 < B.n_reads && r1 - r0 < cap) {
             const Target& t = d->targets[B.target[r1]];
             const int n = (int)(B.off[r1 + 1] - B.off[r1]);

@@ -94,7 +94,15 @@ template <int EPL, int SPL> struct VitLds {
 
 // SS: every model of the launch is single-stage (no silent state has a silent predecessor outside
 // its chain) -- the silent phase is then straight-line code: gather, chain sweeps, store.
-template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP, bool SS>
+//
+// MARK (modification pass): the flanked model is one-way -- prefix profile, repeat loop, suffix profile --
+// so the samples decoded into `repeat` states (STRique.py:608) are one contiguous stretch of the window.
+// Instead of back-pointers for every (time step, state) the best path carries, next to its repeat count,
+// the time of its first emission inside the repeat section and of its first emission after it: the 8
+// payload bytes of a cell hold  lo = count | enter[11:0] << 20,  hi = enter[21:12] | leave << 10  (windows below
+// 2^21 samples): the split keeps every update a 32-bit operation (64-bit shifts are slow on the VALU).
+#define VIT_MARK_T_MAX ((int64_t)1 << 21)
+template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP, bool SS, bool MARK = false>
 __global__ void __launch_bounds__((64 * VitLds<EPL, SPL>::WAVES))
 viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
                int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
@@ -107,23 +115,34 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     constexpr int DEMAX = DE_HI > DE_LO ? DE_HI : DE_LO;
     auto de_of = [](int s) constexpr { return s < (EPL + 1) / 2 ? DE_HI : DE_LO; };
     const double NEGINF = -__builtin_inf();
-    struct alignas(16) Cell { double v; int c; int pad; };
+    using Pay = std::conditional_t<MARK, uint64_t, int>;      // what rides along the best path
+    struct alignas(16) Cell { double v; Pay c; };
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     auto ldcell = [](const char* p, int boff) {      // one ds_read_b128
         const v4u q = *reinterpret_cast<const v4u*>(p + boff);
-        Cell x; x.v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x); x.c = (int)q.z; x.pad = 0;
+        Cell x; x.v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
+        if constexpr (MARK) x.c = ((uint64_t)q.w << 32) | q.z; else x.c = (int)q.z;
         return x;
     };
-    auto stcell = [](char* p, int boff, double v, int c) {      // one ds_write_b128
+    auto stcell = [](char* p, int boff, double v, Pay c) {      // one ds_write_b128
         const uint64_t u = __builtin_bit_cast(uint64_t, v);
-        v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = (unsigned)c; q.w = 0u;
+        v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32);
+        if constexpr (MARK) { q.z = (unsigned)c; q.w = (unsigned)((uint64_t)c >> 32); } else { q.z = (unsigned)c; q.w = 0u; }
         *reinterpret_cast<v4u*>(p + boff) = q;
+    };
+    auto pay_add = [](Pay v, int inc) -> Pay {       // count += inc (the count field never carries out of the low half)
+        if constexpr (MARK) return ((uint64_t)v & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)v + (uint32_t)inc);
+        else return v + inc;
+    };
+    auto shr1_pay = [](Pay v) -> Pay {               // payload of lane l-1
+        if constexpr (MARK) return ((uint64_t)(uint32_t)dpp_shr1_i32((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)dpp_shr1_i32((int)(uint32_t)v);
+        else return dpp_shr1_i32(v);
     };
     const VitModel* cur_model = nullptr;
     int n = 0, NP = 0, m_start = 0, m_end = 0, scell0 = 0, dummy = 0, start_state = 0;
     constexpr bool single_stage = SS;
     // everything a lane needs about the states it owns lives in registers (reloaded when the model changes)
-    int own_e[EPL], einc[EPL]; bool enorm[EPL];
+    int own_e[EPL], einc[EPL]; bool enorm[EPL]; bool etag[EPL];
     const char* esrc[EPL][DEMAX]; char* edst[EPL];
     double ea[EPL], eb[EPL], ec[EPL], elp[EPL][DEMAX];
     double ebf[EPL], ecf[EPL];     // branch-free emission: ecf - (x - ea)^2 * ebf  (uniform: ebf = 0; padding: ecf = -inf)
@@ -154,6 +173,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 ec[s] = kind ? M.emis_c[s * 64 + lane] : 0.0;
                 ebf[s] = kind == 1 ? eb[s] : 0.0; ecf[s] = kind ? ec[s] : NEGINF;
                 einc[s] = own_e[s] >= 0 ? M.count_inc[own_e[s]] : 0;
+                etag[s] = own_e[s] >= 0 && M.state_tag[own_e[s]] == 1;
                 edst[s] = vbase + 16 * (own_e[s] >= 0 ? s * 64 + lane : TRASH);
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j) {
@@ -209,7 +229,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             constexpr bool PIN = decltype(pin_c)::value;
             constexpr int OFF = decltype(off_c)::value;
             if constexpr (SS) {
-                double y[SPL]; int yc[SPL], arg[SPL];
+                double y[SPL]; Pay yc[SPL]; int arg[SPL];
                 Cell spc[SPL][DS];
 #pragma unroll
                 for (int s = 0; s < SPL; ++s)
@@ -217,20 +237,20 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     for (int j = 0; j < DS; ++j) spc[s][j] = ldcell(ssrc[s][j], OFF);
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    double cv[DS]; int cc[DS], ca[DS];
+                    double cv[DS]; Pay cc[DS]; int ca[DS];
 #pragma unroll
                     for (int j = 0; j < DS; ++j) { cv[j] = spc[s][j].v + slp[s][j]; cc[j] = spc[s][j].c; ca[j] = BP ? (int)(ssrc[s][j] - vbase) >> 4 : 0; }
                     tournament(cv, cc, ca, DS);
-                    double best = cv[0]; int bc = cc[0], a = ca[0];
-                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = -sinc[s]; a = dummy; }
-                    y[s] = best; yc[s] = bc + sinc[s]; arg[s] = a;
+                    double best = cv[0]; Pay bc = cc[0]; int a = ca[0];
+                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = pay_add((Pay)0, -sinc[s]); a = dummy; }
+                    y[s] = best; yc[s] = pay_add(bc, sinc[s]); arg[s] = a;
                 }
                 for (;;) {
                     bool win_any = false;
 #pragma unroll
                     for (int s = 0; s < SPL; ++s) {
                         const double tin = dpp_shr1_f64(y[s]) + clp[s];
-                        const int cin = dpp_shr1_i32(yc[s]) + sinc[s];
+                        const Pay cin = pay_add(shr1_pay(yc[s]), sinc[s]);
                         const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
                         y[s] = max_f64_raw(y[s], tin);
                         yc[s] = win ? cin : yc[s];
@@ -249,17 +269,17 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 }
                 return;
             }
-            double y[SPL], base_prev[SPL]; int yc[SPL], arg[SPL];
+            double y[SPL], base_prev[SPL]; Pay yc[SPL]; int arg[SPL];
 #pragma unroll
             for (int s = 0; s < SPL; ++s) { y[s] = NEGINF; yc[s] = 0; arg[s] = dummy; base_prev[s] = __builtin_nan(""); }
             for (int outer = 0;; ++outer) {
                 // (A) best non-chain in-edge of every silent state: emitting predecessors (final for
                 //     this time step) and silent predecessors that are not chain neighbours
                 bool base_changed = false;
-                double base[SPL]; int basec[SPL], basea[SPL];
+                double base[SPL]; Pay basec[SPL]; int basea[SPL];
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    double best = NEGINF; int bc = 0, a = dummy;
+                    double best = NEGINF; Pay bc = 0; int a = dummy;
 #pragma unroll
                     for (int j = 0; j < DS; ++j) {
                         const Cell pc = ldcell(ssrc[s][j], OFF);
@@ -269,8 +289,8 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         if (BP) a = gt ? (int)(ssrc[s][j] - vbase) >> 4 : a;
                         best = __builtin_fmax(best, c);
                     }
-                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = -sinc[s]; a = dummy; }
-                    base[s] = best; basec[s] = bc + sinc[s]; basea[s] = a;
+                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = pay_add((Pay)0, -sinc[s]); a = dummy; }
+                    base[s] = best; basec[s] = pay_add(bc, sinc[s]); basea[s] = a;
                     if (!(best == base_prev[s]) && !(best != best)) base_changed = true;
                 }
                 bool changed = false;
@@ -288,7 +308,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #pragma unroll
                         for (int s = 0; s < SPL; ++s) {
                             const double tin = dpp_shr1_f64(y[s]) + clp[s];
-                            const int cin = dpp_shr1_i32(yc[s]) + sinc[s];
+                            const Pay cin = pay_add(shr1_pay(yc[s]), sinc[s]);
                             const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
                             y[s] = max_f64_raw(y[s], tin);
                             yc[s] = win ? cin : yc[s];
@@ -324,20 +344,23 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         // one observation: emitting states from the buffer at RD into the buffer at WR, then its silent states
         auto step = [&](auto rd_c, double x, int64_t t) {
             constexpr int RD = decltype(rd_c)::value, WR = RD ? 0 : BUF;
-            double nv[EPL]; int nc[EPL], na[EPL];
+            double nv[EPL]; Pay nc[EPL]; int na[EPL];
+            const uint32_t tt1 = (uint32_t)(t + 1);                       // wave-uniform: scalar registers
+            const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
+            (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 Cell pcs[DEMAX];          // all reads of the slot in flight before the first use
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j)
                     if (j < de_of(s)) pcs[j] = ldcell(esrc[s][j], RD);
-                double cv[DEMAX]; int cc[DEMAX], ca[DEMAX];
+                double cv[DEMAX]; Pay cc[DEMAX]; int ca[DEMAX];
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j) {
                     if (j < de_of(s)) { cv[j] = pcs[j].v + elp[s][j]; cc[j] = pcs[j].c; ca[j] = BP ? (int)(esrc[s][j] - vbase) >> 4 : 0; }
                 }
                 tournament(cv, cc, ca, de_of(s));
-                const double best = cv[0]; const int bc = cc[0], a = ca[0];
+                const double best = cv[0]; const Pay bc = cc[0]; const int a = ca[0];
                 double em;
                 if (fast_em) {          // every observation of this window lies inside all uniform emissions
                     const double d = x - ea[s];
@@ -348,7 +371,16 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     const double eu = (x >= ea[s] && x <= eb[s]) ? ec[s] : NEGINF;
                     em = enorm[s] ? en : eu;
                 }
-                nv[s] = best + em; nc[s] = bc + einc[s]; na[s] = a;
+                nv[s] = best + em; na[s] = a;
+                if constexpr (MARK) {
+                    // first emission inside the repeat section / first emission after it, at time t + 1
+                    uint32_t lo = (uint32_t)bc + (uint32_t)einc[s], hi = (uint32_t)((uint64_t)bc >> 32);
+                    const bool entered = ((lo >> 20) | (hi & 0x3FFu)) != 0, left = (hi >> 10) != 0;
+                    const bool set_e = etag[s] && !entered, set_l = !etag[s] && entered && !left;
+                    lo |= set_e ? mark_e_lo : 0u;
+                    hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
+                    nc[s] = ((uint64_t)hi << 32) | lo;
+                } else nc[s] = bc + einc[s];
             }
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
@@ -394,9 +426,17 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         }
         const Cell fin = ldcell(vbase + 16 * m_end, (T & 1) ? BUF : 0);
         const double lp = fin.v;
-        const int cnt = fin.c;
-        VitResult r; r.logp = lp; r.counted = (lp > NEGINF) ? cnt : 0; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
+        VitResult r; r.logp = lp; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
         r.dbg[0] = r.dbg[1] = r.dbg[2] = r.dbg[3] = 0;
+        if constexpr (MARK) {
+            const uint32_t plo = (uint32_t)fin.c, phi = (uint32_t)((uint64_t)fin.c >> 32);
+            r.counted = (lp > NEGINF) ? (int64_t)(plo & 0xFFFFFu) : 0;
+            r.dbg[0] = (plo >> 20) | ((phi & 0x3FFu) << 12);       // time (1-based) of the first repeat-section emission, 0 = none
+            r.dbg[1] = phi >> 10;                                  // time of the first emission after the repeat section, 0 = none
+            if (tk.T >= VIT_MARK_T_MAX) r.status = 2;              // window too long for the packed marks
+        } else {
+            r.counted = (lp > NEGINF) ? (int64_t)fin.c : 0;
+        }
         results[ti] = r;     // every lane stores the same value
         VIT_FENCE();
     }
@@ -519,13 +559,15 @@ static int vit_launch_shape(hipStream_t stream, int max_cells, const VitTask* ta
     const int nw = VitLds<E_, S_>::WAVES;
     const size_t lds = (size_t)nw * 2 * VitLds<E_, S_>::BUF;
     const dim3 grid(n_cu), block(64 * nw);
-#define VIT_GO(BP_, SS_)                                                                                                  \
+#define VIT_GO(BP_, SS_, MK_)                                                                                             \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);       \
+        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_, MK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_, MK_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);       \
     } while (0)
-    if (want_bp) { if (single_stage) VIT_GO(true, true); else VIT_GO(true, false); }
-    else { if (single_stage) VIT_GO(false, true); else VIT_GO(false, false); }
+    // want_bp: 0 = count only, 1 = back-pointers, 2 = repeat-section marks carried along the best path
+    if (want_bp == 2) { if (single_stage) VIT_GO(false, true, true); else VIT_GO(false, false, true); }
+    else if (want_bp) { if (single_stage) VIT_GO(true, true, false); else VIT_GO(true, false, false); }
+    else { if (single_stage) VIT_GO(false, true, false); else VIT_GO(false, false, false); }
 #undef VIT_GO
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
