@@ -542,19 +542,23 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
 template <int R, int S, bool PK, int SEG, int WPE>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64 * SEG, 64 * SEG), amdgpu_waves_per_eu(WPE, WPE)))
 align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_groups,
-                         int* __restrict__ queue, AlignParams p)
+                         int* __restrict__ queue, AlignParams p, const int* __restrict__ group_list,
+                         const int* __restrict__ n_list)
 {
     extern __shared__ float lds_all[];
     __shared__ int next_group;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const char* ldsb = reinterpret_cast<const char*>(lds_all);
     const int lds_base = 0;                    // table offsets are relative to lds_all
+    // a second launch over the alignments the combine kernel listed (device-side count): see launch_align_segments
+    if (n_list) n_groups = __builtin_amdgcn_readfirstlane(*n_list);
     for (;;) {
         __syncthreads();                       // every wave is done with the previous table
         if (threadIdx.x == 0) next_group = atomicAdd(queue, 1);
         __syncthreads();
-        const int gi = __builtin_amdgcn_readfirstlane(next_group);
+        int gi = __builtin_amdgcn_readfirstlane(next_group);
         if (gi >= n_groups) break;
+        if (group_list) gi = __builtin_amdgcn_readfirstlane(group_list[gi]);
         {
             const AlignTask& t0 = tasks[(size_t)gi * SEG];      // all pieces share the table of the alignment
             if constexpr (PK) {
@@ -575,11 +579,18 @@ align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __res
     }
 }
 
+// Best piece of every alignment.  `list` / `n_list`: only the listed alignments (second round).
+// `min_score`: the pieces were cut with a shorter overlap than the worst-case span bound; that is exact
+// as long as the best score reaches min_score[a] (every path scoring that much spans less than the overlap
+// used) -- alignments that do not are appended to `redo` and run again with the worst-case overlap.
 __global__ void align_combine_kernel(const AlignTask* __restrict__ tasks, const AlignResult* __restrict__ seg, int n_align,
-                                     int segs, AlignResult* __restrict__ out, int32_t* __restrict__ pick)
+                                     int segs, AlignResult* __restrict__ out, int32_t* __restrict__ pick, int pick_base,
+                                     const int* __restrict__ list, const int* __restrict__ n_list,
+                                     const float* __restrict__ min_score, int* __restrict__ redo, int* __restrict__ redo_count)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n_align) return;
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= (n_list ? *n_list : n_align)) return;
+    if (list) a = list[a];
     int best_k = 0;
     float best = seg[(size_t)a * segs].best;
     for (int k = 1; k < segs; ++k) {
@@ -591,7 +602,8 @@ __global__ void align_combine_kernel(const AlignTask* __restrict__ tasks, const 
     AlignResult r = seg[t];
     r.j_end += tasks[t].col_off;
     out[a] = r;
-    pick[a] = (int32_t)t;
+    pick[a] = pick_base + (int32_t)t;
+    if (min_score && !(best >= min_score[a])) redo[atomicAdd(redo_count, 1)] = a;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -844,13 +856,13 @@ int align_segment_overlap(const AlignParams& p, int m)
 
 template <int R, int S, bool PK, int SEG, int WPE>
 static int launch_seg1(hipStream_t stream, const AlignTask* tasks, AlignResult* seg_results, int n_groups, int* queue,
-                       const AlignParams& p, int lds_dwords, int n_blocks)
+                       const AlignParams& p, int lds_dwords, int n_blocks, const int* group_list, const int* n_list)
 {
     const size_t lds_bytes = (size_t)lds_dwords * 4;
     (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
-                       tasks, seg_results, n_groups, queue, p);
+                       tasks, seg_results, n_groups, queue, p, group_list, n_list);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -859,7 +871,7 @@ static int launch_seg1(hipStream_t stream, const AlignTask* tasks, AlignResult* 
 
 int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* seg_results,
                           int n_groups, int segs, int* queue, const AlignParams& p, int lds_dwords,
-                          int tables_per_cu, int n_cu, int packed)
+                          int tables_per_cu, int n_cu, int packed, const int* group_list, const int* n_list)
 {
     if (!(p.open_h == p.ext_h && p.open_v == p.ext_v)) return 2;
     AlignParams ps = p;
@@ -870,7 +882,7 @@ int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tas
     const int n_blocks = tables_per_cu * n_cu;
 #define STRQ_SEGCASE(R_, S_, PK_, SEG_, WPE_)                                                             \
     if (R == R_ && S == S_ && (packed != 0) == PK_ && segs == SEG_ && wpe == WPE_)                        \
-        return launch_seg1<R_, S_, PK_, SEG_, WPE_>(stream, tasks, seg_results, n_groups, queue, ps, lds_dwords, n_blocks);
+        return launch_seg1<R_, S_, PK_, SEG_, WPE_>(stream, tasks, seg_results, n_groups, queue, ps, lds_dwords, n_blocks, group_list, n_list);
 #define STRQ_SEGSHAPE(R_, S_) STRQ_SEG_CONFIGS(STRQ_SEGCASE, R_, S_, true) STRQ_SEG_CONFIGS(STRQ_SEGCASE, R_, S_, false)
     STRQ_SHAPES(STRQ_SEGSHAPE)
 #undef STRQ_SEGSHAPE
@@ -879,11 +891,22 @@ int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tas
 }
 
 int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const AlignResult* seg_results, int n_align,
-                         int segs, AlignResult* results, int32_t* pick)
+                         int segs, AlignResult* results, int32_t* pick, int pick_base, const int* list, const int* n_list,
+                         const float* min_score, int* redo, int* redo_count)
 {
     if (n_align <= 0) return 0;
-    hipLaunchKernelGGL(align_combine_kernel, dim3((n_align + 255) / 256), dim3(256), 0, stream, tasks, seg_results, n_align, segs, results, pick);
+    hipLaunchKernelGGL(align_combine_kernel, dim3((n_align + 255) / 256), dim3(256), 0, stream, tasks, seg_results, n_align, segs,
+                       results, pick, pick_base, list, n_list, min_score, redo, redo_count);
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+float align_segment_min_score(const AlignParams& p, int m, int overlap_used)
+{
+    // inverse of align_segment_overlap for paths that score at least B: span <= m + (m * dist_offset - B) / c_h (+ 1 % + 64)
+    const double c_h = -(double)(p.open_h > p.ext_h ? p.open_h : p.ext_h);
+    const double h_ok = ((double)overlap_used - (double)m - 65.0) / 1.01;
+    const double b = (double)m * (double)p.dist_offset - h_ok * c_h;
+    return (float)(b + 1.0 + 1e-6 * (b < 0 ? -b : b));       // rounded up
 }
 
 }  // namespace strq

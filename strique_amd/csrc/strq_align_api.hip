@@ -181,6 +181,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_tables = v; }      // older name
     if (const char* e = getenv("STRQ_MAX_WAVES")) { const int v = atoi(e); if (v >= 4 && v <= 16) max_waves = v; }
     bool allow_pack = collapsed && !getenv("STRQ_NO_PACK");
+    // overlap the pieces are cut with first (the worst case is ~15 k columns for an 870-row flank); see the piece planning below
+    int ov_cap = 8192;
+    if (const char* e = getenv("STRQ_OVERLAP")) { const int v = atoi(e); ov_cap = v > 0 ? v : (1 << 30); }      // 0: always the worst-case overlap
     if (collapsed) {
         // Launch geometry.  Measured on MI355X (ms per 8192 alignments per 1000 columns computed, 870-row flanks,
         // tools/dp_sweep.py): one wave per table 0.94 (24-bit tables, 8 waves per CU) / 1.02 (float32, 6 waves);
@@ -190,7 +193,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         static const double rate[5][2] = {{0, 0}, {1.017, 0.941}, {0.79, 0.862}, {0, 0}, {0.69, 0.80}};
         double mean_n = 0, mean_l = 0; int cnt = 0; bool all_packable = allow_pack;
         for (int i = 0; i < nb; ++i) if (in.NS[i] == 1) {
-            mean_n += in.n[i]; mean_l += align_segment_overlap(c->ap, in.m[i]); ++cnt;
+            mean_n += in.n[i]; mean_l += std::min(align_segment_overlap(c->ap, in.m[i]), ov_cap); ++cnt;
             all_packable = all_packable && info[i].packed && info[i].n_hard == 0;
         }
         if (cnt) { mean_n /= cnt; mean_l /= cnt; }
@@ -274,41 +277,72 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         if (NS > 1) n_up += (int)v.size();
     }
     { size_t up = n_tasks; for (auto& L : launches) if (L.NS > 1) { L.first_up = (int)up; up += L.count; } }
-    // piece boundaries and checkpoint areas
+    // Piece boundaries and checkpoint areas.  Two geometries per segmented launch: the pieces that run first
+    // are cut with a short overlap (`ov_fast` columns), which is exact whenever the alignment's best score
+    // reaches align_segment_min_score -- true for every read that contains the flank; the combine kernel
+    // lists the alignments that do not, and those run a second time with the worst-case overlap (`safe`
+    // pieces, same checkpoint areas).  Task array: [fast pieces | upper strips | heads | safe pieces].
     struct Piece { int col_off, n; size_t ck; };
-    std::vector<Piece> pieces(n_tasks);
+    const size_t safe0 = n_tasks + n_up + (size_t)nb;
+    std::vector<Piece> pieces(n_tasks), safe(n_tasks);
+    std::vector<float> min_score(nb, -INFINITY);            // by alignment position
+    std::vector<char> two_round(launches.size(), 0);
     std::vector<size_t> ck_up(nb, 0);
     size_t ck_floats = 0;
-    for (auto& L : launches) {
+    auto cut = [](int n, int segs, int ov, Piece* out) {     // returns the number of pieces used
+        int use = segs;
+        while (use > 1 && (ov <= 0 || (long)n < (long)(use + 1) * ov)) --use;      // every piece owns >= `overlap` columns
+        const long len = use > 1 ? ((long)n + (long)(use - 1) * ov + use - 1) / use : n;      // columns each piece computes
+        long o = 0;                                                                        // columns owned so far
+        for (int k = 0; k < segs; ++k) {
+            if (k >= use) { out[k].col_off = 0; out[k].n = 0; continue; }
+            const long start = k == 0 ? 0 : o - ov;
+            long end = k == use - 1 ? n : start + len; if (end > n) end = n;
+            out[k].col_off = (int)start; out[k].n = (int)(end - start);
+            o = end;
+        }
+        return use;
+    };
+    for (size_t li = 0; li < launches.size(); ++li) {
+        auto& L = launches[li];
         for (int x = 0; x < L.count; ++x) {
-            const int i = out.order[L.first + x];
+            const int pos = L.first + x, i = out.order[pos];
             const int n = in.n[i], R = in.R[i], ov = overlap[i];
             const size_t per_ckpt = (size_t)STRQ_CKPT_FIELDS(R) * 64;
-            int use = L.segs;
-            while (use > 1 && (ov <= 0 || (long)n < (long)(use + 1) * ov)) --use;      // every piece owns >= `overlap` columns
-            const long len = use > 1 ? ((long)n + (long)(use - 1) * ov + use - 1) / use : n;      // columns each piece computes
-            long o = 0;                                                                        // columns owned so far
+            Piece* pf = &pieces[(size_t)L.first_task + (size_t)x * L.segs];
+            Piece* ps = &safe[(size_t)L.first_task + (size_t)x * L.segs];
+            cut(n, L.segs, ov, ps);
+            const int ov_fast = std::min(ov, ov_cap);
+            if (L.segs > 1 && ov_fast < ov && cut(n, L.segs, ov_fast, pf) > 1) {
+                min_score[pos] = align_segment_min_score(c->ap, in.m[i], ov_fast);
+                two_round[li] = 1;
+            } else {
+                for (int k = 0; k < L.segs; ++k) pf[k] = ps[k];
+            }
             for (int k = 0; k < L.segs; ++k) {
-                Piece& pc = pieces[(size_t)L.first_task + (size_t)x * L.segs + k];
-                if (k >= use) { pc = {0, 0, ck_floats}; continue; }
-                const long start = k == 0 ? 0 : o - ov;
-                long end = k == use - 1 ? n : start + len; if (end > n) end = n;
-                pc.col_off = (int)start; pc.n = (int)(end - start); pc.ck = ck_floats;
-                ck_floats += (size_t)align_num_ckpts(pc.n) * per_ckpt;
-                o = end;
+                pf[k].ck = ps[k].ck = ck_floats;
+                ck_floats += (size_t)align_num_ckpts(std::max(pf[k].n, ps[k].n)) * per_ckpt;
             }
             if (L.NS > 1) { ck_up[i] = ck_floats; ck_floats += (size_t)align_num_ckpts(n) * per_ckpt; }
         }
     }
+    bool any_two_round = false;
+    for (char t : two_round) any_two_round |= t != 0;
+    const size_t n_all_tasks = safe0 + (any_two_round ? n_tasks : 0);
     STRQ_HIP(c, c->ckpt.reserve(ck_floats * 4 + 256));
-    STRQ_HIP(c, c->tasks.reserve((n_tasks + n_up + nb) * sizeof(AlignTask)));
-    STRQ_HIP(c, c->results.reserve((n_tasks + nb) * sizeof(AlignResult) + (size_t)nb * 4 + 64));
-    std::vector<AlignTask> tasks(n_tasks + n_up + nb);      // pieces, upper strips, one head per alignment
+    STRQ_HIP(c, c->tasks.reserve(n_all_tasks * sizeof(AlignTask)));
+    // results: [fast pieces | per alignment | safe pieces], then pick, min_score, redo lists and counters
+    STRQ_HIP(c, c->results.reserve((2 * n_tasks + nb) * sizeof(AlignResult) + (size_t)nb * 12 + launches.size() * 4 + 256));
+    std::vector<AlignTask> tasks(n_all_tasks);      // pieces, upper strips, one head per alignment, safe pieces
     AlignTask* d_tasks = c->tasks.as<AlignTask>();
     AlignTask* d_heads = d_tasks + n_tasks + n_up;
     AlignResult* d_seg = c->results.as<AlignResult>();
     AlignResult* d_res = d_seg + n_tasks;
-    int32_t* d_pick = reinterpret_cast<int32_t*>(d_res + nb);
+    AlignResult* d_seg_safe = d_res + nb;
+    int32_t* d_pick = reinterpret_cast<int32_t*>(d_seg_safe + n_tasks);
+    float* d_min_score = reinterpret_cast<float*>(d_pick + nb);
+    int* d_redo = reinterpret_cast<int*>(d_min_score + nb);
+    int* d_redo_count = d_redo + nb;                // one counter per launch
     for (auto& L : launches) {
         for (int x = 0; x < L.count; ++x) {
             const int pos = L.first + x, i = out.order[pos];
@@ -329,10 +363,15 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             tasks[n_tasks + n_up + pos] = strip(0, M, 0);       // head: what finalize reads (rec, m_total, n)
             if (L.NS == 1) {
                 for (int k = 0; k < L.segs; ++k) {
-                    const Piece& pc = pieces[(size_t)L.first_task + (size_t)x * L.segs + k];
-                    AlignTask t = strip(0, M, pc.ck);
-                    t.levels += pc.col_off; t.n = pc.n; t.col_off = pc.col_off;
-                    tasks[(size_t)L.first_task + (size_t)x * L.segs + k] = t;
+                    const size_t ti = (size_t)L.first_task + (size_t)x * L.segs + k;
+                    AlignTask t = strip(0, M, pieces[ti].ck);
+                    t.levels += pieces[ti].col_off; t.n = pieces[ti].n; t.col_off = pieces[ti].col_off;
+                    tasks[ti] = t;
+                    if (any_two_round) {
+                        AlignTask u = strip(0, M, safe[ti].ck);
+                        u.levels += safe[ti].col_off; u.n = safe[ti].n; u.col_off = safe[ti].col_off;
+                        tasks[safe0 + ti] = u;
+                    }
                 }
             } else {
                 const int rows0 = 64 * R;
@@ -341,11 +380,16 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 top.bnd_out = bnd; bot.bnd_in = bnd;
                 bot.up = d_tasks + L.first_up + x;
                 tasks[(size_t)L.first_task + x] = bot; tasks[(size_t)L.first_up + x] = top;
+                if (any_two_round) tasks[safe0 + (size_t)L.first_task + x] = bot;
             }
         }
     }
     STRQ_HIP(c, hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(AlignTask), hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, hipMemsetAsync(d_seg, 0, (n_tasks + nb) * sizeof(AlignResult), st));
+    STRQ_HIP(c, hipMemsetAsync(d_seg, 0, (2 * n_tasks + nb) * sizeof(AlignResult), st));
+    if (any_two_round) {
+        STRQ_HIP(c, hipMemcpyAsync(d_min_score, min_score.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+        STRQ_HIP(c, hipMemsetAsync(d_redo_count, 0, launches.size() * 4, st));
+    }
     size_t scratch_words = 0;
     for (auto& L : launches) scratch_words = std::max(scratch_words, align_trace_scratch_words_per_wave(L.R));
     const int trace_wpb = 8;
@@ -373,13 +417,25 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             ++qi; ++out.n_launches;
         }
     }
-    for (auto& L : launches)
-        if (launch_align_combine(st, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, d_res + L.first, d_pick + L.first)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
+    for (size_t li = 0; li < launches.size(); ++li) {
+        auto& L = launches[li];
+        int* redo = d_redo + L.first; int* cnt = d_redo_count + li;
+        if (launch_align_combine(st, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, d_res + L.first, d_pick + L.first, L.first_task,
+                                 nullptr, nullptr, two_round[li] ? d_min_score + L.first : nullptr, redo, cnt)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
+        if (!two_round[li]) continue;
+        // second round (normally empty): the listed alignments again, cut with the worst-case overlap
+        if (launch_align_segments(st, L.R, S, d_tasks + safe0 + L.first_task, d_seg_safe + L.first_task, L.count, L.segs, c->queue.as<int>() + qi,
+                                  c->ap, L.lds_floats, L.tables, c->n_cu, L.packed, redo, cnt)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
+        ++qi;
+        if (launch_align_combine(st, d_tasks + safe0 + L.first_task, d_seg_safe + L.first_task, L.count, L.segs, d_res + L.first, d_pick + L.first,
+                                 (int)safe0 + L.first_task, redo, cnt, nullptr, nullptr, nullptr)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
+    }
     STRQ_HIP(c, hipEventRecord(c->ev[3], st));
     for (auto& L : launches) {
-        // the trace pass keeps one table per wave (it re-runs a few blocks of one piece per alignment)
+        // the trace pass keeps one table per wave (it re-runs a few blocks of one piece per alignment); pick holds
+        // absolute task indices (a fast or a safe piece)
         const int wpb = std::min(trace_wpb, (160 * 1024) / (std::max(L.lds_floats, 1) * 4));
-        if (launch_align(st, L.R, S, d_tasks + L.first_task, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, wpb, c->n_cu,
+        if (launch_align(st, L.R, S, d_tasks, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, wpb, c->n_cu,
                          c->scratch.as<uint64_t>(), 1, 0, L.packed, d_pick + L.first)) { c->err = "trace launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
     }

@@ -186,28 +186,41 @@ def _overlap(m, params):
     return int(m + m * off / -max(open_h, ext_h) * 1.01 + 64.0) + 1
 
 
+def _seams(n, segs, ov):
+    use = segs
+    while use > 1 and n < (use + 1) * ov:
+        use -= 1
+    if use < 2:
+        return [], []
+    ln = (n + (use - 1) * ov + use - 1) // use
+    own_end = [ln + j * (ln - ov) for j in range(use - 1)]            # last column owned by piece j
+    return own_end, [e - ov for e in own_end]                         # ... and the cold-start column of piece j + 1
+
+
 @pytest.mark.parametrize("segs", [2, 4])
-@pytest.mark.parametrize("k,n", [(40, 30000), (145, 100000)])
-def test_column_segments_seam_adversarial(ctx, orc, monkeypatch, segs, k, n):
+@pytest.mark.parametrize("k,n,ov_env", [(40, 30000, None), (145, 100000, None), (145, 100000, "0"), (145, 60000, "1500")])
+def test_column_segments_seam_adversarial(ctx, orc, monkeypatch, segs, k, n, ov_env):
     """Several waves per alignment (column segments with a cold-started overlap): the flank
     is planted so that its best path ends exactly on / next to every piece boundary, starts exactly at a
     piece's cold-start column, lies inside an overlap zone, or occurs twice with identical samples in
     two different pieces (tie: the leftmost must win).  Score bits, end column, start column and the
-    whole path must equal the single-matrix oracle's."""
+    whole path must equal the single-matrix oracle's.  The pieces are first cut with a short overlap
+    (STRQ_OVERLAP, default 8192 columns) and alignments whose best score does not certify it run again
+    with the worst-case overlap: "0" forces the worst case everywhere, "1500" sends the weak alignments
+    through the second round."""
     rng = np.random.default_rng(1000 * segs + k)
     params = orc.align_params(None)
     ctx.set_align_params(*[float(v) for v in params])
     monkeypatch.setenv("STRQ_SEG", str(segs))
+    if ov_env is not None:
+        monkeypatch.setenv("STRQ_OVERLAP", ov_env)
     scale = 0.45
     cls = rng.uniform(60, 120, k).astype(np.float32)
     flank = np.repeat(cls, 6)
     m = len(flank)
     lval = (40 + scale * np.arange(256)).astype(np.float32)
     ov = _overlap(m, params)
-    assert n >= (segs + 1) * ov
-    ln = (n + (segs - 1) * ov + segs - 1) // segs
-    own_end = [ln + j * (ln - ov) for j in range(segs - 1)]            # last column owned by piece j
-    cold = [e - ov for e in own_end]                                   # cold-start column of piece j + 1
+    ov_fast = ov if ov_env == "0" else min(ov, int(ov_env) if ov_env else 8192)
     emb = np.repeat(np.clip(np.round((cls - 40) / scale), 0, 255).astype(np.uint8), rng.integers(6, 10, k))
     w = len(emb)
 
@@ -215,14 +228,18 @@ def test_column_segments_seam_adversarial(ctx, orc, monkeypatch, segs, k, n):
         return np.repeat(rng.integers(30, 200, n // 5 + 1), rng.integers(3, 10, n // 5 + 1))[:n].astype(np.uint8)
 
     cases = []
-    for e, c0 in zip(own_end, cold):
-        for end in (e - 1, e, e + 1, e + 2, e + w // 2):               # path ends around the boundary
-            cases.append([end - w])
-        for start in (c0 - 1, c0, c0 + 1, c0 + ov // 2):               # path starts at the cold column / inside the overlap
-            cases.append([start])
-        cases.append([c0 - w - 50, e + 50])                            # identical occurrences left and right of the seam
-        cases.append([e + 50, c0 - w - 50])
-    cases.append([])                                                   # no occurrence at all
+    for o in sorted({ov, ov_fast}):
+        own_end, cold = _seams(n, segs, o)
+        for e, c0 in zip(own_end, cold):
+            for end in (e - 1, e, e + 1, e + 2, e + w // 2):               # path ends around the boundary
+                cases.append([end - w])
+            for start in (c0 - 1, c0, c0 + 1, c0 + o // 2):                # path starts at the cold column / inside the overlap
+                cases.append([start])
+            cases.append([c0 - w - 50, e + 50])                            # identical occurrences left and right of the seam
+            cases.append([e + 50, c0 - w - 50])
+    cases.append([])                                                       # no occurrence at all: a weak best score
+    cases.append([])
+    assert len(cases) > 4
     levels, offs = [], [0]
     for plant in cases:
         lv = background()
