@@ -159,15 +159,26 @@ class Fast5Index(object):
                             except Exception:
                                 print("[ERROR] Failed to open %s, skip file for indexing" % m.name, file=sys.stderr)
                 continue
-            f = fast5.H5File(fpath)
-            top = f.listdir("/")
-            if "Raw" in top:
-                grp = "/Raw/Reads/" + f.listdir("/Raw/Reads")[0]
-                yield "\t".join([rel, f.attrs(grp)["read_id"]])
-            else:
-                for g in top:
-                    if g.startswith("read_"):
-                        yield "\t".join([os.path.join(rel, g), f.attrs("/%s/Raw" % g).get("read_id", g[5:])])
+            try:                                      # like the reference: a file that cannot be opened is reported and skipped
+                f = fast5.H5File(fpath)
+                top = f.listdir("/")
+                recs = []
+                if "Raw" in top:
+                    rd = f.listdir("/Raw/Reads")[0]
+                    grp = "/Raw/Reads/" + rd
+                    rid = f.attrs(grp).get("read_id")
+                    if rid is None:                       # attribute in a form the subset reader does not decode
+                        rid = os.path.splitext(os.path.basename(fpath))[0]
+                    recs.append("\t".join([rel, rid]))
+                else:
+                    for g in top:
+                        if g.startswith("read_"):
+                            recs.append("\t".join([os.path.join(rel, g), f.attrs("/%s/Raw" % g).get("read_id", g[5:])]))
+            except Exception as e:
+                print("[ERROR] Failed to open %s (%s), skip file for indexing" % (fpath, e), file=sys.stderr)
+                continue
+            for r in recs:
+                yield r
 
 
 def count(argv):

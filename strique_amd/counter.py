@@ -110,19 +110,31 @@ class repeatCounter(object):
             return []
         tcs = [self._classifier_for(t, s) for t, _, s in items]
         sigs = [np.asarray(r) for _, r, _ in items]
-        integer = all(s.dtype.kind in 'iu' and s.dtype.itemsize <= 2 for s in sigs)
-        if integer:
-            arrs = [s.astype(np.int16, copy=False) for s in sigs]; stats = None
-        else:
-            arrs = [s.astype(np.float64) for s in sigs]
-            stats = np.array([self._host_stats(a) for a in arrs])
-        off = np.zeros(len(arrs) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in arrs])
-        res = self.ctx.detect_batch(np.concatenate(arrs), off, [tc.target_id for tc in tcs], stats)
-        mods = self.ctx.batch_fetch_mod() if self.pm is not self.pm_mod else ['-'] * len(res)
-        out = []
-        for r, m in zip(res, mods):
-            n = int(r['count']); p = float(r['log_p']) if n or r['log_p'] != 0 else 0
-            out.append((n, float(r['score_prefix']), float(r['score_suffix']), p, int(r['offset']), int(r['ticks']), m))
+        # DAC samples that fit int16 take the all-GPU path (exact histograms); everything else is float64
+        # (order statistics by numpy on the host).  A mixed batch runs as two device batches.
+        def fits_int16(s):
+            if s.dtype.kind not in 'iu':
+                return False
+            if s.dtype in (np.int8, np.uint8, np.int16):
+                return True
+            return s.size == 0 or (int(s.min()) >= -32768 and int(s.max()) <= 32767)
+        is_int = [fits_int16(s) for s in sigs]
+        out = [None] * len(items)
+        for want_int in (True, False):
+            idx = [i for i, f in enumerate(is_int) if f == want_int]
+            if not idx:
+                continue
+            if want_int:
+                arrs = [sigs[i].astype(np.int16, copy=False) for i in idx]; stats = None
+            else:
+                arrs = [sigs[i].astype(np.float64) for i in idx]
+                stats = np.array([self._host_stats(a) for a in arrs])
+            off = np.zeros(len(arrs) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in arrs])
+            res = self.ctx.detect_batch(np.concatenate(arrs), off, [tcs[i].target_id for i in idx], stats)
+            mods = self.ctx.batch_fetch_mod() if self.pm is not self.pm_mod else ['-'] * len(res)
+            for i, r, m in zip(idx, res, mods):
+                n = int(r['count']); p = float(r['log_p']) if n or r['log_p'] != 0 else 0
+                out[i] = (n, float(r['score_prefix']), float(r['score_suffix']), p, int(r['offset']), int(r['ticks']), m)
         return out
 
     def detect(self, target_name, raw_signal, strand):

@@ -4,7 +4,8 @@ Covers what STRique's fast5Index.get_raw needs for single- and multi-read fast5 
 (reference STRique_lib/fast5Index.py:76-84,220-233): old-style groups (symbol tables, B-tree v1,
 local heaps), version-1 object headers with continuation blocks, chunked int16 datasets with the
 deflate (and optional shuffle) filter, contiguous datasets, and the string / integer attributes that
-carry `read_id`.  HDF5 features outside that subset raise NotImplementedError.
+carry `read_id` (fixed-length and variable-length strings, the latter through the global heap), files with a
+user block (non-zero base address).  HDF5 features outside that subset raise NotImplementedError.
 """
 import mmap
 import struct
@@ -28,8 +29,13 @@ class H5File(object):
                 except (ValueError, OSError):          # empty file, or a file system without mmap
                     self.buf = fp.read()
         b = self.buf
-        if b[:8] != _SIG:
-            raise ValueError("not an HDF5 file")
+        sb = 0                                    # the superblock sits at 0 or, behind a user block, at 512, 1024, 2048, ...
+        while bytes(b[sb:sb + 8]) != _SIG:
+            sb = 512 if sb == 0 else sb * 2
+            if sb + 8 > len(b):
+                raise ValueError("not an HDF5 file")
+        if sb:
+            self.buf = b = memoryview(b)[sb:]     # addresses are relative to the base address = start of the superblock here
         ver = b[8]
         if ver not in (0, 1):
             raise NotImplementedError("HDF5 superblock version %d" % ver)
@@ -40,13 +46,15 @@ class H5File(object):
         p = 24 if ver == 0 else 28
         self.base, = struct.unpack_from("<Q", b, p)
         p += 32                                   # base, free-space, eof, driver-info addresses
+        if self.base not in (0, UNDEF) and self.base != sb:
+            raise NotImplementedError("HDF5 base address %d differs from the superblock offset %d" % (self.base, sb))
         # root group symbol table entry
         self.root = self._symbol_entry(p)
 
     # ---- low level -----------------------------------------------------------------------
     def _symbol_entry(self, p):
         name_off, ohdr, cache_type = struct.unpack_from("<QQI", self.buf, p)
-        scratch = self.buf[p + 24:p + 40]
+        scratch = bytes(self.buf[p + 24:p + 40])
         return {"name_off": name_off, "ohdr": ohdr, "cache": cache_type, "scratch": scratch}
 
     def _messages(self, addr):
@@ -64,7 +72,7 @@ class H5File(object):
             end = p + size
             while p + 8 <= end and seen < nmsg:
                 mtype, msize, mflags = struct.unpack_from("<HHB", b, p)
-                payload = b[p + 8:p + 8 + msize]
+                payload = bytes(b[p + 8:p + 8 + msize])
                 p += 8 + msize
                 seen += 1
                 if mtype == 0x10:                    # continuation
@@ -75,14 +83,15 @@ class H5File(object):
 
     def _heap_string(self, heap_addr, off):
         b = self.buf
-        if b[heap_addr:heap_addr + 4] != b"HEAP":
+        if bytes(b[heap_addr:heap_addr + 4]) != b"HEAP":
             raise ValueError("bad local heap")
         data_addr, = struct.unpack_from("<Q", b, heap_addr + 24)
         p = data_addr + off
-        e = b.find(b"\x00", p)
+        chunk = bytes(b[p:p + 1024])
+        e = chunk.find(b"\x00")
         if e < 0:
             raise ValueError("unterminated heap string")
-        return b[p:e].decode()
+        return chunk[:e].decode()
 
     def _group_entries(self, ohdr):
         """name -> object header address of an old-style group."""
@@ -120,7 +129,7 @@ class H5File(object):
 
     def _walk_group_btree(self, addr, heap, out):
         b = self.buf
-        if b[addr:addr + 4] == b"SNOD":
+        if bytes(b[addr:addr + 4]) == b"SNOD":
             n, = struct.unpack_from("<H", b, addr + 6)
             p = addr + 8
             for _ in range(n):
@@ -128,7 +137,7 @@ class H5File(object):
                 out[self._heap_string(heap, e["name_off"])] = e["ohdr"]
                 p += 40
             return
-        if b[addr:addr + 4] != b"TREE":
+        if bytes(b[addr:addr + 4]) != b"TREE":
             raise ValueError("bad group B-tree node")
         level = b[addr + 5]
         n, = struct.unpack_from("<H", b, addr + 6)
@@ -168,14 +177,38 @@ class H5File(object):
             cls = dt[0] & 0x0F
             size, = struct.unpack_from("<I", dt, 4)
             raw = pl[p:p + size]
+            raw = bytes(raw)
             if cls == 3:
                 out[name] = raw.split(b"\x00")[0].decode(errors="replace")
+            elif cls == 9 and (dt[1] & 0x0F) == 1 and len(raw) >= 16:
+                # variable-length string (what h5py / ont_fast5_api write for read_id): length, global heap
+                # collection address, object index
+                _ln, gaddr, gidx = struct.unpack_from("<IQI", raw, 0)
+                val = self._global_heap_object(gaddr, gidx)
+                if val is not None:
+                    out[name] = val.split(b"\x00")[0].decode(errors="replace")
             elif cls == 0 and size in (1, 2, 4, 8):
                 signed = bool(dt[1] & 0x08)
                 out[name] = int.from_bytes(raw, "little", signed=signed)
             elif cls == 1 and size in (4, 8):
                 out[name] = struct.unpack("<f" if size == 4 else "<d", raw)[0]
         return out
+
+    def _global_heap_object(self, addr, index):
+        """Object `index` of the global heap collection at `addr` (HDF5 spec III.E), or None."""
+        b = self.buf
+        if addr in (0, UNDEF) or bytes(b[addr:addr + 4]) != b"GCOL":
+            return None
+        size, = struct.unpack_from("<Q", b, addr + 8)
+        p, end = addr + 16, addr + size
+        while p + 16 <= end:
+            idx, _refs, _res, osize = struct.unpack_from("<HHIQ", b, p)
+            if idx == 0:
+                break                                   # free space object: end of the used part
+            if idx == index:
+                return bytes(b[p + 16:p + 16 + osize])
+            p += 16 + ((osize + 7) & ~7)
+        return None
 
     def dataset(self, path):
         b = self.buf
@@ -247,7 +280,7 @@ class H5File(object):
         b = self.buf
         if addr == UNDEF:
             return
-        if b[addr:addr + 4] != b"TREE":
+        if bytes(b[addr:addr + 4]) != b"TREE":
             raise ValueError("bad chunk B-tree node")
         level = b[addr + 5]
         n, = struct.unpack_from("<H", b, addr + 6)
@@ -261,7 +294,7 @@ class H5File(object):
             if level == 0:
                 if fmask:
                     raise NotImplementedError("chunk with skipped filters")
-                yield offs[0], b[child:child + csize]
+                yield offs[0], bytes(b[child:child + csize])
             else:
                 for x in self._chunks(child, rank):
                     yield x

@@ -41,6 +41,24 @@ def _string_attr(name, value):
     return _msg(0x0C, struct.pack("<BxHHH", 1, len(name_b), len(dt), len(ds)) + pad(name_b) + pad(dt) + pad(ds) + val)
 
 
+def _vlen_string_attr(f, name, value):
+    """The form h5py / ont_fast5_api give `read_id`: a variable-length string whose bytes live in a
+    global heap collection (HDF5 spec III.E); the attribute holds (length, collection address, index)."""
+    val = value.encode()
+    obj = struct.pack("<HHIQ", 1, 1, 0, len(val)) + val + b"\x00" * (-len(val) % 8)
+    free = struct.pack("<HHIQ", 0, 0, 0, 0)
+    size = 16 + len(obj) + len(free)
+    gcol = f.alloc(b"GCOL" + struct.pack("<B3xQ", 1, size) + obj + free)
+    name_b = name.encode() + b"\x00"
+    # datatype: version 1, class 9 (variable length), type = string (bits 0-3 of the class bit field), base type char
+    base = struct.pack("<BBBBI", 0x13, 0, 0, 0, 1)
+    dt = struct.pack("<BBBBI", 0x19, 0x01, 0, 0, 16) + base
+    ds = struct.pack("<BBBx4x", 1, 0, 0)
+    pad = lambda x: x + b"\x00" * (-len(x) % 8)
+    data = struct.pack("<IQI", len(val), gcol, 1)
+    return _msg(0x0C, struct.pack("<BxHHH", 1, len(name_b), len(dt), len(ds)) + pad(name_b) + pad(dt) + pad(ds) + data)
+
+
 def _dataset(f, array, attrs=()):
     data = array.astype("<i2").tobytes()
     addr = f.alloc(data)
@@ -71,22 +89,44 @@ def _group(f, entries, attrs=()):
     return _object_header(f, [_msg(0x11, struct.pack("<QQ", tree_addr, heap))] + [_string_attr(k, v) for k, v in attrs])
 
 
-def _finish(f, root):
+def _finish(f, root, base=0):
     sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBxHHI", 0, 0, 0, 0, 0, 8, 8, 64, 32, 0)
-    sb += struct.pack("<QQQQ", 0, UNDEF, len(f.buf), UNDEF)
+    sb += struct.pack("<QQQQ", base, UNDEF, len(f.buf), UNDEF)
     sb += struct.pack("<QQI4x16x", 0, root, 0)                        # root group symbol table entry
     f.buf[:len(sb)] = sb
     return bytes(f.buf)
 
 
-def single_read_fast5(read_id, signal, read_number=7):
-    """/Raw/Reads/Read_<n>/Signal with the read_id attribute on the Read group."""
+def single_read_fast5(read_id, signal, read_number=7, vlen_id=False, user_block=0):
+    """/Raw/Reads/Read_<n>/Signal with the read_id attribute on the Read group.
+    vlen_id: read_id as a variable-length string (global heap); user_block: bytes in front of the
+    superblock (every address in the file is then relative to that base address)."""
     f = _File()
     sig = _dataset(f, signal)
-    rd = _group(f, {"Signal": sig}, attrs=[("read_id", read_id)])
+    if vlen_id:
+        rd = _group(f, {"Signal": sig})
+        # append the attribute message to the group's object header: rebuild it with the extra message
+        f2 = _File(); sig = _dataset(f2, signal)
+        attr = _vlen_string_attr(f2, "read_id", read_id)
+        rd = _group_with_messages(f2, {"Signal": sig}, [attr])
+        f = f2
+    else:
+        rd = _group(f, {"Signal": sig}, attrs=[("read_id", read_id)])
     reads = _group(f, {"Read_%d" % read_number: rd})
     raw = _group(f, {"Reads": reads})
-    return _finish(f, _group(f, {"Raw": raw}))
+    blob = _finish(f, _group(f, {"Raw": raw}), base=user_block)
+    return b"\x00" * user_block + blob
+
+
+def _group_with_messages(f, entries, extra_msgs):
+    """_group() with ready-made extra header messages."""
+    addr = _group(f, entries)
+    # the object header just written is the last allocation: re-emit it with the extra messages
+    nmsg, = struct.unpack_from("<H", f.buf, addr + 2)
+    hsize, = struct.unpack_from("<I", f.buf, addr + 8)
+    body = bytes(f.buf[addr + 16:addr + 16 + hsize]) + b"".join(extra_msgs)
+    hdr = struct.pack("<BxHII4x", 1, nmsg + len(extra_msgs), 1, len(body))
+    return f.alloc(hdr + body)
 
 
 def multi_read_fast5(reads):

@@ -112,3 +112,30 @@ def test_reader_threads_keep_the_row_order(cfg):
         cli.run_count(iter(lines), loci, get_raw, FakeCounter(), log, 7, 0, 1, buf, readers=readers)
         outs.append(buf.getvalue())
     assert outs[0] == outs[1] and len(outs[0].splitlines()) == 1 + 38
+
+
+def test_vlen_read_id_and_user_block(tmp_path):
+    """read_id stored as a variable-length string (global heap), and a file with a user block in front of
+    the superblock (non-zero base address): both forms real fast5 writers produce."""
+    import io
+    from contextlib import redirect_stdout
+    import numpy as np
+    import h5write
+    from strique_amd import cli, fast5
+    sig = (np.arange(3000) % 701 - 300).astype(np.int16)
+    blob = h5write.single_read_fast5("0f0f0f0f-vlen-4000-8000-000000000001", sig, vlen_id=True)
+    (rid, got), = fast5.read_raw(blob)
+    assert rid == "0f0f0f0f-vlen-4000-8000-000000000001" and np.array_equal(got, sig)
+    # a user block of 1024 bytes: the superblock is found at 1024 and every address is relative to it
+    blob = h5write.single_read_fast5("base-0001", sig, user_block=1024)
+    (rid, got), = fast5.read_raw(blob)
+    assert rid == "base-0001" and np.array_equal(got, sig)
+    d = tmp_path / "d"; d.mkdir()
+    (d / "a.fast5").write_bytes(h5write.single_read_fast5("id-a", sig, vlen_id=True))
+    (d / "broken.fast5").write_bytes(b"this is not an hdf5 file")
+    buf = io.StringIO(); err = io.StringIO()
+    import contextlib
+    with redirect_stdout(buf), contextlib.redirect_stderr(err):
+        cli.main(["index", str(d)])
+    assert buf.getvalue() == "a.fast5\tid-a\n"                 # the broken file is reported and skipped
+    assert "broken.fast5" in err.getvalue()
