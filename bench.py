@@ -213,7 +213,7 @@ def main():
         # implementation removes the per-cell trace stream, GCUPS / VALU is the binding roofline.
         prof = _profile_constants()
         segs, tables, packed, R = int(counters[3]), int(counters[4]), int(counters[5]), int(counters[6])
-        kname = "align_forward_seg_kernel<%d, 6, %s, %d, *>" % (R, "true" if packed else "false", segs)
+        kname = "align_forward_seg_kernel<%d, 6, %s, %d, %d, false>" % (R, "true" if packed else "false", segs, max(2 if segs == 1 else 3, (segs * tables + 3) // 4))
         ipstep = prof.get("valu_insts_per_wave_step", {}).get("packed" if packed else "float32")
         wave_steps_per_launch = counters[0] / max(1, fwd_launches)
         valu_peak = N_SIMD * CLOCK_HZ / 2.0 / 1e9                     # wave64 VALU instructions per second, all SIMDs (G/s)

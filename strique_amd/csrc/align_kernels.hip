@@ -539,7 +539,9 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
 // pass of one piece of the read (AlignTask::col_off; the pieces of alignment g are tasks[g * SEG + w]).
 // More waves per CU at the same LDS footprint is what the issue-latency-bound DP needs; WPE (waves per
 // SIMD) caps the registers the compiler may use so that all of them are resident.
-template <int R, int S, bool PK, int SEG, int WPE>
+// LISTED: the (normally empty) second round over the alignments the combine kernel listed -- a kernel of its
+// own so that profiles show the first round alone.
+template <int R, int S, bool PK, int SEG, int WPE, bool LISTED = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64 * SEG, 64 * SEG), amdgpu_waves_per_eu(WPE, WPE)))
 align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_groups,
                          int* __restrict__ queue, AlignParams p, const int* __restrict__ group_list,
@@ -551,14 +553,14 @@ align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __res
     const char* ldsb = reinterpret_cast<const char*>(lds_all);
     const int lds_base = 0;                    // table offsets are relative to lds_all
     // a second launch over the alignments the combine kernel listed (device-side count): see launch_align_segments
-    if (n_list) n_groups = __builtin_amdgcn_readfirstlane(*n_list);
+    if constexpr (LISTED) n_groups = __builtin_amdgcn_readfirstlane(*n_list);
     for (;;) {
         __syncthreads();                       // every wave is done with the previous table
         if (threadIdx.x == 0) next_group = atomicAdd(queue, 1);
         __syncthreads();
         int gi = __builtin_amdgcn_readfirstlane(next_group);
         if (gi >= n_groups) break;
-        if (group_list) gi = __builtin_amdgcn_readfirstlane(group_list[gi]);
+        if constexpr (LISTED) gi = __builtin_amdgcn_readfirstlane(group_list[gi]);
         {
             const AlignTask& t0 = tasks[(size_t)gi * SEG];      // all pieces share the table of the alignment
             if constexpr (PK) {
@@ -859,10 +861,17 @@ static int launch_seg1(hipStream_t stream, const AlignTask* tasks, AlignResult* 
                        const AlignParams& p, int lds_dwords, int n_blocks, const int* group_list, const int* n_list)
 {
     const size_t lds_bytes = (size_t)lds_dwords * 4;
-    (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
-                       tasks, seg_results, n_groups, queue, p, group_list, n_list);
+    if (group_list && n_list) {
+        (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE, true>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
+                           tasks, seg_results, n_groups, queue, p, group_list, n_list);
+    } else {
+        (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE, false>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
+                           tasks, seg_results, n_groups, queue, p, group_list, n_list);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

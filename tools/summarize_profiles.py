@@ -86,7 +86,7 @@ def main():
             fv = sum(fetch[k]) / len(fetch[k])
             wv = sum(write.get(k, [0.0])) / max(1, len(write.get(k, [0.0])))
             f.write("| %s | %d | %.1f | %.1f | %.1f | %.3e |\n" % (k, len(fetch[k]), fv, 2 * fv, wv, (2 * fv + wv) * 1024))
-    fk = [k for k in fetch if "align_forward" in k]
+    fk = [k for k in fetch if "align_forward" in k and not second_round(k)]
     if fk:
         k = fk[0]
         n_launch = len(fetch[k])
@@ -118,6 +118,14 @@ def main():
         print(json.dumps(consts, indent=1))
 
 
+def second_round(kernel):
+    """align_forward_seg_kernel<R, S, PK, SEG, WPE, true>: the (normally empty) second round of the column segments."""
+    if "seg_kernel" not in kernel:
+        return False
+    targs = [x.strip() for x in kernel.split("<", 1)[1].rstrip(">").split(",")]
+    return len(targs) >= 6 and targs[5] == "true"
+
+
 def bench_json(log):
     if not os.path.exists(log):
         return None
@@ -140,7 +148,7 @@ def sq_summary(tag, src, out, pmc_reads, consts):
             continue
         iv = counters(h[-1], "SQ_INSTS_VALU"); wc = counters(h[-1], "SQ_WAVE_CYCLES"); ai = counters(h[-1], "SQ_ACTIVE_INST_VALU")
         for k in iv:
-            if "align_forward" not in k:
+            if "align_forward" not in k or second_round(k):
                 continue
             steps = b["roofline"]["wave_steps_per_launch"]
             targs = [x.strip() for x in k.split("<", 1)[1].rstrip(">").split(",")]
