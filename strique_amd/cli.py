@@ -429,6 +429,77 @@ def index(argv):
         print(record)
 
 
+def plot(argv):
+    """Signal plots over STR expansions: the reference's `plot` command (scripts/STRique.py:948-1024),
+    same arguments, same three panels (whole repeat region, prefix and suffix boundaries).  Host code."""
+    parser = argparse.ArgumentParser(description="Signal plots over STR expansions")
+    parser.add_argument("f5Index", help="Fast5 index")
+    parser.add_argument("--counts", default=None, help="Repeat count output from STRique, if not given read from stdin")
+    parser.add_argument("--output", default=None, help="Output directory for plots, use instead of interactive GUI")
+    parser.add_argument("--format", default='png', choices=["png", "pdf", "svg"], help="Output format when writing to files")
+    parser.add_argument("--width", default=16, type=int, help="Plot width")
+    parser.add_argument("--height", default=9, type=int, help="Plot height")
+    parser.add_argument("--dpi", default=80, type=int, help="Resolution of plot")
+    parser.add_argument("--extension", type=float, default=0.1, help="Extension as fraction of repeat signal around STR region to plot")
+    parser.add_argument("--zoom", type=int, default=500, help="Region around prefix and suffix to plot")
+    parser.add_argument("--log_level", default='warning', choices=LEVELS, help="Log level")
+    args = parser.parse_args(argv)
+    log = Log(args.log_level)
+    if not os.path.isfile(args.f5Index):
+        log("Main: Fast5 index file does not exist.", 'error'); raise SystemExit(1)
+    import matplotlib
+    if args.output:
+        matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    import scipy.signal as sp
+    f5 = Fast5Index(args.f5Index)
+    if args.output:
+        os.makedirs(args.output, exist_ok=True)
+    stream = open(args.counts) if args.counts else sys.stdin
+    for line in stream:
+        if line.startswith('ID') or not line.strip():
+            continue
+        ID, target, strand, count, score_prefix, score_suffix, _, offset, ticks = line.strip().split('\t')[:9]
+        offset, ticks = int(offset), int(ticks)
+        score_prefix, score_suffix = float(score_prefix), float(score_suffix)
+        raw_signal = f5.get_raw(ID)
+        if raw_signal is None:
+            log("Plot: No fast5 for ID %s" % ID, 'warning'); continue
+        flt = sp.medfilt(raw_signal, kernel_size=3)
+        flt = (flt - np.median(flt)) / np.std(flt)
+        prefix_extend = max(0, offset - int(ticks * args.extension))
+        suffix_extend = min(len(flt), offset + ticks + int(ticks * args.extension))
+        prefix_begin = max(offset - args.zoom, 0)
+        prefix_end = prefix_begin + args.zoom * 2
+        suffix_begin = max(offset + ticks - args.zoom, 0)
+        suffix_end = min(len(flt), suffix_begin + args.zoom * 2)
+        plt.figure(num=None, figsize=(args.width, args.height), dpi=args.dpi, facecolor='w', edgecolor='k')
+        plt.subplot(2, 1, 1)
+        plt.plot(flt[prefix_extend:suffix_extend], 'k-', linewidth=0.5, label='genome')
+        plt.plot(np.arange(len(flt[offset:offset + ticks])) + (offset - prefix_extend), flt[offset:offset + ticks], 'b-', linewidth=1.0, label='STR')
+        plt.legend()
+        plt.title("Read {} with {} repeats".format(ID, count))
+        plt.subplot(2, 2, 3)
+        plt.plot(flt[prefix_begin:prefix_end], 'k-', label='prefix')
+        seg = flt[prefix_begin + args.zoom:prefix_end]
+        plt.plot(np.arange(args.zoom, args.zoom + len(seg)), seg, 'b-')
+        plt.axvline(args.zoom, color='red', label='STR begin')
+        plt.legend()
+        plt.title("Prefix region with score {:.2f}".format(score_prefix))
+        plt.subplot(2, 2, 4)
+        plt.plot(flt[suffix_begin:suffix_end], 'k-', label='suffix')
+        plt.plot(flt[suffix_begin:max(suffix_begin, suffix_end - args.zoom)], 'b-')
+        plt.axvline(args.zoom, color='red', label='STR end')
+        plt.legend()
+        plt.title("Suffix region with score {:.2f}".format(score_suffix))
+        plt.tight_layout()
+        if args.output:
+            plt.savefig(os.path.join(args.output, '_'.join([target, count, ID]) + '.' + args.format))
+            plt.close()
+        else:
+            plt.show()
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     parser = argparse.ArgumentParser(description='STRique: a nanopore raw signal repeat detection pipeline (MI355X engine)',
@@ -436,6 +507,7 @@ def main(argv=None):
 Available commands are:
    index      Index batch(es) of bulk-fast5 or tar archived single fast5
    count      Count single read repeat expansions
+   plot       Plot repeat signal after counting
 ''')
     parser.add_argument('command', help='Subcommand to run')
     args = parser.parse_args(argv[:1])
@@ -443,6 +515,8 @@ Available commands are:
         count(argv[1:])
     elif args.command == 'index':
         index(argv[1:])
+    elif args.command == 'plot':
+        plot(argv[1:])
     else:
         print('Unrecognized command', file=sys.stderr)
         parser.print_help(file=sys.stderr)

@@ -1,140 +1,3 @@
-"""Test helper: write a small HDF5 file (superblock v0, old-style groups, contiguous int16 datasets,
-fixed-length string attributes) byte by byte from the HDF5 file-format specification, so that the
-reader in strique_amd/fast5.py is exercised on layouts the one bundled file does not have
-(multi-read fast5, several reads per group, tar archives).  Not part of the product.
-"""
-import struct
-
-UNDEF = 0xFFFFFFFFFFFFFFFF
-
-
-class _File(object):
-    def __init__(self):
-        self.buf = bytearray(96)          # superblock (v0: 24 + 32 + 40 bytes) written last
-
-    def alloc(self, data, align=8):
-        while len(self.buf) % align:
-            self.buf.append(0)
-        addr = len(self.buf)
-        self.buf += data
-        return addr
-
-
-def _msg(mtype, payload, flags=0):
-    payload = bytes(payload)
-    payload += b"\x00" * (-len(payload) % 8)
-    return struct.pack("<HHB3x", mtype, len(payload), flags) + payload
-
-
-def _object_header(f, msgs):
-    body = b"".join(msgs)
-    hdr = struct.pack("<BxHII4x", 1, len(msgs), 1, len(body))      # version, #messages, refcount, header size
-    return f.alloc(hdr + body)
-
-
-def _string_attr(name, value):
-    name_b = name.encode() + b"\x00"
-    val = value.encode()
-    dt = struct.pack("<BBBBI", 0x13, 0, 0, 0, len(val))             # version 1, class 3 (string), null-terminated ascii
-    ds = struct.pack("<BBBx4x", 1, 0, 0)                              # dataspace version 1, scalar
-    pad = lambda x: x + b"\x00" * (-len(x) % 8)
-    return _msg(0x0C, struct.pack("<BxHHH", 1, len(name_b), len(dt), len(ds)) + pad(name_b) + pad(dt) + pad(ds) + val)
-
-
-def _vlen_string_attr(f, name, value):
-    """The form h5py / ont_fast5_api give `read_id`: a variable-length string whose bytes live in a
-    global heap collection (HDF5 spec III.E); the attribute holds (length, collection address, index)."""
-    val = value.encode()
-    obj = struct.pack("<HHIQ", 1, 1, 0, len(val)) + val + b"\x00" * (-len(val) % 8)
-    free = struct.pack("<HHIQ", 0, 0, 0, 0)
-    size = 16 + len(obj) + len(free)
-    gcol = f.alloc(b"GCOL" + struct.pack("<B3xQ", 1, size) + obj + free)
-    name_b = name.encode() + b"\x00"
-    # datatype: version 1, class 9 (variable length), type = string (bits 0-3 of the class bit field), base type char
-    base = struct.pack("<BBBBI", 0x13, 0, 0, 0, 1)
-    dt = struct.pack("<BBBBI", 0x19, 0x01, 0, 0, 16) + base
-    ds = struct.pack("<BBBx4x", 1, 0, 0)
-    pad = lambda x: x + b"\x00" * (-len(x) % 8)
-    data = struct.pack("<IQI", len(val), gcol, 1)
-    return _msg(0x0C, struct.pack("<BxHHH", 1, len(name_b), len(dt), len(ds)) + pad(name_b) + pad(dt) + pad(ds) + data)
-
-
-def _dataset(f, array, attrs=()):
-    data = array.astype("<i2").tobytes()
-    addr = f.alloc(data)
-    space = struct.pack("<BBBx4xQ", 1, 1, 0, len(array))            # version 1, rank 1, no max dims
-    dtype = struct.pack("<BBBBIHH", 0x10, 0x08, 0, 0, 2, 0, 16)      # version 1 class 0 (fixed point), signed, 2 bytes
-    layout = struct.pack("<BBQQ", 3, 1, addr, len(data))             # version 3, contiguous
-    return _object_header(f, [_msg(0x01, space), _msg(0x03, dtype), _msg(0x08, layout)] + [_string_attr(k, v) for k, v in attrs])
-
-
-def _group(f, entries, attrs=()):
-    """entries: {name: object header address}.  One symbol-table node per group (<= 2 * leaf_k names)."""
-    names = sorted(entries)
-    heap_data = bytearray(8)                                          # offset 0: the empty string
-    offs = []
-    for n in names:
-        offs.append(len(heap_data))
-        heap_data += n.encode() + b"\x00"
-        heap_data += b"\x00" * (-len(heap_data) % 8)
-    data_addr = f.alloc(bytes(heap_data))
-    heap = f.alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, data_addr))
-    snod = bytearray(b"SNOD" + struct.pack("<BxH", 1, len(names)))
-    for n, o in zip(names, offs):
-        snod += struct.pack("<QQI4x16x", o, entries[n], 0)
-    snod_addr = f.alloc(bytes(snod))
-    # B-tree v1, node type 0 (group), level 0, one child: key0 | child | key1
-    tree = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) + struct.pack("<QQQ", 0, snod_addr, offs[-1] if offs else 0)
-    tree_addr = f.alloc(tree)
-    return _object_header(f, [_msg(0x11, struct.pack("<QQ", tree_addr, heap))] + [_string_attr(k, v) for k, v in attrs])
-
-
-def _finish(f, root, base=0):
-    sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBxHHI", 0, 0, 0, 0, 0, 8, 8, 64, 32, 0)
-    sb += struct.pack("<QQQQ", base, UNDEF, len(f.buf), UNDEF)
-    sb += struct.pack("<QQI4x16x", 0, root, 0)                        # root group symbol table entry
-    f.buf[:len(sb)] = sb
-    return bytes(f.buf)
-
-
-def single_read_fast5(read_id, signal, read_number=7, vlen_id=False, user_block=0):
-    """/Raw/Reads/Read_<n>/Signal with the read_id attribute on the Read group.
-    vlen_id: read_id as a variable-length string (global heap); user_block: bytes in front of the
-    superblock (every address in the file is then relative to that base address)."""
-    f = _File()
-    sig = _dataset(f, signal)
-    if vlen_id:
-        rd = _group(f, {"Signal": sig})
-        # append the attribute message to the group's object header: rebuild it with the extra message
-        f2 = _File(); sig = _dataset(f2, signal)
-        attr = _vlen_string_attr(f2, "read_id", read_id)
-        rd = _group_with_messages(f2, {"Signal": sig}, [attr])
-        f = f2
-    else:
-        rd = _group(f, {"Signal": sig}, attrs=[("read_id", read_id)])
-    reads = _group(f, {"Read_%d" % read_number: rd})
-    raw = _group(f, {"Reads": reads})
-    blob = _finish(f, _group(f, {"Raw": raw}), base=user_block)
-    return b"\x00" * user_block + blob
-
-
-def _group_with_messages(f, entries, extra_msgs):
-    """_group() with ready-made extra header messages."""
-    addr = _group(f, entries)
-    # the object header just written is the last allocation: re-emit it with the extra messages
-    nmsg, = struct.unpack_from("<H", f.buf, addr + 2)
-    hsize, = struct.unpack_from("<I", f.buf, addr + 8)
-    body = bytes(f.buf[addr + 16:addr + 16 + hsize]) + b"".join(extra_msgs)
-    hdr = struct.pack("<BxHII4x", 1, nmsg + len(extra_msgs), 1, len(body))
-    return f.alloc(hdr + body)
-
-
-def multi_read_fast5(reads):
-    """reads: [(read_id, signal)] -> /read_<id>/Raw/Signal, read_id attribute on every Raw group."""
-    f = _File()
-    top = {}
-    for rid, signal in reads:
-        sig = _dataset(f, signal)
-        raw = _group(f, {"Signal": sig}, attrs=[("read_id", rid)])
-        top["read_" + rid] = _group(f, {"Raw": raw})
-    return _finish(f, _group(f, top))
+"""Test helper: the package's minimal HDF5 writer (strique_amd/h5write.py)."""
+from strique_amd.h5write import *      # noqa: F401,F403
+from strique_amd.h5write import _File, _dataset, _group, _finish, _string_attr, _vlen_string_attr, _group_with_messages      # noqa: F401
