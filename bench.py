@@ -262,7 +262,7 @@ def main():
             "host": {"synth_s": t_gen, "upload_s": t_up, "upload_GBs": n_samples * 2 / t_up / 1e9 if t_up > 0 else None},
             "check": checked,
         }
-        if not args.no_host_leg:
+        if not args.no_host_leg and world == 1:
             # SURVEY.md 8d quotes the metric with the signals in host RAM: the boundary's host-buffer entry
             # (strq_detect_batch) over `host_leg_batches` sub-batches, samples in pageable host memory, uploads of
             # sub-batch k + 1 overlapping the kernels of sub-batch k.  Reported beside `value`, never as `value`.
@@ -283,7 +283,7 @@ def main():
                                    "note": "PCIe-inclusive: int16 signals start in pageable host memory and go through a pinned staging ring; "
                                            "only the first sub-batch's upload is exposed"}
             del big
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(sigs, strands)
         print(json.dumps(out))
     if dist is not None:

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <stdlib.h>
 #include "viterbi_kernels.h"
 
 namespace strq {
@@ -556,7 +557,8 @@ static int vit_launch_shape(hipStream_t stream, int max_cells, const VitTask* ta
 {
     if (max_cells > VitLds<E_, S_>::TRASH) return 3;
     // per wave: two buffers of 16-byte {value, count} cells; waves of a block are independent
-    const int nw = VitLds<E_, S_>::WAVES;
+    int nw = VitLds<E_, S_>::WAVES;
+    if (const char* e = getenv("STRQ_VIT_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= nw) nw = v; }      // experiments: fewer waves per CU
     const size_t lds = (size_t)nw * 2 * VitLds<E_, S_>::BUF;
     const dim3 grid(n_cu), block(64 * nw);
 #define VIT_GO(BP_, SS_, MK_)                                                                                             \

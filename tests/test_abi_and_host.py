@@ -65,3 +65,15 @@ def test_synth_is_seeded_and_has_the_repeat(pm, cfg):
     assert 6 * 5995 <= len(a) <= 9 * 5995
     idx = t.indices(b"ACGTACGTAC")
     assert np.allclose(t.mean[idx], pm.level_means("ACGTACGTAC"))
+
+
+def test_oracle_does_not_import_the_product():
+    """The oracle stands alone: nothing under oracle/ imports, loads or reads anything of strique_amd."""
+    import os
+    import re
+    from conftest import ROOT
+    bad = re.compile(r"^\s*(import|from)\s+strique_amd\b|libstrique_hip", re.M)
+    for name in os.listdir(os.path.join(ROOT, "oracle")):
+        if name.endswith((".py", ".c", ".h")) or name == "Makefile":
+            text = open(os.path.join(ROOT, "oracle", name)).read()
+            assert not bad.search(text), name

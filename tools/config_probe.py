@@ -2,7 +2,7 @@
 
   configs[1]: 10 kb reads, 30 x GGGGCC (C9orf72)
   configs[3]: 50 kb reads, C9orf72 / FMR1 (CGG) / HTT (CAG) targets 1:1:1, n ~ U{30..1000}
-              (HTT: repeat CAG with flanks fixed here -- the reference's repeat_config.tsv has no HTT row)
+              (HTT: tests/golden/repeat_config_htt.tsv -- the reference's repeat_config.tsv has no HTT row)
   configs[4]: see tools/mod_probe.py
 
 usage (GPU box): python tools/config_probe.py [n_reads]
@@ -16,8 +16,8 @@ from strique_amd.counter import repeatCounter
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 pm, cfg = bench.load_inputs()
-rng = np.random.Generator(np.random.PCG64(4242))
-HTT = ("CAG", "".join(rng.choice(list("ACGT"), 150)), "".join(rng.choice(list("ACGT"), 150)))
+from strique_amd.cli import parse_config
+HTT = tuple(parse_config(os.path.join(R, "tests", "golden", "repeat_config_htt.tsv"))["repeat"]["htt"][3:6])      # the committed HTT/CAG row
 table = synth.KmerTable(pm)
 
 
