@@ -22,6 +22,13 @@ struct PatTask {
     const int32_t* status;   // status of the modification-model Viterbi of this read (device): 0 = a path exists
 };
 
+// hub records of the modification-model Viterbi (viterbi_kernels.hip, HUB) -> one character per repeat unit
+struct HubTask {
+    const uint64_t* rec;     // T + 1 records: low 32 bits = time of the previous e0 emission, high = branch (1 = modified)
+    const void* result;      // VitResult of the window (device): status, dbg[0] = time of the last e0 emission
+    char* out;
+};
+int launch_mod_hub_pattern(hipStream_t s, const HubTask* tasks, int n, int64_t* out_len);
 int launch_mod_compact(hipStream_t s, const ModTask* tasks, int n, int64_t* out_len);
 int launch_mod_pattern(hipStream_t s, const PatTask* tasks, int n, int64_t* out_len);
 

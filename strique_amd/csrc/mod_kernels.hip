@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mod_kernels.h"
+#include "viterbi_kernels.h"
 
 namespace strq {
 
@@ -67,6 +68,33 @@ mod_pattern_kernel(const PatTask* __restrict__ tasks, int n, int64_t* __restrict
         carry = hubs >> 63;
     }
     if (lane == 0) out_len[i] = k;
+}
+
+// one thread per read: hop from hub record to hub record (one hop per repeat unit), last unit first
+__global__ void __launch_bounds__(64)
+mod_hub_pattern_kernel(const HubTask* __restrict__ tasks, int n, int64_t* __restrict__ out_len)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const HubTask tk = tasks[i];
+    const VitResult* r = reinterpret_cast<const VitResult*>(tk.result);
+    if (r->status != 0) { tk.out[0] = '-'; out_len[i] = 1; return; }
+    int64_t cnt = 0;
+    for (uint32_t t = r->dbg[0]; t != 0; t = (uint32_t)tk.rec[t]) ++cnt;
+    int64_t k = cnt;
+    for (uint32_t t = r->dbg[0]; t != 0;) {
+        const uint64_t v = tk.rec[t];
+        tk.out[--k] = (v >> 32) ? '1' : '0';
+        t = (uint32_t)v;
+    }
+    out_len[i] = cnt;
+}
+
+int launch_mod_hub_pattern(hipStream_t s, const HubTask* tasks, int n, int64_t* out_len)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mod_hub_pattern_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tasks, n, out_len);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int launch_mod_compact(hipStream_t s, const ModTask* tasks, int n, int64_t* out_len)

@@ -208,23 +208,28 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     int64_t* d_len = d->modlen.as<int64_t>();
     STRQ_HIP(c, hipMemcpyAsync(d_mt, mt.data(), (size_t)nm * sizeof(ModTask), hipMemcpyHostToDevice, st));
     if (launch_mod_compact(st, d_mt, nm, d_len)) { c->err = "compaction launch failed"; return STRQ_ERR_DEVICE; }
-    // 3. Viterbi on the modification model, with state path
+    // 3. Viterbi on the modification model.  Hub records (one 8-byte record per time step, read back with one
+    //    hop per repeat unit) when the model has the hub structure; back-pointers + traceback otherwise.
     std::map<int, std::vector<int>> by_shape;
+    bool use_hub = !getenv("STRQ_MOD_BACKPOINTERS");
     for (int k = 0; k < nm; ++k) {
         HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
         const int shape = vit_shape_of(hm->h);
         if (shape < 0) { c->err = "modification model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
         by_shape[shape].push_back(k);
+        if (hm->h.rec_state < 0 || hm->h.epl > 2 || len[k] >= ((int64_t)1 << 31)) use_hub = false;
     }
     std::vector<VitTask> vt2(nm); std::vector<int> slot2(nm); std::vector<int32_t*> tp2(nm);
     size_t bp2 = 0, p2 = 0; std::vector<size_t> bp2_off(nm), p2_off(nm);
     for (int k = 0; k < nm; ++k) {
         HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
-        bp2_off[k] = bp2; bp2 += (size_t)(len[k] + 1) * hm->h.n_states; p2_off[k] = p2; p2 += (size_t)len[k] + 1;
+        // back-pointers: uint16 per (time step, state); hub records: 8 bytes per time step (in uint16 units: 4)
+        bp2_off[k] = bp2; bp2 += use_hub ? (size_t)(len[k] + 1) * 4 : (size_t)(len[k] + 1) * hm->h.n_states;
+        p2_off[k] = p2; p2 += (size_t)len[k] + 1;
     }
     STRQ_HIP(c, d->bp.reserve(bp2 * 2 + 64));
-    STRQ_HIP(c, d->pattern.reserve(p2 * 5 + (size_t)nm * 8 + 64));
-    int32_t* d_path2 = d->pattern.as<int32_t>(); char* d_chars = reinterpret_cast<char*>(d_path2 + p2);
+    STRQ_HIP(c, d->pattern.reserve((use_hub ? 0 : p2 * 4) + p2 + (size_t)nm * 8 + (size_t)nm * sizeof(HubTask) + 64));
+    int32_t* d_path2 = d->pattern.as<int32_t>(); char* d_chars = reinterpret_cast<char*>(d_path2 + (use_hub ? 0 : p2));
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
     { int sidx = 0, qi = 0;
       for (auto& g : by_shape) {
@@ -241,23 +246,37 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
             d_order = d->order.as<int>() + first;
             if (launch_vit_sort(st, d_tb + first, sidx - first, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
         }
-        if (launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, 1, d_order)) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
+        if (launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, use_hub ? 3 : 1, d_order)) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
       } }
-    STRQ_HIP(c, hipMemcpyAsync(d_tp, tp2.data(), (size_t)nm * 8, hipMemcpyHostToDevice, st));
-    if (launch_vit_traceback(st, d_tb, d_tr, d_tp, nm)) { c->err = "traceback launch failed"; return STRQ_ERR_DEVICE; }
-    // 4. pattern strings
-    std::vector<PatTask> pt(nm);
-    for (int k = 0; k < nm; ++k) {
-        const int sl = slot2[k];
-        HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
-        pt[sl].path = tp2[sl]; pt[sl].tag = hm->h.state_tag; pt[sl].out = d_chars + p2_off[k]; pt[sl].T = len[k];
-        pt[sl].status = &d_tr[sl].status;
+    int64_t* d_plen = d_len;
+    if (use_hub) {
+        // 4. pattern strings from the hub records
+        std::vector<HubTask> ht(nm);
+        for (int k = 0; k < nm; ++k) {
+            const int sl = slot2[k];
+            ht[sl].rec = reinterpret_cast<const uint64_t*>(d->bp.as<uint16_t>() + bp2_off[k]);
+            ht[sl].result = d_tr + sl; ht[sl].out = d_chars + p2_off[k];
+        }
+        HubTask* d_ht = reinterpret_cast<HubTask*>(d_chars + ((p2 + 15) & ~(size_t)15));
+        STRQ_HIP(c, hipMemcpyAsync(d_ht, ht.data(), (size_t)nm * sizeof(HubTask), hipMemcpyHostToDevice, st));
+        if (launch_mod_hub_pattern(st, d_ht, nm, d_plen)) { c->err = "pattern launch failed"; return STRQ_ERR_DEVICE; }
+    } else {
+        STRQ_HIP(c, hipMemcpyAsync(d_tp, tp2.data(), (size_t)nm * 8, hipMemcpyHostToDevice, st));
+        if (launch_vit_traceback(st, d_tb, d_tr, d_tp, nm)) { c->err = "traceback launch failed"; return STRQ_ERR_DEVICE; }
+        // 4. pattern strings
+        std::vector<PatTask> pt(nm);
+        for (int k = 0; k < nm; ++k) {
+            const int sl = slot2[k];
+            HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
+            pt[sl].path = tp2[sl]; pt[sl].tag = hm->h.state_tag; pt[sl].out = d_chars + p2_off[k]; pt[sl].T = len[k];
+            pt[sl].status = &d_tr[sl].status;
+        }
+        STRQ_HIP(c, hipMemcpyAsync(d_pt, pt.data(), (size_t)nm * sizeof(PatTask), hipMemcpyHostToDevice, st));
+        if (launch_mod_pattern(st, d_pt, nm, d_plen)) { c->err = "pattern launch failed"; return STRQ_ERR_DEVICE; }
     }
-    STRQ_HIP(c, hipMemcpyAsync(d_pt, pt.data(), (size_t)nm * sizeof(PatTask), hipMemcpyHostToDevice, st));
-    if (launch_mod_pattern(st, d_pt, nm, d_len)) { c->err = "pattern launch failed"; return STRQ_ERR_DEVICE; }
     std::vector<int64_t> plen(nm); std::vector<char> chars(p2);
-    STRQ_HIP(c, hipMemcpyAsync(plen.data(), d_len, (size_t)nm * 8, hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipMemcpyAsync(plen.data(), d_plen, (size_t)nm * 8, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(chars.data(), d_chars, p2, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
     for (int k = 0; k < nm; ++k) {

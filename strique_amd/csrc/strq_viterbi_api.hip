@@ -158,6 +158,8 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     m.chain_src = reinterpret_cast<const int32_t*>(d + parts[9].off);
     m.chain_logp = reinterpret_cast<const double*>(d + parts[10].off);
     m.state_tag = reinterpret_cast<const int32_t*>(d + parts[11].off);
+    m.rec_state = -1;
+    for (int e = in_ptr[end]; e < in_ptr[end + 1]; ++e) if (in_src[e] < ne && state_tag && state_tag[in_src[e]] == 2) m.rec_state = in_src[e];
     m.cell_state = reinterpret_cast<const int32_t*>(d + parts[12].off);
     hm->dev = reinterpret_cast<const VitModel*>(d + o_m);
     std::vector<char> host(total, 0);

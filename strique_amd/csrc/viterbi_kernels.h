@@ -37,6 +37,7 @@ struct VitModel {
     const int32_t* count_inc;         // n_states + 1, by state
     const int32_t* state_tag;         // n_states + 1, by state
     double uni_lo_max, uni_hi_min;    // tightest bounds of the uniform emissions: observations inside them need no range test
+    int32_t rec_state, pad2_;         // the hub state (tag 2) with an edge into `end` (e0 of the modification model), or -1
 };
 
 enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };
@@ -47,7 +48,7 @@ struct VitTask {
     int64_t T;
     int32_t src_kind, pad_;
     double c1, h1, h2, c2, lo, hi;    // x = clip((s - c1) / h1 * h2 + c2, lo, hi)  (STRique.py:159-160,178-179)
-    uint16_t* bp;            // (T + 1) x (n_states) predecessor states, nullable (count-only mode)
+    uint16_t* bp;            // (T + 1) x (n_states) predecessor states, nullable (count-only mode); hub mode: (T + 1) 8-byte hub records
 };
 
 struct VitResult {
@@ -64,6 +65,7 @@ struct VitResult {
 int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fits
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);
+// want_bp: 0 = count only, 1 = back-pointers, 2 = repeat-section marks (flanked model), 3 = hub records (modification model)
 int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order);   // order by descending T (n <= 8192)
 int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResult* results,
                          int32_t* const* paths, int n_tasks);

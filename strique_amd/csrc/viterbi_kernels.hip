@@ -103,7 +103,13 @@ template <int EPL, int SPL> struct VitLds {
 // payload bytes of a cell hold  lo = count | enter[11:0] << 20,  hi = enter[21:12] | leave << 10  (windows below
 // 2^21 samples): the split keeps every update a 32-bit operation (64-bit shifts are slow on the VALU).
 #define VIT_MARK_T_MAX ((int64_t)1 << 21)
-template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP, bool SS, bool MARK = false>
+//
+// HUB (modification model): every path passes through the emitting hub states between two repeat units
+// (s0 -> base | modified unit profile -> e0 -> s0 ...), and all states of a unit belong to one branch.  The
+// best path carries the time of its last e0 emission and the branch of its current unit; every e0 emission
+// at time t stores that pair as record t (8 bytes) -- so the per-unit '0'/'1' string is read back by hopping
+// from hub to hub (one hop per repeat unit) instead of tracing a back-pointer per (time step, state).
+template <int EPL, int SPL, int DE_HI, int DE_LO, int DS, bool BP, bool SS, bool MARK = false, bool HUB = false>
 __global__ void __launch_bounds__((64 * VitLds<EPL, SPL>::WAVES))
 viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
                int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
@@ -116,34 +122,36 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     constexpr int DEMAX = DE_HI > DE_LO ? DE_HI : DE_LO;
     auto de_of = [](int s) constexpr { return s < (EPL + 1) / 2 ? DE_HI : DE_LO; };
     const double NEGINF = -__builtin_inf();
-    using Pay = std::conditional_t<MARK, uint64_t, int>;      // what rides along the best path
+    constexpr bool WIDE = MARK || HUB;
+    using Pay = std::conditional_t<WIDE, uint64_t, int>;      // what rides along the best path
     struct alignas(16) Cell { double v; Pay c; };
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     auto ldcell = [](const char* p, int boff) {      // one ds_read_b128
         const v4u q = *reinterpret_cast<const v4u*>(p + boff);
         Cell x; x.v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
-        if constexpr (MARK) x.c = ((uint64_t)q.w << 32) | q.z; else x.c = (int)q.z;
+        if constexpr (WIDE) x.c = ((uint64_t)q.w << 32) | q.z; else x.c = (int)q.z;
         return x;
     };
     auto stcell = [](char* p, int boff, double v, Pay c) {      // one ds_write_b128
         const uint64_t u = __builtin_bit_cast(uint64_t, v);
         v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32);
-        if constexpr (MARK) { q.z = (unsigned)c; q.w = (unsigned)((uint64_t)c >> 32); } else { q.z = (unsigned)c; q.w = 0u; }
+        if constexpr (WIDE) { q.z = (unsigned)c; q.w = (unsigned)((uint64_t)c >> 32); } else { q.z = (unsigned)c; q.w = 0u; }
         *reinterpret_cast<v4u*>(p + boff) = q;
     };
     auto pay_add = [](Pay v, int inc) -> Pay {       // count += inc (the count field never carries out of the low half)
-        if constexpr (MARK) return ((uint64_t)v & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)v + (uint32_t)inc);
+        if constexpr (HUB) return v;          // the modification model counts nothing
+        else if constexpr (MARK) return ((uint64_t)v & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)v + (uint32_t)inc);
         else return v + inc;
     };
     auto shr1_pay = [](Pay v) -> Pay {               // payload of lane l-1
-        if constexpr (MARK) return ((uint64_t)(uint32_t)dpp_shr1_i32((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)dpp_shr1_i32((int)(uint32_t)v);
+        if constexpr (WIDE) return ((uint64_t)(uint32_t)dpp_shr1_i32((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)dpp_shr1_i32((int)(uint32_t)v);
         else return dpp_shr1_i32(v);
     };
     const VitModel* cur_model = nullptr;
     int n = 0, NP = 0, m_start = 0, m_end = 0, scell0 = 0, dummy = 0, start_state = 0;
     constexpr bool single_stage = SS;
     // everything a lane needs about the states it owns lives in registers (reloaded when the model changes)
-    int own_e[EPL], einc[EPL]; bool enorm[EPL]; bool etag[EPL];
+    int own_e[EPL], einc[EPL]; bool enorm[EPL]; bool etag[EPL]; bool ehub[EPL], erec[EPL];
     const char* esrc[EPL][DEMAX]; char* edst[EPL];
     double ea[EPL], eb[EPL], ec[EPL], elp[EPL][DEMAX];
     double ebf[EPL], ecf[EPL];     // branch-free emission: ecf - (x - ea)^2 * ebf  (uniform: ebf = 0; padding: ecf = -inf)
@@ -175,6 +183,8 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 ebf[s] = kind == 1 ? eb[s] : 0.0; ecf[s] = kind ? ec[s] : NEGINF;
                 einc[s] = own_e[s] >= 0 ? M.count_inc[own_e[s]] : 0;
                 etag[s] = own_e[s] >= 0 && M.state_tag[own_e[s]] == 1;
+                ehub[s] = own_e[s] >= 0 && M.state_tag[own_e[s]] == 2;
+                erec[s] = own_e[s] >= 0 && own_e[s] == M.rec_state;
                 edst[s] = vbase + 16 * (own_e[s] >= 0 ? s * 64 + lane : TRASH);
 #pragma unroll
                 for (int j = 0; j < DEMAX; ++j) {
@@ -381,6 +391,14 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     lo |= set_e ? mark_e_lo : 0u;
                     hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
                     nc[s] = ((uint64_t)hi << 32) | lo;
+                } else if constexpr (HUB) {
+                    uint32_t lo = (uint32_t)bc, hi = (uint32_t)((uint64_t)bc >> 32);      // last e0 time, branch of the current unit
+                    if (!ehub[s]) hi = etag[s] ? 1u : 0u;
+                    if (erec[s] && tk.bp) {
+                        reinterpret_cast<uint64_t*>(tk.bp)[t + 1] = ((uint64_t)hi << 32) | lo;      // record of this e0 emission
+                        lo = tt1;
+                    }
+                    nc[s] = ((uint64_t)hi << 32) | lo;
                 } else nc[s] = bc + einc[s];
             }
 #pragma unroll
@@ -429,7 +447,10 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         const double lp = fin.v;
         VitResult r; r.logp = lp; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
         r.dbg[0] = r.dbg[1] = r.dbg[2] = r.dbg[3] = 0;
-        if constexpr (MARK) {
+        if constexpr (HUB) {
+            r.counted = 0;
+            r.dbg[0] = (uint32_t)fin.c;          // time of the last e0 emission on the best path (= T when the path ends properly)
+        } else if constexpr (MARK) {
             const uint32_t plo = (uint32_t)fin.c, phi = (uint32_t)((uint64_t)fin.c >> 32);
             r.counted = (lp > NEGINF) ? (int64_t)(plo & 0xFFFFFu) : 0;
             r.dbg[0] = (plo >> 20) | ((phi & 0x3FFu) << 12);       // time (1-based) of the first repeat-section emission, 0 = none
@@ -561,15 +582,19 @@ static int vit_launch_shape(hipStream_t stream, int max_cells, const VitTask* ta
     if (const char* e = getenv("STRQ_VIT_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= nw) nw = v; }      // experiments: fewer waves per CU
     const size_t lds = (size_t)nw * 2 * VitLds<E_, S_>::BUF;
     const dim3 grid(n_cu), block(64 * nw);
-#define VIT_GO(BP_, SS_, MK_)                                                                                             \
+#define VIT_GO(BP_, SS_, MK_, HB_)                                                                                        \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_, MK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_, MK_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);       \
+        (void)hipFuncSetAttribute((const void*)viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_, MK_, HB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((viterbi_kernel<E_, S_, H_, L_, D_, BP_, SS_, MK_, HB_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);       \
     } while (0)
-    // want_bp: 0 = count only, 1 = back-pointers, 2 = repeat-section marks carried along the best path
-    if (want_bp == 2) { if (single_stage) VIT_GO(false, true, true); else VIT_GO(false, false, true); }
-    else if (want_bp) { if (single_stage) VIT_GO(true, true, false); else VIT_GO(true, false, false); }
-    else { if (single_stage) VIT_GO(false, true, false); else VIT_GO(false, false, false); }
+    // want_bp: 0 = count only, 1 = back-pointers, 2 = repeat-section marks carried along the best path, 3 = hub records
+    if (want_bp == 3) {
+        if constexpr (E_ <= 2) { if (single_stage) VIT_GO(false, true, false, true); else VIT_GO(false, false, false, true); }
+        else return 2;
+    }
+    else if (want_bp == 2) { if (single_stage) VIT_GO(false, true, true, false); else VIT_GO(false, false, true, false); }
+    else if (want_bp) { if (single_stage) VIT_GO(true, true, false, false); else VIT_GO(true, false, false, false); }
+    else { if (single_stage) VIT_GO(false, true, false, false); else VIT_GO(false, false, false, false); }
 #undef VIT_GO
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -220,3 +220,23 @@ def test_config4_modification_pass_full_size(pm, pm_mod, cfg, orc, opm, opm_mod,
         assert abs(g[0] - planted) <= 2 and abs(len(g[6]) - g[0]) <= 3
     # the mCpG read is called mostly modified, the base read mostly unmodified
     assert got[0][6].count("1") > 0.8 * len(got[0][6]) and got[1][6].count("0") > 0.8 * len(got[1][6])
+
+
+def test_modification_pass_hub_records_equal_backpointers(pm, pm_mod, cfg, targets, monkeypatch):
+    """The modification model is decoded with hub records (one hop per repeat unit); the general
+    back-pointer + traceback path (STRQ_MOD_BACKPOINTERS=1, also the fallback for models without the hub
+    structure) must give the same strings."""
+    from strique_amd import synth
+    from strique_amd.counter import repeatCounter
+    rc = repeatCounter(pm, mod_model_file=pm_mod, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    for name in ("c9orf72", "fmr1"):
+        rc.add_target(name, *targets[name])
+    items = []
+    for i in range(6):
+        name = ["c9orf72", "fmr1"][i % 2]; strand = "+-"[(i // 2) % 2]
+        table = synth.KmerTable(pm_mod if i % 3 else pm)
+        items.append((name, synth.make_read(table, 6, i, 5000 + 700 * i, targets[name], 12 + 9 * i, strand=strand)[0], strand))
+    a = rc.detect_batch(items)
+    monkeypatch.setenv("STRQ_MOD_BACKPOINTERS", "1")
+    b = rc.detect_batch(items)
+    assert a == b and all(set(x[6]) <= set("01") and len(x[6]) > 0 for x in a)
