@@ -11,6 +11,7 @@ output tuple.
 """
 from collections import namedtuple
 
+import os
 import warnings
 
 import numpy as np
@@ -128,7 +129,13 @@ class repeatCounter(object):
                 arrs = [sigs[i].astype(np.int16, copy=False) for i in idx]; stats = None
             else:
                 arrs = [sigs[i].astype(np.float64) for i in idx]
-                stats = np.array([self._host_stats(a) for a in arrs])
+                # numpy's sorts / selections release the GIL: one thread per read up to the core count
+                if len(arrs) > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1, len(arrs))) as pool:
+                        stats = np.array(list(pool.map(self._host_stats, arrs)))
+                else:
+                    stats = np.array([self._host_stats(a) for a in arrs])
             off = np.zeros(len(arrs) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in arrs])
             res = self.ctx.detect_batch(np.concatenate(arrs), off, [tcs[i].target_id for i in idx], stats)
             mods = self.ctx.batch_fetch_mod() if self.pm is not self.pm_mod else ['-'] * len(res)
