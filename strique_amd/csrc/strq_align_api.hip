@@ -184,66 +184,71 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // overlap the pieces are cut with first (the worst case is ~15 k columns for an 870-row flank); see the piece planning below
     int ov_cap = 8192;
     if (const char* e = getenv("STRQ_OVERLAP")) { const int v = atoi(e); ov_cap = v > 0 ? v : (1 << 30); }      // 0: always the worst-case overlap
-    if (collapsed) {
-        // Launch geometry.  Measured on MI355X (ms per 8192 alignments per 1000 columns computed, 870-row flanks,
-        // tools/dp_sweep.py): one wave per table 0.94 (24-bit tables, 8 waves per CU) / 1.02 (float32, 6 waves);
-        // two waves per table 0.86 (24-bit, 16 waves) / 0.79 (float32, 12 waves); four waves per table 0.80 /
-        // 0.69 (float32, 16 waves).  Three waves per table place unevenly on the four SIMDs (0.85 and worse).
-        // Every extra wave recomputes `overlap` columns, so short reads prefer fewer pieces.
-        static const double rate[5][2] = {{0, 0}, {1.017, 0.941}, {0.79, 0.862}, {0, 0}, {0.69, 0.80}};
-        double mean_n = 0, mean_l = 0; int cnt = 0; bool all_packable = allow_pack;
-        for (int i = 0; i < nb; ++i) if (in.NS[i] == 1) {
-            mean_n += in.n[i]; mean_l += std::min(align_segment_overlap(c->ap, in.m[i]), ov_cap); ++cnt;
-            all_packable = all_packable && info[i].packed && info[i].n_hard == 0;
-        }
-        if (cnt) { mean_n /= cnt; mean_l /= cnt; }
-        double best_cost = 0; int best_s = 1, best_p = all_packable ? 1 : 0;
-        for (int sgs : {1, 2, 4}) {
-            if (seg_want && sgs != seg_want) continue;
-            if (sgs > 1 && (mean_l <= 0 || mean_n < (sgs + 1) * mean_l)) continue;
-            for (int pk = 0; pk < 2; ++pk) {
-                if (pk && !all_packable) continue;
-                const double cost = (mean_n + (sgs - 1) * mean_l) * rate[sgs][pk];
-                if (best_cost == 0 || cost < best_cost) { best_cost = cost; best_s = sgs; best_p = pk; }
-            }
-        }
-        if (seg_want == 3) { best_s = 3; best_p = allow_pack && all_packable && getenv("STRQ_PACK") ? 1 : 0; }
-        seg_want = best_s;
-        if (!getenv("STRQ_PACK")) allow_pack = allow_pack && best_p;      // STRQ_PACK=1: 24-bit tables whenever they are exact
-    } else seg_want = 1;
+    // Launch geometry, per alignment.  Measured on MI355X (ms per 8192 alignments per 1000 columns computed,
+    // 870-row flanks, tools/dp_sweep.py): one wave per table 0.94 (24-bit tables, 8 waves per CU) / 1.02 (float32,
+    // 6 waves); two waves per table 0.86 (24-bit, 16 waves) / 0.79 (float32, 12 waves); four waves per table
+    // 0.80 / 0.69 (float32, 16 waves).  Three waves per table place unevenly on the four SIMDs (0.85 and worse).
+    // Every extra wave recomputes `overlap` columns, so short reads prefer fewer pieces: a batch of mixed read
+    // lengths runs as up to three launches (4, 2 and 1 waves per alignment).
+    static const double rate[5][2] = {{0, 0}, {1.017, 0.941}, {0.79, 0.862}, {0.85, 0.85}, {0.69, 0.80}};
     auto tables_for = [&](int dwords, int segs) {
         int t = std::min(max_tables, (160 * 1024 - 64) / (std::max(dwords, 1) * 4));
         if (segs > 1) t = std::min(t, max_waves / segs);
         return t;
     };
-    // 24-bit tables (lut_kernels.hip) are used by the collapsed single-strip kernels when every entry of
-    // the table is exact in that format; they are 3/4 of the size
-    const bool pack_ok = allow_pack;
     auto packed_dwords = [](int entries) { return (((2 * entries + 3) & ~3) + entries + 3) / 4; };
     std::vector<char> packed(nb, 0), segmentable(nb, 0);
-    std::vector<int> overlap(nb, 0);
-    // key: rows per lane, strips, -tables per CU, 0 = packed / 1 = float32 (packed first among equals)
-    std::map<std::tuple<int, int, int, int>, std::vector<int>> groups;
+    std::vector<int> overlap(nb, 0), segs_of(nb, 1);
+    const bool force_pack = getenv("STRQ_PACK") != nullptr;
+    int class_count[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < nb; ++i) {
-        packed[i] = pack_ok && in.NS[i] == 1 && info[i].packed && info[i].n_hard == 0;
         segmentable[i] = collapsed && in.NS[i] == 1;
         overlap[i] = segmentable[i] ? align_segment_overlap(c->ap, in.m[i]) : 0;
-        const int w = tables_for(packed[i] ? packed_dwords(info[i].total) : info[i].total, segmentable[i] ? seg_want : 1);
+        const bool can_pack = allow_pack && in.NS[i] == 1 && info[i].packed && info[i].n_hard == 0;
+        int best_s = 1, best_p = can_pack ? 1 : 0;
+        if (segmentable[i]) {
+            const double l = std::min(overlap[i], ov_cap);
+            double best_cost = 0;
+            for (int sgs : {1, 2, 3, 4}) {
+                if (seg_want ? sgs != seg_want : sgs == 3) continue;
+                if (sgs > 1 && !seg_want && (l <= 0 || in.n[i] < (sgs + 1) * l)) continue;
+                for (int pk = 0; pk < 2; ++pk) {
+                    if ((pk && !can_pack) || (force_pack && can_pack && !pk)) continue;
+                    const double cost = (in.n[i] + (sgs - 1) * l) * rate[sgs][pk];
+                    if (best_cost == 0 || cost < best_cost) { best_cost = cost; best_s = sgs; best_p = pk; }
+                }
+            }
+        }
+        segs_of[i] = best_s; packed[i] = (char)best_p;
+        ++class_count[best_s];
+    }
+    if (!seg_want) {
+        // a length class too small to fill the chip once joins the class with fewer waves per alignment
+        int few = 2 * c->n_cu;
+        if (const char* e = getenv("STRQ_CLASS_MIN")) few = atoi(e);      // tests: keep small length classes apart
+        if (class_count[4] && class_count[4] < few) { for (int i = 0; i < nb; ++i) if (segs_of[i] == 4) segs_of[i] = 2; class_count[2] += class_count[4]; class_count[4] = 0; }
+        if (class_count[2] && class_count[2] < few && class_count[1]) { for (int i = 0; i < nb; ++i) if (segs_of[i] == 2) segs_of[i] = 1; class_count[1] += class_count[2]; class_count[2] = 0; }
+    }
+    // key: rows per lane, strips, waves per alignment (descending), -tables per CU, 0 = packed / 1 = float32 (packed first among equals)
+    std::map<std::tuple<int, int, int, int, int>, std::vector<int>> groups;
+    for (int i = 0; i < nb; ++i) {
+        const int w = tables_for(packed[i] ? packed_dwords(info[i].total) : info[i].total, segs_of[i]);
         if (w < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
-        groups[std::make_tuple(in.R[i], in.NS[i], -w, packed[i] ? 0 : 1)].push_back(i);
+        groups[std::make_tuple(in.R[i], in.NS[i], -segs_of[i], -w, packed[i] ? 0 : 1)].push_back(i);
     }
     // Every launch ends with a ragged tail (alignments take tens of ms each), so a group that would not
     // keep its waves busy for a few rounds joins the next group with fewer tables per CU (larger LDS
-    // slices); groups are ordered by descending tables per CU within (R, strips).
+    // slices); groups are ordered by descending tables per CU within (R, strips, waves per alignment).
     {
         int min_rounds = 4;
         if (const char* e = getenv("STRQ_MIN_ROUNDS")) min_rounds = atoi(e);
         for (auto it = groups.begin(); it != groups.end();) {
             auto nx = std::next(it);
-            const int w = -std::get<2>(it->first);
+            const int w = -std::get<3>(it->first);
             // a packed alignment also has its float32 table, so it can join a float32 launch -- not the other way round
             const bool same_kind = nx != groups.end() && std::get<0>(nx->first) == std::get<0>(it->first) && std::get<1>(nx->first) == std::get<1>(it->first)
-                                   && !(std::get<3>(it->first) == 1 && std::get<3>(nx->first) == 0);
+                                   && std::get<2>(nx->first) == std::get<2>(it->first)
+                                   && !(std::get<4>(it->first) == 1 && std::get<4>(nx->first) == 0);
             if (same_kind && (long)it->second.size() < (long)min_rounds * w * c->n_cu) {
                 nx->second.insert(nx->second.end(), it->second.begin(), it->second.end());
                 it = groups.erase(it);
@@ -258,18 +263,11 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         auto& v = g.second;
         std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return in.n[x] > in.n[y]; });
         const int NS = std::get<1>(g.first);
-        const int pk = std::get<3>(g.first) == 0;
+        const int pk = std::get<4>(g.first) == 0;
         int lds_floats = 0;      // LDS slice of a table in dwords
-        bool seg_ok = true;
-        for (int i : v) { lds_floats = std::max(lds_floats, pk ? packed_dwords(info[i].total) : info[i].total); seg_ok &= segmentable[i] != 0; }
-        int segs = seg_ok ? seg_want : 1;
-        // column segments pay `overlap` extra columns per piece: only worth it when the reads are long
-        if (segs > 1) {
-            long tot_n = 0, tot_l = 0;
-            for (int i : v) { tot_n += in.n[i]; tot_l += overlap[i]; }
-            if (tot_l <= 0) segs = 1;
-        }
-        const int tables = std::min(-std::get<2>(g.first), tables_for(lds_floats, segs));       // members that joined from a smaller-slice group
+        for (int i : v) lds_floats = std::max(lds_floats, pk ? packed_dwords(info[i].total) : info[i].total);
+        const int segs = -std::get<2>(g.first);
+        const int tables = std::min(-std::get<3>(g.first), tables_for(lds_floats, segs));       // members that joined from a smaller-slice group
         if (tables < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
         launches.push_back({std::get<0>(g.first), NS, tables, (int)out.order.size(), (int)v.size(), (int)n_tasks, 0, lds_floats, pk, segs});
         out.order.insert(out.order.end(), v.begin(), v.end());

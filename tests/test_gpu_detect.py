@@ -240,3 +240,15 @@ def test_modification_pass_hub_records_equal_backpointers(pm, pm_mod, cfg, targe
     monkeypatch.setenv("STRQ_MOD_BACKPOINTERS", "1")
     b = rc.detect_batch(items)
     assert a == b and all(set(x[6]) <= set("01") and len(x[6]) > 0 for x in a)
+
+
+def test_mixed_read_lengths_run_as_length_classes(gpu_counter, want, pm, targets, monkeypatch):
+    """Reads of very different lengths in one batch: the forward DP runs them as separate launches with 1, 2
+    and 4 waves per alignment (STRQ_CLASS_MIN=1 keeps even tiny classes apart); every field equals the oracle's."""
+    monkeypatch.setenv("STRQ_CLASS_MIN", "1")
+    plan = [("c9orf72", "+", 3000, 12), ("fmr1", "-", 3500, 20), ("c9orf72", "-", 5000, 25), ("htt", "+", 6000, 40),
+            ("c9orf72", "+", 12000, 60), ("fmr1", "+", 30000, 300), ("c9orf72", "-", 60000, 500)]
+    items = [(name, _read(pm, targets, name, st, nt, nrep, 900 + i), st) for i, (name, st, nt, nrep) in enumerate(plan)]
+    got = _check(gpu_counter, want, items)
+    assert [abs(g[0] - p[3]) <= 2 for g, p in zip(got, plan)] == [True] * len(plan)
+    assert gpu_counter.ctx.last_timing()[7] >= 3            # at least three forward-DP launches
