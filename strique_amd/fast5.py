@@ -94,7 +94,13 @@ class H5File(object):
         return chunk[:e].decode()
 
     def _group_entries(self, ohdr):
-        """name -> object header address of an old-style group."""
+        """name -> object header address of a group (memoised: a bulk file's root group holds thousands of reads)."""
+        cache = self.__dict__.setdefault("_gcache", {})
+        if ohdr not in cache:
+            cache[ohdr] = self._group_entries_uncached(ohdr)
+        return cache[ohdr]
+
+    def _group_entries_uncached(self, ohdr):
         btree = heap = None
         out = {}
         dense = False
@@ -257,7 +263,7 @@ class H5File(object):
             raise ValueError("not a dataset: %s" % path)
         n = int(np.prod(shape)) if shape else 1
         if layout[0] == "contiguous":
-            return np.frombuffer(b, dtype, n, layout[1]).reshape(shape).copy()
+            return np.frombuffer(b, dtype, n, layout[1]).reshape(shape)      # a read-only view of the mapped file (it keeps the mapping alive)
         if len(shape) != 1:
             raise NotImplementedError("only 1-D chunked datasets")
         out = np.zeros(n, dtype)
