@@ -44,16 +44,36 @@ def test_int16_and_float64_reads(gpu_counter, want, pm, targets):
     _check(gpu_counter, want, flts)
 
 
-def test_reference_scenarios(gpu_counter, pm, cfg):
-    """scripts/STRique_test.py:47-62,86-100: noise-free float signals, n must equal i."""
+def test_reference_scenarios(pm, pm_mod, cfg):
+    """All four tests of the reference's scripts/STRique_test.py through the drop-in `repeatCounter`, with their
+    own loops and assertions (`n == i`): test_Detection (:43-62), test_Interpolation with its own flanks
+    (:66-82), test_Normalization (:85-100), test_Modification (:103-124).  Class defaults, no JSON config,
+    float64 signals from generate_signal -- exactly how the reference's tests call it (backbone and noise seeded here)."""
+    import random
+    from strique_amd.counter import repeatCounter
+    from test_oracle_golden import _INTERP_PREFIX, _INTERP_SUFFIX
+    rnd = random.Random(20260102)
+    backbone = ''.join(rnd.choice('ACTG') for _ in range(2000))
     chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
-    rng = np.random.default_rng(5)
-    backbone = "".join(rng.choice(list("ACTG"), 2000))
-    for i in (100, 300):
+    dt = repeatCounter(pm, device=0)
+    dt.add_target('c9orf72', repeat, prefix, suffix)
+    for i in range(100, 301, 100):
         seq = backbone[:1000] + prefix + repeat * i + suffix + backbone[-1000:]
-        assert gpu_counter.detect("c9orf72", pm.generate_signal(seq, samples=8), "+")[0] == i
-    for i in (10, 60):
-        assert gpu_counter.detect("c9orf72", pm.generate_signal(prefix + repeat * i + suffix, samples=8), "+")[0] == i
+        assert dt.detect('c9orf72', pm.generate_signal(seq, samples=8), '+')[0] == i
+    for i in range(10, 100, 10):
+        assert dt.detect('c9orf72', pm.generate_signal(prefix + repeat * i + suffix, samples=8), '+')[0] == i
+    dt.add_target('fmr1', 'GCG', _INTERP_PREFIX, _INTERP_SUFFIX)
+    for i in range(100, 301, 100):
+        seq = backbone[:1000] + _INTERP_PREFIX + 'GCG' * i + _INTERP_SUFFIX + backbone[-1000:]
+        assert dt.detect('fmr1', pm.generate_signal(seq, samples=8), '+')[0] == i
+    dm = repeatCounter(pm, mod_model_file=pm_mod, device=0)
+    dm.add_target('c9orf72', repeat, prefix, suffix)
+    rng = np.random.default_rng(20260103)
+    for i in range(100, 301, 100):
+        seq = backbone[:1000] + prefix + repeat * i + suffix + backbone[-1000:]
+        dm.detect('c9orf72', pm.generate_signal(seq, samples=8, noise=True, rng=rng), '+')
+        n = dm.detect('c9orf72', pm_mod.generate_signal(seq, samples=8, noise=True, rng=rng), '+')[0]
+        assert n == i
 
 
 def test_bad_reads_do_not_kill_the_batch(gpu_counter, want, pm, targets):

@@ -108,3 +108,38 @@ def test_normalization_scenario_without_backbone(pm, cfg, orc, opm):
     for i in (10, 50, 90):
         res, _ = orc.detect(pm.generate_signal(prefix + repeat * i + suffix, samples=8), tc, opm, orc.align_params(None))
         assert res[0] == i
+
+
+# the flanks of the reference's interpolation test differ by one base from configs/repeat_config.tsv (scripts/STRique_test.py:70-71)
+_INTERP_PREFIX = 'AGCGGGCCGGGGGTTCGGCCTCAGTCAGGCGCTCAGCTCCGTTTCGGTTTCACTTCCGGTGGAGGGCCGCCTCTGAGCGGGCGGCGGGCCGACGGCGAGCGCGGGCGGCGGCGGTGACGGAGGCGCCGCTGCCAGGGGGCGTGCGGCAGC'
+_INTERP_SUFFIX = 'GAGGCGGCGGCGGCGGCGGCGGCGGCGGCGGCTGGGCCTCGAGCGCCCGCAGCCCACCTCTCGGGGGCGGGCTCCCGGCGCTAGCAGGGCTGAAGAGAAGATGGAGGAGCTGGTGGTGGAAGTGCGGGGCTCCAATGGCGCTTTCTACAA'
+
+
+def test_every_scenario_of_the_reference_unit_tests(pm, pm_mod, cfg, orc, opm, opm_mod):
+    """All four tests of scripts/STRique_test.py with their own loops and assertions (`n == i`):
+    test_Detection (:43-62), test_Interpolation with its own flanks (:66-82), test_Normalization (:85-100),
+    test_Modification (:103-124: noisy signals from the base and the mCpG model, count asserted on the mCpG run).
+    The reference draws its backbone and noise unseeded; here they are seeded."""
+    import random
+    rnd = random.Random(20260102)
+    backbone = ''.join(rnd.choice('ACTG') for _ in range(2000))
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    params = orc.align_params(None)                      # repeatCounter(model_file): class defaults, no JSON
+    tc = orc.classifier(repeat, prefix, suffix, "+", opm, None, None)
+    for i in range(100, 301, 100):                       # test_Detection
+        seq = backbone[:1000] + prefix + repeat * i + suffix + backbone[-1000:]
+        assert orc.detect(pm.generate_signal(seq, samples=8), tc, opm, params)[0][0] == i
+    for i in range(10, 100, 10):                         # test_Normalization
+        assert orc.detect(pm.generate_signal(prefix + repeat * i + suffix, samples=8), tc, opm, params)[0][0] == i
+    tg = orc.classifier('GCG', _INTERP_PREFIX, _INTERP_SUFFIX, "+", opm, None, None)
+    for i in range(100, 301, 100):                       # test_Interpolation
+        seq = backbone[:1000] + _INTERP_PREFIX + 'GCG' * i + _INTERP_SUFFIX + backbone[-1000:]
+        assert orc.detect(pm.generate_signal(seq, samples=8), tg, opm, params)[0][0] == i
+    tm = orc.classifier(repeat, prefix, suffix, "+", opm, opm_mod, None)
+    rng = np.random.default_rng(20260103)
+    for i in range(100, 301, 100):                       # test_Modification
+        seq = backbone[:1000] + prefix + repeat * i + suffix + backbone[-1000:]
+        base = orc.detect(pm.generate_signal(seq, samples=8, noise=True, rng=rng), tm, opm, params, pm_mod=opm_mod)[0]
+        mod = orc.detect(pm_mod.generate_signal(seq, samples=8, noise=True, rng=rng), tm, opm, params, pm_mod=opm_mod)[0]
+        assert mod[0] == i
+        assert base[6].count('0') > 0.9 * len(base[6]) and mod[6].count('1') > 0.9 * len(mod[6])
