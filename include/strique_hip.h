@@ -144,8 +144,10 @@ int strq_viterbi_batch(strq_ctx* ctx, int32_t model_id, int64_t n_seq, const dou
  *                       median-filtered signal, (c1, h1) of its minmax map and of the raw signal's;
  *                       for int16 everything is computed on the GPU from exact histograms and
  *                       host_stats is ignored (may be NULL).
- * A read whose normalisation is undefined (constant signal, empty tails) gets status 1 and the
- * n = 0 row the reference writes for a failed gate; it never aborts the batch.
+ * A read whose normalisation is undefined (constant signal, empty percentile tails: numpy hands the
+ * reference NaN medians there) gets status 1 and the n = 0 row the reference writes for it -- its
+ * offset / ticks come from aligning an all-NaN signal, every cell scoring dist_min, which is what
+ * align_overlap makes of it (src/align_raw.h:100); it never aborts the batch.
  */
 typedef struct strq_result {
     int32_t count;          /* repeat count n (0 if the gate failed, STRique.py:602-603) */

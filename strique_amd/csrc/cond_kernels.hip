@@ -294,7 +294,9 @@ hist_stats_kernel(const uint32_t* __restrict__ hist_all, int nbins, int bias, Re
         v = v * h2 + c2;
         v = v < ps.clip_lo ? ps.clip_lo : v;
         v = v > ps.clip_hi ? ps.clip_hi : v;
-        level_val_all[(size_t)blockIdx.x * 256 + t] = degenerate ? 0.0f : (float)v;
+        // empty tails: the reference's medians are NaN and so is every value it hands to align_overlap, which
+        // then scores every cell dist_min (src/align_raw.h:100 -- the comparison with NaN is false)
+        level_val_all[(size_t)blockIdx.x * 256 + t] = degenerate ? __builtin_nanf("") : (float)v;
     } else {
         if (t == 0) { rc.r_c1 = c1; rc.r_h1 = h1; if (degenerate) rc.status = COND_DEGENERATE; }
     }
@@ -315,7 +317,7 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
     const ReadCond rc = rc_all[blockIdx.y];
     const int n = rc.n;
     const int t0 = blockIdx.x * COND_TILE;
-    if (t0 >= n || rc.status != COND_OK) return;
+    if (t0 >= n || !(rc.mad > 0.0)) return;      // constant signal: z-score undefined, no levels (hist_stats reports NaN level values)
     const T* flt = flt_all + rc.off;
     const int lo = t0 - COND_HALO, span = COND_TILE + 2 * COND_HALO;
     h8[threadIdx.x] = 0;

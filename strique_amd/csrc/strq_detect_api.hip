@@ -69,7 +69,9 @@ __global__ void finalize_kernel(FinalizeArgs a)
     const ReadCond rc = a.rc[r];
     ReadGeom g = {};
     VitTask vt = {};
-    if (rc.status == COND_OK) {
+    // the alignments run on whatever the conditioning produced (an all-NaN signal scores dist_min in every
+    // cell, as it does in the reference), so the positions are reported for every non-empty read
+    if (rc.n > 0) {
         const AlignTask& tp = a.tasks[a.task_of[2 * r]]; const AlignResult& rp = a.results[a.task_of[2 * r]];
         const AlignTask& ts = a.tasks[a.task_of[2 * r + 1]]; const AlignResult& rs = a.results[a.task_of[2 * r + 1]];
         {
@@ -84,7 +86,7 @@ __global__ void finalize_kernel(FinalizeArgs a)
             g.suffix_begin = b;
             g.suffix_end = row_position(ts.rec, ts.m_total, ts.m_total - 1 - a.trim[2 * r + 1], ts.n);
         }
-        g.gate = (g.prefix_begin < g.suffix_end && g.score_prefix > 0.0 && g.score_suffix > 0.0) ? 1 : 0;
+        g.gate = (rc.status == COND_OK && g.prefix_begin < g.suffix_end && g.score_prefix > 0.0 && g.score_suffix > 0.0) ? 1 : 0;
     }
     vt.model = a.model_of[r];
     if (g.gate) {

@@ -272,3 +272,34 @@ def test_mixed_read_lengths_run_as_length_classes(gpu_counter, want, pm, targets
     got = _check(gpu_counter, want, items)
     assert [abs(g[0] - p[3]) <= 2 for g, p in zip(got, plan)] == [True] * len(plan)
     assert gpu_counter.ctx.last_timing()[7] >= 3            # at least three forward-DP launches
+
+
+def test_odd_signals_against_the_oracle(gpu_counter, want, pm, targets):
+    """Signals a sequencer would never produce on purpose: saturated samples, long constant stretches, ramps,
+    spikes, pure noise, a locus cut in half -- whatever comes out (mostly failed gates), every field equals the
+    oracle's."""
+    rng = np.random.default_rng(4711)
+    names = ["c9orf72", "fmr1", "htt"]
+    items = []
+    for k in range(24):
+        name = names[k % 3]; strand = "+-"[(k // 3) % 2]
+        n = int(rng.integers(900, 6000))
+        kind = k % 8
+        if kind == 0:
+            sig = rng.integers(-32768, 32768, n)                                   # full-range noise
+        elif kind == 1:
+            sig = np.repeat(rng.integers(300, 900, n // 40 + 1), 40)[:n]            # long plateaus
+        elif kind == 2:
+            sig = np.linspace(200, 1000, n) + rng.normal(0, 3, n)                   # a ramp
+        elif kind == 3:
+            sig = rng.normal(600, 40, n); sig[rng.integers(0, n, 30)] = 32767; sig[rng.integers(0, n, 30)] = -32768      # saturated spikes
+        elif kind == 4:
+            sig = _read(pm, targets, name, strand, 4000, 15, 1200 + k).astype(np.float64); sig = sig[:len(sig) // 2]     # the locus cut in half
+        elif kind == 5:
+            sig = np.where(np.arange(n) % 2, 650, 640)                              # two alternating values
+        elif kind == 6:
+            base = _read(pm, targets, name, strand, 3500, 8, 1300 + k).astype(np.float64); sig = base[::-1]              # a read played backwards
+        else:
+            sig = _read(pm, targets, name, strand, 3000 + 100 * k, 5 + k, 1400 + k).astype(np.float64) * 1.7 - 300       # strongly rescaled
+        items.append((name, np.clip(np.round(sig), -32768, 32767).astype(np.int16), strand))
+    _check(gpu_counter, want, items)
