@@ -150,7 +150,7 @@ def run(raw, pm, cfg, v):
         sp, pb, pe_ = orc.detect_range(morph, tc["prefix_ext"], params, pre_trim=tp)
         ss, sb, se_ = orc.detect_range(morph, tc["suffix_ext"], params, post_trim=ts)
         n, lp = 0, 0.0
-        if pb < se_ and sp > 0 and ss > 0:
+        if pb < se_ and sp > 0 and ss > 0 and not v.get("scores_only"):
             lp, path, counted = orc.viterbi(tc["hmm"], fltn[pb:se_])
             n = counted + tc["count_bias"] if path is not None else 0
     finally:
@@ -209,6 +209,80 @@ def variants():
     return V
 
 
+def _merge(a, b):
+    """two variant dicts as one (switch lists concatenated, config blocks merged); None if they set the same switch"""
+    out = dict(a)
+    for k, val in b.items():
+        if k not in out:
+            out[k] = val
+        elif k == "defines":
+            if {x.split("=")[0].split("(")[0] for x in out[k]} & {x.split("=")[0].split("(")[0] for x in val}:
+                return None
+            out[k] = list(out[k]) + list(val)
+        elif k in ("align_cfg", "hmm_cfg", "prepare"):
+            if set(out[k]) & set(val):
+                return None
+            out[k] = dict(out[k], **val)
+        else:
+            return None
+    return out
+
+
+_PAIR_CTX = {}
+
+
+def _pair_job(job):
+    name, v = job
+    c = _PAIR_CTX
+    try:
+        r = run(c["raw"], c["pm"], c["cfg"], dict(v, scores_only=True))
+        return name, r
+    except Exception as ex:
+        return name, str(ex)
+
+
+def pairs(raw, pm, cfg, out, workers):
+    """Every PAIR of the variants that touch the two flank scores (aligner, normalisation, morphology), scores only:
+    the documented scores have 16 digits, so a pair that reproduced the reference's arithmetic would hit both exactly."""
+    import multiprocessing as mp
+    singles = [(n, v) for n, v in variants()[1:] if not ({"hmm_cfg", "prepare", "hmm_on_morph", "flt_mode"} & set(v)) and "samples" not in v]
+    jobs = []
+    for i in range(len(singles)):
+        for j in range(i + 1, len(singles)):
+            m = _merge(singles[i][1], singles[j][1])
+            if m is not None:
+                jobs.append((singles[i][0] + "  +  " + singles[j][0], m))
+    _PAIR_CTX.update(raw=raw, pm=pm, cfg=cfg)
+    for _, v in jobs:                        # compile the variant libraries once, before the fork
+        if v.get("defines"):
+            variant_lib(v["defines"])
+    with mp.get_context("fork").Pool(workers) as pool:
+        res = pool.map(_pair_job, jobs, chunksize=1)
+    rows = []
+    for name, r in res:
+        if isinstance(r, str):
+            rows.append((9e9, name, None, r)); continue
+        dp = r["score_prefix"] / DOCS["score_prefix"] - 1.0; ds = r["score_suffix"] / DOCS["score_suffix"] - 1.0
+        rows.append((max(abs(dp), abs(ds)), name, r, (dp, ds)))
+    rows.sort(key=lambda x: x[0])
+    hits = [x for x in rows if x[2] is not None and x[2]["score_prefix"] == DOCS["score_prefix"] and x[2]["score_suffix"] == DOCS["score_suffix"]]
+    lines = ["", "## Pairs", "",
+             "`python -m oracle.residual_probe --pairs`: all %d compatible pairs of the %d variants above that can move the two flank" % (len(jobs), len(singles)),
+             "scores (aligner, normalisation, morphology), alignment only.  Pairs reproducing both documented scores exactly: %s." % (
+                 ", ".join(x[1] for x in hits) if hits else "**none**"),
+             "The twelve closest (largest relative deviation of the two scores):", "",
+             "| pair | score_prefix | score_suffix | offset | ticks |", "|---|---|---|---|---|"]
+    for dev, name, r, d in rows[:12]:
+        lines.append("| %s | %.10f (%+.3f %%) | %.10f (%+.3f %%) | %d (%+d) | %d (%+d) |" % (
+            name, r["score_prefix"], 100 * d[0], r["score_suffix"], 100 * d[1], r["offset"], r["offset"] - DOCS["offset"],
+            r["ticks"], r["ticks"] - DOCS["ticks"]))
+    lines.append("")
+    print("\n".join(lines), flush=True)
+    if out:
+        with open(out, "a") as fp:
+            fp.write("\n".join(lines))
+
+
 def fmt_row(name, r, secs):
     d = lambda k: r[k] - DOCS[k]
     rel = lambda k: 100.0 * (r[k] / DOCS[k] - 1.0)
@@ -223,6 +297,8 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", nargs="*", default=None, help="substring filters on the variant name")
     ap.add_argument("--mod-model", action="store_true", help="also run every variant with the mCpG table as base model")
+    ap.add_argument("--pairs", action="store_true", help="only the pairwise sweep of the score-moving variants (appended to --out)")
+    ap.add_argument("--workers", type=int, default=max(1, (os.cpu_count() or 2) - 1))
     a = ap.parse_args()
     z = np.load(os.path.join(GOLDEN, "bundled_read.npz"))
     raw = z["signal"]
@@ -230,6 +306,9 @@ def main():
     pm = orc.PoreModel(table=(t["base_kmer"], t["base_mean"], t["base_stdv"]))
     pmm = orc.PoreModel(table=(t["mod_kmer"], t["mod_mean"], t["mod_stdv"]))
     cfg = json.load(open(os.path.join(GOLDEN, "config.json")))
+    if a.pairs:
+        pairs(raw, pm, cfg, a.out, a.workers)
+        return
     lines = ["# Residual probe: the bundled read under every enumerated alternative semantic",
              "",
              "Generated by `python -m oracle.residual_probe` (CPU, oracle only).  Target row "
