@@ -241,6 +241,15 @@ def main():
             roof["frac"] = roof["achieved"] / valu_peak
             roof["instr_per_cell"] = ipstep / (2.0 * R)                    # per lane: R rows x 2 columns per step
             roof["instr_per_cell_floor"] = 4.0                             # 3 v_add_f32 + 1 v_max3_f32
+            rates = _measured_rates()
+            if rates:
+                # what the chip actually issues on this kernel's instruction mix (tools/valu_rates.hip): the nominal
+                # peak assumes a 2-cycle issue for every instruction at 2.4 GHz
+                roof["measured_issue_ceiling"] = {"unit": "G wave-instructions/s", "v_add_f32_stream": rates.get("v_add_f32_stream"),
+                                                  "dp_cell_mix": rates.get("dp_cell_mix_independent"),
+                                                  "dp_cell_mix_chained": rates.get("dp_cell_mix_chained"), "source": rates.get("source")}
+                if rates.get("dp_cell_mix_independent"):
+                    roof["frac_of_measured_ceiling"] = roof["achieved"] / rates["dp_cell_mix_independent"]
         else:
             roof["achieved"] = None; roof["frac"] = None
         out = {
@@ -296,6 +305,14 @@ def _cpu_check(sig, strand):
     t0 = time.time()
     res, _ = orc.detect(sig, tc, opm, params, use_lut=True)
     return time.time() - t0, int(res[0])
+
+
+def _measured_rates():
+    p = os.path.join(ROOT, "profiles", "valu_rates.json")
+    try:
+        return json.load(open(p))
+    except (OSError, ValueError):
+        return {}
 
 
 def _profile_constants():
