@@ -139,11 +139,13 @@ int strq_viterbi_batch(strq_ctx* ctx, int32_t model_id, int64_t n_seq, const dou
  *                       (STRique.py:374-378,412,437).
  * strq_detect_batch     detect() for n_reads reads.  signals: concatenated raw samples,
  *                       dtype 0 = int16 (fast5 DAC values), 1 = float64 (pA, as the reference's
- *                       unit tests feed them).  For float64 the caller passes host_stats, six
- *                       doubles per read that numpy gives in O(N log N): median and MAD of the
- *                       median-filtered signal, (c1, h1) of its minmax map and of the raw signal's;
- *                       for int16 everything is computed on the GPU from exact histograms and
- *                       host_stats is ignored (may be NULL).
+ *                       unit tests feed them).  For int16 every order statistic of the conditioning
+ *                       comes from exact histograms on the GPU and host_stats is ignored.  float64
+ *                       reads have no histogram: their six scalars per read -- median and MAD of the
+ *                       median-filtered signal, (c1, h1) of its minmax map and of the raw signal's
+ *                       (STRique.py:142-143,152-160,590-592) -- are taken on the host with numpy's
+ *                       arithmetic, by the library itself when host_stats is NULL (strq_host_stats,
+ *                       one thread per core) or by the caller (six doubles per read).
  * A read whose normalisation is undefined (constant signal, empty percentile tails: numpy hands the
  * reference NaN medians there) gets status 1 and the n = 0 row the reference writes for it -- its
  * offset / ticks come from aligning an all-NaN signal, every cell scoring dist_min, which is what
@@ -177,6 +179,10 @@ int strq_batch_upload(strq_ctx* ctx, int64_t n_reads, const void* signals, int32
                       const int64_t* offsets, const int32_t* target_id, const double* host_stats);
 int strq_batch_run(strq_ctx* ctx);
 int strq_batch_fetch(strq_ctx* ctx, strq_result* out);
+/* The host-side statistics of float64 reads (no context, no device): out[6 * i ..] = median, MAD, c1, h1 of
+ * medfilt(read i, 3) and c1, h1 of read i itself (0, 1 unless want_raw) -- what numpy's median / mean / percentile
+ * give repeatCounter.detect (STRique.py:590-597). */
+int strq_host_stats(const double* signals, const int64_t* offsets, int64_t n_reads, int32_t want_raw, double* out);
 /* Test hook: conditioning outputs (8-bit morphology levels, their 256 float32 values, and
  * {median, MAD, c1/h1 of the filtered, morphology and raw signal, h2, c2}) of read `read` of the
  * last sub-batch processed by strq_batch_run. */

@@ -11,8 +11,6 @@ output tuple.
 """
 from collections import namedtuple
 
-import os
-import warnings
 
 import numpy as np
 
@@ -90,19 +88,6 @@ class repeatCounter(object):
         raise ValueError("RepeatCounter: Strand must be + or -.")
 
     # -------------------------------------------------------------------------------------
-    def _host_stats(self, raw):
-        """Order statistics numpy provides for float64 signals (see include/strique_hip.h)."""
-        if len(raw) == 0:
-            return [np.nan] * 6          # the library reports such a read as status 1 (n = 0 row)
-        p = np.concatenate([[0.0], raw, [0.0]])
-        flt = np.sort(np.stack([p[:-2], p[1:-1], p[2:]]), axis=0)[1]          # medfilt(raw, 3)
-        with np.errstate(all='ignore'), warnings.catch_warnings():
-            warnings.simplefilter("ignore")          # empty tails of very short reads: NaN, flagged by the library
-            med = np.median(flt); mad = self.pm.MAD(flt)
-            c1, h1, _, _ = self.pm.minmax_coefficients(flt)
-            r1, rh, _, _ = self.pm.minmax_coefficients(raw) if self.pm is not self.pm_mod else (0.0, 1.0, 0, 0)
-        return [med, mad, c1, h1, r1, rh]
-
     def detect_batch(self, items):
         """items: iterable of (target_name, raw_signal, strand).  Returns a list of the tuples
         detect() returns, in input order."""
@@ -112,7 +97,7 @@ class repeatCounter(object):
         tcs = [self._classifier_for(t, s) for t, _, s in items]
         sigs = [np.asarray(r) for _, r, _ in items]
         # DAC samples that fit int16 take the all-GPU path (exact histograms); everything else is float64
-        # (order statistics by numpy on the host).  A mixed batch runs as two device batches.
+        # (the library takes its order statistics on the host, strq_host_stats).  A mixed batch runs as two device batches.
         def fits_int16(s):
             if s.dtype.kind not in 'iu':
                 return False
@@ -125,19 +110,9 @@ class repeatCounter(object):
             idx = [i for i, f in enumerate(is_int) if f == want_int]
             if not idx:
                 continue
-            if want_int:
-                arrs = [sigs[i].astype(np.int16, copy=False) for i in idx]; stats = None
-            else:
-                arrs = [sigs[i].astype(np.float64) for i in idx]
-                # numpy's sorts / selections release the GIL: one thread per read up to the core count
-                if len(arrs) > 1:
-                    from concurrent.futures import ThreadPoolExecutor
-                    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1, len(arrs))) as pool:
-                        stats = np.array(list(pool.map(self._host_stats, arrs)))
-                else:
-                    stats = np.array([self._host_stats(a) for a in arrs])
+            arrs = [sigs[i].astype(np.int16 if want_int else np.float64, copy=False) for i in idx]
             off = np.zeros(len(arrs) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in arrs])
-            res = self.ctx.detect_batch(np.concatenate(arrs), off, [tcs[i].target_id for i in idx], stats)
+            res = self.ctx.detect_batch(np.concatenate(arrs), off, [tcs[i].target_id for i in idx])
             mods = self.ctx.batch_fetch_mod() if self.pm is not self.pm_mod else ['-'] * len(res)
             for i, r, m in zip(idx, res, mods):
                 n = int(r['count']); p = float(r['log_p']) if n or r['log_p'] != 0 else 0

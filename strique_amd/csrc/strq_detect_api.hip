@@ -598,7 +598,7 @@ static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int3
 {
     if (!c) return STRQ_ERR_ARG;
     DetectState* d = dstate(c);
-    if (n_reads < 0 || (n_reads > 0 && (!signals || !offsets || !target_id)) || (dtype != 0 && dtype != 1) || (dtype == 1 && n_reads > 0 && !host_stats)) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+    if (n_reads < 0 || (n_reads > 0 && (!signals || !offsets || !target_id)) || (dtype != 0 && dtype != 1)) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     if (!d->have_ps) { c->err = "strq_set_pore_stats has not been called"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
     Batch& B = d->batch;
@@ -610,7 +610,14 @@ static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int3
         if (B.off[i + 1] < B.off[i] || B.off[i + 1] - B.off[i] > ((int64_t)1 << 30)) { c->err = "bad offsets"; return STRQ_ERR_ARG; }
     }
     B.host_stats.clear();
-    if (dtype == 1) B.host_stats.assign(host_stats, host_stats + n_reads * 6);
+    if (dtype == 1 && host_stats) B.host_stats.assign(host_stats, host_stats + n_reads * 6);
+    else if (dtype == 1) {
+        // float64 reads have no exact histogram: their order statistics are taken on the host (host_stats.hip)
+        bool want_raw = false;
+        for (int64_t i = 0; i < n_reads; ++i) want_raw |= d->targets[B.target[i]].mod_model_id >= 0;
+        B.host_stats.resize((size_t)n_reads * 6);
+        host_stats_batch(static_cast<const double*>(signals), offsets, n_reads, want_raw, B.host_stats.data());
+    }
     const size_t bytes = (size_t)(n_reads ? B.off[n_reads] : 0) * (dtype == 0 ? 2 : 8);
     STRQ_HIP(c, B.raw.reserve(bytes + 64));
     B.host_src = static_cast<const char*>(signals); B.uploaded = 0;

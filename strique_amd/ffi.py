@@ -46,6 +46,18 @@ def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+def host_stats(signals, offsets, want_raw=False):
+    """strq_host_stats: the six host-side scalars per float64 read (median, MAD, c1, h1 of the median-filtered signal;
+    c1, h1 of the raw one), with numpy's arithmetic.  No context and no device involved."""
+    lib = load_library()
+    signals = _c(signals, np.float64); offsets = _c(offsets, np.int64)
+    out = np.zeros((len(offsets) - 1, 6), np.float64)
+    rc = lib.strq_host_stats(_ptr(signals), _ptr(offsets), ctypes.c_int64(len(offsets) - 1), ctypes.c_int32(1 if want_raw else 0), _ptr(out))
+    if rc != STRQ_OK:
+        raise StriqueHipError(rc, "strq_host_stats: bad argument")
+    return out
+
+
 class Context(object):
     """One HIP context / stream / workspace on one GPU (strq_ctx)."""
 

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import warnings
 
 import numpy as np
 import pytest
@@ -77,3 +78,40 @@ def test_oracle_does_not_import_the_product():
         if name.endswith((".py", ".c", ".h")) or name == "Makefile":
             text = open(os.path.join(ROOT, "oracle", name)).read()
             assert not bad.search(text), name
+
+
+def test_host_stats_equal_numpy():
+    """strq_host_stats (float64 reads: no exact histogram on the GPU) against the numpy calls of the reference:
+    scipy medfilt(3), np.median, MAD = np.mean(|x - median|) (STRique.py:142-143), np.percentile([1, 99]) and the
+    medians of the two tails (STRique.py:152-160).  Bit for bit, sizes around every blocking boundary of numpy's
+    pairwise summation and of the selection."""
+    import scipy.signal
+    from strique_amd import ffi
+    rng = np.random.default_rng(99)
+    sizes = [1, 2, 3, 7, 8, 9, 100, 127, 128, 129, 1000, 8191, 8192, 8193, 8200, 16384, 16385, 40000, 100003, 284184]
+    sigs = []
+    for k, n in enumerate(sizes):
+        if k % 3 == 0:
+            s = rng.normal(90, 12, n)
+        elif k % 3 == 1:
+            s = np.round(rng.normal(90, 12, n) * 4) / 4            # many ties
+        else:
+            s = rng.normal(90, 12, n); s[rng.integers(0, n, max(1, n // 50))] = 300.0
+        sigs.append(s)
+    sigs.append(np.full(500, 42.0))                                 # constant: empty tails
+    sigs.append(np.where(np.arange(9000) % 2, 1.0, 2.0))            # two values
+    off = np.zeros(len(sigs) + 1, np.int64); off[1:] = np.cumsum([len(s) for s in sigs])
+    got = ffi.host_stats(np.concatenate(sigs), off, want_raw=True)
+
+    def tails(x):
+        q_lo, q_hi = np.percentile(x, [1, 99])
+        m_lo = np.median(x[x < q_lo]); m_hi = np.median(x[x > q_hi])
+        return m_lo + (m_hi - m_lo) / 2, (m_hi - m_lo) / 2
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for s, g in zip(sigs, got):
+            flt = scipy.signal.medfilt(s, 3)
+            med = np.median(flt)
+            want = [med, np.mean(np.absolute(np.subtract(flt, med)))] + list(tails(flt)) + list(tails(s))
+            assert np.array_equal(np.asarray(want), g, equal_nan=True), (len(s), want, g)
+    assert np.array_equal(ffi.host_stats(np.concatenate(sigs), off)[:, 4:], np.tile([0.0, 1.0], (len(sigs), 1)))
