@@ -819,6 +819,9 @@ int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
         for (int r : single) if (64 * r >= m) { *rows_per_lane = r; *n_strips = 1; return r; }
     for (int r : two) if (64 * r < m && 128 * r >= m) { *rows_per_lane = r; *n_strips = 2; return r; }
     for (int r : single) if (64 * r >= m) { *rows_per_lane = r; *n_strips = 1; return r; }
+    // longer flanks: strips of 64 x 12 rows (128 k-mer classes each, so that every strip's score table fits the LDS
+    // of the kernel that builds it), top to bottom with the strip's last row handed on through HBM
+    if (m <= STRQ_MAX_STRIPS * 64 * 12) { *rows_per_lane = 12; *n_strips = (m + 64 * 12 - 1) / (64 * 12); return 12; }
     return 0;
 }
 

@@ -63,10 +63,16 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // cls_off / col0_off: flank class values and column 0 of the DP are shared by all alignments of
     // the same flank / flank length (a batch has a handful of distinct ones); desc_off: per-alignment
     // band descriptors
-    std::vector<size_t> cls_off(nb), col0_off(nb), tab_off(nb), bnd_off(nb), desc_off(nb);
+    std::vector<size_t> cls_off(nb), col0_off(nb), bnd_off(nb);
     std::map<const float*, size_t> cls_of_flank; std::map<int, size_t> col0_of_m;
     std::vector<int> cls_first, col0_first;        // first alignment that uses each shared array
     out.rec_off.assign(nb, 0);
+    // Score-table jobs.  A flank of at most STRQ_LUT_MAX_K classes has one table; a longer one (more than
+    // 948 samples at 6 per k-mer) runs as several strips of 64 x R rows and gets one table per strip, so
+    // that a table -- full width in the worst case -- always fits the LDS of the kernel that builds it.
+    std::vector<int> J0(nb), NJ(nb);               // first job / number of jobs of an alignment
+    std::vector<int> job_align, job_k0, job_k;
+    std::vector<size_t> tab_off, desc_off;
     int max_k = 0;
     for (int i = 0; i < nb; ++i) {
         auto fc = cls_of_flank.find(in.flank[i]);
@@ -75,12 +81,23 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         auto f0 = col0_of_m.find(in.m[i]);
         if (f0 == col0_of_m.end()) { f0 = col0_of_m.emplace(in.m[i], col0_tot).first; col0_tot += in.m[i] + 1; col0_first.push_back(i); }
         col0_off[i] = f0->second;
-        desc_off[i] = desc_tot; desc_tot += in.k[i];
+        J0[i] = (int)job_align.size();
+        NJ[i] = in.k[i] > STRQ_LUT_MAX_K ? in.NS[i] : 1;
+        for (int sidx = 0; sidx < NJ[i]; ++sidx) {
+            int k0 = 0, kn = in.k[i];
+            if (NJ[i] > 1) {
+                const int row0 = sidx * 64 * in.R[i], rows = std::min(64 * in.R[i], in.m[i] - row0);
+                k0 = row0 / S; kn = (row0 + rows - 1) / S - k0 + 1;
+            }
+            job_align.push_back(i); job_k0.push_back(k0); job_k.push_back(kn);
+            desc_off.push_back(desc_tot); desc_tot += kn;
+            tab_off.push_back(tab_tot); tab_tot += STRQ_TABLE_SLOT_FLOATS(kn);
+            max_k = std::max(max_k, kn);
+        }
         out.rec_off[i] = rec_tot; rec_tot += in.m[i];
-        tab_off[i] = tab_tot; tab_tot += STRQ_TABLE_SLOT_FLOATS(in.k[i]);
         bnd_off[i] = bnd_floats; if (in.NS[i] > 1) bnd_floats += (size_t)(in.NS[i] - 1) * 2 * ((size_t)in.n[i] + 2);
-        max_k = std::max(max_k, in.k[i]);
     }
+    const int nj = (int)job_align.size();
     out.rec_total = rec_tot;
     std::vector<float> h_cls(cls_tot), h_col0(col0_tot);
     for (int i : cls_first) {
@@ -92,10 +109,10 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, c->col0.reserve(col0_tot * 4));
     STRQ_HIP(c, c->band_lo.reserve(desc_tot * 4));
     STRQ_HIP(c, c->tables.reserve(tab_tot * 4));
-    STRQ_HIP(c, c->tables3.reserve(tab_tot * 3 + (size_t)nb * 8 + 64));
+    STRQ_HIP(c, c->tables3.reserve(tab_tot * 3 + (size_t)nj * 8 + 64));
     STRQ_HIP(c, c->bnd.reserve(bnd_floats * 4 + 256));
     STRQ_HIP(c, c->rec.reserve(rec_tot * 4 + 256));
-    STRQ_HIP(c, c->lutinfo.reserve((size_t)nb * (sizeof(LutJob) + sizeof(LutInfo))));
+    STRQ_HIP(c, c->lutinfo.reserve((size_t)nj * (sizeof(LutJob) + sizeof(LutInfo))));
     const int hard_cap = 1 << 16;
     STRQ_HIP(c, c->hard.reserve((size_t)hard_cap * (sizeof(HardEntry) + 4) + 64));
     STRQ_HIP(c, c->queue.reserve(1024));
@@ -104,35 +121,36 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
 
     // ---- score tables
-    std::vector<LutJob> jobs(nb);
+    std::vector<LutJob> jobs(nj);
     LutJob* d_jobs = c->lutinfo.as<LutJob>();
-    LutInfo* d_info = reinterpret_cast<LutInfo*>(d_jobs + nb);
-    for (int i = 0; i < nb; ++i) {
-        jobs[i].level_val = in.d_level_val + (size_t)in.read[i] * 256;
-        jobs[i].cls_val = c->flank_cls.as<float>() + cls_off[i];
-        jobs[i].table = c->tables.as<float>() + tab_off[i];
-        jobs[i].table3 = c->tables3.as<uint8_t>() + tab_off[i] * 3 + (size_t)i * 8 - (tab_off[i] * 3 + (size_t)i * 8) % 4;      // 4-byte aligned slot
-        jobs[i].band_lo = c->band_lo.as<int32_t>() + desc_off[i];
-        jobs[i].k = in.k[i]; jobs[i].pad_ = 0;
+    LutInfo* d_info = reinterpret_cast<LutInfo*>(d_jobs + nj);
+    for (int j = 0; j < nj; ++j) {
+        const int i = job_align[j];
+        jobs[j].level_val = in.d_level_val + (size_t)in.read[i] * 256;
+        jobs[j].cls_val = c->flank_cls.as<float>() + cls_off[i] + job_k0[j];
+        jobs[j].table = c->tables.as<float>() + tab_off[j];
+        jobs[j].table3 = c->tables3.as<uint8_t>() + tab_off[j] * 3 + (size_t)j * 8 - (tab_off[j] * 3 + (size_t)j * 8) % 4;      // 4-byte aligned slot
+        jobs[j].band_lo = c->band_lo.as<int32_t>() + desc_off[j];
+        jobs[j].k = job_k[j]; jobs[j].pad_ = 0;
     }
-    STRQ_HIP(c, hipMemcpyAsync(d_jobs, jobs.data(), (size_t)nb * sizeof(LutJob), hipMemcpyHostToDevice, st));
+    STRQ_HIP(c, hipMemcpyAsync(d_jobs, jobs.data(), (size_t)nj * sizeof(LutJob), hipMemcpyHostToDevice, st));
     HardEntry* d_hard = c->hard.as<HardEntry>();
     float* d_hard_vals = reinterpret_cast<float*>(d_hard + hard_cap);
     int* d_hard_count = c->queue.as<int>() + 224;
     STRQ_HIP(c, hipEventRecord(c->ev[0], st));
-    if (launch_lut_build(st, d_jobs, d_info, nb, max_k, d_hard, d_hard_count, hard_cap, c->ap)) { c->err = "lut launch failed"; return STRQ_ERR_DEVICE; }
+    if (launch_lut_build(st, d_jobs, d_info, nj, max_k, d_hard, d_hard_count, hard_cap, c->ap)) { c->err = "lut launch failed"; return STRQ_ERR_DEVICE; }
     STRQ_HIP(c, hipEventRecord(c->ev[1], st));
-    std::vector<LutInfo> info(nb);
+    std::vector<LutInfo> info(nj);
     int hard_count = 0;
-    STRQ_HIP(c, hipMemcpyAsync(info.data(), d_info, (size_t)nb * sizeof(LutInfo), hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipMemcpyAsync(info.data(), d_info, (size_t)nj * sizeof(LutInfo), hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(&hard_count, d_hard_count, 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
     STRQ_DBG("lut done nb=%d hard=%d floats0=%d", nb, hard_count, info[0].total);
-    if (getenv("STRQ_DEBUG")) { int hist[9] = {0}; for (int i = 0; i < nb; ++i) hist[std::min(8, info[i].need / 8)]++; STRQ_DBG("band need histogram (x8 levels): %d %d %d %d %d %d %d %d %d", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]); }
-    if (getenv("STRQ_DEBUG")) { long tot = 0; int mx = 0; for (int i = 0; i < nb; ++i) { tot += info[i].total; mx = std::max(mx, info[i].total); } STRQ_DBG("table floats: mean %.0f max %d (k=%d)", (double)tot / nb, mx, in.k[0]); }
+    if (getenv("STRQ_DEBUG")) { int hist[9] = {0}; for (int i = 0; i < nj; ++i) hist[std::min(8, info[i].need / 8)]++; STRQ_DBG("band need histogram (x8 levels): %d %d %d %d %d %d %d %d %d", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]); }
+    if (getenv("STRQ_DEBUG")) { long tot = 0; int mx = 0; for (int i = 0; i < nj; ++i) { tot += info[i].total; mx = std::max(mx, info[i].total); } STRQ_DBG("table floats: mean %.0f max %d (k=%d)", (double)tot / nj, mx, in.k[0]); }
     if (hard_count > hard_cap) { c->err = "too many borderline table entries"; return STRQ_ERR_DEVICE; }
     bool any_rebuild = false;
-    for (int i = 0; i < nb; ++i) any_rebuild |= info[i].n_hard < 0;
+    for (int j = 0; j < nj; ++j) any_rebuild |= info[j].n_hard < 0;
     std::vector<float> h_lval;      // level values of the reads involved in host work (fetched lazily)
     auto level_vals_of = [&](int read, float* dst) -> int {
         STRQ_HIP(c, hipMemcpy(dst, in.d_level_val + (size_t)read * 256, 256 * 4, hipMemcpyDeviceToHost));
@@ -143,29 +161,32 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         STRQ_HIP(c, hipMemcpy(he.data(), d_hard, (size_t)hard_count * sizeof(HardEntry), hipMemcpyDeviceToHost));
         float lv[256]; int last_read = -1;
         for (int i = 0; i < hard_count; ++i) {
-            const int rd = in.read[he[i].job];
+            const int rd = in.read[job_align[he[i].job]];
             if (rd != last_read) { const int rc = level_vals_of(rd, lv); if (rc) return rc; last_read = rd; }
-            hv[i] = host_cell_score(c->ap, lv[he[i].level], h_cls[cls_off[he[i].job] + he[i].k]);
+            hv[i] = host_cell_score(c->ap, lv[he[i].level], h_cls[cls_off[job_align[he[i].job]] + job_k0[he[i].job] + he[i].k]);
         }
         STRQ_HIP(c, hipMemcpyAsync(d_hard_vals, hv.data(), (size_t)hard_count * 4, hipMemcpyHostToDevice, st));
         if (launch_lut_patch(st, d_jobs, d_hard, d_hard_vals, hard_count)) { c->err = "patch launch failed"; return STRQ_ERR_DEVICE; }
         STRQ_HIP(c, hipStreamSynchronize(st));
     }
-    if (any_rebuild) for (int i = 0; i < nb; ++i) if (info[i].n_hard < 0) {
+    if (any_rebuild) for (int j = 0; j < nj; ++j) if (info[j].n_hard < 0) {
         // whole table from the host libm, full width
-        const int kk = in.k[i];
+        const int kk = job_k[j], i = job_align[j];
         std::vector<float> tab((size_t)kk * 256); std::vector<int32_t> blo(kk);
         float lv[256];
         { const int rc = level_vals_of(in.read[i], lv); if (rc) return rc; }
         for (int x = 0; x < kk; ++x) {
             float* row = &tab[(size_t)x * 256];
-            for (int q = 0; q < 256; ++q) row[q] = host_cell_score(c->ap, lv[q], h_cls[cls_off[i] + x]);
+            for (int q = 0; q < 256; ++q) row[q] = host_cell_score(c->ap, lv[q], h_cls[cls_off[i] + job_k0[j] + x]);
             blo[x] = (int32_t)((255u << 8) | ((uint32_t)(x * 256) << 16));     // levels 0..255, row offset x * 256
         }
-        STRQ_HIP(c, hipMemcpy(jobs[i].table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-        STRQ_HIP(c, hipMemcpy(jobs[i].band_lo, blo.data(), (size_t)kk * 4, hipMemcpyHostToDevice));
-        info[i].total = kk * 256;
+        STRQ_HIP(c, hipMemcpy(jobs[j].table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        STRQ_HIP(c, hipMemcpy(jobs[j].band_lo, blo.data(), (size_t)kk * 4, hipMemcpyHostToDevice));
+        info[j].total = kk * 256;
     }
+    // LDS slice an alignment needs: its table, or the largest of its strips' tables
+    std::vector<int> tab_total(nb, 0);
+    for (int j = 0; j < nj; ++j) tab_total[job_align[j]] = std::max(tab_total[job_align[j]], info[j].total);
     out.n_hard = hard_count;
 
     // ---- tasks.  Alignments are grouped by (rows per lane, strips, score tables per CU), longest first.
@@ -204,7 +225,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     for (int i = 0; i < nb; ++i) {
         segmentable[i] = collapsed && in.NS[i] == 1;
         overlap[i] = segmentable[i] ? align_segment_overlap(c->ap, in.m[i]) : 0;
-        const bool can_pack = allow_pack && in.NS[i] == 1 && info[i].packed && info[i].n_hard == 0;
+        const bool can_pack = allow_pack && in.NS[i] == 1 && info[J0[i]].packed && info[J0[i]].n_hard == 0;
         int best_s = 1, best_p = can_pack ? 1 : 0;
         if (segmentable[i]) {
             const double l = std::min(overlap[i], ov_cap);
@@ -232,7 +253,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // key: rows per lane, strips, waves per alignment (descending), -tables per CU, 0 = packed / 1 = float32 (packed first among equals)
     std::map<std::tuple<int, int, int, int, int>, std::vector<int>> groups;
     for (int i = 0; i < nb; ++i) {
-        const int w = tables_for(packed[i] ? packed_dwords(info[i].total) : info[i].total, segs_of[i]);
+        const int w = tables_for(packed[i] ? packed_dwords(tab_total[i]) : tab_total[i], segs_of[i]);
         if (w < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
         groups[std::make_tuple(in.R[i], in.NS[i], -segs_of[i], -w, packed[i] ? 0 : 1)].push_back(i);
     }
@@ -265,16 +286,16 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         const int NS = std::get<1>(g.first);
         const int pk = std::get<4>(g.first) == 0;
         int lds_floats = 0;      // LDS slice of a table in dwords
-        for (int i : v) lds_floats = std::max(lds_floats, pk ? packed_dwords(info[i].total) : info[i].total);
+        for (int i : v) lds_floats = std::max(lds_floats, pk ? packed_dwords(tab_total[i]) : tab_total[i]);
         const int segs = -std::get<2>(g.first);
         const int tables = std::min(-std::get<3>(g.first), tables_for(lds_floats, segs));       // members that joined from a smaller-slice group
         if (tables < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
         launches.push_back({std::get<0>(g.first), NS, tables, (int)out.order.size(), (int)v.size(), (int)n_tasks, 0, lds_floats, pk, segs});
         out.order.insert(out.order.end(), v.begin(), v.end());
         n_tasks += (size_t)v.size() * segs;
-        if (NS > 1) n_up += (int)v.size();
+        if (NS > 1) n_up += (int)v.size() * (NS - 1);
     }
-    { size_t up = n_tasks; for (auto& L : launches) if (L.NS > 1) { L.first_up = (int)up; up += L.count; } }
+    { size_t up = n_tasks; for (auto& L : launches) if (L.NS > 1) { L.first_up = (int)up; up += (size_t)L.count * (L.NS - 1); } }      // upper strips: level-major per launch
     // Piece boundaries and checkpoint areas.  Two geometries per segmented launch: the pieces that run first
     // are cut with a short overlap (`ov_fast` columns), which is exact whenever the alignment's best score
     // reaches align_segment_min_score -- true for every read that contains the flank; the combine kernel
@@ -321,7 +342,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 pf[k].ck = ps[k].ck = ck_floats;
                 ck_floats += (size_t)align_num_ckpts(std::max(pf[k].n, ps[k].n)) * per_ckpt;
             }
-            if (L.NS > 1) { ck_up[i] = ck_floats; ck_floats += (size_t)align_num_ckpts(n) * per_ckpt; }
+            if (L.NS > 1) { ck_up[i] = ck_floats; ck_floats += (size_t)(L.NS - 1) * align_num_ckpts(n) * per_ckpt; }
         }
     }
     bool any_two_round = false;
@@ -348,37 +369,47 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             AlignTask base; std::memset(&base, 0, sizeof(base));
             base.levels = in.d_levels + in.read_off[in.read[i]];
             base.rec = c->rec.as<int32_t>() + out.rec_off[i];
-            base.n = in.n[i]; base.n_full = in.n[i]; base.m_total = M; base.tsize = info[i].total;
-            auto strip = [&](int row0, int rows, size_t ck) {
+            base.n = in.n[i]; base.n_full = in.n[i]; base.m_total = M;
+            auto strip = [&](int row0, int rows, size_t ck, int sidx) {
                 AlignTask t = base;
+                const int j = NJ[i] > 1 ? J0[i] + sidx : J0[i];            // the table that covers this strip's classes
                 const int k0 = row0 / S, k1 = (row0 + rows - 1) / S;
-                t.row0 = row0; t.m = rows; t.k = k1 - k0 + 1;
-                t.table = jobs[i].table; t.table3 = jobs[i].table3; t.band_lo = jobs[i].band_lo + k0;
+                t.row0 = row0; t.m = rows; t.k = k1 - k0 + 1; t.tsize = info[j].total;
+                t.table = jobs[j].table; t.table3 = jobs[j].table3; t.band_lo = jobs[j].band_lo + (k0 - job_k0[j]);
                 t.col0 = c->col0.as<float>() + col0_off[i] + row0;
                 t.ckpt = c->ckpt.as<float>() + ck;
                 return t;
             };
-            tasks[n_tasks + n_up + pos] = strip(0, M, 0);       // head: what finalize reads (rec, m_total, n)
+            tasks[n_tasks + n_up + pos] = strip(0, M, 0, 0);       // head: what finalize reads (rec, m_total, n)
             if (L.NS == 1) {
                 for (int k = 0; k < L.segs; ++k) {
                     const size_t ti = (size_t)L.first_task + (size_t)x * L.segs + k;
-                    AlignTask t = strip(0, M, pieces[ti].ck);
+                    AlignTask t = strip(0, M, pieces[ti].ck, 0);
                     t.levels += pieces[ti].col_off; t.n = pieces[ti].n; t.col_off = pieces[ti].col_off;
                     tasks[ti] = t;
                     if (any_two_round) {
-                        AlignTask u = strip(0, M, safe[ti].ck);
+                        AlignTask u = strip(0, M, safe[ti].ck, 0);
                         u.levels += safe[ti].col_off; u.n = safe[ti].n; u.col_off = safe[ti].col_off;
                         tasks[safe0 + ti] = u;
                     }
                 }
             } else {
-                const int rows0 = 64 * R;
-                AlignTask top = strip(0, rows0, ck_up[i]), bot = strip(rows0, M - rows0, pieces[(size_t)L.first_task + x].ck);
+                // strips top to bottom: the upper ones (level-major behind the pieces) hand their last row {S, V} to the
+                // next through HBM; the bottom strip sits in the launch's piece slot and holds the result
+                const int rows_s = 64 * R;
+                const size_t ck_strip = (size_t)align_num_ckpts(in.n[i]) * STRQ_CKPT_FIELDS(R) * 64;
                 float* bnd = c->bnd.as<float>() + bnd_off[i];
-                top.bnd_out = bnd; bot.bnd_in = bnd;
-                bot.up = d_tasks + L.first_up + x;
-                tasks[(size_t)L.first_task + x] = bot; tasks[(size_t)L.first_up + x] = top;
-                if (any_two_round) tasks[safe0 + (size_t)L.first_task + x] = bot;
+                const size_t bnd_stride = 2 * ((size_t)in.n[i] + 2);
+                for (int sidx = 0; sidx < L.NS; ++sidx) {
+                    const bool last = sidx == L.NS - 1;
+                    const int row0 = sidx * rows_s, rows = last ? M - row0 : rows_s;
+                    const size_t slot = last ? (size_t)L.first_task + x : (size_t)L.first_up + (size_t)sidx * L.count + x;
+                    AlignTask t = strip(row0, rows, last ? pieces[(size_t)L.first_task + x].ck : ck_up[i] + (size_t)sidx * ck_strip, sidx);
+                    if (sidx > 0) { t.bnd_in = bnd + (size_t)(sidx - 1) * bnd_stride; t.up = d_tasks + L.first_up + (size_t)(sidx - 1) * L.count + x; }
+                    if (!last) t.bnd_out = bnd + (size_t)sidx * bnd_stride;
+                    tasks[slot] = t;
+                    if (last && any_two_round) tasks[safe0 + slot] = t;
+                }
             }
         }
     }
@@ -397,17 +428,20 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     out.n_launches = 0; out.wave_steps = 0; out.columns = 0;
     for (size_t t = 0; t < n_tasks + n_up; ++t) if (tasks[t].n > 0) { out.wave_steps += align_num_steps(tasks[t].n); out.columns += tasks[t].n; }
     if (!launches.empty()) { const Launch& L = launches.back(); out.segs = L.segs; out.tables = L.tables; out.packed = L.packed; out.rows_per_lane = L.R; }
-    for (int level = 0; level < 2; ++level) {          // first strips, then the strips below them
+    int max_ns = 1;
+    for (auto& L : launches) max_ns = std::max(max_ns, L.NS);
+    for (int level = 0; level < max_ns; ++level) {          // top strips first, then the strips below them
         for (auto& L : launches) {
-            if (level == 1 && L.NS == 1) continue;
+            if (level >= L.NS) continue;
             STRQ_DBG("forward launch R=%d strips=%d slice dwords=%d packed=%d level=%d count=%d tables/CU=%d segments=%d", L.R, L.NS, L.lds_floats, L.packed, level, L.count, L.tables, L.segs);
             int rc;
             if (L.NS == 1 && collapsed) {
                 rc = launch_align_segments(st, L.R, S, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, c->queue.as<int>() + qi,
                                            c->ap, L.lds_floats, L.tables, c->n_cu, L.packed);
             } else {
-                const AlignTask* dt = level == 0 && L.NS > 1 ? d_tasks + L.first_up : d_tasks + L.first_task;
-                const int mode = L.NS == 1 ? 0 : (level == 0 ? 2 : 1);
+                const bool last = level == L.NS - 1;
+                const AlignTask* dt = last ? d_tasks + L.first_task : d_tasks + L.first_up + (size_t)level * L.count;
+                const int mode = (level > 0 ? 1 : 0) | (last ? 0 : 2);
                 rc = launch_align(st, L.R, S, dt, d_seg + L.first_task, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, L.tables, c->n_cu,
                                   c->scratch.as<uint64_t>(), 0, mode, L.packed);
             }
@@ -466,7 +500,8 @@ int align_validate_flank(strq_ctx* c, const float* f, int64_t mm, int S, int* k_
     for (int64_t i = 0; i < mm; ++i)
         if (std::memcmp(&f[i], &f[i - i % S], 4) != 0) { c->err = "flank is not made of runs of `samples` equal values"; return STRQ_ERR_UNSUPPORTED; }
     int R = 0, NS = 0;
-    if (!align_plan((int)mm, S, &R, &NS) || mm / S > STRQ_LUT_MAX_K) { c->err = "flank shape not covered by the compiled kernels"; return STRQ_ERR_UNSUPPORTED; }
+    if (mm > STRQ_MAX_STRIPS * 64 * 12 || !align_plan((int)mm, S, &R, &NS)) { c->err = "flank shape not covered by the compiled kernels"; return STRQ_ERR_UNSUPPORTED; }
+    if (mm / S > STRQ_LUT_MAX_K && NS == 1) { R = 12; NS = (int)((mm + 64 * 12 - 1) / (64 * 12)); }      // one table would not fit: one per strip of 128 classes
     *k_out = (int)(mm / S); *R_out = R; *NS_out = NS;
     return STRQ_OK;
 }

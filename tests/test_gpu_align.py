@@ -256,3 +256,29 @@ def test_column_segments_seam_adversarial(ctx, orc, monkeypatch, segs, k, n, ov_
         assert np.float32(o[0]).tobytes() == np.float32(got[0][i]).tobytes(), (i, cases[i])
         assert (o[4], o[5]) == (int(got[1][i]), int(got[2][i])), (i, cases[i])
         assert np.array_equal(o[3], got[3][i * m:(i + 1) * m]), (i, cases[i])
+
+
+@pytest.mark.parametrize("k", [159, 160, 200, 256, 257, 300, 384, 385, 512, 1024])
+@pytest.mark.parametrize("params", [None, [-3, -1, -20, -4, 16, 0]])
+def test_long_flanks_run_as_strips_with_their_own_tables(ctx, orc, k, params):
+    """Flanks of more than 158 k-mer classes (948 samples): strips of 768 rows, each with its own score table,
+    the boundary row handed on through HBM, the traceback climbing from strip to strip.  STRique's collapsed
+    parameters and a general affine set; reads that contain the flank, and one shorter than it."""
+    rng = np.random.default_rng(900 + k)
+    p = orc.align_params(None) if params is None else np.array(params, np.float32)
+    ctx.set_align_params(*[float(v) for v in p])
+    try:
+        for n in (20000, 6 * k - 100):
+            lv, lval, flank = _toy(rng, n, k=k)
+            a = lval[lv]
+            _same(orc.align_overlap(a, flank, p), ctx.align_overlap(a, flank))
+    finally:
+        ctx.set_align_params(*[float(v) for v in orc.align_params(None)])
+
+
+def test_flank_beyond_the_strip_limit_takes_the_generic_kernel(ctx, orc):
+    rng = np.random.default_rng(4)
+    params = orc.align_params(None)
+    lv, lval, flank = _toy(rng, 9000, k=1025)
+    a = lval[lv]
+    _same(orc.align_overlap(a, flank, params), ctx.align_overlap(a, flank))

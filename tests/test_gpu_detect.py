@@ -303,3 +303,32 @@ def test_odd_signals_against_the_oracle(gpu_counter, want, pm, targets):
             sig = _read(pm, targets, name, strand, 3000 + 100 * k, 5 + k, 1400 + k).astype(np.float64) * 1.7 - 300       # strongly rescaled
         items.append((name, np.clip(np.round(sig), -32768, 32767).astype(np.int16), strand))
     _check(gpu_counter, want, items)
+
+
+def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
+    """repeat_config.tsv rows are the user's: flanks shorter than the 50 nt the HMM takes (no trim), much longer
+    than the bundled 150 nt (a flank of more than 960 samples runs as two strips), a two-letter and a twelve-letter
+    repeat.  Every field equals the oracle's on both strands."""
+    from strique_amd import synth
+    from strique_amd.counter import repeatCounter
+    rng = np.random.default_rng(31337)
+    nt = lambda n: "".join(rng.choice(list("ACGT"), n))
+    custom = {"short": ("CAG", nt(30), nt(44)), "long": ("GGCCTG", nt(230), nt(201)), "uneven": ("CA", nt(64), nt(170)),
+              "dodeca": ("CCCCGCCCCGCG", nt(120), nt(98)), "longer": ("CTG", nt(300), nt(415)), "longest": ("GAA", nt(1029), nt(163))}
+    rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    for name, t in custom.items():
+        rc.add_target(name, *t)
+    table = synth.KmerTable(pm)
+    params = orc.align_params(cfg["align"])
+    items = []
+    for k, name in enumerate(custom):
+        for strand in "+-":
+            sig = synth.make_read(table, 9, 7000 + 2 * k + (strand == "-"), 6500 + 700 * k, custom[name], 12 + 9 * k, strand=strand)[0]
+            items.append((name, sig, strand))
+    got = rc.detect_batch(items)
+    for (name, sig, strand), g in zip(items, got):
+        w = orc.detect(sig, oracle_tc(orc, opm, custom, name, strand, cfg["HMM"]), opm, params)[0]
+        assert tuple(g[:6]) == tuple(w[:6]), (name, strand, g, w)
+        assert g[0] > 0, (name, strand, g)
+    with pytest.raises(Exception, match="flank shape"):
+        rc.add_target("too_long", "CAG", nt(1030), nt(100))
