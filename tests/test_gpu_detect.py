@@ -314,7 +314,8 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
     rng = np.random.default_rng(31337)
     nt = lambda n: "".join(rng.choice(list("ACGT"), n))
     custom = {"short": ("CAG", nt(30), nt(44)), "long": ("GGCCTG", nt(230), nt(201)), "uneven": ("CA", nt(64), nt(170)),
-              "dodeca": ("CCCCGCCCCGCG", nt(120), nt(98)), "longer": ("CTG", nt(300), nt(415)), "longest": ("GAA", nt(1029), nt(163))}
+              "dodeca": ("CCCCGCCCCGCG", nt(120), nt(98)), "longer": ("CTG", nt(300), nt(415)), "longest": ("GAA", nt(1029), nt(163)),
+              "vntr33": (nt(33), nt(150), nt(150)), "vntr48": (nt(48), nt(150), nt(150))}      # larger HMMs: other kernel shapes
     rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
     for name, t in custom.items():
         rc.add_target(name, *t)
@@ -332,3 +333,5 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
         assert g[0] > 0, (name, strand, g)
     with pytest.raises(Exception, match="flank shape"):
         rc.add_target("too_long", "CAG", nt(1030), nt(100))
+    with pytest.raises(Exception, match="model too large"):      # 600 emitting states: more than 8 per lane
+        rc.add_target("vntr70", nt(70), nt(150), nt(150))
