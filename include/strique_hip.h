@@ -136,9 +136,10 @@ int strq_viterbi_batch(strq_ctx* ctx, int32_t model_id, int64_t n_seq, const dou
  *                       samples) as float32, trim_prefix = len(prefix_ext) - len(prefix) and
  *                       trim_suffix likewise (STRique.py:598-599), the flanked-repeat HMM uploaded
  *                       with strq_model_create and count_bias = flanking_count - repeat_offset
- *                       (STRique.py:374-378,412,437).  samples = 6 (what STRique passes); a template of
- *                       up to 6144 samples (a flank of 1029 nt; the bundled loci have 150 nt = 870
- *                       samples) -- longer ones return STRQ_ERR_UNSUPPORTED.
+ *                       (STRique.py:374-378,412,437).  samples: the run length of the templates (6 is
+ *                       what STRique ships; any value works, on slower kernel shapes).  A template of up
+ *                       to 1024 k-mer classes (6144 samples at samples = 6: a flank of 1029 nt; the
+ *                       bundled loci have 150 nt = 870 samples) -- longer ones return STRQ_ERR_UNSUPPORTED.
  * strq_detect_batch     detect() for n_reads reads.  signals: concatenated raw samples,
  *                       dtype 0 = int16 (fast5 DAC values), 1 = float64 (pA, as the reference's
  *                       unit tests feed them).  For int16 every order statistic of the conditioning

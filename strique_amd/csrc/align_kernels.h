@@ -44,6 +44,7 @@ static inline int align_num_ckpts(int n) { return (align_num_steps(n) - 1) / STR
 // rows per lane and number of strips for a flank of m rows; 0 if no compiled shape fits
 #define STRQ_MAX_STRIPS 8           // flanks up to 8 x 64 x 12 = 6144 samples (1029 nt at 6 samples per k-mer)
 int align_plan(int m, int samples, int* rows_per_lane, int* n_strips);
+int align_effective_samples(int samples);
 // Column segments (several waves per alignment, one score table per workgroup).
 // A read of n columns is cut into `segs` pieces; piece k owns the columns (o_k, o_k+1] and starts its DP
 // cold (the column-0 rule) `overlap` columns to the left of o_k.  With dist_min >= 0 and negative

@@ -802,12 +802,60 @@ static int launch_shape(hipStream_t stream, const AlignTask* tasks, AlignResult*
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// Shapes for `samples` other than 6: R = 2 * samples rows per lane (a lane holds exactly two k-mer classes: no
+// class selects), 128 classes per strip.  Only the general affine kernels are instantiated for them -- the
+// collapsed recurrence, column segments and 24-bit tables are optimisations of STRique's own configuration.
+template <int R, int S>
+static int launch_shape_general(hipStream_t stream, const AlignTask* tasks, AlignResult* results, int n_tasks,
+                                int* queue, const AlignParams& p, int lds_floats_per_wave, int waves_per_block,
+                                int n_blocks, uint64_t* scratch, int phase, int mode, int packed, const int32_t* pick)
+{
+    if (packed) return 2;
+    const size_t lds_bytes = (size_t)lds_floats_per_wave * 4 * waves_per_block;
+    const dim3 grid(n_blocks), block(64 * waves_per_block);
+#define STRQ_FWDG(MODE_)                                                                                \
+    do {                                                                                                \
+        (void)hipFuncSetAttribute((const void*)align_forward_kernel<R, S, false, false, MODE_, false>,  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);          \
+        hipLaunchKernelGGL((align_forward_kernel<R, S, false, false, MODE_, false>), grid, block, lds_bytes, stream,\
+                           tasks, results, n_tasks, queue, p, lds_floats_per_wave);                     \
+    } while (0)
+    if (phase == 0) {
+        if (mode == 0) STRQ_FWDG(0); else if (mode == 1) STRQ_FWDG(1); else if (mode == 2) STRQ_FWDG(2); else STRQ_FWDG(3);
+    } else {
+        (void)hipFuncSetAttribute((const void*)align_trace_kernel<R, S, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((align_trace_kernel<R, S, false>), grid, block, lds_bytes, stream, tasks, results,
+                           n_tasks, queue, p, lds_floats_per_wave, scratch, pick);
+    }
+#undef STRQ_FWDG
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 #define STRQ_SHAPES(X) X(6, 6) X(7, 6) X(8, 6) X(12, 6) X(15, 6)
+#define STRQ_GENERAL_SHAPES(X) X(2, 1) X(4, 2) X(6, 3) X(8, 4) X(10, 5) X(14, 7) X(16, 8) X(18, 9) X(20, 10)
+
+// The run length the kernels work with: 6 when `samples` is a multiple of 6 (STRique's value), else the largest
+// divisor of `samples` up to 10 -- a run of `samples` equal values is so many runs of that length.
+int align_effective_samples(int samples)
+{
+    if (samples < 1) return 0;
+    if (samples % 6 == 0) return 6;
+    for (int d = 10; d > 1; --d) if (samples % d == 0) return d;
+    return 1;
+}
 
 // Rows per lane R and number of strips for a flank of m rows.
 int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
 {
-    if (samples != 6 || m < 1) return 0;
+    if (samples < 1 || m < 1) return 0;
+    if (samples != 6) {
+        if (align_effective_samples(samples) != samples) return 0;       // callers pass the effective run length
+        const int r = 2 * samples, rows = 64 * r;
+        if (m > STRQ_MAX_STRIPS * rows) return 0;
+        *rows_per_lane = r; *n_strips = (m + rows - 1) / rows;
+        return r;
+    }
     // Measured on MI355X (50 kb reads, 870-row flanks): two strips at two waves per SIMD take as long
     // as one strip at one wave per SIMD -- the per-step overhead is amortised over half the rows --
     // so one strip is preferred whenever a single-strip shape fits.  STRQ_STRIPS=2 forces two.
@@ -840,6 +888,12 @@ int launch_align(hipStream_t stream, int R, int S, const AlignTask* tasks, Align
         return launch_shape<R_, S_>(stream, tasks, results, n_tasks, queue, p, lds_floats_per_wave,     \
                                     waves_per_block, n_blocks, scratch, phase, mode, packed, pick);
     STRQ_SHAPES(STRQ_CASE)
+#undef STRQ_CASE
+#define STRQ_CASE(R_, S_)                                                                               \
+    if (R == R_ && S == S_)                                                                             \
+        return launch_shape_general<R_, S_>(stream, tasks, results, n_tasks, queue, p, lds_floats_per_wave, \
+                                            waves_per_block, n_blocks, scratch, phase, mode, packed, pick);
+    STRQ_GENERAL_SHAPES(STRQ_CASE)
 #undef STRQ_CASE
     return 2;
 }

@@ -195,7 +195,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // Layout of the task array: per launch, `segs` consecutive tasks per alignment (in result order);
     // the first strips of two-strip alignments follow at the end.  seg_results is indexed like the
     // tasks; results / pick / heads are indexed by alignment position.
-    const bool collapsed = c->ap.open_h == c->ap.ext_h && c->ap.open_v == c->ap.ext_v;
+    const bool collapsed = S == 6 && c->ap.open_h == c->ap.ext_h && c->ap.open_v == c->ap.ext_v;      // the collapsed / segmented / packed kernels exist for samples = 6
     int seg_want = 0, max_tables = 8, max_waves = 16;      // seg_want 0: chosen below from the read lengths
     if (const char* e = getenv("STRQ_SEG")) { const int v = atoi(e); if (v >= 1 && v <= 4) seg_want = v; }
     if (const char* e = getenv("STRQ_TABLES")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_tables = v; }
@@ -494,21 +494,22 @@ size_t align_workspace_bytes(int n, int m, int R, int NS)
     return b;
 }
 
-int align_validate_flank(strq_ctx* c, const float* f, int64_t mm, int S, int* k_out, int* R_out, int* NS_out)
+int align_validate_flank(strq_ctx* c, const float* f, int64_t mm, int samples, int* k_out, int* R_out, int* NS_out)
 {
-    if (mm < 1 || S < 1 || mm % S != 0) { c->err = "flank length must be a positive multiple of `samples`"; return STRQ_ERR_UNSUPPORTED; }
+    if (mm < 1 || samples < 1 || mm % samples != 0) { c->err = "flank length must be a positive multiple of `samples`"; return STRQ_ERR_UNSUPPORTED; }
     for (int64_t i = 0; i < mm; ++i)
-        if (std::memcmp(&f[i], &f[i - i % S], 4) != 0) { c->err = "flank is not made of runs of `samples` equal values"; return STRQ_ERR_UNSUPPORTED; }
+        if (std::memcmp(&f[i], &f[i - i % samples], 4) != 0) { c->err = "flank is not made of runs of `samples` equal values"; return STRQ_ERR_UNSUPPORTED; }
+    const int S = align_effective_samples(samples);       // the run length the kernels work with (k-mer classes of S rows)
     int R = 0, NS = 0;
-    if (mm > STRQ_MAX_STRIPS * 64 * 12 || !align_plan((int)mm, S, &R, &NS)) { c->err = "flank shape not covered by the compiled kernels"; return STRQ_ERR_UNSUPPORTED; }
-    if (mm / S > STRQ_LUT_MAX_K && NS == 1) { R = 12; NS = (int)((mm + 64 * 12 - 1) / (64 * 12)); }      // one table would not fit: one per strip of 128 classes
+    if (mm > (1 << 20) || !align_plan((int)mm, S, &R, &NS)) { c->err = "flank shape not covered by the compiled kernels"; return STRQ_ERR_UNSUPPORTED; }
+    if (S == 6 && mm / S > STRQ_LUT_MAX_K && NS == 1) { R = 12; NS = (int)((mm + 64 * 12 - 1) / (64 * 12)); }      // one table would not fit: one per strip of 128 classes
     *k_out = (int)(mm / S); *R_out = R; *NS_out = NS;
     return STRQ_OK;
 }
 
 static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 {
-    const int S = in.samples;
+    const int S = align_effective_samples(in.samples);
     const int64_t NA = in.n_align;
     std::fill(c->timing, c->timing + 8, 0.0f);
     if (NA == 0) return STRQ_OK;
@@ -519,7 +520,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
         if (rd < 0 || rd >= in.n_reads) { c->err = "align_read out of range"; return STRQ_ERR_ARG; }
         const int64_t nn = in.read_off[rd + 1] - in.read_off[rd];
         if (nn < 0 || nn > (int64_t)1 << 30) { c->err = "bad read length"; return STRQ_ERR_ARG; }
-        const int rc = align_validate_flank(c, in.flank + in.flank_off[a], mm, S, &k[a], &R[a], &NS[a]);
+        const int rc = align_validate_flank(c, in.flank + in.flank_off[a], mm, in.samples, &k[a], &R[a], &NS[a]);
         if (rc) return rc;
         m[a] = (int)mm; n[a] = (int)nn;
     }
@@ -773,13 +774,18 @@ int strq_align_overlap(strq_ctx* c, const float* a, int64_t n, const float* b, i
     std::vector<float> vals(a, a + n);
     std::sort(vals.begin(), vals.end(), [](float x, float y) { return __builtin_bit_cast(uint32_t, x) < __builtin_bit_cast(uint32_t, y); });
     vals.erase(std::unique(vals.begin(), vals.end(), [](float x, float y) { return std::memcmp(&x, &y, 4) == 0; }), vals.end());
-    bool fast = vals.size() <= 256 && m % 6 == 0 && !getenv("STRQ_GENERIC_ALIGN");
+    // run length of the flank: the gcd of its runs of equal values (6 for what detect passes)
+    int run = 0;
+    { int64_t start = 0;
+      for (int64_t i = 1; i <= m; ++i)
+          if (i == m || std::memcmp(&b[i], &b[start], 4) != 0) { int len = (int)std::min<int64_t>(i - start, 1 << 20); run = run ? std::__gcd(run, len) : len; start = i; } }
+    bool fast = vals.size() <= 256 && run >= 1 && !getenv("STRQ_GENERIC_ALIGN");
     for (float v : vals) if (v != v) fast = false;
     if (fast) {
         std::sort(vals.begin(), vals.end());
         for (size_t x = 1; x < vals.size(); ++x) if (vals[x] == vals[x - 1]) fast = false;      // -0.0 and +0.0 both present
         int kk, RR, NN;
-        if (fast && align_validate_flank(c, b, m, 6, &kk, &RR, &NN) != STRQ_OK) fast = false;
+        if (fast && align_validate_flank(c, b, m, run, &kk, &RR, &NN) != STRQ_OK) fast = false;
     }
     if (fast) {
         std::vector<uint8_t> lv((size_t)n);
@@ -788,7 +794,7 @@ int strq_align_overlap(strq_ctx* c, const float* a, int64_t n, const float* b, i
         std::copy(vals.begin(), vals.end(), lval.begin());
         const int64_t roff[2] = {0, n}, foff[2] = {0, m};
         const int32_t ar = 0;
-        BatchIn in{1, 1, lv.data(), roff, lval.data(), &ar, b, foff, 6};
+        BatchIn in{1, 1, lv.data(), roff, lval.data(), &ar, b, foff, run};
         BatchOut out{score, &je, &j0, rec.data()};
         const int rc = run_align_batch(c, in, out);
         if (rc) return rc;

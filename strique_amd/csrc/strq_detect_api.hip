@@ -563,7 +563,7 @@ int strq_target_add(strq_ctx* c, const float* prefix_ext, int64_t m_prefix, cons
     int rc = align_validate_flank(c, prefix_ext, m_prefix, samples, &t.kp, &t.Rp, &t.NSp); if (rc) return rc;
     rc = align_validate_flank(c, suffix_ext, m_suffix, samples, &t.ks, &t.Rs, &t.NSs); if (rc) return rc;
     t.prefix_ext.assign(prefix_ext, prefix_ext + m_prefix); t.suffix_ext.assign(suffix_ext, suffix_ext + m_suffix);
-    t.trim_prefix = trim_prefix; t.trim_suffix = trim_suffix; t.samples = samples; t.model_id = hmm_model_id; t.count_bias = count_bias;
+    t.trim_prefix = trim_prefix; t.trim_suffix = trim_suffix; t.samples = align_effective_samples(samples); t.model_id = hmm_model_id; t.count_bias = count_bias;
     d->targets.push_back(t);
     *target_id = (int32_t)d->targets.size() - 1;
     return STRQ_OK;

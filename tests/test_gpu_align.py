@@ -282,3 +282,22 @@ def test_flank_beyond_the_strip_limit_takes_the_generic_kernel(ctx, orc):
     lv, lval, flank = _toy(rng, 9000, k=1025)
     a = lval[lv]
     _same(orc.align_overlap(a, flank, params), ctx.align_overlap(a, flank))
+
+
+@pytest.mark.parametrize("s", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 14, 16, 25])
+@pytest.mark.parametrize("params", [None, [-3, -1, -20, -4, 16, 0]])
+def test_other_samples_per_kmer(ctx, orc, s, params):
+    """`samples` of the JSON `align` block (STRique.py:513,529) other than 6: the kernels work on the largest
+    run length up to 10 that divides it (6 for multiples of 6), two classes per lane, strips of 128 classes."""
+    rng = np.random.default_rng(1200 + s)
+    p = orc.align_params(None) if params is None else np.array(params, np.float32)
+    ctx.set_align_params(*[float(v) for v in p])
+    try:
+        for k, n in ((20, 3000), (145 if s > 1 else 100, 12000), (7, 5)):
+            if s in (11,) and k * s > 1024:
+                k = 1024 // s
+            lv, lval, flank = _toy(rng, n, k=k, s=s)
+            a = lval[lv]
+            _same(orc.align_overlap(a, flank, p), ctx.align_overlap(a, flank))
+    finally:
+        ctx.set_align_params(*[float(v) for v in orc.align_params(None)])

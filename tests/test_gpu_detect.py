@@ -335,3 +335,20 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
         rc.add_target("too_long", "CAG", nt(1030), nt(100))
     with pytest.raises(Exception, match="model too large"):      # 600 emitting states: more than 8 per lane
         rc.add_target("vntr70", nt(70), nt(150), nt(150))
+
+
+@pytest.mark.parametrize("samples", [4, 8, 9, 12])
+def test_other_samples_setting(pm, cfg, orc, opm, targets, samples):
+    """`"samples"` in the `align` block of the JSON config changes the flank templates (STRique.py:562-565)."""
+    from strique_amd.counter import repeatCounter
+    acfg = dict(cfg["align"], samples=samples)
+    rc = repeatCounter(pm, align_config=acfg, HMM_config=cfg["HMM"], device=0)
+    rc.add_target("c9orf72", *targets["c9orf72"])
+    params = orc.align_params(acfg)
+    items = [("c9orf72", _read(pm, targets, "c9orf72", st, 7000 + 500 * k, 25 + 10 * k, 3100 + k), st) for k, st in enumerate("+-+")]
+    got = rc.detect_batch(items)
+    for (name, sig, strand), g in zip(items, got):
+        tc = orc.classifier(*targets[name], strand, opm, None, cfg["HMM"], samples=samples)
+        w = orc.detect(sig, tc, opm, params)[0]
+        assert tuple(g[:6]) == tuple(w[:6]), (samples, strand, g, w)
+    rc.ctx.close()
