@@ -20,6 +20,9 @@ Fixtures written (all small):
     c9orf72.fast5 / .sam   the bundled data files themselves (data, copied byte for byte)
     hmm_topology.json      states / edges emitted by the reference's HMM classes run against a
                            recording stand-in for pomegranate              (STRique.py:201-500)
+    sam_cases.json         hand-written SAM lines (edge cases: clips, '*' fields, short lines, flags) with what
+                           the reference's __decode_sam__ / __intersect_target__ / strand rule make of them
+                           (STRique.py:656-692); `--only sam_cases` regenerates just this file
 """
 import json
 import os
@@ -123,6 +126,48 @@ def _graph(model):
     return {"start": ids[id(model.start)], "end": ids[id(model.end)], "states": states, "edges": edges}
 
 
+# SAM lines written for this repository (inputs); the expected fields come from the reference when this script runs
+_SEQ = "ACGT" * 5
+_SAM_CASES = [
+    ("spanning, soft clips", "r1\t0\tchr9\t27540000\t60\t100S40000M50S\t*\t0\t0\t%s\t*" % _SEQ),
+    ("reverse strand", "r2\t16\tchr9\t27540000\t60\t40000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("hard + soft clips", "r3\t0\tchr9\t27573000\t60\t5H700S30000M20S3H\t*\t0\t0\t%s\t*" % _SEQ),
+    ("three clip-like ops at the start: only the first two count", "r4\t0\tchr9\t27573400\t60\t5H10S10M600S30000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("locus begins inside the leading clip", "r5\t0\tchr9\t27573500\t60\t100S30000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("locus begins before the clip-extended start", "r6\t0\tchr9\t27573600\t60\t10S30000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("ends inside the locus; trailing clip reaches over it", "r7\t0\tchr9\t27570000\t60\t3500M2000S\t*\t0\t0\t%s\t*" % _SEQ),
+    ("N, =, X, D, I, P in the reference span", "r8\t0\tchr9\t27570000\t60\t1000=5X2000N10I20D3P4000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("unmapped", "r9\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t*" % _SEQ),
+    ("ten columns only", "r10\t0\tchr9\t27540000\t60\t40000M\t*\t0\t0\t%s" % _SEQ),
+    ("POS not a number", "r11\t0\tchr9\tabc\t60\t40000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("other chromosome", "r12\t0\tchr4\t27540000\t60\t40000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("secondary + supplementary + reverse", "r13\t2320\tchr9\t27540000\t0\t40000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("optional tags, trailing newline", "r14\t0\tchrX\t147910000\t60\t3S5000M\t*\t0\t0\t%s\t*\tNM:i:3\tMD:Z:10\n" % _SEQ),
+    ("both loci's chromosome names differ in case", "r15\t0\tCHR9\t27540000\t60\t40000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("lower-case CIGAR operators", "r16\t0\tchr9\t27540000\t60\t10s40000m\t*\t0\t0\t%s\t*" % _SEQ),
+    ("CIGAR without a leading count", "r17\t0\tchr9\t27540000\t60\tM40000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("empty QNAME", "\t0\tchr9\t27540000\t60\t40000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("FLAG with a sign", "r19\t+16\tchr9\t27540000\t60\t40000M\t*\t0\t0\t%s\t*" % _SEQ),
+    ("header line", "@SQ\tSN:chr9\tLN:138394717"),
+]
+
+
+def sam_cases(ref, cfg, base):
+    rd = ref.repeatDetector(cfg["repeat"], base, None)
+    for tname, (chrom, begin, end, repeat, prefix, suffix) in cfg["repeat"].items():
+        rd.repeatLoci[chrom].append((tname, begin, end))
+    out = []
+    for what, line in _SAM_CASES:
+        sr = rd.__decode_sam__(line)
+        out.append({"what": what, "line": line,
+                    "record": {"QNAME": sr.QNAME, "FLAG": sr.FLAG, "RNAME": sr.RNAME, "POS": sr.POS, "TLEN": sr.TLEN,
+                               "CLIP_BEGIN": sr.CLIP_BEGIN, "CLIP_END": sr.CLIP_END},
+                    "parsed": bool(sr.QNAME),                                   # STRique.py:685: an empty QNAME is the error path
+                    "strand": "+" if sr.FLAG & 0x10 == 0 else "-",              # STRique.py:688-691
+                    "targets": rd.__intersect_target__(sr)})
+    json.dump(out, open(os.path.join(OUT, "sam_cases.json"), "w"), indent=1)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: fixtures can only be regenerated in the build container")
@@ -130,6 +175,11 @@ def main():
     sys.path.insert(0, os.path.join(REF, "scripts"))
     import STRique as ref
     ref.logger.log = staticmethod(lambda *a, **k: None)
+    if sys.argv[1:3] == ["--only", "sam_cases"]:
+        cfg = ref.parse_config(os.path.join(REF, "configs", "repeat_config.tsv"), os.path.join(REF, "configs", "STRique.json"))
+        sam_cases(ref, cfg, os.path.join(REF, "models", "r9_4_450bps.model"))
+        print("sam_cases.json written")
+        return
 
     base = os.path.join(REF, "models", "r9_4_450bps.model")
     mod = os.path.join(REF, "models", "r9_4_450bps_mCpG.model")

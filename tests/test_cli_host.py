@@ -198,3 +198,28 @@ def test_fast5_masker_and_plot(tmp_path):
     cli.main(["plot", str(src / "reads.fofn"), "--counts", str(counts), "--output", str(plots), "--zoom", "200", "--width", "6", "--height", "4"])
     made = sorted(p.name for p in plots.glob("*.png"))
     assert made == sorted("c9orf72_17_%s.png" % r for r in ids) and all((plots / m).stat().st_size > 2000 for m in made)
+
+
+def test_sam_edge_cases_equal_the_reference():
+    """tests/golden/sam_cases.json: twenty hand-written SAM lines and what the reference's __decode_sam__,
+    __intersect_target__ and strand rule make of them (recorded by make_golden.py --only sam_cases): clips counted
+    from the first / last two CIGAR operations (twice when there are only two), '*' fields, short lines, signs."""
+    import io
+    from strique_amd import cli
+    cases = json.load(open(os.path.join(GOLDEN, "sam_cases.json")))
+    cfg = json.load(open(os.path.join(GOLDEN, "config.json")))
+    loci = {}
+    for name, (chrom, begin, end, repeat, prefix, suffix) in cfg["repeat"].items():
+        loci.setdefault(chrom, []).append((name, begin, end))
+    assert len(cases) >= 20
+    for c in cases:
+        sr = cli.decode_sam(c["line"])
+        got = {k: getattr(sr, k) for k in c["record"]}
+        assert got == c["record"], c["what"]
+        assert bool(sr.QNAME) == c["parsed"], c["what"]
+        assert cli.intersect_targets(sr, loci) == c["targets"], c["what"]
+        routed = list(cli.route(io.StringIO(c["line"] + "\n"), loci, lambda *a: None))
+        if c["parsed"] and c["targets"]:
+            assert [(r[0], r[1], r[2]) for r in routed] == [(c["record"]["QNAME"], c["strand"], c["targets"])], c["what"]
+        else:
+            assert routed == [], c["what"]
