@@ -352,3 +352,47 @@ def test_other_samples_setting(pm, cfg, orc, opm, targets, samples):
         w = orc.detect(sig, tc, opm, params)[0]
         assert tuple(g[:6]) == tuple(w[:6]), (samples, strand, g, w)
     rc.ctx.close()
+
+
+def test_randomised_configurations(pm, pm_mod, cfg, orc, opm, opm_mod):
+    """Sixteen random configurations -- gap parameters (collapsed and general affine), dist_offset / dist_min,
+    `samples`, every HMM probability and std scale, flank lengths, repeat units, with and without the modification
+    model -- three reads each (both strands, int16 and float64): the whole tuple equals the oracle's."""
+    from strique_amd import synth
+    from strique_amd.counter import repeatCounter
+    rng = np.random.default_rng(20261002)
+    nt = lambda n: "".join(rng.choice(list("ACGT"), n))
+    for trial in range(16):
+        collapsed = trial % 2 == 0
+        gh = -float(rng.integers(1, 4)); gv = -float(rng.integers(4, 20))
+        acfg = dict(gap_open_h=gh, gap_extension_h=gh if collapsed else -float(rng.integers(1, 4)),
+                    gap_open_v=gv, gap_extension_v=gv if collapsed else -float(rng.integers(4, 20)),
+                    dist_offset=float(rng.choice([8.0, 12.0, 16.0, 20.0])), dist_min=float(rng.choice([0.0, 0.0, -1.0, -4.0])),
+                    samples=int(rng.choice([6, 6, 6, 5, 8, 12])))
+        hcfg = dict(cfg["HMM"])
+        for key in ("match_loop", "match_match", "match_insert", "match_delete"):
+            hcfg[key] = float(hcfg[key] * rng.uniform(0.6, 1.4))
+        hcfg.update(leave_repeat=float(rng.uniform(0.0005, 0.01)), e1_ratio=float(rng.uniform(0.05, 0.5)),
+                    seq_std_scale=float(rng.uniform(0.8, 1.5)), rep_std_scale=float(rng.uniform(0.8, 1.6)),
+                    rep_std_offset=float(rng.choice([0.0, 0.1])), delete_delete=float(rng.uniform(0.001, 0.05)))
+        with_mod = trial % 4 == 3
+        unit = [nt(int(rng.integers(2, 9))), "CGG", "GGCCCC", "CAG"][trial % 4]
+        if with_mod:
+            unit = "GGCCCC"                                    # CpG in every unit
+        target = (unit, nt(int(rng.integers(40, 260))), nt(int(rng.integers(40, 260))))
+        rc = repeatCounter(pm, mod_model_file=pm_mod if with_mod else None, align_config=acfg, HMM_config=hcfg, device=0)
+        rc.add_target("t", *target)
+        table = synth.KmerTable(pm_mod if with_mod and trial % 8 == 7 else pm)
+        params = orc.align_params(acfg)
+        items = []
+        for k in range(3):
+            strand = "+-"[(trial + k) % 2]
+            sig = synth.make_read(table, 11, 100 * trial + k, int(rng.integers(3000, 9000)), target, int(rng.integers(5, 60)),
+                                  strand=strand, as_int16=(k != 1))[0]
+            items.append(("t", sig, strand))
+        got = rc.detect_batch(items)
+        for (name, sig, strand), g in zip(items, got):
+            tc = orc.classifier(*target, strand, opm, opm_mod if with_mod else None, hcfg, samples=acfg["samples"])
+            w = orc.detect(sig, tc, opm, params, pm_mod=opm_mod if with_mod else None)[0]
+            assert tuple(g) == tuple(w), (trial, acfg, strand, g, w)
+        rc.ctx.close()
