@@ -3,7 +3,7 @@
 Covers what STRique's fast5Index.get_raw needs for single- and multi-read fast5 files
 (reference STRique_lib/fast5Index.py:76-84,220-233): old-style groups (symbol tables, B-tree v1,
 local heaps), version-1 object headers with continuation blocks, chunked int16 datasets with the
-deflate (and optional shuffle) filter, contiguous datasets, and the string / integer attributes that
+deflate (and optional shuffle) or VBZ (strique_amd/vbz.py) filter, contiguous datasets, and the string / integer attributes that
 carry `read_id` (fixed-length and variable-length strings, the latter through the global heap), files with a
 user block (non-zero base address).  HDF5 features outside that subset raise NotImplementedError.
 """
@@ -12,6 +12,8 @@ import struct
 import zlib
 
 import numpy as np
+
+from . import vbz
 
 _SIG = b"\x89HDF\r\n\x1a\n"
 UNDEF = 0xFFFFFFFFFFFFFFFF
@@ -255,10 +257,11 @@ class H5File(object):
                     fid, nlen, fflags, ncd = struct.unpack_from("<HHHH", pl, p); p += 8
                     if ver == 1 or fid >= 256:
                         p += (nlen + 7) & ~7 if ver == 1 else nlen
+                    cd = struct.unpack_from("<%dI" % ncd, pl, p)
                     p += 4 * ncd
                     if ver == 1 and ncd % 2:
                         p += 4
-                    filters.append(fid)
+                    filters.append((fid, cd))
         if shape is None or dtype is None or layout is None:
             raise ValueError("not a dataset: %s" % path)
         n = int(np.prod(shape)) if shape else 1
@@ -269,12 +272,14 @@ class H5File(object):
         out = np.zeros(n, dtype)
         csize = layout[2][0]
         for off, data in self._chunks(layout[1], len(shape)):
-            for fid in reversed(filters):
+            for fid, cd in reversed(filters):
                 if fid == 1:
                     data = zlib.decompress(data)
                 elif fid == 2:
                     a = np.frombuffer(data, np.uint8).reshape(dtype.itemsize, -1)
                     data = a.T.tobytes()
+                elif fid == vbz.FILTER_ID:
+                    data = vbz.decode(data, cd)
                 else:
                     raise NotImplementedError("HDF5 filter %d" % fid)
             vals = np.frombuffer(data, dtype)

@@ -7,6 +7,8 @@ have (multi-read fast5, several reads per group, tar archives).
 """
 import struct
 
+import numpy as np
+
 UNDEF = 0xFFFFFFFFFFFFFFFF
 
 
@@ -78,6 +80,48 @@ def _vlen_string_attr(f, name, value):
     pad = lambda x: x + b"\x00" * (-len(x) % 8)
     data = struct.pack("<IQI", len(val), gcol, 1)
     return _msg(0x0C, struct.pack("<BxHHH", 1, len(name_b), len(dt), len(ds)) + pad(name_b) + pad(dt) + pad(ds) + data)
+
+
+def _chunked_dataset(f, array, chunk, filters, encode, attrs=()):
+    """1-D int16 dataset in chunks of `chunk` samples behind a filter pipeline: filters = [(id, name, cd_values)],
+    encode(int16 chunk) -> stored bytes.  One leaf node of a version-1 B-tree indexes the chunks."""
+    a = array.astype("<i2")
+    n = len(a)
+    nchunks = max(1, (n + chunk - 1) // chunk)
+    stored = []
+    for c in range(nchunks):
+        part = a[c * chunk:(c + 1) * chunk]
+        if len(part) < chunk:
+            part = np.concatenate([part, np.zeros(chunk - len(part), "<i2")])       # edge chunks are stored whole
+        data = encode(part)
+        stored.append((f.alloc(data), len(data)))
+    node = b"TREE" + struct.pack("<BBHQQ", 1, 0, nchunks, UNDEF, UNDEF)
+    for c, (addr, size) in enumerate(stored):
+        node += struct.pack("<IIQQ", size, 0, c * chunk, 0) + struct.pack("<Q", addr)
+    node += struct.pack("<IIQQ", 0, 0, nchunks * chunk, 0)
+    tree = f.alloc(node)
+    space = struct.pack("<BBBx4xQ", 1, 1, 0, n)
+    dtype = struct.pack("<BBBBIHH", 0x10, 0x08, 0, 0, 2, 0, 16)
+    layout = struct.pack("<BBBQII", 3, 2, 2, tree, chunk, 2)           # version 3, chunked, rank + 1, B-tree, chunk dims, element size
+    pipe = struct.pack("<BB6x", 1, len(filters))
+    for fid, name, cd in filters:
+        nm = name.encode() + b"\x00"
+        nm += b"\x00" * (-len(nm) % 8)
+        pipe += struct.pack("<HHHH", fid, len(nm), 1, len(cd)) + nm + struct.pack("<%dI" % len(cd), *cd)
+        if len(cd) % 2:
+            pipe += b"\x00" * 4
+    return _object_header(f, [_msg(0x01, space), _msg(0x03, dtype), _msg(0x08, layout), _msg(0x0B, pipe)] + [_attr(k, v) for k, v in attrs])
+
+
+def _vbz_dataset(f, array, attrs=(), version=0, level=1, chunk=8192):
+    from . import vbz
+    cd = vbz.encode(np.zeros(1, "<i2"), version=version, level=level)[1]
+    return _chunked_dataset(f, array, chunk, [(vbz.FILTER_ID, "vbz", cd)], lambda part: vbz.encode(part, version=version, level=level)[0], attrs)
+
+
+def _deflate_dataset(f, array, attrs=(), chunk=8192):
+    import zlib
+    return _chunked_dataset(f, array, chunk, [(1, "deflate", (4,))], lambda part: zlib.compress(part.tobytes(), 4), attrs)
 
 
 def _dataset(f, array, attrs=()):
@@ -160,12 +204,18 @@ def _group_with_messages(f, entries, extra_msgs):
     return f.alloc(hdr + body)
 
 
-def multi_read_fast5(reads):
-    """reads: [(read_id, signal)] -> /read_<id>/Raw/Signal, read_id attribute on every Raw group."""
+def multi_read_fast5(reads, compression=None, vbz_version=0):
+    """reads: [(read_id, signal)] -> /read_<id>/Raw/Signal, read_id attribute on every Raw group.
+    compression: None (contiguous), "gzip" or "vbz" (chunked, as MinKNOW writes bulk files)."""
     f = _File()
     top = {}
     for rid, signal in reads:
-        sig = _dataset(f, signal)
+        if compression == "vbz":
+            sig = _vbz_dataset(f, signal, version=vbz_version)
+        elif compression == "gzip":
+            sig = _deflate_dataset(f, signal)
+        else:
+            sig = _dataset(f, signal)
         raw = _group(f, {"Signal": sig}, attrs=[("read_id", rid)])
         top["read_" + rid] = _group(f, {"Raw": raw})
     return _finish(f, _group(f, top))

@@ -223,3 +223,41 @@ def test_sam_edge_cases_equal_the_reference():
             assert [(r[0], r[1], r[2]) for r in routed] == [(c["record"]["QNAME"], c["strand"], c["targets"])], c["what"]
         else:
             assert routed == [], c["what"]
+
+
+def test_vbz_chunks(tmp_path):
+    """VBZ (HDF5 filter 32020).  No VBZ file or plugin exists in this image, so the decoder is held to hand-worked
+    vectors of the published layout, to its own encoder on signals with every code length, and to its length checks."""
+    import numpy as np
+    from strique_amd import fast5, h5write, vbz
+    # [1, 2, 3, -1] as int16, version 0, no zstd: 8 bytes; deltas 1 1 1 -4 -> zig-zag 2 2 2 7; one key byte (all one-byte
+    # codes), four data bytes
+    assert vbz.decode(bytes.fromhex("08000000" "00" "02020207"), (0, 2, 1, 0)) == np.array([1, 2, 3, -1], "<i2").tobytes()
+    # version 1 (one key bit per 16-bit integer): [1, 2, 3, -1, 300]: zig-zag 2 2 2 7 602; key bits 0 0 0 0 1 -> 0x10;
+    # 602 = 0x025a little-endian
+    assert vbz.decode(bytes.fromhex("0a000000" "10" "02020207" "5a02"), (1, 2, 1, 0)) == np.array([1, 2, 3, -1, 300], "<i2").tobytes()
+    # version 0 without delta: -2 widens to 0xfffffffe (four data bytes, code 3), 258 = 0x0102 (code 1)
+    assert vbz.decode(bytes.fromhex("04000000" "07" "feffffff" "0201"), (0, 2, 0, 0)) == np.array([-2, 258], "<i2").tobytes()
+    rng = np.random.default_rng(8)
+    sig = np.clip(np.cumsum(rng.normal(0, 40, 20000)) + 400, -32768, 32767).astype(np.int16)
+    sig[100:104] = [-32768, 32767, -32768, 32767]                     # three-byte codes in version 0
+    for version in (0, 1):
+        for level in (0, 1, 3):
+            chunk, cd = vbz.encode(sig, version=version, level=level)
+            assert np.array_equal(np.frombuffer(vbz.decode(chunk, cd), "<i2"), sig)
+            with pytest.raises(ValueError):
+                vbz.decode(chunk[:-1] if level == 0 else chunk[:len(chunk) // 2], cd)      # truncated
+            if level == 0:
+                with pytest.raises(ValueError):
+                    vbz.decode(chunk + b"\x00", cd)                                          # trailing bytes
+    # through the file reader: a multi-read file with chunked VBZ signals, like the bulk files MinKNOW writes
+    reads = [("a%d" % i, np.roll(sig, 7 * i)[: 5000 + 4000 * i]) for i in range(4)]
+    for version in (0, 1):
+        p = tmp_path / ("bulk_v%d.fast5" % version)
+        p.write_bytes(h5write.multi_read_fast5(reads, compression="vbz", vbz_version=version))
+        got = dict(fast5.read_raw(str(p)))
+        assert all(np.array_equal(got[r], s) for r, s in reads)
+    p = tmp_path / "bulk_gzip.fast5"
+    p.write_bytes(h5write.multi_read_fast5(reads, compression="gzip"))
+    got = dict(fast5.read_raw(str(p)))
+    assert all(np.array_equal(got[r], s) for r, s in reads)
