@@ -833,15 +833,15 @@ static int launch_shape_general(hipStream_t stream, const AlignTask* tasks, Alig
 }
 
 #define STRQ_SHAPES(X) X(6, 6) X(7, 6) X(8, 6) X(12, 6) X(15, 6)
-#define STRQ_GENERAL_SHAPES(X) X(2, 1) X(4, 2) X(6, 3) X(8, 4) X(10, 5) X(14, 7) X(16, 8) X(18, 9) X(20, 10)
+#define STRQ_GENERAL_SHAPES(X) X(2, 1) X(4, 2) X(6, 3) X(8, 4) X(10, 5) X(14, 7) X(16, 8) X(18, 9) X(20, 10) X(22, 11) X(26, 13)
 
 // The run length the kernels work with: 6 when `samples` is a multiple of 6 (STRique's value), else the largest
-// divisor of `samples` up to 10 -- a run of `samples` equal values is so many runs of that length.
+// divisor of `samples` among the compiled run lengths -- a run of `samples` equal values is so many runs of that length.
 int align_effective_samples(int samples)
 {
     if (samples < 1) return 0;
     if (samples % 6 == 0) return 6;
-    for (int d = 10; d > 1; --d) if (samples % d == 0) return d;
+    for (int d : {13, 11, 10, 9, 8, 7, 5, 4, 3, 2}) if (samples % d == 0) return d;
     return 1;
 }
 

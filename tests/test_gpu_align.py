@@ -284,17 +284,18 @@ def test_flank_beyond_the_strip_limit_takes_the_generic_kernel(ctx, orc):
     _same(orc.align_overlap(a, flank, params), ctx.align_overlap(a, flank))
 
 
-@pytest.mark.parametrize("s", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 14, 16, 25])
+@pytest.mark.parametrize("s", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 22, 25, 26])
 @pytest.mark.parametrize("params", [None, [-3, -1, -20, -4, 16, 0]])
 def test_other_samples_per_kmer(ctx, orc, s, params):
     """`samples` of the JSON `align` block (STRique.py:513,529) other than 6: the kernels work on the largest
-    run length up to 10 that divides it (6 for multiples of 6), two classes per lane, strips of 128 classes."""
+    compiled run length that divides it (6 for multiples of 6; 1 ... 5, 7 ... 11, 13), two classes per lane, strips of
+    128 classes."""
     rng = np.random.default_rng(1200 + s)
     p = orc.align_params(None) if params is None else np.array(params, np.float32)
     ctx.set_align_params(*[float(v) for v in p])
     try:
         for k, n in ((20, 3000), (145 if s > 1 else 100, 12000), (7, 5)):
-            if s in (11,) and k * s > 1024:
+            if s == 17 and k * s > 1024:      # a prime above 13 runs as 17 x 1: 1024 rows at most
                 k = 1024 // s
             lv, lval, flank = _toy(rng, n, k=k, s=s)
             a = lval[lv]
