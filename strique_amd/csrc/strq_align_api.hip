@@ -203,8 +203,30 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     if (const char* e = getenv("STRQ_MAX_WAVES")) { const int v = atoi(e); if (v >= 4 && v <= 16) max_waves = v; }
     bool allow_pack = collapsed && !getenv("STRQ_NO_PACK");
     // overlap the pieces are cut with first (the worst case is ~15 k columns for an 870-row flank); see the piece planning below
-    int ov_cap = 8192;
-    if (const char* e = getenv("STRQ_OVERLAP")) { const int v = atoi(e); ov_cap = v > 0 ? v : (1 << 30); }      // 0: always the worst-case overlap
+    int ov_cap = 8192; bool ov_fixed = false;
+    if (const char* e = getenv("STRQ_OVERLAP")) { const int v = atoi(e); ov_cap = v > 0 ? v : (1 << 30); ov_fixed = true; }      // 0: always the worst-case overlap
+    // Without the variable: 8192 columns for the first sub-batch, afterwards the overlap that would have been cheapest
+    // for the previous sub-batch -- extra columns per piece against the share of alignments whose best score would
+    // not certify that overlap and which therefore run twice (any choice is exact; this one only sets the cost).
+    std::map<int, int> ov_of_m;
+    auto overlap_for = [&](int m, int ov_worst) -> int {
+        if (ov_fixed || c->score_fracs.size() < 64 || c->mean_n <= 0) return std::min(ov_worst, ov_cap);
+        auto it = ov_of_m.find(m);
+        if (it != ov_of_m.end()) return it->second;
+        const std::vector<float>& f = c->score_fracs;
+        double best_cost = 0; int best_ov = std::min(ov_worst, ov_cap);
+        for (int ov = 1024; ; ov += 512) {
+            if (ov > ov_worst) ov = ov_worst;
+            const float need = align_segment_min_score(c->ap, m, ov) / ((float)m * c->ap.dist_offset) + 0.01f;      // 1 % margin on last batch's scores
+            const double redo = (double)(std::lower_bound(f.begin(), f.end(), need) - f.begin()) / (double)f.size();
+            const double cost = 3.0 * ov / c->mean_n + redo * (1.0 + 3.0 * ov_worst / c->mean_n);
+            if (best_cost == 0 || cost < best_cost) { best_cost = cost; best_ov = ov; }
+            if (ov >= ov_worst) break;
+        }
+        ov_of_m[m] = best_ov;
+        STRQ_DBG("overlap for %d-row flanks: %d columns (worst case %d; previous sub-batch: median score fraction %.3f, mean read %.0f samples)", m, best_ov, ov_worst, f[f.size() / 2], c->mean_n);
+        return best_ov;
+    };
     // Launch geometry, per alignment.  Measured on MI355X (ms per 8192 alignments per 1000 columns computed,
     // 870-row flanks, tools/dp_sweep.py): one wave per table 0.94 (24-bit tables, 8 waves per CU) / 1.02 (float32,
     // 6 waves); two waves per table 0.86 (24-bit, 16 waves) / 0.79 (float32, 12 waves); four waves per table
@@ -228,7 +250,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         const bool can_pack = allow_pack && in.NS[i] == 1 && info[J0[i]].packed && info[J0[i]].n_hard == 0;
         int best_s = 1, best_p = can_pack ? 1 : 0;
         if (segmentable[i]) {
-            const double l = std::min(overlap[i], ov_cap);
+            const double l = overlap_for(in.m[i], overlap[i]);
             double best_cost = 0;
             for (int sgs : {1, 2, 3, 4}) {
                 if (seg_want ? sgs != seg_want : sgs == 3) continue;
@@ -331,7 +353,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             Piece* pf = &pieces[(size_t)L.first_task + (size_t)x * L.segs];
             Piece* ps = &safe[(size_t)L.first_task + (size_t)x * L.segs];
             cut(n, L.segs, ov, ps);
-            const int ov_fast = std::min(ov, ov_cap);
+            const int ov_fast = overlap_for(in.m[i], ov);
             if (L.segs > 1 && ov_fast < ov && cut(n, L.segs, ov_fast, pf) > 1) {
                 min_score[pos] = align_segment_min_score(c->ap, in.m[i], ov_fast);
                 two_round[li] = 1;

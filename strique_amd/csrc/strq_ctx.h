@@ -73,6 +73,9 @@ struct strq_ctx {
     std::vector<strq::HostModel*> models;
     void* detect = nullptr;                   // DetectState (strq_detect_api.hip)
     size_t max_ws_bytes = (size_t)96 << 30;   // cap for checkpoint workspace per sub-batch
+    // best flank scores of the previous detect sub-batch as fractions of m * dist_offset (sorted), and its mean read
+    // length: the column segments of the next sub-batch are cut with the overlap that is cheapest for that distribution
+    std::vector<float> score_fracs; double mean_n = 0;
 };
 
 namespace strq {

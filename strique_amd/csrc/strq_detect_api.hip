@@ -30,6 +30,7 @@ struct ReadGeom {           // per read, written by finalize_kernel
     double score_prefix, score_suffix;
     int64_t prefix_begin, prefix_end, suffix_begin, suffix_end;
     int32_t gate, pad_;
+    float best_prefix, best_suffix;      // raw alignment scores (the overlap planning of the next sub-batch reads their distribution)
 };
 
 // position of flank row k in the read: argmin_i |a_idx[i] - b_idx[k]| of __detect_range__
@@ -77,12 +78,14 @@ __global__ void finalize_kernel(FinalizeArgs a)
         {
             const int64_t b = row_position(tp.rec, tp.m_total, 0, tp.n), e = row_position(tp.rec, tp.m_total, tp.m_total - 1, tp.n);
             g.score_prefix = e > b ? (double)rp.best / (double)(e - b) : 0.0;
+            g.best_prefix = rp.best;
             g.prefix_begin = row_position(tp.rec, tp.m_total, a.trim[2 * r], tp.n);
             g.prefix_end = e;
         }
         {
             const int64_t b = row_position(ts.rec, ts.m_total, 0, ts.n), e = row_position(ts.rec, ts.m_total, ts.m_total - 1, ts.n);
             g.score_suffix = e > b ? (double)rs.best / (double)(e - b) : 0.0;
+            g.best_suffix = rs.best;
             g.suffix_begin = b;
             g.suffix_end = row_position(ts.rec, ts.m_total, ts.m_total - 1 - a.trim[2 * r + 1], ts.n);
         }
@@ -526,6 +529,19 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
             o.count = (int32_t)v.counted + d->targets[B.target[r0 + i]].count_bias;
             o.log_p = v.logp;
         }
+    }
+    // score distribution of this sub-batch for the overlap planning of the next one (align_core)
+    if (c->ap.dist_offset > 0.0f) {
+        c->score_fracs.clear(); double sum_n = 0;
+        for (int i = 0; i < nr; ++i) {
+            if (rc_out[i].n <= 0) continue;
+            const Target& t = d->targets[B.target[r0 + i]];
+            c->score_fracs.push_back(geom[i].best_prefix / ((float)t.prefix_ext.size() * c->ap.dist_offset));
+            c->score_fracs.push_back(geom[i].best_suffix / ((float)t.suffix_ext.size() * c->ap.dist_offset));
+            sum_n += rc_out[i].n;
+        }
+        std::sort(c->score_fracs.begin(), c->score_fracs.end());
+        c->mean_n = c->score_fracs.empty() ? 0.0 : sum_n / (double)(c->score_fracs.size() / 2);
     }
     if (any_mod) {
         const int rcm = run_mod_pass(c, d, r0, nr, rc_out, geom, vres, vit_slot);
