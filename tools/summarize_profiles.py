@@ -61,7 +61,8 @@ def main():
         f.write("# rocprofv3 --kernel-trace --stats (%s)\n\n" % tag)
         f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s/kt -o %s -- "
                 "python3 bench.py --steps 2 --warmup 1 --reads 4096 --no-cpu-baseline --no-host-leg --check 0`\n"
-                "(3 passes over 4096 reads of 50 kb: 1 warm-up + 2 timed).  Raw table: `%s_kernel_stats.csv`.\n\n" % (tag, tag, tag))
+                "(3 passes over 4096 reads of 50 kb: 1 warm-up + 2 timed; the warm-up pass cuts the column segments with the initial 8192-column overlap, the timed ones with "
+                "the overlap chosen from its scores, so the forward DP's average here sits ~2 ms above bench.py's timed average).  Raw table: `%s_kernel_stats.csv`.\n\n" % (tag, tag, tag))
         f.write("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n")
         for r in rows:
             f.write("| %s | %s | %.3f | %.1f | %s |\n" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
