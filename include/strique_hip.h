@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 5 (5: strq_host_stats; host_stats of strq_detect_batch / strq_batch_upload optional) */
+int strq_abi_version(void);   /* currently 6 (5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -176,6 +176,11 @@ int strq_batch_fetch_mod(strq_ctx* ctx, char* pool, int64_t pool_cap, int64_t* o
 int strq_detect_batch(strq_ctx* ctx, int64_t n_reads, const void* signals, int32_t dtype,
                       const int64_t* offsets, const int32_t* target_id, const double* host_stats,
                       strq_result* out);
+/* The same with one buffer per read (reads[i]: lengths[i] samples of `dtype`) instead of one concatenated buffer:
+ * a caller that holds a list of arrays -- repeatCounter.detect_batch, the `count` command -- does not have to copy
+ * them together first. */
+int strq_detect_batch_reads(strq_ctx* ctx, int64_t n_reads, const void* const* reads, const int64_t* lengths, int32_t dtype,
+                            const int32_t* target_id, const double* host_stats, strq_result* out);
 /* The same in three steps, so that a caller can keep the signals resident in HBM and time (or
  * repeat) the device work alone: upload = host -> HBM copy, run = all kernels, fetch = results. */
 int strq_batch_upload(strq_ctx* ctx, int64_t n_reads, const void* signals, int32_t dtype,

@@ -111,8 +111,7 @@ class repeatCounter(object):
             if not idx:
                 continue
             arrs = [sigs[i].astype(np.int16 if want_int else np.float64, copy=False) for i in idx]
-            off = np.zeros(len(arrs) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in arrs])
-            res = self.ctx.detect_batch(np.concatenate(arrs), off, [tcs[i].target_id for i in idx])
+            res = self.ctx.detect_batch_reads(arrs, [tcs[i].target_id for i in idx])      # one pointer per read: no host-side concatenation
             mods = self.ctx.batch_fetch_mod() if self.pm is not self.pm_mod else ['-'] * len(res)
             for i, r, m in zip(idx, res, mods):
                 n = int(r['count']); p = float(r['log_p']) if n or r['log_p'] != 0 else 0

@@ -134,7 +134,8 @@ void host_read_stats(const double* raw, int64_t n, bool want_raw, double* out)
     } else { out[4] = 0.0; out[5] = 1.0; }
 }
 
-void host_stats_batch(const double* signals, const int64_t* offsets, int64_t n_reads, bool want_raw, double* out)
+void host_stats_batch(const double* signals, const int64_t* offsets, int64_t n_reads, bool want_raw, double* out,
+                      const double* const* reads)
 {
     int threads = (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
@@ -146,7 +147,7 @@ void host_stats_batch(const double* signals, const int64_t* offsets, int64_t n_r
         for (;;) {
             const int64_t i = next.fetch_add(1);
             if (i >= n_reads) break;
-            host_read_stats(signals + offsets[i], offsets[i + 1] - offsets[i], want_raw, out + 6 * i);
+            host_read_stats(reads ? reads[i] : signals + offsets[i], offsets[i + 1] - offsets[i], want_raw, out + 6 * i);
         }
     };
     if (threads <= 1) { work(); return; }
@@ -161,6 +162,6 @@ extern "C" int strq_host_stats(const double* signals, const int64_t* offsets, in
 {
     if (n_reads < 0 || (n_reads > 0 && (!signals || !offsets || !out))) return STRQ_ERR_ARG;
     for (int64_t i = 0; i < n_reads; ++i) if (offsets[i + 1] < offsets[i]) return STRQ_ERR_ARG;
-    strq::host_stats_batch(signals, offsets, n_reads, want_raw != 0, out);
+    strq::host_stats_batch(signals, offsets, n_reads, want_raw != 0, out, nullptr);
     return STRQ_OK;
 }

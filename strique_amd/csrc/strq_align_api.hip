@@ -598,7 +598,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 
 extern "C" {
 
-int strq_abi_version(void) { return 5; }
+int strq_abi_version(void) { return 6; }
 
 int strq_ctx_create(int device_id, strq_ctx** out)
 {

@@ -85,7 +85,8 @@ int align_validate_flank(strq_ctx* c, const float* f, int64_t m, int samples, in
 size_t align_workspace_bytes(int n, int m, int R, int NS);   // checkpoints + strip boundary of one alignment
 float host_cell_score(const AlignParams& p, float h, float v);
 void detect_state_free(strq_ctx* c);
-void host_stats_batch(const double* signals, const int64_t* offsets, int64_t n_reads, bool want_raw, double* out);   // host_stats.hip
+void host_stats_batch(const double* signals, const int64_t* offsets, int64_t n_reads, bool want_raw, double* out,
+                      const double* const* reads = nullptr);   // host_stats.hip; reads: one buffer per read instead of `signals`
 }
 
 #define STRQ_HIP(ctx, call)                                                                    \

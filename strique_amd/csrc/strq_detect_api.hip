@@ -118,6 +118,7 @@ struct Batch {
     std::vector<double> host_stats;      // 6 per read (float64 input only)
     DevBuf raw;                          // all reads, resident
     const char* host_src = nullptr;      // strq_detect_batch: caller's buffer, uploaded sub-batch by sub-batch
+    std::vector<const char*> host_reads; // strq_detect_batch_reads: one buffer per read instead (host_src is then a non-null marker)
     int64_t uploaded = 0;                // reads whose samples are in `raw`
     std::vector<strq_result> results;
     std::vector<std::string> mod;        // modification pattern per read ('-' if none)
@@ -291,6 +292,20 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     return STRQ_OK;
 }
 
+// bytes [pos, pos + len) of the batch (reads back to back) from the caller's memory: one buffer, or one per read
+static void host_bytes(const Batch& B, size_t esz, char* dst, size_t pos, size_t len)
+{
+    if (B.host_reads.empty()) { std::memcpy(dst, B.host_src + pos, len); return; }
+    // the read that holds byte `pos`
+    size_t r = (size_t)(std::upper_bound(B.off.begin(), B.off.end(), (int64_t)(pos / esz)) - B.off.begin()) - 1;
+    while (len > 0) {
+        const size_t r_begin = (size_t)B.off[r] * esz, r_end = (size_t)B.off[r + 1] * esz;
+        const size_t take = std::min(len, r_end - pos);
+        if (take) std::memcpy(dst, B.host_reads[r] + (pos - r_begin), take);
+        dst += take; pos += take; len -= take; ++r;
+    }
+}
+
 // Samples of reads [B.uploaded, upto) from the caller's (pageable) buffer into `raw`.  The runtime's own
 // pageable path measures 8.3 GB/s; here the bytes go through a ring of pinned staging buffers: a few host
 // threads copy the next piece into a free slot while the DMA engine drains the previous ones on the copy
@@ -307,7 +322,11 @@ static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
     int n_threads = 6;
     if (const char* e = getenv("STRQ_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 0 && v <= 32) n_threads = v; }
     if (b1 > b0 && n_threads == 0) {          // the runtime's pageable path
-        STRQ_HIP(c, hipMemcpyAsync(B.raw.as<char>() + b0, B.host_src + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
+        if (B.host_reads.empty()) STRQ_HIP(c, hipMemcpyAsync(B.raw.as<char>() + b0, B.host_src + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
+        else for (int64_t r = B.uploaded; r < upto; ++r) {
+            const size_t rb = (size_t)B.off[r] * esz, rl = (size_t)(B.off[r + 1] - B.off[r]) * esz;
+            if (rl) STRQ_HIP(c, hipMemcpyAsync(B.raw.as<char>() + rb, B.host_reads[r], rl, hipMemcpyHostToDevice, d->copy_stream));
+        }
         STRQ_HIP(c, hipStreamSynchronize(d->copy_stream));
     } else if (b1 > b0) {
         if (!d->stage[0]) {
@@ -322,14 +341,14 @@ static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
             const size_t len = std::min(SLOT, b1 - pos);
             if (d->stage_busy[slot]) { STRQ_HIP(c, hipEventSynchronize(d->stage_ev[slot])); d->stage_busy[slot] = false; }
             char* dst = static_cast<char*>(d->stage[slot]);
-            const char* src = B.host_src + pos;
             const size_t part = ((len + n_threads - 1) / n_threads + 4095) & ~(size_t)4095;
             std::vector<std::thread> th;
+            const Batch* Bp = &B;
             for (int t = 1; t < n_threads; ++t) {
                 const size_t o = (size_t)t * part;
-                if (o < len) th.emplace_back([=] { std::memcpy(dst + o, src + o, std::min(part, len - o)); });
+                if (o < len) th.emplace_back([=] { host_bytes(*Bp, esz, dst + o, pos + o, std::min(part, len - o)); });
             }
-            std::memcpy(dst, src, std::min(part, len));
+            host_bytes(B, esz, dst, pos, std::min(part, len));
             for (auto& t : th) t.join();
             STRQ_HIP(c, hipMemcpyAsync(B.raw.as<char>() + pos, dst, len, hipMemcpyHostToDevice, d->copy_stream));
             STRQ_HIP(c, hipEventRecord(d->stage_ev[slot], d->copy_stream));
@@ -610,11 +629,11 @@ int strq_batch_fetch_mod(strq_ctx* c, char* pool, int64_t pool_cap, int64_t* off
 }
 
 static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
-                         const int32_t* target_id, const double* host_stats, bool lazy)
+                         const int32_t* target_id, const double* host_stats, bool lazy, const void* const* reads = nullptr)
 {
     if (!c) return STRQ_ERR_ARG;
     DetectState* d = dstate(c);
-    if (n_reads < 0 || (n_reads > 0 && (!signals || !offsets || !target_id)) || (dtype != 0 && dtype != 1)) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+    if (n_reads < 0 || (n_reads > 0 && ((!signals && !reads) || !offsets || !target_id)) || (dtype != 0 && dtype != 1)) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     if (!d->have_ps) { c->err = "strq_set_pore_stats has not been called"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
     Batch& B = d->batch;
@@ -632,15 +651,18 @@ static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int3
         bool want_raw = false;
         for (int64_t i = 0; i < n_reads; ++i) want_raw |= d->targets[B.target[i]].mod_model_id >= 0;
         B.host_stats.resize((size_t)n_reads * 6);
-        host_stats_batch(static_cast<const double*>(signals), offsets, n_reads, want_raw, B.host_stats.data());
+        host_stats_batch(static_cast<const double*>(signals), offsets, n_reads, want_raw, B.host_stats.data(),
+                         reinterpret_cast<const double* const*>(reads));
     }
     const size_t bytes = (size_t)(n_reads ? B.off[n_reads] : 0) * (dtype == 0 ? 2 : 8);
     STRQ_HIP(c, B.raw.reserve(bytes + 64));
     B.host_src = static_cast<const char*>(signals); B.uploaded = 0;
+    B.host_reads.clear();
+    if (reads) { B.host_reads.assign(reinterpret_cast<const char* const*>(reads), reinterpret_cast<const char* const*>(reads) + n_reads); B.host_src = ""; }
     if (!lazy) {
         const int rc = upload_reads(c, d, n_reads);      // resident batch: everything now
         if (rc) return rc;
-        B.host_src = nullptr;
+        B.host_src = nullptr; B.host_reads.clear();
     }
     B.results.assign((size_t)n_reads, strq_result());
     B.mod.assign((size_t)n_reads, std::string("-"));
@@ -696,7 +718,7 @@ int strq_batch_run(strq_ctx* c)
         if (rc) return rc;
         STRQ_DBG("sub-batch %zu: reads %ld..%ld  %.1f ms", k, (long)cuts[k], (long)cuts[k + 1], (now_s() - t1) * 1e3);
     }
-    B.host_src = nullptr;      // the caller's buffer is not referenced after the call
+    B.host_src = nullptr; B.host_reads.clear();      // the caller's buffers are not referenced after the call
     std::fill(c->timing, c->timing + 8, 0.0f);
     c->timing[0] = B.t_lut; c->timing[1] = B.t_fwd; c->timing[2] = B.t_trace; c->timing[5] = B.t_cond; c->timing[6] = B.t_vit;
     c->timing[3] = B.t_lut + B.t_fwd + B.t_trace + B.t_cond + B.t_vit; c->timing[4] = (float)B.n_hard; c->timing[7] = (float)B.n_fwd_launches;
@@ -719,6 +741,26 @@ int strq_detect_batch(strq_ctx* c, int64_t n_reads, const void* signals, int32_t
     if (rc) return rc;
     rc = strq_batch_run(c);
     dstate(c)->batch.host_src = nullptr;
+    if (rc) return rc;
+    return strq_batch_fetch(c, out);
+}
+
+int strq_detect_batch_reads(strq_ctx* c, int64_t n_reads, const void* const* reads, const int64_t* lengths, int32_t dtype,
+                            const int32_t* target_id, const double* host_stats, strq_result* out)
+{
+    // one buffer per read (what a caller holding a list of arrays has): no concatenated copy on the host, the staging
+    // threads gather straight from the reads
+    if (!c) return STRQ_ERR_ARG;
+    if (n_reads < 0 || (n_reads > 0 && (!reads || !lengths))) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+    std::vector<int64_t> off((size_t)n_reads + 1, 0);
+    for (int64_t i = 0; i < n_reads; ++i) {
+        if (lengths[i] < 0 || (lengths[i] > 0 && !reads[i])) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+        off[(size_t)i + 1] = off[(size_t)i] + lengths[i];
+    }
+    int rc = batch_prepare(c, n_reads, nullptr, dtype, off.data(), target_id, host_stats, true, reads);
+    if (rc) return rc;
+    rc = strq_batch_run(c);
+    dstate(c)->batch.host_src = nullptr; dstate(c)->batch.host_reads.clear();
     if (rc) return rc;
     return strq_batch_fetch(c, out);
 }

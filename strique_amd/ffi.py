@@ -231,6 +231,29 @@ class Context(object):
                                                 _ptr(offsets), _ptr(target_ids), _ptr(hs), _ptr(out)))
         return out
 
+    def detect_batch_reads(self, reads, target_ids):
+        """strq_detect_batch_reads: `reads` is a list of 1-D arrays, all int16 or all float64 (C-contiguous); nothing
+        is concatenated on the host."""
+        n = len(reads)
+        if n == 0:
+            return np.zeros(0, dtype=RESULT_DTYPE)
+        dt = reads[0].dtype
+        if dt == np.int16:
+            dtype = 0
+        elif dt == np.float64:
+            dtype = 1
+        else:
+            raise ValueError("signals must be int16 or float64")
+        reads = [np.ascontiguousarray(r, dtype=dt) for r in reads]          # views where possible; kept alive through the call
+        ptrs = (ctypes.c_void_p * n)(*[r.ctypes.data for r in reads])
+        lengths = np.array([len(r) for r in reads], np.int64)
+        target_ids = _c(target_ids, np.int32)
+        self._n_batch = n
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        self._check(self._lib.strq_detect_batch_reads(self._h, ctypes.c_int64(n), ptrs, _ptr(lengths), ctypes.c_int32(dtype),
+                                                      _ptr(target_ids), None, _ptr(out)))
+        return out
+
     def debug_conditioning(self, read, n):
         levels = np.zeros(n, np.uint8); lval = np.zeros(256, np.float32); sc = np.zeros(10)
         self._check(self._lib.strq_debug_conditioning(self._h, ctypes.c_int64(read), _ptr(levels), ctypes.c_int64(n), _ptr(lval), _ptr(sc)))

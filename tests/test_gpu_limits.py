@@ -64,3 +64,22 @@ def test_context_returns_its_device_memory(pm, cfg, targets):
         assert tuple(cycle()) == tuple(first)
     free1 = _free_bytes()
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+def test_one_buffer_per_read_equals_one_concatenated_buffer(gpu_counter, pm, targets):
+    """strq_detect_batch_reads (a pointer per read, what repeatCounter.detect_batch passes) against strq_detect_batch
+    on the concatenated copy: int16 and float64, empty reads in between, reads that straddle the staging slots."""
+    rng = np.random.default_rng(12)
+    pairs = [(_read(pm, targets, "c9orf72", "+-"[k % 2], int(rng.integers(3000, 30000)), int(rng.integers(5, 80)), 4000 + k), "+-"[k % 2]) for k in range(40)]
+    empty = (np.zeros(0, np.int16), "+")
+    pairs.insert(3, empty); pairs.insert(17, empty); pairs.append(empty)
+    reads = [p[0] for p in pairs]; strands = [p[1] for p in pairs]
+    tids = [gpu_counter._classifier_for("c9orf72", s).target_id for s in strands]
+    ctx = gpu_counter.ctx
+    for dtype in (np.int16, np.float64):
+        arrs = [r.astype(dtype) for r in reads]
+        off = np.zeros(len(arrs) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in arrs])
+        flat = ctx.detect_batch(np.concatenate(arrs), off, tids)
+        scattered = ctx.detect_batch_reads(arrs, tids)
+        assert flat.tobytes() == scattered.tobytes()
+        assert (flat["count"] > 0).sum() == 40
