@@ -191,6 +191,11 @@ int strq_batch_fetch(strq_ctx* ctx, strq_result* out);
  * medfilt(read i, 3) and c1, h1 of read i itself (0, 1 unless want_raw) -- what numpy's median / mean / percentile
  * give repeatCounter.detect (STRique.py:590-597). */
 int strq_host_stats(const double* signals, const int64_t* offsets, int64_t n_reads, int32_t want_raw, double* out);
+/* Host-side helper of the fast5 reader (strique_amd/vbz.py): the variable-byte layer of a VBZ chunk -- n integers of
+ * isize (2 | 4) bytes from key_bits (2: StreamVByte, 1: the 16-bit variant) keys + data, optionally zig-zag coded
+ * differences.  Returns the stream bytes consumed (the caller checks it against the stream length) or -1. */
+int64_t strq_svb_decode(const uint8_t* stream, int64_t stream_len, int64_t n, int32_t key_bits, int32_t zigzag,
+                        int32_t isize, void* out);
 /* Test hook: conditioning outputs (8-bit morphology levels, their 256 float32 values, and
  * {median, MAD, c1/h1 of the filtered, morphology and raw signal, h2, c2}) of read `read` of the
  * last sub-batch processed by strq_batch_run. */

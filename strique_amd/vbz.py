@@ -134,6 +134,33 @@ def svb16_encode(vals):
     return _scatter(vals, lens, np.packbits(bits, bitorder="little"))
 
 
+_native = False
+
+
+def _native_decode(payload, n, key_bits, zigzag, isize):
+    """the variable-byte layer through libstrique_hip's host helper (strq_svb_decode; ctypes releases the GIL, so the
+    reader threads of `count` decode in parallel); None when the library is not built -- the numpy path below is the
+    same arithmetic"""
+    global _native
+    if _native is False:
+        try:
+            from . import ffi
+            lib = ffi.load_library()
+            lib.strq_svb_decode.restype = ctypes.c_int64
+            lib.strq_svb_decode.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_void_p]
+            _native = lib
+        except (ImportError, OSError, AttributeError):
+            _native = None
+    if _native is None:
+        return None
+    out = np.empty(n, "<u%d" % isize)
+    used = _native.strq_svb_decode(payload, len(payload), n, key_bits, zigzag, isize, out.ctypes.data)
+    if used != len(payload):
+        raise ValueError("VBZ chunk: variable-byte stream of %d bytes, %d consumed" % (len(payload), used))
+    return out.tobytes()
+
+
 # ---------------------------------------------------------------------------------------------
 # the filter
 # ---------------------------------------------------------------------------------------------
@@ -156,6 +183,11 @@ def decode(chunk, cd_values):
         if isize * n != size:
             raise ValueError("VBZ chunk: size is not a multiple of the integer size")
         narrow = version == 1 and isize == 2
+        fast = _native_decode(payload, n, 1 if narrow else 2, 1 if zigzag else 0, isize)
+        if fast is not None:
+            if len(fast) != size:
+                raise ValueError("VBZ chunk: %d bytes decoded, %d stated" % (len(fast), size))
+            return fast
         u = svb16_decode(payload, n) if narrow else svb32_decode(payload, n)
         if zigzag:
             if narrow:

@@ -245,6 +245,12 @@ def test_vbz_chunks(tmp_path):
         for level in (0, 1, 3):
             chunk, cd = vbz.encode(sig, version=version, level=level)
             assert np.array_equal(np.frombuffer(vbz.decode(chunk, cd), "<i2"), sig)
+            saved = vbz._native
+            try:                                   # the numpy path (library not built) and the library's host helper agree
+                vbz._native = None
+                assert np.array_equal(np.frombuffer(vbz.decode(chunk, cd), "<i2"), sig)
+            finally:
+                vbz._native = saved
             with pytest.raises(ValueError):
                 vbz.decode(chunk[:-1] if level == 0 else chunk[:len(chunk) // 2], cd)      # truncated
             if level == 0:
