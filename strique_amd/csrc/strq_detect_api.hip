@@ -117,8 +117,10 @@ struct Batch {
     std::vector<int32_t> target;
     std::vector<double> host_stats;      // 6 per read (float64 input only)
     DevBuf raw;                          // all reads, resident
-    const char* host_src = nullptr;      // strq_detect_batch: caller's buffer, uploaded sub-batch by sub-batch
-    std::vector<const char*> host_reads; // strq_detect_batch_reads: one buffer per read instead (host_src is then a non-null marker)
+    bool on_host = false;                // samples still (partly) in the caller's memory: uploaded sub-batch by sub-batch
+    const char* host_src = nullptr;      // strq_detect_batch: the caller's concatenated buffer
+    std::vector<const char*> host_reads; // strq_detect_batch_reads: one buffer per read instead
+    void forget_host() { on_host = false; host_src = nullptr; host_reads.clear(); }
     int64_t uploaded = 0;                // reads whose samples are in `raw`
     std::vector<strq_result> results;
     std::vector<std::string> mod;        // modification pattern per read ('-' if none)
@@ -314,7 +316,7 @@ static void host_bytes(const Batch& B, size_t esz, char* dst, size_t pos, size_t
 static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
 {
     Batch& B = d->batch;
-    if (!B.host_src || upto <= B.uploaded) return STRQ_OK;
+    if (!B.on_host || upto <= B.uploaded) return STRQ_OK;
     if (!d->copy_stream) STRQ_HIP(c, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     const size_t esz = B.dtype == 0 ? 2 : 8;
     const size_t b0 = (size_t)B.off[B.uploaded] * esz, b1 = (size_t)B.off[upto] * esz;
@@ -446,7 +448,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     // kernels running under the upload of the next (only the first piece's upload is exposed); a resident
     // or prefetched sub-batch is one piece.  The Viterbi launches below always cover the whole sub-batch.
     int parts = 1;
-    if (B.host_src && B.uploaded < r1 && nr >= 1024) { parts = 2; if (const char* e = getenv("STRQ_UPLOAD_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= 16) parts = v; } }
+    if (B.on_host && B.uploaded < r1 && nr >= 1024) { parts = 2; if (const char* e = getenv("STRQ_UPLOAD_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= 16) parts = v; } }
     for (int part = 0; part < parts; ++part) {
         const int i0 = (int)((int64_t)nr * part / parts), i1 = (int)((int64_t)nr * (part + 1) / parts), np_ = i1 - i0;
         if (np_ <= 0) continue;
@@ -656,13 +658,13 @@ static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int3
     }
     const size_t bytes = (size_t)(n_reads ? B.off[n_reads] : 0) * (dtype == 0 ? 2 : 8);
     STRQ_HIP(c, B.raw.reserve(bytes + 64));
-    B.host_src = static_cast<const char*>(signals); B.uploaded = 0;
-    B.host_reads.clear();
-    if (reads) { B.host_reads.assign(reinterpret_cast<const char* const*>(reads), reinterpret_cast<const char* const*>(reads) + n_reads); B.host_src = ""; }
+    B.forget_host();
+    B.host_src = static_cast<const char*>(signals); B.uploaded = 0; B.on_host = true;
+    if (reads) B.host_reads.assign(reinterpret_cast<const char* const*>(reads), reinterpret_cast<const char* const*>(reads) + n_reads);
     if (!lazy) {
         const int rc = upload_reads(c, d, n_reads);      // resident batch: everything now
         if (rc) return rc;
-        B.host_src = nullptr; B.host_reads.clear();
+        B.forget_host();
     }
     B.results.assign((size_t)n_reads, strq_result());
     B.mod.assign((size_t)n_reads, std::string("-"));
@@ -718,7 +720,7 @@ int strq_batch_run(strq_ctx* c)
         if (rc) return rc;
         STRQ_DBG("sub-batch %zu: reads %ld..%ld  %.1f ms", k, (long)cuts[k], (long)cuts[k + 1], (now_s() - t1) * 1e3);
     }
-    B.host_src = nullptr; B.host_reads.clear();      // the caller's buffers are not referenced after the call
+    B.forget_host();      // the caller's buffers are not referenced after the call
     std::fill(c->timing, c->timing + 8, 0.0f);
     c->timing[0] = B.t_lut; c->timing[1] = B.t_fwd; c->timing[2] = B.t_trace; c->timing[5] = B.t_cond; c->timing[6] = B.t_vit;
     c->timing[3] = B.t_lut + B.t_fwd + B.t_trace + B.t_cond + B.t_vit; c->timing[4] = (float)B.n_hard; c->timing[7] = (float)B.n_fwd_launches;
@@ -740,7 +742,7 @@ int strq_detect_batch(strq_ctx* c, int64_t n_reads, const void* signals, int32_t
     int rc = batch_prepare(c, n_reads, signals, dtype, offsets, target_id, host_stats, true);
     if (rc) return rc;
     rc = strq_batch_run(c);
-    dstate(c)->batch.host_src = nullptr;
+    dstate(c)->batch.forget_host();
     if (rc) return rc;
     return strq_batch_fetch(c, out);
 }
@@ -760,7 +762,7 @@ int strq_detect_batch_reads(strq_ctx* c, int64_t n_reads, const void* const* rea
     int rc = batch_prepare(c, n_reads, nullptr, dtype, off.data(), target_id, host_stats, true, reads);
     if (rc) return rc;
     rc = strq_batch_run(c);
-    dstate(c)->batch.host_src = nullptr; dstate(c)->batch.host_reads.clear();
+    dstate(c)->batch.forget_host();
     if (rc) return rc;
     return strq_batch_fetch(c, out);
 }
