@@ -63,12 +63,13 @@ medfilt_kernel(const T* __restrict__ raw_all, T* __restrict__ flt_all, const Rea
 
 // 65536-bin histogram of an int16 signal.  One workgroup takes HIST_TILE consecutive samples of
 // one read, histograms them in LDS in a window of HIST_WIN values anchored at the tile minimum
-// (nanopore DAC values of a tile span a few thousand counts), and flushes only the non-empty bins
+// (nanopore DAC values of a tile span one or two thousand counts; 16 KB of LDS leave room for eight workgroups per CU,
+// which is what hides the latency of this streaming kernel), and flushes only the non-empty bins
 // with global atomics: ~20x fewer global atomics than one per sample.  Samples outside the window
 // (never seen on real signals) take the global atomic directly, so the result is exact either way.
 #define HSTAT_LDS_BINS 14336      // bins hist_stats_kernel can stage in LDS (56 KB)
 #define HIST_TILE 16384
-#define HIST_WIN 12288
+#define HIST_WIN 4096
 __global__ void __launch_bounds__(256)
 hist16_kernel(const int16_t* __restrict__ sig_all, const ReadCond* __restrict__ rc_all, uint32_t* __restrict__ hist_all,
               uint32_t* __restrict__ range_all, int range_stride)
