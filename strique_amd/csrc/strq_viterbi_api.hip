@@ -64,26 +64,54 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     std::vector<std::vector<int>> chains;
     for (int b = ne; b < n_states; ++b) if (chain_pred[b] < 0) { std::vector<int> ch; for (int x = b; x >= 0; x = chain_succ[x]) ch.push_back(x); chains.push_back(ch); }
     std::stable_sort(chains.begin(), chains.end(), [](const std::vector<int>& x, const std::vector<int>& y) { return x.size() > y.size(); });
+    // Chains zig-zag through the Z silent slots of a lane (the chains back to back; cell p of that sequence: lane p / Z,
+    // slot p % Z; the first cell of a chain has no chain edge), so that one lane shift of the kernel's chain sweep carries
+    // a value Z positions along (viterbi_kernels.hip).  Z is the slot count of the kernel shape the model runs on: the smallest layout is tried
+    // first and widened until the shape that fits it has exactly that many silent slots.
     std::vector<int32_t> own_s, chain_src_v; std::vector<double> chain_lp_v;
-    {   // first-fit: a chain never straddles two slots (a straddling edge falls back to the edge list)
-        std::vector<int> fill;   // lanes used per slot
+    auto lay_out = [&](int Z) -> bool {
+        if (ns > 64 * Z) return false;
+        own_s.assign((size_t)Z * 64, -1); chain_src_v.assign((size_t)Z * 64, -1); chain_lp_v.assign((size_t)Z * 64, 0.0);
+        int p = 0;
         for (auto& ch : chains) {
-            size_t pos = 0;
-            while (pos < ch.size()) {
-                const int want = (int)std::min<size_t>(ch.size() - pos, 64);
-                int slot = -1;
-                for (size_t sl = 0; sl < fill.size(); ++sl) if (fill[sl] + want <= 64) { slot = (int)sl; break; }
-                if (slot < 0) { fill.push_back(0); slot = (int)fill.size() - 1; own_s.resize(fill.size() * 64, -1); chain_src_v.resize(fill.size() * 64, -1); chain_lp_v.resize(fill.size() * 64, 0.0); }
-                for (int q = 0; q < want; ++q) {
-                    const int lane = fill[slot] + q, st = ch[pos + q];
-                    own_s[slot * 64 + lane] = st;
-                    if (q > 0) { chain_src_v[slot * 64 + lane] = ch[pos + q - 1]; chain_lp_v[slot * 64 + lane] = chain_lp[st]; }
-                }
-                fill[slot] += want; pos += want;
+            for (size_t q = 0; q < ch.size(); ++q, ++p) {
+                const int lane = p / Z, slot = p % Z, st = ch[q];
+                own_s[(size_t)slot * 64 + lane] = st;
+                if (q > 0) { chain_src_v[(size_t)slot * 64 + lane] = ch[q - 1]; chain_lp_v[(size_t)slot * 64 + lane] = chain_lp[st]; }
             }
         }
-        if ((int)fill.size() > 4) { delete hm; c->err = "too many silent states for the compiled Viterbi kernels"; return STRQ_ERR_UNSUPPORTED; }
-        m.spl = (int)fill.size();
+        m.spl = Z;
+        return true;
+    };
+    auto slot_degrees = [&]() {
+        for (int s2 = 0; s2 < 8; ++s2) m.s_deg[s2] = 0;
+        for (int s2 = 0; s2 < m.spl; ++s2) {
+            int deg = 0;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int st = own_s[(size_t)s2 * 64 + lane];
+                if (st < 0) continue;
+                int dg = 0;
+                for (int e = in_ptr[st]; e < in_ptr[st + 1]; ++e) if (chain_src_v[(size_t)s2 * 64 + lane] != in_src[e]) ++dg;
+                deg = std::max(deg, dg);
+            }
+            m.s_deg[s2] = deg;
+        }
+    };
+    for (int s2 = 0; s2 < epl; ++s2) {       // the shape test below needs the emitting degrees
+        int deg = 0;
+        for (int lane = 0; lane < 64; ++lane) if (own_e[s2 * 64 + lane] >= 0) deg = std::max(deg, deg_of(own_e[s2 * 64 + lane]));
+        m.e_deg[s2] = deg;
+    }
+    {
+        bool placed = false;
+        for (int Z = 1; Z <= 4 && !placed; Z *= 2) {
+            if (!lay_out(Z)) continue;
+            slot_degrees();
+            m.single_stage = 1;      // refined below; the shape does not depend on it
+            const int shape = vit_shape_of(m);
+            if (shape >= 0 && vit_shape_silent_slots(shape) == Z) placed = true;
+        }
+        if (!placed) { delete hm; c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
     }
     const int spl2 = m.spl;
     auto is_chain_edge = [&](int dst, int srcst) {

@@ -11,8 +11,8 @@ namespace strq {
 // the j-th in-edge of all lanes of a slot reads consecutive LDS cells (no bank conflicts);
 // otherwise states are dealt to slots by descending in-degree.
 // Silent states are laid out in chains: when the highest-numbered silent predecessor of a silent
-// state is free, the pair becomes lane neighbours (lane-1 -> lane) of one slot and that edge leaves
-// the edge list (chain_src / chain_logp).
+// state is free, the pair becomes chain neighbours and that edge leaves the edge list (chain_src /
+// chain_logp).  A chain zig-zags through the silent slots: position p sits in lane p / spl, slot p % spl.
 // In-edge j of the state owned by (slot, lane) is entry (base[slot] + j) * 64 + lane of
 // edge_src / edge_logp; padding edges point at the extra cell v[n_states] == -inf.
 struct VitModel {
@@ -28,7 +28,7 @@ struct VitModel {
     const double* edge_logp;          // n_edge_rows * 64
     const int32_t* own_e;             // epl * 64: state owned by (slot, lane) or -1
     const int32_t* own_s;             // spl * 64
-    const int32_t* chain_src;         // spl * 64: state in (slot, lane-1) when it is the chain predecessor, else -1
+    const int32_t* chain_src;         // spl * 64: the chain predecessor of the cell -- the state in (slot - 1, lane), for slot 0 in (spl - 1, lane - 1) -- or -1
     const double* chain_logp;         // spl * 64: log-probability of that chain edge
     const int32_t* emis_kind;         // epl * 64, by owner slot  (0 = padding)
     const double* emis_a;             // mu | lo
@@ -63,6 +63,7 @@ struct VitResult {
 // (`shape_of`); `max_cells` = largest n_cells among them (checked against the shape's LDS buffers).
 #define VIT_SHAPE_SS 16                            // flag in the shape id: single-stage model
 int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fits
+int vit_shape_silent_slots(int shape);             // silent slots per lane of that kernel shape
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);
 // want_bp: 0 = count only, 1 = back-pointers, 2 = repeat-section marks (flanked model), 3 = hub records (modification model)

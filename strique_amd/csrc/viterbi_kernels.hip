@@ -210,6 +210,9 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             }
         }
         const int64_t T = tk.T;
+#ifdef STRQ_VIT_STATS
+        uint32_t stat_sweeps = 0;      // debug build (-DSTRQ_VIT_STATS): chain sweeps of the whole window, reported in place of the count
+#endif
         // clipped observations (detect pipeline) that cannot leave any uniform emission's support
         const bool fast_em = tk.src_kind != VIT_SRC_F64 && tk.lo >= uni_lo_max && tk.hi <= uni_hi_min;
         for (int i = lane; i < NP; i += 64) { stcell(vbase, 16 * i, NEGINF, 0); stcell(vbase, BUF + 16 * i, NEGINF, 0); }
@@ -235,6 +238,33 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             }
         };
 
+        // Chains of silent states (the delete states of a profile) zig-zag through the silent slots: the chain
+        // predecessor of a cell in slot s > 0 is the cell of the same lane in slot s - 1, that of a cell in slot 0 the
+        // cell of the previous lane in the last slot.  One sweep therefore carries a value SPL positions along a chain
+        // for one lane shift (a time step needs ~7 positions on the C9orf72 model), every hop the same sequential
+        // float64 addition as when each state is evaluated once in topological order.  After a sweep the only values
+        // not yet carried on are those that changed in the last slot (the next lane reads them in the next sweep).
+        auto chain_sweeps = [&](double (&y)[SPL], Pay (&yc)[SPL], int (&arg)[SPL]) {
+            for (;;) {
+                bool win_any = false;
+#ifdef STRQ_VIT_STATS
+                ++stat_sweeps;
+#endif
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) {
+                    double tin; Pay cin;
+                    if (s == 0) { tin = dpp_shr1_f64(y[SPL - 1]) + clp[0]; cin = pay_add(shr1_pay(yc[SPL - 1]), sinc[0]); }
+                    else { tin = y[s - 1] + clp[s]; cin = pay_add(yc[s - 1], sinc[s]); }
+                    const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
+                    y[s] = max_f64_raw(y[s], tin);
+                    yc[s] = win ? cin : yc[s];
+                    if (BP) arg[s] = win ? (s == 0 ? scell0 + (SPL - 1) * 64 + lane - 1 : scell0 + (s - 1) * 64 + lane) : arg[s];     // the chain predecessor's cell
+                    if (s == SPL - 1) win_any = win;     // wins in the earlier slots were carried on inside this sweep already
+                }
+                if (!__any(win_any)) break;
+            }
+        };
+
         // Silent states of the buffer at byte offset OFF to their fixed point.  PIN: keep start at 0 (t = 0).
         auto relax_silent = [&](auto pin_c, auto off_c, int64_t trow) {
             constexpr bool PIN = decltype(pin_c)::value;
@@ -256,20 +286,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     if (PIN && own_s[s] == start_state) { best = 0.0; bc = pay_add((Pay)0, -sinc[s]); a = dummy; }
                     y[s] = best; yc[s] = pay_add(bc, sinc[s]); arg[s] = a;
                 }
-                for (;;) {
-                    bool win_any = false;
-#pragma unroll
-                    for (int s = 0; s < SPL; ++s) {
-                        const double tin = dpp_shr1_f64(y[s]) + clp[s];
-                        const Pay cin = pay_add(shr1_pay(yc[s]), sinc[s]);
-                        const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
-                        y[s] = max_f64_raw(y[s], tin);
-                        yc[s] = win ? cin : yc[s];
-                        if (BP) arg[s] = win ? scell0 + s * 64 + lane - 1 : arg[s];     // the chain predecessor's cell
-                        win_any |= win;
-                    }
-                    if (!__any(win_any)) break;
-                }
+                chain_sweeps(y, yc, arg);
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) stcell(sdst[s], OFF, y[s], yc[s]);
                 VIT_FENCE();
@@ -314,20 +331,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         if (base[s] >= y[s]) { y[s] = base[s]; yc[s] = basec[s]; arg[s] = basea[s]; }
                         base_prev[s] = base[s];
                     }
-                    for (;;) {
-                        bool win_any = false;
-#pragma unroll
-                        for (int s = 0; s < SPL; ++s) {
-                            const double tin = dpp_shr1_f64(y[s]) + clp[s];
-                            const Pay cin = pay_add(shr1_pay(yc[s]), sinc[s]);
-                            const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
-                            y[s] = max_f64_raw(y[s], tin);
-                            yc[s] = win ? cin : yc[s];
-                            if (BP) arg[s] = win ? scell0 + s * 64 + lane - 1 : arg[s];     // the chain predecessor's cell
-                            win_any |= win;
-                        }
-                        if (!__any(win_any)) break;
-                    }
+                    chain_sweeps(y, yc, arg);
                     if (!single_stage) {
 #pragma unroll
                         for (int s = 0; s < SPL; ++s) {
@@ -459,6 +463,9 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         } else {
             r.counted = (lp > NEGINF) ? (int64_t)fin.c : 0;
         }
+#ifdef STRQ_VIT_STATS
+        r.counted = stat_sweeps;
+#endif
         results[ti] = r;     // every lane stores the same value
         VIT_FENCE();
     }
@@ -564,6 +571,14 @@ static int vit_shape_base(const VitModel& mh)
     if (e <= 4 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) return 3;
     if (e <= 8 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) return 4;
     return -1;
+}
+
+// silent slots per lane of a kernel shape (the template's SPL)
+int vit_shape_silent_slots(int shape)
+{
+    static const int spl[5] = {2, 1, 2, 4, 4};
+    const int b = shape & ~VIT_SHAPE_SS;
+    return b >= 0 && b < 5 ? spl[b] : 0;
 }
 
 int vit_shape_of(const VitModel& mh)
