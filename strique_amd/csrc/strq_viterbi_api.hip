@@ -139,7 +139,12 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     m.n_cells = (epl + spl2) * 64 + 1;
     std::vector<int32_t> cell_of(n_states, -1), cell_state((size_t)m.n_cells, -1);
     for (int i = 0; i < epl * 64; ++i) if (own_e[i] >= 0) { cell_of[own_e[i]] = i; cell_state[i] = own_e[i]; }
-    for (int i = 0; i < spl2 * 64; ++i) if (own_s[i] >= 0) { cell_of[own_s[i]] = epl * 64 + i; cell_state[epl * 64 + i] = own_s[i]; }
+    // silent cells are interleaved (cell = first silent cell + lane * spl + slot = position along the zig-zag), so that
+    // the emitting states of consecutive lanes read their delete predecessors from consecutive LDS cells
+    for (int i = 0; i < spl2 * 64; ++i) if (own_s[i] >= 0) {
+        const int cell = epl * 64 + (i % 64) * spl2 + i / 64;
+        cell_of[own_s[i]] = cell; cell_state[cell] = own_s[i];
+    }
     m.start_cell = cell_of[start]; m.end_cell = cell_of[end];
     std::vector<int32_t> src((size_t)std::max(rows, 1) * 64, m.n_cells - 1);   // padding -> the -inf cell
     std::vector<double> lp((size_t)std::max(rows, 1) * 64, 0.0);

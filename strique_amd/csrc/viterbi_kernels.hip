@@ -200,7 +200,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 sinc[s] = own_s[s] >= 0 ? M.count_inc[own_s[s]] : 0;
                 const bool has_chain = on && M.chain_src[s * 64 + lane] >= 0;
                 clp[s] = has_chain ? M.chain_logp[s * 64 + lane] : NEGINF;
-                sdst[s] = vbase + 16 * (own_s[s] >= 0 ? scell0 + s * 64 + lane : TRASH);
+                sdst[s] = vbase + 16 * (own_s[s] >= 0 ? scell0 + lane * SPL + s : TRASH);      // chain position p = lane * SPL + s sits in cell scell0 + p
 #pragma unroll
                 for (int j = 0; j < DS; ++j) {
                     const bool ej = on && j < M.s_deg[s];
@@ -258,7 +258,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
                     y[s] = max_f64_raw(y[s], tin);
                     yc[s] = win ? cin : yc[s];
-                    if (BP) arg[s] = win ? (s == 0 ? scell0 + (SPL - 1) * 64 + lane - 1 : scell0 + (s - 1) * 64 + lane) : arg[s];     // the chain predecessor's cell
+                    if (BP) arg[s] = win ? scell0 + lane * SPL + s - 1 : arg[s];     // the chain predecessor's cell
                     if (s == SPL - 1) win_any = win;     // wins in the earlier slots were carried on inside this sweep already
                 }
                 if (!__any(win_any)) break;
