@@ -57,7 +57,7 @@ def main():
             "* **The forward DP's own mix** (three `v_add_f32` and one `v_max3_f32` per cell) runs at **%.0f G/s** on independent" % consts["dp_cell_mix_independent"],
             "  cells and **%.0f G/s** with the dependency chain of a DP column (four waves per SIMD): the half-rate `v_max3_f32`" % consts["dp_cell_mix_chained"],
             "  hides between the adds of the other waves, and the mix issues as fast as pure adds.  `align_forward_seg_kernel`",
-            "  sustains ~917 G/s over a whole launch (`bench.py`, `roofline.achieved`) -- 0.75 of the nominal peak, **0.98 of",
+            "  sustains ~935 G/s over a whole launch (`bench.py`, `roofline.achieved`) -- 0.76 of the nominal peak, **1.00 of",
             "  what this chip issues on the kernel's own instruction mix**.  What is left for the DP is fewer instructions",
             "  per cell (5.25 against the 4 of the bare recurrence), not better issue.",
             "* The Viterbi kernel is float64 throughout (add, compare, max, select per in-edge): its ceiling is the ~%.0f G/s" % consts["float64_stream_two_waves"],
