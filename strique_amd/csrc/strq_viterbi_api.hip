@@ -52,6 +52,21 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
         if (!hinted) std::fill(own_e.begin(), own_e.end(), -1);
     }
     if (!hinted) for (int i = 0; i < ne; ++i) own_e[i] = eord[i];
+    else if (epl >= 2) {
+        // the few states with more than five in-edges (the first match / insert of the repeat unit) move into free lanes of
+        // slot 0, so that the second busy slot gets by with five in-edge registers (kernel shape 5)
+        std::vector<int> movers;
+        for (int lane = 0; lane < 64; ++lane) { const int st = own_e[64 + lane]; if (st >= 0 && deg_of(st) > 5) movers.push_back(lane); }
+        int free0 = 0;
+        for (int lane = 0; lane < 64; ++lane) if (own_e[lane] < 0) ++free0;
+        if (!movers.empty() && (int)movers.size() <= free0 && movers.size() <= 4) {
+            int lane0 = 0;
+            for (int lane : movers) {
+                while (own_e[lane0] >= 0) ++lane0;
+                own_e[lane0] = own_e[64 + lane]; own_e[64 + lane] = -1;
+            }
+        }
+    }
     // silent states: chains.  The chain predecessor of b is its highest-numbered silent predecessor
     // (the last in-edge in evaluation order, so a strict '>' reproduces the tie rule) if that state
     // does not already lead another chain.

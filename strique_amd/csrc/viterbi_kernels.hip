@@ -119,8 +119,11 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     constexpr int TRASH = VitLds<EPL, SPL>::TRASH, BUF = VitLds<EPL, SPL>::BUF;
     // one 16-byte cell per state: {double value; int count; int pad} -> one ds_read_b128 per in-edge
     char* const vbase = reinterpret_cast<char*>(lds_d) + (size_t)wave * 2 * BUF;
-    constexpr int DEMAX = DE_HI > DE_LO ? DE_HI : DE_LO;
-    auto de_of = [](int s) constexpr { return s < (EPL + 1) / 2 ? DE_HI : DE_LO; };
+    // DE_HI above 16 packs two degrees: tens = in-edge registers of slot 0, units = of the other busy slots (65: the one
+    // or two states of a flanked-repeat model with six in-edges sit in slot 0, the matches with five in the next)
+    constexpr int HI0 = DE_HI > 16 ? DE_HI / 10 : DE_HI, HI1 = DE_HI > 16 ? DE_HI % 10 : DE_HI;
+    constexpr int DEMAX = HI0 > DE_LO ? HI0 : DE_LO;
+    auto de_of = [](int s) constexpr { return s == 0 ? HI0 : (s < (EPL + 1) / 2 ? HI1 : DE_LO); };
     const double NEGINF = -__builtin_inf();
     constexpr bool WIDE = MARK || HUB;
     using Pay = std::conditional_t<WIDE, uint64_t, int>;      // what rides along the best path
@@ -565,6 +568,7 @@ static int vit_shape_base(const VitModel& mh)
     int hi = 0, lo = 0, ds = 0;
     for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
     for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
+    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 3) return 5;      // flanked-repeat models, six-edge states in slot 0
     if (e <= 4 && s <= 2 && e > 2 && hi <= 6 && lo <= 3 && ds <= 3) return 0;      // flanked-repeat models
     if (e <= 1 && s <= 1 && hi <= 8 && ds <= 4) return 1;                          // modification models
     if (e <= 2 && s <= 2 && hi <= 8 && lo <= 8 && ds <= 4) return 2;
@@ -576,9 +580,9 @@ static int vit_shape_base(const VitModel& mh)
 // silent slots per lane of a kernel shape (the template's SPL)
 int vit_shape_silent_slots(int shape)
 {
-    static const int spl[5] = {2, 1, 2, 4, 4};
+    static const int spl[6] = {2, 1, 2, 4, 4, 2};
     const int b = shape & ~VIT_SHAPE_SS;
-    return b >= 0 && b < 5 ? spl[b] : 0;
+    return b >= 0 && b < 6 ? spl[b] : 0;
 }
 
 int vit_shape_of(const VitModel& mh)
@@ -625,6 +629,7 @@ int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* 
         case 2: return vit_launch_shape<2, 2, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 3: return vit_launch_shape<4, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 4: return vit_launch_shape<8, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
+        case 5: return vit_launch_shape<4, 2, 65, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         default: return 2;
     }
 }
