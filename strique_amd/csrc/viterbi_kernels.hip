@@ -568,7 +568,7 @@ static int vit_shape_base(const VitModel& mh)
     int hi = 0, lo = 0, ds = 0;
     for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
     for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
-    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 3) return 5;      // flanked-repeat models, six-edge states in slot 0
+    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2) return 5;      // flanked-repeat models: six-edge states in slot 0, two in-edges per delete state besides its chain
     if (e <= 4 && s <= 2 && e > 2 && hi <= 6 && lo <= 3 && ds <= 3) return 0;      // flanked-repeat models
     if (e <= 1 && s <= 1 && hi <= 8 && ds <= 4) return 1;                          // modification models
     if (e <= 2 && s <= 2 && hi <= 8 && lo <= 8 && ds <= 4) return 2;
@@ -629,7 +629,7 @@ int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* 
         case 2: return vit_launch_shape<2, 2, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 3: return vit_launch_shape<4, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 4: return vit_launch_shape<8, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
-        case 5: return vit_launch_shape<4, 2, 65, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
+        case 5: return vit_launch_shape<4, 2, 65, 3, 2>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         default: return 2;
     }
 }
