@@ -570,6 +570,7 @@ static int vit_shape_base(const VitModel& mh)
     for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
     if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2) return 5;      // flanked-repeat models: six-edge states in slot 0, two in-edges per delete state besides its chain
     if (e <= 4 && s <= 2 && e > 2 && hi <= 6 && lo <= 3 && ds <= 3) return 0;      // flanked-repeat models
+    if (e <= 1 && s <= 1 && hi <= 5 && ds <= 1) return 6;                          // STRique's dual base / mCpG model: 26 + 2 states, at most five in-edges
     if (e <= 1 && s <= 1 && hi <= 8 && ds <= 4) return 1;                          // modification models
     if (e <= 2 && s <= 2 && hi <= 8 && lo <= 8 && ds <= 4) return 2;
     if (e <= 4 && s <= 4 && hi <= 8 && lo <= 8 && ds <= 8) return 3;
@@ -580,9 +581,9 @@ static int vit_shape_base(const VitModel& mh)
 // silent slots per lane of a kernel shape (the template's SPL)
 int vit_shape_silent_slots(int shape)
 {
-    static const int spl[6] = {2, 1, 2, 4, 4, 2};
+    static const int spl[7] = {2, 1, 2, 4, 4, 2, 1};
     const int b = shape & ~VIT_SHAPE_SS;
-    return b >= 0 && b < 6 ? spl[b] : 0;
+    return b >= 0 && b < 7 ? spl[b] : 0;
 }
 
 int vit_shape_of(const VitModel& mh)
@@ -629,6 +630,7 @@ int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* 
         case 2: return vit_launch_shape<2, 2, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 3: return vit_launch_shape<4, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 4: return vit_launch_shape<8, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
+        case 6: return vit_launch_shape<1, 1, 5, 5, 1>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 5: return vit_launch_shape<4, 2, 65, 3, 2>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         default: return 2;
     }
