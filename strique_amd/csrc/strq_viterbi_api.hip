@@ -113,9 +113,12 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
         }
     };
     for (int s2 = 0; s2 < epl; ++s2) {       // the shape test below needs the emitting degrees
-        int deg = 0;
-        for (int lane = 0; lane < 64; ++lane) if (own_e[s2 * 64 + lane] >= 0) deg = std::max(deg, deg_of(own_e[s2 * 64 + lane]));
-        m.e_deg[s2] = deg;
+        int deg = 0; bool flat = true;
+        for (int lane = 0; lane < 64; ++lane) if (own_e[s2 * 64 + lane] >= 0) {
+            deg = std::max(deg, deg_of(own_e[s2 * 64 + lane]));
+            flat = flat && emis_kind[own_e[s2 * 64 + lane]] != 1;
+        }
+        m.e_deg[s2] = deg; m.e_flat[s2] = flat ? 1 : 0;
     }
     {
         bool placed = false;

@@ -122,8 +122,12 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     // DE_HI above 16 packs two degrees: tens = in-edge registers of slot 0, units = of the other busy slots (65: the one
     // or two states of a flanked-repeat model with six in-edges sit in slot 0, the matches with five in the next)
     constexpr int HI0 = DE_HI > 16 ? DE_HI / 10 : DE_HI, HI1 = DE_HI > 16 ? DE_HI % 10 : DE_HI;
-    constexpr int DEMAX = HI0 > DE_LO ? HI0 : DE_LO;
-    auto de_of = [](int s) constexpr { return s == 0 ? HI0 : (s < (EPL + 1) / 2 ? HI1 : DE_LO); };
+    // DE_LO above 10: the units are the degree, and the slots of the second half hold no Normal emission (the inserts of
+    // a profile: uniform) -- with clipped observations inside every uniform support their emission is the constant ecf
+    constexpr int LO = DE_LO > 10 ? DE_LO % 10 : DE_LO;
+    constexpr bool LO_FLAT = DE_LO > 10;
+    constexpr int DEMAX = HI0 > LO ? HI0 : LO;
+    auto de_of = [](int s) constexpr { return s == 0 ? HI0 : (s < (EPL + 1) / 2 ? HI1 : LO); };
     const double NEGINF = -__builtin_inf();
     constexpr bool WIDE = MARK || HUB;
     using Pay = std::conditional_t<WIDE, uint64_t, int>;      // what rides along the best path
@@ -381,8 +385,13 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 const double best = cv[0]; const Pay bc = cc[0]; const int a = ca[0];
                 double em;
                 if (fast_em) {          // every observation of this window lies inside all uniform emissions
-                    const double d = x - ea[s];
-                    em = ecf[s] - (d * d) * ebf[s];
+                    if constexpr (LO_FLAT) {
+                        if (s >= (EPL + 1) / 2) em = ecf[s];
+                        else { const double d = x - ea[s]; em = ecf[s] - (d * d) * ebf[s]; }
+                    } else {
+                        const double d = x - ea[s];
+                        em = ecf[s] - (d * d) * ebf[s];
+                    }
                 } else {
                     const double d = x - ea[s];
                     const double en = ec[s] - (d * d) * eb[s];
@@ -568,7 +577,13 @@ static int vit_shape_base(const VitModel& mh)
     int hi = 0, lo = 0, ds = 0;
     for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
     for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
-    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2) return 5;      // flanked-repeat models: six-edge states in slot 0, two in-edges per delete state besides its chain
+    // flanked-repeat models: six-edge states in slot 0, two in-edges per delete state besides its chain
+    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2) {
+        bool flat = true;
+        for (int i = (e + 1) / 2; i < e; ++i) flat = flat && mh.e_flat[i];
+        if (flat && e == 4) return 7;          // ... and only uniform emissions (the inserts) in the last two slots
+        return 5;
+    }
     if (e <= 4 && s <= 2 && e > 2 && hi <= 6 && lo <= 3 && ds <= 3) return 0;      // flanked-repeat models
     if (e <= 1 && s <= 1 && hi <= 5 && ds <= 1) return 6;                          // STRique's dual base / mCpG model: 26 + 2 states, at most five in-edges
     if (e <= 1 && s <= 1 && hi <= 8 && ds <= 4) return 1;                          // modification models
@@ -581,9 +596,9 @@ static int vit_shape_base(const VitModel& mh)
 // silent slots per lane of a kernel shape (the template's SPL)
 int vit_shape_silent_slots(int shape)
 {
-    static const int spl[7] = {2, 1, 2, 4, 4, 2, 1};
+    static const int spl[8] = {2, 1, 2, 4, 4, 2, 1, 2};
     const int b = shape & ~VIT_SHAPE_SS;
-    return b >= 0 && b < 7 ? spl[b] : 0;
+    return b >= 0 && b < 8 ? spl[b] : 0;
 }
 
 int vit_shape_of(const VitModel& mh)
@@ -630,6 +645,7 @@ int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* 
         case 2: return vit_launch_shape<2, 2, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 3: return vit_launch_shape<4, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 4: return vit_launch_shape<8, 4, 8, 8, 8>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
+        case 7: return vit_launch_shape<4, 2, 65, 13, 2>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 6: return vit_launch_shape<1, 1, 5, 5, 1>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 5: return vit_launch_shape<4, 2, 65, 3, 2>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         default: return 2;
