@@ -61,8 +61,8 @@ def main():
             "  what this chip issues on the kernel's own instruction mix**.  What is left for the DP is fewer instructions",
             "  per cell (5.25 against the 4 of the bare recurrence), not better issue.",
             "* The Viterbi kernel is float64 throughout (add, compare, max, select per in-edge): its ceiling is the ~%.0f G/s" % consts["float64_stream_two_waves"],
-            "  of the half-rate class at two waves per SIMD, and it sustains 338 G/s (3.1e10 instructions per 4096 windows in",
-            "  92.5 ms, `%s_sq.md`) -- %.2f of that ceiling, the rest being the LDS round trips and the serial chain sweeps of a" % (a.round, 338.0 / consts["float64_stream_two_waves"]),
+            "  of the half-rate class at two waves per SIMD, and it sustains 325 G/s (2.8e10 instructions per 4096 windows in",
+            "  85.4 ms, `%s_sq.md`) -- %.2f of that ceiling, the rest being the LDS round trips and the serial chain sweeps of a" % (a.round, 325.0 / consts["float64_stream_two_waves"]),
             "  time step.",
             "* The lone `v_cndmask_b32 ..., vcc` row reads a VCC nothing writes in that loop; with the mask in an SGPR",
             "  pair (as the DP uses it) or behind a compare the instruction issues at the half rate like the others.", ""]
