@@ -51,11 +51,11 @@ def main():
             else:
                 ref[i] = r
         fb = free_bytes()
-        if call == 1:
+        if call == min(5, a.calls - 1):      # the grow-only device buffers have reached their high-water mark by then
             f0 = fb
         print("call %2d: %4d reads %.2f s (%.0f reads/s), device memory free %.2f GB" % (call, len(order), dt, len(order) / dt, fb / 2**30), flush=True)
     ok = sum(1 for i in range(a.reads) if i in ref and abs(ref[i][0] - nreps[i]) <= 2)
-    print("planted counts recovered (+-2): %d / %d; free memory drift since call 1: %.1f MB" % (ok, len(ref), (f0 - fb) / 2**20))
+    print("planted counts recovered (+-2): %d / %d; free memory drift since call 5: %.1f MB" % (ok, len(ref), (f0 - fb) / 2**20))
 
 
 if __name__ == "__main__":
