@@ -136,7 +136,7 @@ int strq_oracle_align(const float *a, int64_t n, const float *b, int64_t m,
         free(slot); free(key);
         if (na * nb > (int64_t)1 << 28) { use_lut = 0; }
         else {
-            lut = (float *)malloc(sizeof(float) * (na * nb ? na * nb : 1));
+            lut = (float *)malloc(sizeof(float) * ((na * nb) != 0 ? na * nb : 1));
             for (int64_t x = 0; x < na; ++x)
                 for (int64_t y = 0; y < nb; ++y) lut[x * nb + y] = cell_score(&p, av[x], bv[y]);
         }
