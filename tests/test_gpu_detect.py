@@ -396,3 +396,35 @@ def test_randomised_configurations(pm, pm_mod, cfg, orc, opm, opm_mod):
             w = orc.detect(sig, tc, opm, params, pm_mod=opm_mod if with_mod else None)[0]
             assert tuple(g) == tuple(w), (trial, acfg, strand, g, w)
         rc.ctx.close()
+
+
+def test_overlap_chosen_from_the_previous_batch_changes_nothing(pm, cfg, targets, monkeypatch):
+    """The column segments of a sub-batch are cut with the overlap that was cheapest for the previous sub-batch's
+    scores: the first call of a context runs at the initial 8192 columns, the second at the adapted one, a third context
+    always at the worst case (STRQ_OVERLAP=0) -- the rows must not differ, whatever the read contains."""
+    from strique_amd.counter import repeatCounter
+    items = []
+    for k in range(48):
+        name = ["c9orf72", "fmr1", "htt"][k % 3]; strand = "+-"[(k // 3) % 2]
+        if k % 8 == 7:      # no locus at all: these alignments never certify a short overlap and run twice
+            rng = np.random.default_rng(k)
+            items.append((name, rng.normal(600, 80, 90000).astype(np.int16), strand))
+        else:
+            items.append((name, _read(pm, targets, name, strand, 11000 + 500 * (k % 5), 20 + k, 5200 + k), strand))
+
+    def fresh():
+        rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+        for name, t in targets.items():
+            rc.add_target(name, *t)
+        return rc
+    rc = fresh()
+    first = rc.detect_batch(items)
+    second = rc.detect_batch(items)          # overlap adapted to the first call's scores
+    third = rc.detect_batch(list(reversed(items)))[::-1]
+    rc.ctx.close()
+    monkeypatch.setenv("STRQ_OVERLAP", "0")
+    rc = fresh()
+    worst = rc.detect_batch(items)
+    rc.ctx.close()
+    assert first == second == third == worst
+    assert sum(1 for r in first if r[0] > 0) >= 40
