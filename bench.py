@@ -12,6 +12,9 @@ signals are uploaded once and stay resident in HBM; the timed region covers ever
 pipeline and the (tiny) result read-back.  Reads shard over ranks (weak scaling: the batch per GPU is
 fixed); with N > 1 every step ends with the gather of the result records to rank 0 (RCCL).
 
+Every step runs a DIFFERENT resident batch (--batches, default 3, all uploaded before the timed region), so the
+column-segment overlap a step is cut with was adapted to another batch's scores, never to its own.
+
 Rank 0 prints one JSON line.  `roofline` names what binds the dominant kernel (the forward flank DP):
 VALU issue -- wave instructions per second against 1024 SIMDs x 2.4 GHz / 2, with the instruction count
 per wave-step taken from the committed SQ_INSTS_VALU profile (profiles/dp_constants.json) and the
@@ -58,6 +61,32 @@ def make_batch(pm, cfg, n_reads, read_nt, first_index, config_id=3):
     return sigs, strands, nreps
 
 
+def _synth_chunk(args):
+    """Worker process: reads [first, first + count) of the synthetic recipe."""
+    first, count, read_nt = args
+    pm, cfg = load_inputs()
+    return make_batch(pm, cfg, count, read_nt, first)
+
+
+def make_batches_parallel(n_reads, read_nt, first_index, workers):
+    """The same reads as make_batch(..., first_index), synthesised by a few worker processes (a 50 kb read takes
+    ~7 ms of numpy; 3 x 4096 of them would otherwise dominate the run)."""
+    import multiprocessing as mp
+    workers = max(1, min(workers, n_reads // 64 or 1))
+    if workers == 1:
+        pm, cfg = load_inputs()
+        return make_batch(pm, cfg, n_reads, read_nt, first_index)
+    per = (n_reads + workers - 1) // workers
+    # chunks start at multiples of len(REPEAT_SWEEP) offsets of first_index: make_batch derives the repeat count from the index
+    jobs = [(first_index + k * per, min(per, n_reads - k * per), read_nt) for k in range(workers) if k * per < n_reads]
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        parts = pool.map(_synth_chunk, jobs)
+    sigs, strands, nreps = [], [], []
+    for a, b, c in parts:
+        sigs += a; strands += b; nreps += c
+    return sigs, strands, nreps
+
+
 def _oracle_side(strand):
     """The CPU oracle's own pore model and classifier (built inside oracle/, nothing from the product)."""
     from oracle import strique_oracle as orc
@@ -78,6 +107,53 @@ def _cpu_one(args):
     return time.time() - t0, res[0]
 
 
+def _pin_worker(cpus, counter):
+    """Pool initializer: one worker per physical core (first logical CPU of each)."""
+    with counter.get_lock():
+        k = counter.value; counter.value += 1
+    try:
+        os.sched_setaffinity(0, {cpus[k % len(cpus)]})
+    except (AttributeError, OSError):
+        pass
+
+
+def physical_cores():
+    """First logical CPU of every physical core this process may run on (/proc/cpuinfo: physical id, core id)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    seen = {}
+    try:
+        cpu = phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("processor"):
+                cpu = int(ln.split(":")[1])
+            elif ln.startswith("physical id"):
+                phys = int(ln.split(":")[1])
+            elif ln.startswith("core id"):
+                core = int(ln.split(":")[1])
+            elif not ln.strip():
+                if cpu is not None and cpu in allowed:
+                    seen.setdefault((phys, core if core is not None else cpu), cpu)
+                cpu = phys = core = None
+        if cpu is not None and cpu in allowed:
+            seen.setdefault((phys, core if core is not None else cpu), cpu)
+    except OSError:
+        pass
+    return sorted(seen.values()) or sorted(allowed)
+
+
+def _mem_available_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                return int(ln.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 16.0
+
+
 def _cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -88,32 +164,38 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sigs, strands, max_workers=32):
+def cpu_baseline(sigs, strands, max_workers=0):
     """The CPU oracle (reference arithmetic: full matrix, one double pow per cell, float64 Viterbi) on the
-    host cores, one worker process per core like STRique's --t N, one read per worker."""
+    host cores: one worker process per PHYSICAL core, pinned, one read per worker -- STRique's --t N with N = cores.
+    `value` is what those workers delivered together (measured wall time, nothing extrapolated)."""
     import multiprocessing as mp
+    cpus = physical_cores()
     host_cores = os.cpu_count() or 1
-    cores = max(1, min(max_workers, host_cores, len(sigs)))
+    # a worker holds the full (N + 1) x 871 float32 matrix and its byte trace: ~2.5 GB at 50 kb
+    mem_cap = max(1, int(_mem_available_gb() * 0.8 / 2.6))
+    cores = max(1, min(max_workers or len(cpus), len(cpus), len(sigs), mem_cap))
     sample = [(s, st, False) for s, st in zip(sigs[:cores], strands[:cores])]
-    with mp.get_context("spawn").Pool(cores) as pool:
-        pool.map(_cpu_one, [(sigs[0][:20000], strands[0], True)] * cores)      # start the workers, load the oracle
+    ctx = mp.get_context("spawn")
+    counter = ctx.Value("i", 0)
+    with ctx.Pool(cores, initializer=_pin_worker, initargs=(cpus, counter)) as pool:
+        pool.map(_cpu_one, [(sigs[0][:20000], strands[0], True)] * cores, chunksize=1)      # start the workers, load the oracle
         t0 = time.time()
-        out = pool.map(_cpu_one, sample)
+        out = pool.map(_cpu_one, sample, chunksize=1)
         wall = time.time() - t0
         t0 = time.time()
-        out_lut = pool.map(_cpu_one, [(s, st, True) for s, st, _ in sample])
+        out_lut = pool.map(_cpu_one, [(s, st, True) for s, st, _ in sample], chunksize=1)
         wall_lut = time.time() - t0
     per_core = float(np.mean([o[0] for o in out]))
     return {"value": len(sample) / wall, "unit": "reads/s", "cores": cores, "kind": "port",
-            "host_cpu_count": host_cores, "cpu_model": _cpu_model(),
-            "cores_note": "one worker process per logical CPU, capped at %d workers" % max_workers,
-            "per_core_reads_per_s": 1.0 / per_core, "seconds_per_read_per_core": per_core,
-            "whole_host_estimate_reads_per_s": host_cores / per_core,
-            "lut_variant": {"value": len(sample) / wall_lut, "unit": "reads/s", "same_counts": [int(o[1]) for o in out_lut] == [int(o[1]) for o in out],
+            "host_cpu_count": host_cores, "physical_cores": len(cpus), "cpu_model": _cpu_model(),
+            "cores_note": "one pinned worker process per physical core%s" % ("" if cores == len(cpus) else " (capped at %d by --cpu-workers / memory / sample size)" % cores),
+            "wall_s": wall, "per_core_reads_per_s": 1.0 / per_core, "seconds_per_read_per_core": per_core,
+            "lut_variant": {"value": len(sample) / wall_lut, "unit": "reads/s", "wall_s": wall_lut,
+                            "same_counts": [int(o[1]) for o in out_lut] == [int(o[1]) for o in out],
                             "note": "same oracle with scores memoised per (level, class) instead of one pow per cell"},
             "sample": "%d reads of the timed batch (one per worker process, like STRique's --t), full 2x(N+1)x871 "
-                      "float32 DP with one double pow per cell + float64 Viterbi; %.1f s per read per core"
-                      % (len(sample), per_core),
+                      "float32 DP with one double pow per cell + float64 Viterbi; %.1f s per read per core, %.1f s wall"
+                      % (len(sample), per_core, wall),
             "counts": [int(o[1]) for o in out]}
 
 
@@ -124,10 +206,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=4096, help="reads per GPU per step (16 per CU: the forward DP launch ends without a ragged tail)")
     ap.add_argument("--read-nt", type=int, default=50000)
+    ap.add_argument("--batches", type=int, default=3, help="distinct resident batches per GPU, one per step in rotation")
+    ap.add_argument("--synth-workers", type=int, default=0, help="processes synthesising the reads (0: a share of the host's cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the CPU baseline (0: one per physical core)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive strq_detect_batch measurement")
     ap.add_argument("--host-leg-batches", type=int, default=3, help="sub-batches of the PCIe-inclusive leg")
-    ap.add_argument("--check", type=int, default=2, help="reads verified against the CPU oracle (LUT variant)")
+    ap.add_argument("--check", type=int, default=2, help="reads verified against the CPU oracle, all six fields (LUT variant: same bits)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="testing only: all ranks use HIP device 0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -135,6 +220,15 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+    n_batches = max(1, args.batches)
+
+    # ---- synthetic reads (before anything touches the GPU): `batches` distinct batches per rank
+    t_gen = time.time()
+    synth_workers = args.synth_workers or max(1, min(32, (os.cpu_count() or 1) // max(1, 2 * world)))
+    first_read = rank * n_batches * args.reads
+    sigs, strands, nreps = make_batches_parallel(n_batches * args.reads, args.read_nt, first_read, synth_workers)
+    t_gen = time.time() - t_gen
+
     dist = None
     device = 0 if args.share_device else local
     if world > 1:
@@ -150,15 +244,12 @@ def main():
     chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
     counter.add_target("c9orf72", repeat, prefix, suffix)
 
-    t_gen = time.time()
-    sigs, strands, nreps = make_batch(pm, cfg, args.reads, args.read_nt, rank * args.reads)
-    t_gen = time.time() - t_gen
     off = np.zeros(len(sigs) + 1, np.int64); off[1:] = np.cumsum([len(s) for s in sigs])
     tids = [counter._classifier_for("c9orf72", s).target_id for s in strands]
     ctx = counter.ctx
     flat = np.concatenate(sigs)
     t_up = time.time()
-    ctx.batch_upload(flat, off, tids)           # host -> HBM, not timed
+    ctx.batch_upload(flat, off, tids)           # host -> HBM, not timed: all batches resident before the timed region
     t_up = time.time() - t_up
     del flat
 
@@ -170,24 +261,33 @@ def main():
             import torch
             torch.cuda.synchronize()
 
-    def step():
-        ctx.batch_run()
-        res = ctx.batch_fetch()
-        if dist is not None:
-            sdist.gather_records(res, np.arange(rank * args.reads, (rank + 1) * args.reads), world * args.reads,
-                                 device="cuda" if args.backend == "nccl" else "cpu")
-        return res
+    world_seen = [1]
+    n_total = world * n_batches * args.reads
 
+    def step(k):
+        bi = k % n_batches                      # a different resident batch every step
+        lo, hi = bi * args.reads, (bi + 1) * args.reads
+        ctx.batch_run_range(lo, hi)
+        res = ctx.batch_fetch()[lo:hi]
+        if dist is not None:
+            world_seen[0] = dist.get_world_size()
+            sdist.gather_records(res, first_read + np.arange(lo, hi), n_total, device="cuda" if args.backend == "nccl" else "cpu")
+        return bi, res
+
+    k_step = 0
     for _ in range(args.warmup):
-        step()
+        step(k_step); k_step += 1
     barrier()
     t0 = time.time()
     fwd_ms = 0.0; fwd_launches = 0; stage_ms = np.zeros(8); counters = np.zeros(8)
+    last = {}; geoms = []
     for _ in range(args.steps):
-        res = step()
+        bi, res = step(k_step); k_step += 1
+        last[bi] = res.copy()
         tm = ctx.last_timing(); cn = ctx.last_counters()
         fwd_ms += float(tm[1]); fwd_launches += int(tm[7]); stage_ms += tm
         counters[:3] += cn[:3]; counters[3:7] = cn[3:7]; counters[7] += cn[7]
+        geoms.append(ctx.last_geometry())
     barrier()
     elapsed = time.time() - t0
     if dist is not None:
@@ -196,37 +296,58 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- correctness spot check against the oracle (same arithmetic, memoised scores)
-    checked = []
+    # ---- correctness spot check against the oracle (same arithmetic, memoised scores): all six fields of a row
+    checked = []; check_ok = True
     if rank == 0 and args.check > 0:
-        for i in range(min(args.check, len(sigs))):
-            dt, n_or = _cpu_check(sigs[i], strands[i])
-            checked.append({"read": i, "expected_repeats": nreps[i], "oracle": n_or, "gpu": int(res[i]["count"])})
+        ran = sorted(last)
+        for i in range(args.check):
+            bi = ran[i % len(ran)]; j = i                  # read j of batch bi (different batches when several ran)
+            if j >= args.reads:
+                break
+            g = bi * args.reads + j
+            w = _cpu_check(sigs[g], strands[g])
+            r = last[bi][j]
+            got = (int(r["count"]), float(r["score_prefix"]), float(r["score_suffix"]), float(r["log_p"]), int(r["offset"]), int(r["ticks"]))
+            want = (int(w[0]), float(w[1]), float(w[2]), float(w[3]), int(w[4]), int(w[5]))
+            same = got == want
+            check_ok = check_ok and same
+            checked.append({"batch": bi, "read": j, "expected_repeats": nreps[g], "oracle": list(want), "gpu": list(got), "all_fields_equal": same})
 
     if rank == 0:
         total_reads = world * args.reads * args.steps
         value = total_reads / elapsed
-        n_samples = int(off[-1])
+        n_samples = int(off[-1]) // n_batches                      # samples of one batch (they are equally large)
         launches_per_step = max(1, fwd_launches // max(1, args.steps))
         avg_launch_s = (fwd_ms / 1e3) / max(1, fwd_launches)
         # --- what binds the dominant kernel (the forward flank DP): VALU issue.  SURVEY.md 8d: when the
         # implementation removes the per-cell trace stream, GCUPS / VALU is the binding roofline.
         prof = _profile_constants()
-        segs, tables, packed, R = int(counters[3]), int(counters[4]), int(counters[5]), int(counters[6])
-        kname = "align_forward_seg_kernel<%d, 6, %s, %d, %d, false>" % (R, "true" if packed else "false", segs, max(2 if segs == 1 else 3, (segs * tables + 3) // 4))
-        ipstep = prof.get("valu_insts_per_wave_step", {}).get("packed" if packed else "float32")
+        geo = geoms[-1] if geoms else ctx.last_geometry()
+        segs, tables, packed, R, wpe = geo["waves_per_alignment"], geo["tables_per_cu"], geo["packed"], geo["rows_per_lane"], geo["wpe"]
+        kname = "align_forward_seg_kernel<%d, 6, %s, %d, %d, false>" % (R, "true" if packed else "false", segs, wpe)      # the instance the library launched (strq_last_geometry)
+        by_kernel = prof.get("valu_insts_per_wave_step_by_kernel", {})
+        ipstep = by_kernel.get(kname)
+        ipstep_note = None
+        if ipstep is None:
+            ipstep = prof.get("valu_insts_per_wave_step", {}).get("packed" if packed else "float32")
+            known = prof.get("kernels", {}).get("packed" if packed else "float32", "")
+            if ipstep is not None and kname not in known:
+                ipstep_note = "no committed SQ_INSTS_VALU profile of this kernel instance; constant measured on %s" % known
         wave_steps_per_launch = counters[0] / max(1, fwd_launches)
         valu_peak = N_SIMD * CLOCK_HZ / 2.0 / 1e9                     # wave64 VALU instructions per second, all SIMDs (G/s)
-        cells = sum(2 * (FLANK_ROWS + 1) * (len(s) + 1) for s in sigs)
-        bytes_per_step = sum(2 * len(s) + 2 * (FLANK_ROWS + 1) * (len(s) + 1) for s in sigs)
+        one = sigs[:args.reads]
+        cells = sum(2 * (FLANK_ROWS + 1) * (len(s) + 1) for s in one)
+        bytes_per_step = sum(2 * len(s) + 2 * (FLANK_ROWS + 1) * (len(s) + 1) for s in one)
         hbm_alg = bytes_per_step / launches_per_step / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        gcups = cells / (fwd_ms / 1e3 / max(1, args.steps)) / 1e9 if fwd_ms > 0 else None
         roof = {"bound": "valu", "unit": "G wave-instructions/s", "peak": valu_peak,
                 "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches_per_step,
                 "waves_per_alignment": segs, "score_tables_per_cu": tables, "waves_per_cu": segs * tables,
+                "overlap_columns_per_step": [g["overlap_first"] for g in geoms], "overlap_worst_case": geo["overlap_worst"],
                 "wave_steps_per_launch": wave_steps_per_launch,
                 "columns_computed_over_columns_of_the_reads": counters[1] / max(1.0, 2.0 * n_samples * args.steps),
                 "lane_utilisation": FLANK_ROWS / float(64 * R) if R else None,
-                "gcups": cells / (fwd_ms / 1e3 / max(1, args.steps)) / 1e9 if fwd_ms > 0 else None,
+                "gcups": gcups,
                 "traffic": (prof.get("hbm_bytes_per_column", 0.0) * counters[1] / max(1, fwd_launches)) or None,
                 "traffic_source": prof.get("traffic_source"),
                 "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBS,
@@ -234,9 +355,16 @@ def main():
                                     "note": "SURVEY.md 8d algorithmic bytes (int16 signal once + the reference's 1 B/cell trace) over the measured "
                                             "launch time.  These bytes never move here (checkpoint + recompute instead of a per-cell trace), "
                                             "so this figure is a work rate in the reference's units, not HBM utilisation; it may exceed 1."}}
+        if gcups:
+            # the bare recurrence is 4 instructions per cell (3 v_add_f32 + 1 v_max3_f32), one wave instruction = 64 cells' worth:
+            # the share of the nominal issue peak that is the DP itself, without look-ups, selects, lane shifts or idle lanes
+            roof["useful_achieved"] = gcups * 4.0 / 64.0
+            roof["useful_frac"] = roof["useful_achieved"] / valu_peak
         if ipstep and avg_launch_s > 0:
             roof["valu_insts_per_wave_step"] = ipstep
             roof["valu_insts_source"] = prof.get("valu_source")
+            if ipstep_note:
+                roof["valu_insts_note"] = ipstep_note
             roof["achieved"] = ipstep * wave_steps_per_launch / avg_launch_s / 1e9
             roof["frac"] = roof["achieved"] / valu_peak
             roof["instr_per_cell"] = ipstep / (2.0 * R)                    # per lane: R rows x 2 columns per step
@@ -256,11 +384,17 @@ def main():
             "metric": "reads/s for STRique 'count' on 50 kb r9.4 signals", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "value_definition": "whole-job reads/s with the int16 signals resident in HBM when the timed region starts (the benchmark "
+                                "contract); `host_inclusive_reads_per_s` is the same pipeline with the signals starting in pageable host "
+                                "RAM (SURVEY.md 8d's wording), uploads overlapped with the kernels",
+            "vs_baseline_note": "BASELINE.md holds no published number for this metric; `vs_cpu_baseline` = value / cpu_baseline.value of this run",
             "dtype_note": "float32 flank DP (dominant), float64 HMM Viterbi and conditioning statistics",
-            "data": "synthetic (SURVEY.md 8d recipe, seeded), int16 signals resident in HBM",
+            "data": "synthetic (SURVEY.md 8d recipe, seeded), int16 signals resident in HBM; %d distinct batches per GPU, a different one every step" % n_batches,
             "config": {"workload": "BASELINE configs[2]: %d reads/GPU/step, %d nt (N~%d samples), C9orf72 GGGGCC x {200,500,1000,1500,2000}"
-                                   % (args.reads, args.read_nt, n_samples // max(1, len(sigs))),
-                       "reads_per_gpu_per_step": args.reads, "read_nt": args.read_nt, "sharding": "reads over ranks, no data-path collective"},
+                                   % (args.reads, args.read_nt, n_samples // max(1, args.reads)),
+                       "reads_per_gpu_per_step": args.reads, "read_nt": args.read_nt, "distinct_batches_per_gpu": n_batches,
+                       "sharding": "reads over ranks, no data-path collective"},
+            "world_size_seen_by_the_collective": world_seen[0],
             "resident_reads_per_s": value,
             "roofline": roof,
             "stage_ms_per_step": {"conditioning": float(stage_ms[5]) / args.steps, "score_tables": float(stage_ms[0]) / args.steps,
@@ -268,43 +402,51 @@ def main():
                                   "viterbi": float(stage_ms[6]) / args.steps},
             "viterbi": {"time_steps_per_step": counters[7] / args.steps,
                         "us_per_time_step_per_wave_slot": (float(stage_ms[6]) / args.steps * 1e3) / max(1.0, counters[7] / args.steps / (8 * N_SIMD / 4))},
-            "host": {"synth_s": t_gen, "upload_s": t_up, "upload_GBs": n_samples * 2 / t_up / 1e9 if t_up > 0 else None},
-            "check": checked,
+            "host": {"synth_s": t_gen, "synth_workers": synth_workers, "upload_s": t_up, "upload_GBs": int(off[-1]) * 2 / t_up / 1e9 if t_up > 0 else None},
+            "check": checked, "check_ok": check_ok,
         }
         if not args.no_host_leg and world == 1:
             # SURVEY.md 8d quotes the metric with the signals in host RAM: the boundary's host-buffer entry
-            # (strq_detect_batch) over `host_leg_batches` sub-batches, samples in pageable host memory, uploads of
+            # (strq_detect_batch) over `host_leg_batches` distinct sub-batches, samples in pageable host memory, uploads of
             # sub-batch k + 1 overlapping the kernels of sub-batch k.  Reported beside `value`, never as `value`.
             reps = max(1, args.host_leg_batches)
-            big = np.concatenate(sigs * reps)
-            off2 = np.zeros(reps * len(sigs) + 1, np.int64); off2[1:] = np.cumsum([len(s) for s in sigs] * reps)
-            tids2 = np.array(list(tids) * reps, np.int32)
+            pick = [(k % n_batches) for k in range(reps)]
+            big = np.concatenate([s for k in pick for s in sigs[k * args.reads:(k + 1) * args.reads]])
+            lens = [len(s) for k in pick for s in sigs[k * args.reads:(k + 1) * args.reads]]
+            off2 = np.zeros(len(lens) + 1, np.int64); off2[1:] = np.cumsum(lens)
+            tids2 = np.array([t for k in pick for t in tids[k * args.reads:(k + 1) * args.reads]], np.int32)
             t1 = time.time()
             res2 = ctx.detect_batch(big, off2, tids2, None)          # first call: sizes the device buffers for this batch (hipMalloc)
             dt_cold = time.time() - t1
             t1 = time.time()
             res2 = ctx.detect_batch(big, off2, tids2, None)          # steady state of a long-running caller
             dt = time.time() - t1
-            same = all(bool(np.array_equal(res2["count"][k * len(sigs):(k + 1) * len(sigs)], res["count"])) for k in range(reps))
-            out["host_inclusive_reads_per_s"] = reps * len(sigs) / dt
-            out["host_buffers"] = {"reads": reps * len(sigs), "sub_batches": reps, "seconds": dt, "seconds_first_call_with_allocations": dt_cold, "reads_per_s": reps * len(sigs) / dt, "GB": big.nbytes / 1e9,
-                                   "same_counts_as_resident_run": same,
+            same = all(bool(np.array_equal(res2[i * args.reads:(i + 1) * args.reads], last[k])) for i, k in enumerate(pick) if k in last)
+            out["host_inclusive_reads_per_s"] = len(lens) / dt
+            out["host_buffers"] = {"reads": len(lens), "sub_batches": reps, "seconds": dt, "seconds_first_call_with_allocations": dt_cold, "reads_per_s": len(lens) / dt, "GB": big.nbytes / 1e9,
+                                   "same_rows_as_resident_run": same,
                                    "note": "PCIe-inclusive: int16 signals start in pageable host memory and go through a pinned staging ring; "
                                            "only the first sub-batch's upload is exposed"}
             del big
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(sigs, strands)
+            ctx.close()                                       # the oracle workers want the host's memory, not the GPU's buffers
+            out["cpu_baseline"] = cpu_baseline(sigs[:args.reads], strands[:args.reads], args.cpu_workers)
+            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not check_ok:
+        sys.stderr.write("bench.py: GPU rows differ from the CPU oracle -- see \"check\" in the JSON line\n")
+        raise SystemExit(1)
 
 
 def _cpu_check(sig, strand):
+    """The oracle's whole row (n, score_prefix, score_suffix, log_p, offset, ticks, mod) of one read."""
     orc, opm, tc, params = _oracle_side(strand)
-    t0 = time.time()
     res, _ = orc.detect(sig, tc, opm, params, use_lut=True)
-    return time.time() - t0, int(res[0])
+    return res
 
 
 def _measured_rates():

@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 6 (5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads) */
+int strq_abi_version(void);   /* currently 7 (5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -186,6 +186,9 @@ int strq_detect_batch_reads(strq_ctx* ctx, int64_t n_reads, const void* const* r
 int strq_batch_upload(strq_ctx* ctx, int64_t n_reads, const void* signals, int32_t dtype,
                       const int64_t* offsets, const int32_t* target_id, const double* host_stats);
 int strq_batch_run(strq_ctx* ctx);
+/* Only reads [first, last) of the uploaded batch (several batches kept resident side by side: a benchmark that
+ * times a different one every step); strq_batch_fetch still returns the rows of the whole upload. */
+int strq_batch_run_range(strq_ctx* ctx, int64_t first, int64_t last);
 int strq_batch_fetch(strq_ctx* ctx, strq_result* out);
 /* The host-side statistics of float64 reads (no context, no device): out[6 * i ..] = median, MAD, c1, h1 of
  * medfilt(read i, 3) and c1, h1 of read i itself (0, 1 unless want_raw) -- what numpy's median / mean / percentile
@@ -212,6 +215,13 @@ int strq_last_timing(const strq_ctx* ctx, float ms[8]);
  * [3] waves per alignment (column segments) of the last forward launch   [4] score tables per CU
  * [5] 1 = 24-bit tables, 0 = float32   [6] rows per lane   [7] Viterbi time steps. */
 int strq_last_counters(const strq_ctx* ctx, double out[8]);
+/* Launch geometry of the last forward-DP launch of the last batched call (which kernel instance ran; the parity
+ * tests assert it, the benchmark names the kernel of its roofline with it):
+ * [0] waves per alignment (column segments)   [1] score tables per CU   [2] WPE template argument of
+ * align_forward_seg_kernel<R, S, PK, SEG, WPE> (0: the one-wave kernels ran)   [3] rows per lane R
+ * [4] 1 = 24-bit tables   [5] overlap (columns) the pieces were cut with first   [6] the worst-case overlap
+ * [7] forward launch groups of the last sub-batch. */
+int strq_last_geometry(const strq_ctx* ctx, int32_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -196,6 +196,7 @@ def count(argv):
     parser.add_argument("--device", type=int, default=0, help="HIP device")
     parser.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend when launched with torchrun (default: nccl = RCCL)")
     parser.add_argument("--share-device", action="store_true", help="testing: every rank uses --device instead of its LOCAL_RANK")
+    parser.add_argument("--strict", action="store_true", help="Exit with status 2 when any read could not be processed (the reference only logs such reads and exits 0)")
     args = parser.parse_args(argv)
     log = Log(args.log_level)
     config = parse_config(args.repeat, args.config, log)
@@ -232,9 +233,22 @@ def count(argv):
     out = (open(args.out, 'w') if args.out else sys.stdout) if rank == 0 else None
     readers = max(1, args.t)
     stats = {}
-    rows = run_count(stream, loci, f5.get_raw, counter, log, args.batch, rank, world, out if world == 1 else None, readers=readers, stats=stats)
+    fault = 0
+    try:
+        rows = run_count(stream, loci, f5.get_raw, counter, log, args.batch, rank, world, out if world == 1 else None, readers=readers, stats=stats)
+    except DeviceFault:
+        if world == 1:
+            raise SystemExit(3)
+        fault = 1; rows = []
     if world > 1:
         import torch.distributed as dist
+        # a rank that lost its device must not leave the others waiting in the gather: every rank learns about it
+        # here (the faulty rank arrives at once, the others when their share is done) and all of them exit 3
+        if sdist.any_rank(fault):
+            if rank == 0:
+                log("Main: a rank reported a device error; no output written.", 'error')
+            dist.destroy_process_group()
+            raise SystemExit(3)
         merged = gather_rows(rows, stats["items"], sdist)
         if rank == 0:
             write_rows(out, merged)
@@ -243,8 +257,14 @@ def count(argv):
     if args.out and out is not None:
         out.close()
     if stats.get("failed"):
+        # like the reference (STRique.py:704-713): reads that fail are logged, the run itself succeeds
         log("Main: %d read(s) could not be processed (see warnings above)." % stats["failed"], 'error')
-        raise SystemExit(2)
+        if args.strict:
+            raise SystemExit(2)
+
+
+class DeviceFault(Exception):
+    """The GPU engine reported a device error (fault, out of memory): it will not go away read by read."""
 
 
 ROW_DTYPE = np.dtype([("count", np.int32), ("valid", np.int32), ("score_prefix", np.float64), ("score_suffix", np.float64),
@@ -346,7 +366,7 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
             if e.code not in (STRQ_ERR_ARG, STRQ_ERR_UNSUPPORTED):
                 # a device fault or an out-of-memory condition will not go away read by read
                 log("Detector: device error, giving up: %s" % e, 'error')
-                raise SystemExit(3)
+                raise DeviceFault(str(e))
             log("Detector: batch rejected (%s), retrying read by read" % e, 'warning')
         except Exception as e:                                    # a bad batch never kills the run
             log("Detector: batch failed (%s), retrying read by read" % e, 'warning')
@@ -358,7 +378,7 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
                 except StriqueHipError as e1:
                     if e1.code not in (STRQ_ERR_ARG, STRQ_ERR_UNSUPPORTED):
                         log("Detector: device error, giving up: %s" % e1, 'error')
-                        raise SystemExit(3)
+                        raise DeviceFault(str(e1))
                     log("Detector: read failed: %s" % e1, 'warning'); results.append(None); stats["failed"] += 1
                 except Exception as e1:
                     log("Detector: read failed: %s" % e1, 'warning'); results.append(None); stats["failed"] += 1

@@ -59,6 +59,7 @@ int align_segment_overlap(const AlignParams& p, int m);
 int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* seg_results,
                           int n_groups, int segs, int* queue, const AlignParams& p, int lds_dwords,
                           int tables_per_cu, int n_cu, int packed, const int* group_list = nullptr, const int* n_list = nullptr);
+int align_segments_wpe(int segs, int tables_per_cu);      // waves per SIMD the kernel instance of such a launch is compiled for
 // per alignment: best piece -> results[a] (j_end in read columns), pick[a] = pick_base + index of its task.
 // The pieces may be cut with less overlap than align_segment_overlap: the result is exact whenever the best
 // score reaches align_segment_min_score(p, m, overlap_used); alignments below it are appended to `redo`

@@ -907,7 +907,9 @@ int align_segment_overlap(const AlignParams& p, int m)
     if (!(p.dist_min >= 0.0f) || !(p.open_h < 0.0f) || !(p.ext_h < 0.0f) || !(p.dist_offset > 0.0f)) return 0;
     if (!(p.open_v <= 0.0f) || !(p.ext_v <= 0.0f)) return 0;
     const double c_h = -(double)(p.open_h > p.ext_h ? p.open_h : p.ext_h);
-    const double h = (double)m * (double)p.dist_offset / c_h;
+    // a cell scores max(dist_offset - d^1.2, dist_min): at most the larger of the two
+    const double gain = (double)(p.dist_min > p.dist_offset ? p.dist_min : p.dist_offset);
+    const double h = (double)m * gain / c_h;
     const double L = (double)m + h * 1.01 + 64.0;
     if (!(L < 1e8)) return 0;
     return (int)L + 1;
@@ -935,6 +937,19 @@ static int launch_seg1(hipStream_t stream, const AlignTask* tasks, AlignResult* 
 // compiled (segments, waves per SIMD) pairs
 #define STRQ_SEG_CONFIGS(X, R_, S_, PK_) X(R_, S_, PK_, 1, 2) X(R_, S_, PK_, 2, 3) X(R_, S_, PK_, 2, 4) X(R_, S_, PK_, 3, 3) X(R_, S_, PK_, 4, 4) X(R_, S_, PK_, 3, 4) X(R_, S_, PK_, 4, 3)
 
+// the WPE template argument a (waves per table, tables per CU) launch runs on
+int align_segments_wpe(int segs, int tables_per_cu)
+{
+    const int waves = tables_per_cu * segs;
+    int wpe = (waves + 3) / 4; if (wpe < 2) wpe = 2;
+    if (segs == 1) wpe = 2;
+    // WPE only caps the registers of a wave (amdgpu_waves_per_eu); the smallest compiled value for several waves per
+    // table is 3, and a launch with fewer resident waves (large tables: one or two per CU) runs on it unchanged
+    else if (wpe < 3) wpe = 3;
+    if (wpe > 4) wpe = 4;
+    return wpe;
+}
+
 int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* seg_results,
                           int n_groups, int segs, int* queue, const AlignParams& p, int lds_dwords,
                           int tables_per_cu, int n_cu, int packed, const int* group_list, const int* n_list)
@@ -942,9 +957,7 @@ int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tas
     if (!(p.open_h == p.ext_h && p.open_v == p.ext_v)) return 2;
     AlignParams ps = p;
     if (packed) { ps.open_h *= STRQ_PK_SCALE; ps.ext_h *= STRQ_PK_SCALE; ps.open_v *= STRQ_PK_SCALE; ps.ext_v *= STRQ_PK_SCALE; }
-    const int waves = tables_per_cu * segs;
-    int wpe = (waves + 3) / 4; if (wpe < 2) wpe = 2;
-    if (segs == 1) wpe = 2;
+    const int wpe = align_segments_wpe(segs, tables_per_cu);
     const int n_blocks = tables_per_cu * n_cu;
 #define STRQ_SEGCASE(R_, S_, PK_, SEG_, WPE_)                                                             \
     if (R == R_ && S == S_ && (packed != 0) == PK_ && segs == SEG_ && wpe == WPE_)                        \
@@ -971,7 +984,8 @@ float align_segment_min_score(const AlignParams& p, int m, int overlap_used)
     // inverse of align_segment_overlap for paths that score at least B: span <= m + (m * dist_offset - B) / c_h (+ 1 % + 64)
     const double c_h = -(double)(p.open_h > p.ext_h ? p.open_h : p.ext_h);
     const double h_ok = ((double)overlap_used - (double)m - 65.0) / 1.01;
-    const double b = (double)m * (double)p.dist_offset - h_ok * c_h;
+    const double gain = (double)(p.dist_min > p.dist_offset ? p.dist_min : p.dist_offset);
+    const double b = (double)m * gain - h_ok * c_h;
     return (float)(b + 1.0 + 1e-6 * (b < 0 ? -b : b));       // rounded up
 }
 

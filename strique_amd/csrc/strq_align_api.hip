@@ -115,10 +115,10 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, c->lutinfo.reserve((size_t)nj * (sizeof(LutJob) + sizeof(LutInfo))));
     const int hard_cap = 1 << 16;
     STRQ_HIP(c, c->hard.reserve((size_t)hard_cap * (sizeof(HardEntry) + 4) + 64));
-    STRQ_HIP(c, c->queue.reserve(1024));
+    STRQ_HIP(c, c->queue.reserve(STRQ_QUEUE_BYTES));
     STRQ_HIP(c, hipMemcpyAsync(c->flank_cls.p, h_cls.data(), cls_tot * 4, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(c->col0.p, h_col0.data(), col0_tot * 4, hipMemcpyHostToDevice, st));
-    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
+    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, STRQ_QUEUE_BYTES, st));
 
     // ---- score tables
     std::vector<LutJob> jobs(nj);
@@ -136,7 +136,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipMemcpyAsync(d_jobs, jobs.data(), (size_t)nj * sizeof(LutJob), hipMemcpyHostToDevice, st));
     HardEntry* d_hard = c->hard.as<HardEntry>();
     float* d_hard_vals = reinterpret_cast<float*>(d_hard + hard_cap);
-    int* d_hard_count = c->queue.as<int>() + 224;
+    int* d_hard_count = c->queue.as<int>();
     STRQ_HIP(c, hipEventRecord(c->ev[0], st));
     if (launch_lut_build(st, d_jobs, d_info, nj, max_k, d_hard, d_hard_count, hard_cap, c->ap)) { c->err = "lut launch failed"; return STRQ_ERR_DEVICE; }
     STRQ_HIP(c, hipEventRecord(c->ev[1], st));
@@ -445,13 +445,24 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     for (auto& L : launches) scratch_words = std::max(scratch_words, align_trace_scratch_words_per_wave(L.R));
     const int trace_wpb = 8;
     STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * trace_wpb));
-    int qi = 0;
+    int qi = STRQ_QUEUE_FIRST;
     STRQ_HIP(c, hipEventRecord(c->ev[2], st));
     out.n_launches = 0; out.wave_steps = 0; out.columns = 0;
     for (size_t t = 0; t < n_tasks + n_up; ++t) if (tasks[t].n > 0) { out.wave_steps += align_num_steps(tasks[t].n); out.columns += tasks[t].n; }
-    if (!launches.empty()) { const Launch& L = launches.back(); out.segs = L.segs; out.tables = L.tables; out.packed = L.packed; out.rows_per_lane = L.R; }
+    if (!launches.empty()) {
+        const Launch& L = launches.back(); out.segs = L.segs; out.tables = L.tables; out.packed = L.packed; out.rows_per_lane = L.R;
+        const int i = out.order[L.first];
+        out.overlap_worst = overlap[i]; out.overlap_first = L.segs > 1 ? overlap_for(in.m[i], overlap[i]) : 0;
+        const bool seg_kernel = L.NS == 1 && collapsed;
+        const int32_t g[8] = {L.segs, L.tables, seg_kernel ? align_segments_wpe(L.segs, L.tables) : 0, L.R, L.packed, out.overlap_first, out.overlap_worst, (int32_t)launches.size()};
+        std::memcpy(c->geometry, g, sizeof(g));
+    }
     int max_ns = 1;
     for (auto& L : launches) max_ns = std::max(max_ns, L.NS);
+    // one queue head per launch: forward (per strip level), second round, trace
+    if ((size_t)STRQ_QUEUE_FIRST + launches.size() * ((size_t)max_ns + 2) > (size_t)STRQ_QUEUE_SLOTS) {
+        c->err = "too many distinct (flank shape, table size) groups in one batch"; return STRQ_ERR_UNSUPPORTED;
+    }
     for (int level = 0; level < max_ns; ++level) {          // top strips first, then the strips below them
         for (auto& L : launches) {
             if (level >= L.NS) continue;
@@ -598,7 +609,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 
 extern "C" {
 
-int strq_abi_version(void) { return 6; }
+int strq_abi_version(void) { return 7; }
 
 int strq_ctx_create(int device_id, strq_ctx** out)
 {
@@ -672,6 +683,13 @@ int strq_last_counters(const strq_ctx* c, double out[8])
     return STRQ_OK;
 }
 
+int strq_last_geometry(const strq_ctx* c, int32_t out[8])
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    std::memcpy(out, c->geometry, sizeof(c->geometry));
+    return STRQ_OK;
+}
+
 int strq_align_batch(strq_ctx* c, int64_t n_align, int64_t n_reads, const uint8_t* levels,
                      const int64_t* read_off, const float* level_val, const int32_t* align_read,
                      const float* flank, const int64_t* flank_off, int32_t samples,
@@ -719,7 +737,7 @@ static int align_overlap_generic(strq_ctx* c, const float* a, int64_t n, const f
     STRQ_HIP(c, c->gen_trace.reserve(((size_t)n + 1) * ((size_t)m + 1) + 64));
     STRQ_HIP(c, c->gen_hard.reserve((size_t)hard_cap * (sizeof(GenericHard) + 4) + 64));
     STRQ_HIP(c, c->results.reserve(sizeof(AlignResult) + 64));
-    STRQ_HIP(c, c->queue.reserve(1024));
+    STRQ_HIP(c, c->queue.reserve(STRQ_QUEUE_BYTES));
     uint32_t* d_ca = c->gen_codes.as<uint32_t>(); uint32_t* d_cb = d_ca + n;
     float* d_va = reinterpret_cast<float*>(d_cb + m); float* d_vb = d_va + na;
     float* d_tab = c->gen_table.as<float>();

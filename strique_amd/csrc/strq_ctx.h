@@ -27,6 +27,12 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// strq_ctx::queue: work-queue heads of the persistent kernels, one zero-initialised int per launch of a call (index 0:
+// the table kernel's count of borderline entries, launches from index STRQ_QUEUE_FIRST on)
+#define STRQ_QUEUE_BYTES 65536
+#define STRQ_QUEUE_FIRST 8
+#define STRQ_QUEUE_SLOTS (STRQ_QUEUE_BYTES / 4)
+
 // one sub-batch of alignments for align_core (strq_align_api.hip)
 struct AlignCoreIn {
     int nb = 0, samples = 6;
@@ -47,6 +53,7 @@ struct AlignCoreOut {
     int n_launches = 0;                    // forward-kernel launches
     double wave_steps = 0, columns = 0;    // forward work of this sub-batch
     int segs = 1, tables = 0, packed = 0, rows_per_lane = 0;
+    int overlap_first = 0, overlap_worst = 0;      // columns the pieces of the last segmented launch were cut with first / in the worst case
 };
 
 struct HostModel {
@@ -66,6 +73,7 @@ struct strq_ctx {
     std::string err;
     float timing[8] = {};
     double counters[8] = {};
+    int32_t geometry[8] = {};                 // strq_last_geometry
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd,

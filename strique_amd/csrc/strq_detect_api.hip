@@ -681,15 +681,23 @@ int strq_batch_upload(strq_ctx* c, int64_t n_reads, const void* signals, int32_t
 int strq_batch_run(strq_ctx* c)
 {
     if (!c) return STRQ_ERR_ARG;
+    return strq_batch_run_range(c, 0, dstate(c)->batch.n_reads);
+}
+
+int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
+{
+    if (!c) return STRQ_ERR_ARG;
     DetectState* d = dstate(c);
     Batch& B = d->batch;
+    if (first < 0 || last < first || last > B.n_reads) { c->err = "read range outside the uploaded batch"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
     std::fill(c->counters, c->counters + 8, 0.0);
     // partition into sub-batches first, so that the upload of piece k + 1 can overlap the kernels of piece k
-    std::vector<int64_t> cuts(1, 0);
-    int64_t r0 = 0;
-    while (r0 < B.n_reads) {
+    std::vector<int64_t> cuts(1, first);
+    int64_t r0 = first;
+    const int64_t n_end = last;
+    while (r0 < n_end) {
         int64_t r1 = r0; size_t ck = 0; int64_t samples = 0;
         bool mod_batch = false;
         // Sub-batch size: 16 reads (32 alignments) per CU.  The alignments of a batch are about equally
@@ -700,10 +708,10 @@ int strq_batch_run(strq_ctx* c)
         const int64_t full = std::min<int64_t>(16 * (int64_t)c->n_cu, 8192);      // 8192: task limit of vit_sort_kernel
         int64_t full_env = 0;
         if (const char* e = getenv("STRQ_SUBBATCH_READS")) full_env = atoll(e);      // testing: force small sub-batches
-        for (int64_t r = r0; r < B.n_reads && r < r0 + full; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
+        for (int64_t r = r0; r < n_end && r < r0 + full; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
         const int64_t cap = full_env > 0 ? std::min<int64_t>(full_env, 8192) : full;      // (the modification pass keeps back-pointers of the small dual model only: ~3 MB per 50 kb read)
         (void)mod_batch;
-        while (r1 < B.n_reads && r1 - r0 < cap) {
+        while (r1 < n_end && r1 - r0 < cap) {
             const Target& t = d->targets[B.target[r1]];
             const int n = (int)(B.off[r1 + 1] - B.off[r1]);
             const size_t need = align_workspace_bytes(n, 0, t.Rp, t.NSp) + align_workspace_bytes(n, 0, t.Rs, t.NSs);

@@ -34,6 +34,27 @@ def init_process_group(backend=None):
     return rank, world, local
 
 
+def any_rank(flag, device=None):
+    """True on every rank when `flag` is set on at least one (one tiny all_reduce; `count` uses it so that a rank
+    whose device failed does not leave the others blocked in the final gather)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    if dev == "cuda" and flag:
+        dev_ok = False
+        try:
+            t = torch.tensor([1], dtype=torch.int32, device="cuda"); dev_ok = True
+        except Exception:
+            pass
+        if not dev_ok:
+            raise SystemExit(3)      # this rank cannot even talk to its GPU: the launcher tears the job down
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 def gather_results(records, index, n_total, mods=None, device=None):
     """The one collective of a run, used by `bench.py` and by `count` alike: every rank contributes the
     fixed-size result records of the items it processed (structured numpy array), their global

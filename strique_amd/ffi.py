@@ -133,6 +133,13 @@ class Context(object):
         self._check(self._lib.strq_last_counters(self._h, _ptr(t)))
         return t
 
+    def last_geometry(self):
+        """strq_last_geometry as a dict: which forward-DP kernel instance the last batched call ran."""
+        g = np.zeros(8, np.int32)
+        self._check(self._lib.strq_last_geometry(self._h, _ptr(g)))
+        keys = ("waves_per_alignment", "tables_per_cu", "wpe", "rows_per_lane", "packed", "overlap_first", "overlap_worst", "launch_groups")
+        return dict(zip(keys, (int(v) for v in g)))
+
     # ---- HMM ------------------------------------------------------------------------------
     def model_create(self, baked):
         mid = ctypes.c_int32(-1)
@@ -207,6 +214,10 @@ class Context(object):
 
     def batch_run(self):
         self._check(self._lib.strq_batch_run(self._h))
+
+    def batch_run_range(self, first, last):
+        """Reads [first, last) of the uploaded batch only (strq_batch_run_range)."""
+        self._check(self._lib.strq_batch_run_range(self._h, ctypes.c_int64(first), ctypes.c_int64(last)))
 
     def batch_fetch(self):
         out = np.zeros(self._n_batch, dtype=RESULT_DTYPE)

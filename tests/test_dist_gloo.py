@@ -96,3 +96,49 @@ def test_count_rows_shard_and_merge(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "CLI_SHARD_OK" in outs[0]
+
+
+FAULT_WORKER = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from strique_amd import cli, dist as sdist, ffi
+rank, world, local = sdist.init_process_group(backend="gloo")
+cfg = json.load(open(os.path.join(%r, "tests", "golden", "config.json")))
+loci = {}
+for name, (chrom, b, e, *_r) in cfg["repeat"].items():
+    loci.setdefault(chrom, []).append((name, b, e))
+lines = ["\t".join(["read%%d" %% i, "0", "chr9", "27570000", "60", "8000M", "*", "0", "0", "ACGT", "*"]) for i in range(12)]
+
+class Counter(object):
+    def detect_batch(self, items):
+        if rank == 1:
+            raise ffi.StriqueHipError(ffi.STRQ_ERR_DEVICE, "hipErrorLaunchFailure (simulated)")
+        return [(1, 1.5, 2.5, -3.0, 4, 7, "-") for _ in items]
+    detect = None
+
+fault = 0
+try:
+    cli.run_count(iter(lines), loci, lambda q: np.arange(200), Counter(), cli.Log("error"), 4, rank, world, stats={})
+except cli.DeviceFault:
+    fault = 1
+assert fault == (1 if rank == 1 else 0)
+agreed = sdist.any_rank(fault, device="cpu")          # what `count` does before the gather: nobody is left waiting
+assert agreed
+print("FAULT_AGREED")
+import torch.distributed as dist
+dist.destroy_process_group()
+''' % (ROOT, ROOT)
+
+
+def test_device_fault_on_one_rank_does_not_leave_the_others_waiting(tmp_path):
+    """A device error on one rank of `count`: every rank learns about it through one tiny all_reduce placed in
+    front of the gather, so all of them can exit with status 3 instead of the healthy ones blocking in all_gather."""
+    script = tmp_path / "fault_worker.py"
+    script.write_text(FAULT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29521", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("FAULT_AGREED" in o for o in outs), outs

@@ -98,14 +98,70 @@ def test_batch_ragged(ctx, orc):
     assert ctx.align_batch(np.zeros(0, np.uint8), [0], np.zeros((0, 256), np.float32), [], np.zeros(0, np.float32), [0])[0].size == 0
 
 
-def test_full_size_read(ctx, orc):
-    """BASELINE config 3 size: N = 375 000 columns."""
+@pytest.mark.parametrize("seg", [None, "4", "2"])
+def test_full_size_read(ctx, orc, monkeypatch, seg):
+    """BASELINE config 3 size: N = 375 000 columns.  One alignment does not fill the chip and would run on one
+    wave; STRQ_SEG=4 puts it on the benchmark's geometry (four waves sharing the score table, column segments)."""
+    if seg:
+        monkeypatch.setenv("STRQ_SEG", seg)
     rng = np.random.default_rng(9)
     params = orc.align_params(None)
     ctx.set_align_params(*[float(v) for v in params])
     lv, lval, flank = _toy(rng, 375000)
     a = lval[lv]
     _same(orc.align_overlap(a, flank, params, want_idx=False), ctx.align_overlap(a, flank, want_idx=False))
+    if seg:
+        g = ctx.last_geometry()
+        assert g["waves_per_alignment"] == int(seg) and g["rows_per_lane"] == 15 and g["wpe"] >= 3, g
+
+
+@pytest.mark.parametrize("segs", [2, 4])
+@pytest.mark.parametrize("kind", ["permuted", "fine"])
+def test_large_tables_with_several_waves_per_alignment(ctx, orc, monkeypatch, segs, kind):
+    """Score tables that leave room for only one or two per CU -- a host-rebuilt full-width table (148 KB: level
+    values that are not monotone) or wide bands from a fine level spacing -- under column segments: such launches
+    have fewer resident waves than any compiled waves-per-SIMD cap and must still run (and equal the oracle)."""
+    monkeypatch.setenv("STRQ_SEG", str(segs))
+    rng = np.random.default_rng(500 + segs)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    if kind == "permuted":
+        lv, lval, flank = _toy(rng, 100000)
+        perm = rng.permutation(256)
+        lval_p = np.empty_like(lval); lval_p[perm] = lval
+        lv, lval = perm[lv].astype(np.uint8), lval_p
+    else:
+        # every class within 10 pA of every level: all bands are full width (145 x 256 floats)
+        n, k = 100000, 145
+        cls = rng.uniform(84, 90, k).astype(np.float32)
+        flank = np.repeat(cls, 6)
+        lval = (80 + 0.05 * np.arange(256)).astype(np.float32)
+        lv = np.repeat(rng.integers(0, 256, n // 5 + 1), rng.integers(3, 10, n // 5 + 1))[:n].astype(np.uint8)
+        emb = np.repeat(np.clip(np.round((cls - 80) / 0.05), 0, 255).astype(np.uint8), rng.integers(6, 10, k))
+        pos = int(rng.integers(0, n - len(emb)))
+        lv[pos:pos + len(emb)] = emb
+    off = np.array([0, len(lv)]); foff = np.array([0, len(flank)])
+    want = orc.align_overlap(lval[lv], flank, params, want_idx=False)
+    sc, je, j0, rec = ctx.align_batch(lv, off, lval[None, :], [0], flank, foff)
+    g = ctx.last_geometry()
+    assert g["waves_per_alignment"] == segs and g["tables_per_cu"] <= 2, g
+    assert np.float32(want[0]).tobytes() == sc[0].tobytes() and want[4] == je[0] and want[5] == j0[0]
+    assert np.array_equal(want[3], rec)
+
+
+def test_dist_min_above_dist_offset_keeps_segments_exact(ctx, orc, monkeypatch):
+    """`dist_min` > `dist_offset` (a user's `align` block): every cell scores dist_min, so a path gains dist_min per
+    diagonal step, not dist_offset -- the span bound the pieces are cut with must use the larger of the two."""
+    monkeypatch.setenv("STRQ_SEG", "4")
+    rng = np.random.default_rng(77)
+    params = np.array([-1, -1, -16, -16, 4, 6], np.float32)
+    ctx.set_align_params(*[float(v) for v in params])
+    try:
+        lv, lval, flank = _toy(rng, 30000, k=40)
+        a = lval[lv]
+        _same(orc.align_overlap(a, flank, params, want_idx=False), ctx.align_overlap(a, flank, want_idx=False))
+    finally:
+        ctx.set_align_params(*[float(v) for v in orc.align_params(None)])
 
 
 def test_formerly_unsupported_inputs_now_match_the_oracle(ctx, orc):

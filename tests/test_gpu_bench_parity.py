@@ -1,0 +1,105 @@
+"""Parity of exactly what bench.py times: reads of its own configs[2] batch (50 kb, C9orf72 GGGGCC x
+{200, 500, 1000, 1500, 2000}, both strands) through the production launch geometry -- four waves per alignment
+sharing one float32 score table, align_forward_seg_kernel<15, 6, false, 4, 4> -- at the initial 8192-column
+overlap, at the overlap adapted to the previous sub-batch's scores, and on a batch the overlap was NOT tuned on.
+All six fields of every row against the CPU oracle (reference src/align_raw.h:106-158, scripts/STRique.py:581-618)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+import oracle_pool
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh_counter(pm, cfg, targets):
+    from strique_amd.counter import repeatCounter
+    rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    rc.add_target("c9orf72", *targets["c9orf72"])
+    return rc
+
+
+def _bench_batch(pm, cfg, n, first):
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.make_batch(pm, cfg, n, 50000, first)
+
+
+def test_benchmarked_kernel_instance_all_fields(pm, cfg, targets, monkeypatch):
+    monkeypatch.setenv("STRQ_CLASS_MIN", "1")          # 64 alignments do not fill the chip: keep them on four waves per alignment anyway
+    sigs1, strands1, nreps1 = _bench_batch(pm, cfg, 32, 0)          # bench.py's rank-0 batch, reads 0..31
+    sigs2, strands2, nreps2 = _bench_batch(pm, cfg, 16, 4096)       # reads of another step's batch
+    assert set(strands1) == {"+", "-"} and set(nreps1) == {200, 500, 1000, 1500, 2000}
+    b1 = [("c9orf72", s, st) for s, st in zip(sigs1, strands1)]
+    b2 = [("c9orf72", s, st) for s, st in zip(sigs2, strands2)]
+    rc = _fresh_counter(pm, cfg, targets)
+    production = dict(waves_per_alignment=4, tables_per_cu=4, wpe=4, rows_per_lane=15, packed=0)
+
+    first = rc.detect_batch(b1)                        # initial overlap
+    g1 = rc.ctx.last_geometry()
+    second = rc.detect_batch(b1)                       # overlap adapted to this batch's own scores
+    g2 = rc.ctx.last_geometry()
+    third = rc.detect_batch(b2)                        # overlap adapted to a different batch
+    g3 = rc.ctx.last_geometry()
+    rc.ctx.close()
+    for g in (g1, g2, g3):
+        assert {k: g[k] for k in production} == production, g
+    assert g1["overlap_first"] == 8192 and g1["overlap_worst"] > 14000
+    assert g2["overlap_first"] != 8192 and g3["overlap_first"] == g2["overlap_first"], (g1, g2, g3)      # the adapted overlap is live
+
+    target = targets["c9orf72"]
+    want = oracle_pool.detect_many([(s, st, target) for s, st in zip(sigs1 + sigs2, strands1 + strands2)])
+    for i, (w, a, b) in enumerate(zip(want[:32], first, second)):
+        assert tuple(a[:6]) == tuple(w[:6]), (i, a, w)
+        assert tuple(b[:6]) == tuple(w[:6]), (i, b, w)
+        assert abs(a[0] - nreps1[i]) <= 2
+    for i, (w, a) in enumerate(zip(want[32:], third)):
+        assert tuple(a[:6]) == tuple(w[:6]), (i, a, w)
+        assert abs(a[0] - nreps2[i]) <= 2
+
+
+def _run_bench(extra, world=1, port="29541", timeout=900):
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world > 1:
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(world))
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)) if world > 1 else env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(o[0].decode()[-2000:], o[1].decode()[-2000:]) for o in outs]
+    lines = [[ln for ln in o[0].decode().splitlines() if ln.startswith("{")] for o in outs]
+    return lines, [json.loads(l[0]) for l in lines if l]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's own N > 1 path (reference scripts/STRique.py:733-746 spreads reads over worker
+    processes): two rank processes sharing HIP device 0, gloo for the gather -- rank 0 prints the one JSON line,
+    the collective saw two ranks, both ranks' reads are in `value`, and the spot check compares whole rows."""
+    lines, recs = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-device", "--reads", "64", "--steps", "2", "--warmup", "1",
+                              "--no-cpu-baseline", "--check", "1", "--synth-workers", "2"], world=2)
+    assert len(lines[0]) == 1 and len(lines[1]) == 0          # exactly one line, from rank 0
+    r = recs[0]
+    assert r["n_gpus"] == 2 and r["world_size_seen_by_the_collective"] == 2 and r["scaling"] == "weak"
+    assert r["value"] > 0 and abs(r["value"] - 2 * 64 * 2 / (r["ms_per_step"] * 2 / 1e3)) < 1e-6 * r["value"]
+    assert r["check_ok"] and r["check"] and all(c["all_fields_equal"] for c in r["check"])
+    assert r["vs_baseline"] is None and "cpu_baseline" not in r
+
+
+def test_bench_line_single_gpu_small():
+    """The default single-GPU line at a reduced batch (512 reads so that four waves per alignment is what runs):
+    roofline + host leg present, three distinct batches rotated, rows of the host-buffer leg equal the resident
+    run's, the spot check covers all six fields on reads of different batches."""
+    lines, recs = _run_bench(["--reads", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check", "2", "--host-leg-batches", "2"])
+    r = recs[0]
+    roof = r["roofline"]
+    assert roof["bound"] == "valu" and roof["kernel"].startswith("align_forward_seg_kernel<15, 6, false, 4,")
+    assert 0 < roof["useful_frac"] < roof["frac"] < 1
+    assert len(roof["overlap_columns_per_step"]) == 3 and roof["overlap_columns_per_step"][-1] < roof["overlap_worst_case"]
+    assert r["config"]["distinct_batches_per_gpu"] == 3
+    assert r["check_ok"] and len(r["check"]) == 2 and {c["batch"] for c in r["check"]} == {0, 1}
+    assert r["host_buffers"]["same_rows_as_resident_run"] and r["host_inclusive_reads_per_s"] > 0
