@@ -173,7 +173,7 @@ struct TraceWords { uint64_t a[2], b[2]; };
 // max(H+e, S+e) == S+e bit for bit).  KEEP additionally materialises the H / V values the
 // collapsed form does not carry (needed when the state is checkpointed).  TRACE computes the
 // full recurrence with the oracle's tie rules and returns the 4-bit trace codes.
-template <int R, bool LH, bool LV, bool KEEP, bool TRACE>
+template <int R, bool LH, bool LV, bool KEEP, bool TRACE, int RMC = -1>
 static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[R], const float (&rsB)[R],
                                                 float upA, float upB, float upVA, float upVB,
                                                 const AlignParams& p, TraceWords* tw,
@@ -251,7 +251,8 @@ static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[
     st.SbotA = SA[R - 1];
     if constexpr (TRACE || !LV || KEEP) { st.VbotA = vA; st.VbotB = vB; }
     st.upS = upB;
-    if (candA) { *candA = pick_row<R>(SA, rM); *candB = pick_row<R>(SB, rM); }   // last flank row in an interior register
+    if constexpr (RMC >= 0) { *candA = SA[RMC]; *candB = SB[RMC]; }                // last flank row in a register known at compile time
+    else if (candA) { *candA = pick_row<R>(SA, rM); *candB = pick_row<R>(SB, rM); }   // last flank row in an interior register
 }
 
 template <int R, int S, bool PK>
@@ -369,7 +370,8 @@ static __device__ __forceinline__ void load_ckpt(const float* c, int lane, Lane<
 // ------------------------------------------------------------------------------------------
 // MODE: which boundaries the strip has.  bit 0: input from the strip above (else the free top row),
 //       bit 1: output to the strip below (else this strip holds the last flank row and tracks the best).
-template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK>
+// RMC >= 0: the last flank row sits in register RMC of its lane, known at compile time (no runtime-indexed pick)
+template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK, int RMC = -1>
 struct Forward {
     static constexpr bool HAS_IN = (MODE & 1) != 0, HAS_OUT = (MODE & 2) != 0;
     const AlignTask& tk;
@@ -445,6 +447,8 @@ struct Forward {
                 if constexpr (RM_LAST) {
                     dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, 0, nullptr, nullptr);
                     candA = st.SbotA; candB = st.S[R - 1];
+                } else if constexpr (RMC >= 0) {
+                    dp_step2<R, LH, LV, KEEP, false, RMC>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, rM, &candA, &candB);
                 } else {
                     dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, rM, &candA, &candB);
                 }
@@ -462,7 +466,7 @@ struct Forward {
     }
 };
 
-template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK, bool STAGE = true>
+template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK, bool STAGE = true, int RMC = -1>
 static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignResult* res, const AlignParams& p,
                                                    float* lds, int lds_base, const char* ldsb, int lane)
 {
@@ -471,7 +475,7 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
     LaneConst lc; uint64_t pm[Shape<R, S>::NMASK];
     load_lane_consts<R, S, PK>(tk, lane, lds_base, lc, pm);
     const int lM = (tk.m - 1) / R, rM = (tk.m - 1) % R;
-    Forward<R, S, LH, LV, MODE, RM_LAST, PK> f{tk, p, ldsb, lc, pm, lane, rM};
+    Forward<R, S, LH, LV, MODE, RM_LAST, PK, RMC> f{tk, p, ldsb, lc, pm, lane, rM};
     init_lane<R, PK>(tk, lane, f.st);
     f.best = tk.col0[tk.m] * (PK ? STRQ_PK_SCALE : 1.0f); f.bestA = 0.0f; f.bestt = -1;
     __builtin_amdgcn_s_waitcnt(0);   // LDS table written by this wave is visible to it
@@ -576,7 +580,10 @@ align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __res
         const int ti = gi * SEG + wave;
         const AlignTask& tk = tasks[ti];
         if (tk.n <= 0) continue;               // unused piece of a short read (wave-uniform)
+        // STRique's own flanks (145 k-mer classes, 870 rows) at 14 rows per lane end in register 1 of lane 62
+        constexpr int RMC870 = R == 14 ? (870 - 1) % 14 : -1;
         if ((tk.m - 1) % R == R - 1) forward_one<R, S, true, true, 0, true, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+        else if (RMC870 >= 0 && (tk.m - 1) % R == RMC870) forward_one<R, S, true, true, 0, false, PK, false, RMC870>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
         else forward_one<R, S, true, true, 0, false, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
     }
 }
@@ -832,7 +839,7 @@ static int launch_shape_general(hipStream_t stream, const AlignTask* tasks, Alig
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-#define STRQ_SHAPES(X) X(6, 6) X(7, 6) X(8, 6) X(12, 6) X(15, 6)
+#define STRQ_SHAPES(X) X(6, 6) X(7, 6) X(8, 6) X(12, 6) X(14, 6) X(15, 6)
 #define STRQ_GENERAL_SHAPES(X) X(2, 1) X(4, 2) X(6, 3) X(8, 4) X(10, 5) X(14, 7) X(16, 8) X(18, 9) X(20, 10) X(22, 11) X(26, 13)
 
 // The run length the kernels work with: 6 when `samples` is a multiple of 6 (STRique's value), else the largest
@@ -861,12 +868,15 @@ int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
     // so one strip is preferred whenever a single-strip shape fits.  STRQ_STRIPS=2 forces two.
     const char* e = getenv("STRQ_STRIPS");
     const bool force_two = e && e[0] == '2';
-    const int single[] = {6, 7, 8, 12, 15};
+    // 14 rows per lane: STRique's 870-row flanks keep 63 of 64 lanes busy (15 rows: 58).  STRQ_NO_R14 leaves the shape
+    // out (A/B runs).
+    static const bool no14 = getenv("STRQ_NO_R14") != nullptr;
+    const int single[] = {6, 7, 8, 12, 14, 15};
     const int two[] = {6, 7, 8, 12};
     if (!force_two)
-        for (int r : single) if (64 * r >= m) { *rows_per_lane = r; *n_strips = 1; return r; }
+        for (int r : single) if (64 * r >= m && !(r == 14 && no14)) { *rows_per_lane = r; *n_strips = 1; return r; }
     for (int r : two) if (64 * r < m && 128 * r >= m) { *rows_per_lane = r; *n_strips = 2; return r; }
-    for (int r : single) if (64 * r >= m) { *rows_per_lane = r; *n_strips = 1; return r; }
+    for (int r : single) if (64 * r >= m && !(r == 14 && no14)) { *rows_per_lane = r; *n_strips = 1; return r; }
     // longer flanks: strips of 64 x 12 rows (128 k-mer classes each, so that every strip's score table fits the LDS
     // of the kernel that builds it), top to bottom with the strip's last row handed on through HBM
     if (m <= STRQ_MAX_STRIPS * 64 * 12) { *rows_per_lane = 12; *n_strips = (m + 64 * 12 - 1) / (64 * 12); return 12; }

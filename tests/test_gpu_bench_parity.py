@@ -4,6 +4,7 @@ sharing one float32 score table, align_forward_seg_kernel<15, 6, false, 4, 4> --
 overlap, at the overlap adapted to the previous sub-batch's scores, and on a batch the overlap was NOT tuned on.
 All six fields of every row against the CPU oracle (reference src/align_raw.h:106-158, scripts/STRique.py:581-618)."""
 import os
+import re
 import sys
 
 import numpy as np
@@ -36,7 +37,7 @@ def test_benchmarked_kernel_instance_all_fields(pm, cfg, targets, monkeypatch):
     b1 = [("c9orf72", s, st) for s, st in zip(sigs1, strands1)]
     b2 = [("c9orf72", s, st) for s, st in zip(sigs2, strands2)]
     rc = _fresh_counter(pm, cfg, targets)
-    production = dict(waves_per_alignment=4, tables_per_cu=4, wpe=4, rows_per_lane=15, packed=0)
+    production = dict(waves_per_alignment=4, tables_per_cu=4, wpe=4, packed=0)
 
     first = rc.detect_batch(b1)                        # initial overlap
     g1 = rc.ctx.last_geometry()
@@ -46,7 +47,7 @@ def test_benchmarked_kernel_instance_all_fields(pm, cfg, targets, monkeypatch):
     g3 = rc.ctx.last_geometry()
     rc.ctx.close()
     for g in (g1, g2, g3):
-        assert {k: g[k] for k in production} == production, g
+        assert {k: g[k] for k in production} == production and g["rows_per_lane"] in (14, 15), g
     assert g1["overlap_first"] == 8192 and g1["overlap_worst"] > 14000
     assert g2["overlap_first"] != 8192 and g3["overlap_first"] == g2["overlap_first"], (g1, g2, g3)      # the adapted overlap is live
 
@@ -97,7 +98,7 @@ def test_bench_line_single_gpu_small():
     lines, recs = _run_bench(["--reads", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check", "2", "--host-leg-batches", "2"])
     r = recs[0]
     roof = r["roofline"]
-    assert roof["bound"] == "valu" and roof["kernel"].startswith("align_forward_seg_kernel<15, 6, false, 4,")
+    assert roof["bound"] == "valu" and re.match(r"align_forward_seg_kernel<1[45], 6, false, 4, [34], false>", roof["kernel"])
     assert 0 < roof["useful_frac"] < roof["frac"] < 1
     assert len(roof["overlap_columns_per_step"]) == 3 and roof["overlap_columns_per_step"][-1] < roof["overlap_worst_case"]
     assert r["config"]["distinct_batches_per_gpu"] == 3
