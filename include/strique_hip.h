@@ -63,7 +63,7 @@ int strq_get_align_params(const strq_ctx* ctx, float params[6]);
  *   j_end,j0   DP columns where the path ends / leaves the free top row (nullable)
  * Any float32 inputs are accepted, like the reference (src/pyalign.cpp:59-61).  What
  * repeatCounter.detect passes -- `a` with at most 256 distinct values (an 8-bit morphology signal) and `b`
- * made of runs of 6 equal samples, m <= 6144 (scripts/STRique.py:592-601,562-565) -- runs on the
+ * made of runs of 6 equal samples, m <= 49152 (scripts/STRique.py:592-601,562-565) -- runs on the
  * LDS-table wavefront kernels; everything else on a generic kernel (one trace byte per cell in HBM like
  * the reference: (n + 1) x (m + 1) <= 1.7e10, at most 2e9 distinct (a, b) value pairs), same results.
  */
@@ -138,7 +138,7 @@ int strq_viterbi_batch(strq_ctx* ctx, int32_t model_id, int64_t n_seq, const dou
  *                       with strq_model_create and count_bias = flanking_count - repeat_offset
  *                       (STRique.py:374-378,412,437).  samples: the run length of the templates (6 is
  *                       what STRique ships; any value works, on slower kernel shapes).  A template of up
- *                       to 1024 k-mer classes (6144 samples at samples = 6: a flank of 1029 nt; the
+ *                       to 8192 k-mer classes (49152 samples at samples = 6: a flank of 8197 nt; the
  *                       bundled loci have 150 nt = 870 samples) -- longer ones return STRQ_ERR_UNSUPPORTED.
  * strq_detect_batch     detect() for n_reads reads.  signals: concatenated raw samples,
  *                       dtype 0 = int16 (fast5 DAC values), 1 = float64 (pA, as the reference's

@@ -20,6 +20,7 @@
  * name), silent states after them in topological order, in-edges in CSR with ascending source.
  * Emissions: Normal  c - (x - mu)^2 * k   with c = -log(sigma * 2.50662827463), k = 1/(2 sigma^2)
  *            Uniform -log(hi - lo) inside [lo, hi], -inf outside.
+ *            NaN observation: 0 under either (pomegranate's missing-value support since 0.9) [recalled].
  */
 #include <math.h>
 #include <stdint.h>
@@ -74,7 +75,11 @@ int strq_oracle_viterbi(int32_t n_states, int32_t silent_start, int32_t start, i
                 if (c > best) { best = c; arg = in_src[e]; }
             }
             double em;
-            if (emis_kind[l] == KIND_NORMAL) {
+            if (xi != xi) {
+                /* missing observation: pomegranate 0.10 distributions return log-probability 0 for NaN
+                 * (NormalDistribution / UniformDistribution._log_probability, `if isnan(X[i]): log_probability[i] = 0.`) [recalled] */
+                em = 0.0;
+            } else if (emis_kind[l] == KIND_NORMAL) {
                 const double d = xi - emis_a[l];
                 em = emis_c[l] - (d * d) * emis_b[l];
             } else {

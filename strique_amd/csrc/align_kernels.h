@@ -42,7 +42,7 @@ static inline int align_num_steps(int n) { return (n + 1) / 2 + 63; }
 static inline int align_num_ckpts(int n) { return (align_num_steps(n) - 1) / STRQ_CKPT_STEPS; }
 
 // rows per lane and number of strips for a flank of m rows; 0 if no compiled shape fits
-#define STRQ_MAX_STRIPS 8           // flanks up to 8 x 64 x 12 = 6144 samples (1029 nt at 6 samples per k-mer)
+#define STRQ_MAX_STRIPS 64          // flanks up to 64 x 64 x 12 = 49 152 samples (8192 k-mer classes: 8197 nt at 6 samples per k-mer)
 int align_plan(int m, int samples, int* rows_per_lane, int* n_strips);
 int align_effective_samples(int samples);
 // Column segments (several waves per alignment, one score table per workgroup).

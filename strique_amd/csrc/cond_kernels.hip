@@ -260,7 +260,8 @@ hist_stats_kernel(const uint32_t* __restrict__ hist_all, int nbins, int bias, Re
     __syncthreads();
     const long long c_lo = (long long)cnt_lo, c_hi = (long long)cnt_hi;
     bool degenerate = (c_lo == 0 || c_hi == 0);
-    double c1 = 0, h1 = 0;
+    // an empty tail: numpy's median of nothing is NaN, and so are the constants of the map and every sample it is applied to
+    double c1 = __builtin_nan(""), h1 = __builtin_nan("");
     if (!degenerate) {
         if (t == 0) {
             ranks[0] = (c_lo - 1) / 2; ranks[1] = c_lo / 2;

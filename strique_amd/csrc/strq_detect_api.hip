@@ -89,7 +89,10 @@ __global__ void finalize_kernel(FinalizeArgs a)
             g.suffix_begin = b;
             g.suffix_end = row_position(ts.rec, ts.m_total, ts.m_total - 1 - a.trim[2 * r + 1], ts.n);
         }
-        g.gate = (rc.status == COND_OK && g.prefix_begin < g.suffix_end && g.score_prefix > 0.0 && g.score_suffix > 0.0) ? 1 : 0;
+        // the reference's gate (STRique.py:602) looks at the two alignments only: a read whose 8-bit morphology signal
+        // normalises while its filtered signal does not (empty percentile tails: NaN constants) still goes to the HMM,
+        // as a window of NaN observations -- pomegranate's missing-value rule, see viterbi_kernels.hip
+        g.gate = (g.prefix_begin < g.suffix_end && g.score_prefix > 0.0 && g.score_suffix > 0.0) ? 1 : 0;
     }
     vt.model = a.model_of[r];
     if (g.gate) {
@@ -175,7 +178,7 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     std::vector<int> who;                      // reads that reach the modification model
     for (int i = 0; i < nr; ++i) {
         const Target& t = d->targets[B.target[r0 + i]];
-        if (t.mod_model_id < 0 || !geom[i].gate || rc[i].status != COND_OK) continue;
+        if (t.mod_model_id < 0 || !geom[i].gate) continue;
         const VitResult& v = vres[vit_slot[i]];
         if (v.status == 2) { c->err = "modification pass: repeat window of 2^21 samples or more"; return STRQ_ERR_UNSUPPORTED; }
         if (v.status == 0) who.push_back(i);

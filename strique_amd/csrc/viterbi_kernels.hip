@@ -21,6 +21,10 @@
 // oracle's, including the argmax.  The few silent edges that are not chain edges (profile exits,
 // model end) go through LDS like the emitting states, in an outer fixed-point loop.
 //
+// Missing observations: pomegranate >= 0.9 gives a NaN observation log-probability 0 under every distribution, so a
+// window of NaNs is decoded on the transition probabilities alone (the reference reaches this when normalize2model
+// returns NaNs for the filtered signal but not for the morphology signal, STRique.py:596-597,603).
+//
 // Repeat counting does not need a traceback: the number of visits of the counted states
 // (the two `dummy` states of repeatHMM, STRique.py:374-378) is carried along the best path.
 // Back-pointers are written only when the caller wants the state path (modification pass).
@@ -221,7 +225,9 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         uint32_t stat_sweeps = 0;      // debug build (-DSTRQ_VIT_STATS): chain sweeps of the whole window, reported in place of the count
 #endif
         // clipped observations (detect pipeline) that cannot leave any uniform emission's support
-        const bool fast_em = tk.src_kind != VIT_SRC_F64 && tk.lo >= uni_lo_max && tk.hi <= uni_hi_min;
+        // ... and are numbers: a window normalised with NaN constants (detect on a read whose filtered signal has empty
+        // percentile tails, STRique.py:597,603) is all NaN and takes the general emission code below
+        const bool fast_em = tk.src_kind != VIT_SRC_F64 && tk.lo >= uni_lo_max && tk.hi <= uni_hi_min && tk.c1 == tk.c1 && tk.h1 == tk.h1;
         for (int i = lane; i < NP; i += 64) { stcell(vbase, 16 * i, NEGINF, 0); stcell(vbase, BUF + 16 * i, NEGINF, 0); }
         VIT_FENCE();
         if (lane == 0) stcell(vbase, 16 * m_start, 0.0, 0);
@@ -397,6 +403,9 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     const double en = ec[s] - (d * d) * eb[s];
                     const double eu = (x >= ea[s] && x <= eb[s]) ? ec[s] : NEGINF;
                     em = enorm[s] ? en : eu;
+                    // a missing observation (NaN) has log-probability 0 under every distribution (pomegranate 0.10
+                    // NormalDistribution / UniformDistribution._log_probability, [recalled]); slots without a state stay at -inf
+                    if (x != x) em = own_e[s] >= 0 ? 0.0 : NEGINF;
                 }
                 nv[s] = best + em; na[s] = a;
                 if constexpr (MARK) {

@@ -315,7 +315,7 @@ def test_column_segments_seam_adversarial(ctx, orc, monkeypatch, segs, k, n, ov_
         assert np.array_equal(o[3], got[3][i * m:(i + 1) * m]), (i, cases[i])
 
 
-@pytest.mark.parametrize("k", [159, 160, 200, 256, 257, 300, 384, 385, 512, 1024])
+@pytest.mark.parametrize("k", [159, 160, 200, 256, 257, 300, 384, 385, 512, 1024, 1025, 2500])
 @pytest.mark.parametrize("params", [None, [-3, -1, -20, -4, 16, 0]])
 def test_long_flanks_run_as_strips_with_their_own_tables(ctx, orc, k, params):
     """Flanks of more than 158 k-mer classes (948 samples): strips of 768 rows, each with its own score table,
@@ -336,7 +336,7 @@ def test_long_flanks_run_as_strips_with_their_own_tables(ctx, orc, k, params):
 def test_flank_beyond_the_strip_limit_takes_the_generic_kernel(ctx, orc):
     rng = np.random.default_rng(4)
     params = orc.align_params(None)
-    lv, lval, flank = _toy(rng, 9000, k=1025)
+    lv, lval, flank = _toy(rng, 9000, k=8193)
     a = lval[lv]
     _same(orc.align_overlap(a, flank, params), ctx.align_overlap(a, flank))
 

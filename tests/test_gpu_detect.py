@@ -307,15 +307,16 @@ def test_odd_signals_against_the_oracle(gpu_counter, want, pm, targets):
 
 def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
     """repeat_config.tsv rows are the user's: flanks shorter than the 50 nt the HMM takes (no trim), much longer
-    than the bundled 150 nt (a flank of more than 960 samples runs as two strips), a two-letter and a twelve-letter
-    repeat.  Every field equals the oracle's on both strands."""
+    than the bundled 150 nt (a flank of more than 960 samples runs as strips of 768 rows, up to 64 of them), a two-letter
+    and a twelve-letter repeat.  Every field equals the oracle's on both strands."""
     from strique_amd import synth
     from strique_amd.counter import repeatCounter
     rng = np.random.default_rng(31337)
     nt = lambda n: "".join(rng.choice(list("ACGT"), n))
     custom = {"short": ("CAG", nt(30), nt(44)), "long": ("GGCCTG", nt(230), nt(201)), "uneven": ("CA", nt(64), nt(170)),
               "dodeca": ("CCCCGCCCCGCG", nt(120), nt(98)), "longer": ("CTG", nt(300), nt(415)), "longest": ("GAA", nt(1029), nt(163)),
-              "vntr33": (nt(33), nt(150), nt(150)), "vntr48": (nt(48), nt(150), nt(150))}      # larger HMMs: other kernel shapes
+              "vntr33": (nt(33), nt(150), nt(150)), "vntr48": (nt(48), nt(150), nt(150)),      # larger HMMs: other kernel shapes
+              "kb3": ("CAG", nt(3000), nt(260))}                                               # 24 strips of 768 flank rows
     rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
     for name, t in custom.items():
         rc.add_target(name, *t)
@@ -332,7 +333,7 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
         assert tuple(g[:6]) == tuple(w[:6]), (name, strand, g, w)
         assert g[0] > 0, (name, strand, g)
     with pytest.raises(Exception, match="flank shape"):
-        rc.add_target("too_long", "CAG", nt(1030), nt(100))
+        rc.add_target("too_long", "CAG", nt(8198), nt(100))
     with pytest.raises(Exception, match="model too large"):      # 600 emitting states: more than 8 per lane
         rc.add_target("vntr70", nt(70), nt(150), nt(150))
 
@@ -428,3 +429,37 @@ def test_overlap_chosen_from_the_previous_batch_changes_nothing(pm, cfg, targets
     rc.ctx.close()
     assert first == second == third == worst
     assert sum(1 for r in first if r[0] > 0) >= 40
+
+
+def test_filtered_signal_without_tails_is_decoded_as_missing_values(gpu_counter, want, orc, opm, pm, pm_mod, cfg, targets, opm_mod):
+    """A read whose lowest and highest 1 % of filtered samples sit on two saturated values (runs of three samples on a
+    floor / ceiling: they survive the median filter, the 1 x 8 opening / closing removes them): np.percentile puts the
+    1st / 99th percentile ON those values, the strict tails are empty, normalize2model returns NaNs for the filtered
+    signal (STRique.py:155-160,597) -- while the morphology signal normalises, the flanks are found and the gate passes.
+    The reference then decodes a window of NaNs (STRique.py:603), which pomegranate scores as missing values."""
+    from strique_amd.counter import repeatCounter
+    rng = np.random.default_rng(5)
+    items = []
+    for k, (name, strand) in enumerate((("c9orf72", "+"), ("fmr1", "-"), ("c9orf72", "-"))):
+        s = _read(pm, targets, name, strand, 6000 + 500 * k, 20 + 5 * k, 4242 + k).copy()
+        floor, ceil_ = int(s.min()) - 40, int(s.max()) + 40
+        n = len(s)
+        for pos in rng.choice(np.arange(10, n - 10, 12), size=n // 100, replace=False):
+            s[pos:pos + 3] = floor
+        for pos in rng.choice(np.arange(16, n - 10, 12), size=n // 100, replace=False):
+            s[pos:pos + 3] = ceil_
+        flt, u8, morph, fltn = orc.condition(s, opm)
+        assert np.isnan(fltn).all() and np.isfinite(morph).all()
+        items.append((name, s, strand))
+        items.append((name, s.astype(np.float64) * 0.17 + 3.0, strand))          # the float64 input path as well
+    got = _check(gpu_counter, want, [it for it in items if it[1].dtype == np.int16])
+    got += _check(gpu_counter, want, [it for it in items if it[1].dtype != np.int16])
+    assert all(g[0] > 0 and g[3] < 0 for g in got), got          # a path exists: count and log-probability of the transitions alone
+    # with the modification model: the second Viterbi runs on the (finite) raw normalisation of the marked stretch
+    rc = repeatCounter(pm, mod_model_file=pm_mod, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    rc.add_target("c9orf72", *targets["c9orf72"])
+    name, s, strand = items[0]
+    g = rc.detect(name, s, strand)
+    w, _ = orc.detect(s, oracle_tc(orc, opm, targets, name, strand, cfg["HMM"], opm_mod), opm, orc.align_params(cfg["align"]), pm_mod=opm_mod)
+    assert tuple(g) == tuple(w), (g, w)
+    rc.ctx.close()

