@@ -37,7 +37,8 @@ struct VitModel {
     const int32_t* count_inc;         // n_states + 1, by state
     const int32_t* state_tag;         // n_states + 1, by state
     double uni_lo_max, uni_hi_min;    // tightest bounds of the uniform emissions: observations inside them need no range test
-    int32_t rec_state, pad2_;         // the hub state (tag 2) with an edge into `end` (e0 of the modification model), or -1
+    int32_t rec_state;                // the hub state (tag 2) with an edge into `end` (e0 of the modification model), or -1
+    int32_t sil_last;                 // 1: no emitting state has more than one silent in-edge (it then sits in the last edge column of its slot on the flanked-model shapes)
     int32_t e_flat[8];                // emitting slot without a Normal emission (uniform inserts, padding): its emission is a constant per lane
 };
 

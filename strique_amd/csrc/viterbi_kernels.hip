@@ -133,6 +133,11 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     constexpr int DEMAX = HI0 > LO ? HI0 : LO;
     auto de_of = [](int s) constexpr { return s == 0 ? HI0 : (s < (EPL + 1) / 2 ? HI1 : LO); };
     const double NEGINF = -__builtin_inf();
+    // PIPE (flanked-repeat shapes): an emitting state has at most one silent in-edge and the host puts it in the last edge
+    // column of its slot (strq_viterbi_api.hip), so every other column reads emitting cells only.  Those are final as soon
+    // as the emitting phase of a time step is over: the tournament over them for step t + 1 is taken while the silent phase
+    // of step t runs -- independent work next to the serial chain sweeps -- and step t + 1 itself only adds the last column.
+    constexpr bool PIPE = DE_HI > 16 && SS && !BP;
     constexpr bool WIDE = MARK || HUB;
     using Pay = std::conditional_t<WIDE, uint64_t, int>;      // what rides along the best path
     struct alignas(16) Cell { double v; Pay c; };
@@ -221,13 +226,16 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             }
         }
         const int64_t T = tk.T;
+        double pv[EPL]; typename std::conditional<MARK || HUB, uint64_t, int>::type pc[EPL];      // PIPE: partial tournaments carried into the next step
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) { pv[s] = NEGINF; pc[s] = 0; }
 #ifdef STRQ_VIT_STATS
         uint32_t stat_sweeps = 0;      // debug build (-DSTRQ_VIT_STATS): chain sweeps of the whole window, reported in place of the count
 #endif
         // clipped observations (detect pipeline) that cannot leave any uniform emission's support
         // ... and are numbers: a window normalised with NaN constants (detect on a read whose filtered signal has empty
         // percentile tails, STRique.py:597,603) is all NaN and takes the general emission code below
-        const bool fast_em = tk.src_kind != VIT_SRC_F64 && tk.lo >= uni_lo_max && tk.hi <= uni_hi_min && tk.c1 == tk.c1 && tk.h1 == tk.h1;
+        const bool fast_em = __builtin_amdgcn_readfirstlane((int)(tk.src_kind != VIT_SRC_F64 && tk.lo >= uni_lo_max && tk.hi <= uni_hi_min && tk.c1 == tk.c1 && tk.h1 == tk.h1)) != 0;
         for (int i = lane; i < NP; i += 64) { stcell(vbase, 16 * i, NEGINF, 0); stcell(vbase, BUF + 16 * i, NEGINF, 0); }
         VIT_FENCE();
         if (lane == 0) stcell(vbase, 16 * m_start, 0.0, 0);
@@ -257,24 +265,50 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         // for one lane shift (a time step needs ~7 positions on the C9orf72 model), every hop the same sequential
         // float64 addition as when each state is evaluated once in topological order.  After a sweep the only values
         // not yet carried on are those that changed in the last slot (the next lane reads them in the next sweep).
-        auto chain_sweeps = [&](double (&y)[SPL], Pay (&yc)[SPL], int (&arg)[SPL]) {
-            for (;;) {
-                bool win_any = false;
+        auto one_sweep = [&](double (&y)[SPL], Pay (&yc)[SPL], int (&arg)[SPL]) -> bool {
+            bool win_any = false;
 #ifdef STRQ_VIT_STATS
-                ++stat_sweeps;
+            ++stat_sweeps;
 #endif
 #pragma unroll
-                for (int s = 0; s < SPL; ++s) {
-                    double tin; Pay cin;
-                    if (s == 0) { tin = dpp_shr1_f64(y[SPL - 1]) + clp[0]; cin = pay_add(shr1_pay(yc[SPL - 1]), sinc[0]); }
-                    else { tin = y[s - 1] + clp[s]; cin = pay_add(yc[s - 1], sinc[s]); }
-                    const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
-                    y[s] = max_f64_raw(y[s], tin);
-                    yc[s] = win ? cin : yc[s];
-                    if (BP) arg[s] = win ? scell0 + lane * SPL + s - 1 : arg[s];     // the chain predecessor's cell
-                    if (s == SPL - 1) win_any = win;     // wins in the earlier slots were carried on inside this sweep already
-                }
-                if (!__any(win_any)) break;
+            for (int s = 0; s < SPL; ++s) {
+                double tin; Pay cin;
+                if (s == 0) { tin = dpp_shr1_f64(y[SPL - 1]) + clp[0]; cin = pay_add(shr1_pay(yc[SPL - 1]), sinc[0]); }
+                else { tin = y[s - 1] + clp[s]; cin = pay_add(yc[s - 1], sinc[s]); }
+                const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
+                y[s] = max_f64_raw(y[s], tin);
+                yc[s] = win ? cin : yc[s];
+                if (BP) arg[s] = win ? scell0 + lane * SPL + s - 1 : arg[s];     // the chain predecessor's cell
+                if (s == SPL - 1) win_any = win;     // wins in the earlier slots were carried on inside this sweep already
+            }
+            return win_any;
+        };
+        // FIXED sweeps run unconditionally as straight-line code (a sweep at the fixed point changes nothing), so that the
+        // scheduler can place independent work between their dependent instructions; the rest until no lane changes.
+        auto chain_sweeps = [&](double (&y)[SPL], Pay (&yc)[SPL], int (&arg)[SPL], auto fixed_c) {
+            constexpr int FIXED = decltype(fixed_c)::value;
+            bool more = true;
+#pragma unroll
+            for (int i = 0; i < FIXED; ++i) more = one_sweep(y, yc, arg);
+            if (FIXED > 0 && !__any(more)) return;
+            for (;;) { if (!__any(one_sweep(y, yc, arg))) break; }
+        };
+        // PIPE: tournament over the emitting-sourced edge columns (all but the last) of every emitting slot, on the cells at
+        // byte offset OFF -- the values of the time step that has just got its emitting states
+        auto partial = [&](auto off_c) {
+            constexpr int OFF = decltype(off_c)::value;
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {
+                Cell pcs[DEMAX];
+#pragma unroll
+                for (int j = 0; j < DEMAX; ++j)
+                    if (j < de_of(s) - 1) pcs[j] = ldcell(esrc[s][j], OFF);
+                double cv[DEMAX]; Pay cc[DEMAX]; int ca[DEMAX];
+#pragma unroll
+                for (int j = 0; j < DEMAX; ++j)
+                    if (j < de_of(s) - 1) { cv[j] = pcs[j].v + elp[s][j]; cc[j] = pcs[j].c; ca[j] = 0; }
+                tournament(cv, cc, ca, de_of(s) - 1);
+                pv[s] = cv[0]; pc[s] = cc[0];
             }
         };
 
@@ -299,7 +333,10 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     if (PIN && own_s[s] == start_state) { best = 0.0; bc = pay_add((Pay)0, -sinc[s]); a = dummy; }
                     y[s] = best; yc[s] = pay_add(bc, sinc[s]); arg[s] = a;
                 }
-                chain_sweeps(y, yc, arg);
+                if constexpr (PIPE) {
+                    partial(off_c);          // the next step's emitting-sourced candidates: independent of the sweeps below
+                    chain_sweeps(y, yc, arg, std::integral_constant<int, 3>{});
+                } else chain_sweeps(y, yc, arg, std::integral_constant<int, 0>{});
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) stcell(sdst[s], OFF, y[s], yc[s]);
                 VIT_FENCE();
@@ -344,7 +381,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         if (base[s] >= y[s]) { y[s] = base[s]; yc[s] = basec[s]; arg[s] = basea[s]; }
                         base_prev[s] = base[s];
                     }
-                    chain_sweeps(y, yc, arg);
+                    chain_sweeps(y, yc, arg, std::integral_constant<int, 0>{});
                     if (!single_stage) {
 #pragma unroll
                         for (int s = 0; s < SPL; ++s) {
@@ -376,19 +413,34 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             const uint32_t tt1 = (uint32_t)(t + 1);                       // wave-uniform: scalar registers
             const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
             (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
+            Cell lastc[EPL];
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int s = 0; s < EPL; ++s) lastc[s] = ldcell(esrc[s][de_of(s) - 1], RD);      // the last column: the only one that may read a silent cell
+            }
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
-                Cell pcs[DEMAX];          // all reads of the slot in flight before the first use
+                double best; Pay bc; int a = 0;
+                if constexpr (PIPE) {
+                    // the columns before the last were reduced during the previous silent phase (pv, pc); the last candidate
+                    // wins only with a strict '>', like the right-hand side of every tournament pairing
+                    const double c = lastc[s].v + elp[s][de_of(s) - 1];
+                    const bool gt = c > pv[s];
+                    bc = gt ? lastc[s].c : pc[s];
+                    best = __builtin_fmax(pv[s], c);
+                } else {
+                    Cell pcs[DEMAX];          // all reads of the slot in flight before the first use
 #pragma unroll
-                for (int j = 0; j < DEMAX; ++j)
-                    if (j < de_of(s)) pcs[j] = ldcell(esrc[s][j], RD);
-                double cv[DEMAX]; Pay cc[DEMAX]; int ca[DEMAX];
+                    for (int j = 0; j < DEMAX; ++j)
+                        if (j < de_of(s)) pcs[j] = ldcell(esrc[s][j], RD);
+                    double cv[DEMAX]; Pay cc[DEMAX]; int ca[DEMAX];
 #pragma unroll
-                for (int j = 0; j < DEMAX; ++j) {
-                    if (j < de_of(s)) { cv[j] = pcs[j].v + elp[s][j]; cc[j] = pcs[j].c; ca[j] = BP ? (int)(esrc[s][j] - vbase) >> 4 : 0; }
+                    for (int j = 0; j < DEMAX; ++j) {
+                        if (j < de_of(s)) { cv[j] = pcs[j].v + elp[s][j]; cc[j] = pcs[j].c; ca[j] = BP ? (int)(esrc[s][j] - vbase) >> 4 : 0; }
+                    }
+                    tournament(cv, cc, ca, de_of(s));
+                    best = cv[0]; bc = cc[0]; a = ca[0];
                 }
-                tournament(cv, cc, ca, de_of(s));
-                const double best = cv[0]; const Pay bc = cc[0]; const int a = ca[0];
                 double em;
                 if (fast_em) {          // every observation of this window lies inside all uniform emissions
                     if constexpr (LO_FLAT) {
@@ -587,7 +639,7 @@ static int vit_shape_base(const VitModel& mh)
     for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
     for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
     // flanked-repeat models: six-edge states in slot 0, two in-edges per delete state besides its chain
-    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2) {
+    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2 && mh.sil_last) {
         bool flat = true;
         for (int i = (e + 1) / 2; i < e; ++i) flat = flat && mh.e_flat[i];
         if (flat && e == 4) return 7;          // ... and only uniform emissions (the inserts) in the last two slots
