@@ -356,9 +356,10 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
         mine_set = set(int(i) for i in sdist.shard_indices(len(items), rank, world, cost))
         stats["items"] = items
 
-    def flush(batch):
-        if not batch:
-            return
+    def run_batch(batch):
+        """Engine thread: one batch through the GPU pipeline (the library releases the GIL for the whole call), its rows
+        formatted; returns (rows, number of failed reads)."""
+        failed = 0
         results = None
         try:
             results = counter.detect_batch([(t, raw, s) for _, _, t, s, raw in batch])
@@ -379,18 +380,37 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
                     if e1.code not in (STRQ_ERR_ARG, STRQ_ERR_UNSUPPORTED):
                         log("Detector: device error, giving up: %s" % e1, 'error')
                         raise DeviceFault(str(e1))
-                    log("Detector: read failed: %s" % e1, 'warning'); results.append(None); stats["failed"] += 1
+                    log("Detector: read failed: %s" % e1, 'warning'); results.append(None); failed += 1
                 except Exception as e1:
-                    log("Detector: read failed: %s" % e1, 'warning'); results.append(None); stats["failed"] += 1
+                    log("Detector: read failed: %s" % e1, 'warning'); results.append(None); failed += 1
         done = []
         for (seq, qname, target, strand, _), res in zip(batch, results):
             if world > 1:
                 done.append((seq, res))
             elif res is not None:
                 done.append((seq, format_row(qname, target, strand, res)))
-        rows.extend(done)
-        if out is not None:
-            write_rows(out, done, header=False)
+        return done, failed
+
+    # The batches run on an engine thread, one at a time and in order, while this thread routes the next SAM records and
+    # collects their signals: the GPU call of batch k overlaps the host-side preparation of batch k + 1 (at 50 kb per read
+    # that preparation -- SAM decode, index look-ups, waiting for the reader threads -- costs about as much as the call).
+    from concurrent.futures import ThreadPoolExecutor
+    engine = ThreadPoolExecutor(max_workers=1)
+    in_flight = deque()
+
+    def collect(keep):
+        while len(in_flight) > keep:
+            done, failed = in_flight.popleft().result()          # re-raises DeviceFault from the engine thread
+            stats["failed"] += failed
+            rows.extend(done)
+            if out is not None:
+                write_rows(out, done, header=False)
+
+    def flush(batch):
+        if not batch:
+            return
+        collect(1)                                               # at most one batch running and one waiting
+        in_flight.append(engine.submit(run_batch, batch))
 
     def fetch(qname):
         try:
@@ -404,37 +424,56 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
 
     pool = None
     if readers > 1:
-        from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=readers)
-    pending = deque()                      # (qname, strand, [(seq, target)], raw or future), in input order
+    CHUNK = 32                             # reads per reader task: one future per read costs more Python time than a contiguous read does
+    pending = deque()                      # (future or list of raw signals, [(qname, strand, [(seq, target)])]), in input order
+    group = []
     batch = []
+
+    def fetch_many(qnames):
+        return [fetch(q) for q in qnames]
+
+    def push_group():
+        nonlocal group
+        if group:
+            names = [g[0] for g in group]
+            pending.append((pool.submit(fetch_many, names) if pool is not None else fetch_many(names), group))
+            group = []
 
     def drain(keep):
         nonlocal batch
         while len(pending) > keep:
-            qname, strand, mine, raw = pending.popleft()
+            raws, grp = pending.popleft()
             if pool is not None:
-                raw = raw.result()
-            if raw is None:
-                log("Detector: No fast5 for ID %s" % qname, 'warning'); continue
-            for sq, t in mine:
-                batch.append((sq, qname, t, strand, raw))
-            if len(batch) >= batch_size:
-                flush(batch); batch = []
+                raws = raws.result()
+            for (qname, strand, mine), raw in zip(grp, raws):
+                if raw is None:
+                    log("Detector: No fast5 for ID %s" % qname, 'warning'); continue
+                for sq, t in mine:
+                    batch.append((sq, qname, t, strand, raw))
+                if len(batch) >= batch_size:
+                    flush(batch); batch = []
 
     seq = 0
-    lookahead = max(1, 2 * batch_size) if pool is not None else 0
-    for qname, strand, targets, _qlen in records:
-        mine = [(seq + i, t) for i, t in enumerate(targets) if mine_set is None or (seq + i) in mine_set]
-        seq += len(targets)
-        if not mine:
-            continue
-        pending.append((qname, strand, mine, pool.submit(fetch, qname) if pool is not None else fetch(qname)))
-        drain(lookahead)
-    drain(0)
-    flush(batch)
-    if pool is not None:
-        pool.shutdown()
+    lookahead = max(1, 2 * batch_size // CHUNK) if pool is not None else 0
+    try:
+        for qname, strand, targets, _qlen in records:
+            mine = [(seq + i, t) for i, t in enumerate(targets) if mine_set is None or (seq + i) in mine_set]
+            seq += len(targets)
+            if not mine:
+                continue
+            group.append((qname, strand, mine))
+            if len(group) >= CHUNK:
+                push_group()
+                drain(lookahead)
+        push_group()
+        drain(0)
+        flush(batch)
+        collect(0)
+    finally:
+        engine.shutdown(wait=True)
+        if pool is not None:
+            pool.shutdown()
     return rows
 
 

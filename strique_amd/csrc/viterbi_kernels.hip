@@ -137,7 +137,13 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     // column of its slot (strq_viterbi_api.hip), so every other column reads emitting cells only.  Those are final as soon
     // as the emitting phase of a time step is over: the tournament over them for step t + 1 is taken while the silent phase
     // of step t runs -- independent work next to the serial chain sweeps -- and step t + 1 itself only adds the last column.
-    constexpr bool PIPE = DE_HI > 16 && SS && !BP;
+#ifndef STRQ_VIT_PIPE
+#define STRQ_VIT_PIPE 1
+#endif
+#ifndef STRQ_VIT_FIXED
+#define STRQ_VIT_FIXED 3
+#endif
+    constexpr bool PIPE = STRQ_VIT_PIPE && DE_HI > 16 && SS && !BP;
     constexpr bool WIDE = MARK || HUB;
     using Pay = std::conditional_t<WIDE, uint64_t, int>;      // what rides along the best path
     struct alignas(16) Cell { double v; Pay c; };
@@ -335,7 +341,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 }
                 if constexpr (PIPE) {
                     partial(off_c);          // the next step's emitting-sourced candidates: independent of the sweeps below
-                    chain_sweeps(y, yc, arg, std::integral_constant<int, 3>{});
+                    chain_sweeps(y, yc, arg, std::integral_constant<int, STRQ_VIT_FIXED>{});
                 } else chain_sweeps(y, yc, arg, std::integral_constant<int, 0>{});
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) stcell(sdst[s], OFF, y[s], yc[s]);
