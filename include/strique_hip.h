@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 7 (5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry) */
+int strq_abi_version(void);   /* currently 7 (5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -199,6 +199,14 @@ int strq_host_stats(const double* signals, const int64_t* offsets, int64_t n_rea
  * differences.  Returns the stream bytes consumed (the caller checks it against the stream length) or -1. */
 int64_t strq_svb_decode(const uint8_t* stream, int64_t stream_len, int64_t n, int32_t key_bits, int32_t zigzag,
                         int32_t isize, void* out);
+/* Host-side helper of the fast5 reader (strique_amd/fast5.py): n_chunks deflate-compressed chunks of a 1-D chunked HDF5
+ * dataset, chunk k at file offset addr[k] (csize[k] stored bytes, first element elem_off[k]), inflated from the mapped file
+ * `base` into out[n_total] (elements of elem_size bytes; shuffle != 0: undo the HDF5 shuffle filter).  What h5py does
+ * for the reference's get_raw (STRique_lib/fast5Index.py:220-233).  Returns 0, -1 on a bad argument, -(k + 2) when
+ * chunk k is out of bounds or does not inflate. */
+int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, int64_t n_chunks, const int64_t* addr,
+                            const int32_t* csize, const int64_t* elem_off, int32_t elem_size, int32_t shuffle,
+                            int64_t chunk_elems, int64_t n_total, void* out);
 /* Test hook: conditioning outputs (8-bit morphology levels, their 256 float32 values, and
  * {median, MAD, c1/h1 of the filtered, morphology and raw signal, h2, c2}) of read `read` of the
  * last sub-batch processed by strq_batch_run. */

@@ -382,43 +382,35 @@ struct Forward {
     const int lane, rM;
     Lane<R> st;
     float best, bestA; int bestt;
-    // Two register sets for the packed levels (x4) of the two columns of a step and their class scores, fetched one step
-    // ahead: step P consumes set P and fills set 1 - P, so that the steady-state loop (two steps per iteration) carries no
-    // register copies.
-    int qq[2];
-    float sc[2][2][Shape<R, S>::C];           // [set][column A / B][class]
+    int qq;                                   // packed levels (x4) of the two columns of the step about to run
+    float scA[Shape<R, S>::C], scB[Shape<R, S>::C];   // their class scores, fetched one step ahead
     Bnd4 bcur;
 
     // levels of the next step enter at lane 0 (entry `snext` of the chunk register `qsrc`); its scores
     // are read from LDS now and consumed one step later, so the LDS latency hides behind the DP arithmetic
-    template <int P>
-    __device__ __forceinline__ void advance(int qsrc, int snext)
+    __device__ __forceinline__ void advance(int qsrc, int snext, int& qn, float (&nA)[Shape<R, S>::C], float (&nB)[Shape<R, S>::C])
     {
-        qq[1 - P] = dpp_shr1_i(qq[P], __builtin_amdgcn_readlane(qsrc, snext));
-        fetch_scores<R, S, PK>(ldsb, lc, qq[1 - P] & 0xffff, sc[1 - P][0]);
-        fetch_scores<R, S, PK>(ldsb, lc, (int)((unsigned)qq[1 - P] >> 16), sc[1 - P][1]);
-    }
-    __device__ __forceinline__ void rotate()          // set 1 -> set 0 (the predicated edge chunks run every step on set 0)
-    {
-        qq[0] = qq[1];
-#pragma unroll
-        for (int c = 0; c < Shape<R, S>::C; ++c) { sc[0][0][c] = sc[1][0][c]; sc[0][1][c] = sc[1][1][c]; }
+        qn = dpp_shr1_i(qq, __builtin_amdgcn_readlane(qsrc, snext));
+        fetch_scores<R, S, PK>(ldsb, lc, qn & 0xffff, nA);
+        fetch_scores<R, S, PK>(ldsb, lc, (int)((unsigned)qn >> 16), nB);
     }
     __device__ __forceinline__ void prime(int qcur)
     {
-        qq[1] = 0;
-        qq[0] = dpp_shr1_i(qq[1], __builtin_amdgcn_readlane(qcur, 0));
-        fetch_scores<R, S, PK>(ldsb, lc, qq[0] & 0xffff, sc[0][0]);
-        fetch_scores<R, S, PK>(ldsb, lc, (int)((unsigned)qq[0] >> 16), sc[0][1]);
+        qq = 0;
+        int qn; float nA[Shape<R, S>::C], nB[Shape<R, S>::C];
+        advance(qcur, 0, qn, nA, nB);
+        qq = qn;
+#pragma unroll
+        for (int c = 0; c < Shape<R, S>::C; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
     }
 
     // PRED: lanes may be idle (before their first / after their last column).
     // s: position of this step inside its 64-step chunk; (qsrc, snext): where the next step's levels come from.
-    // P: the register set this step consumes.
-    template <bool PRED, bool KEEP, int P = 0>
+    template <bool PRED, bool KEEP>
     __device__ __forceinline__ void step(int t, int s, int qsrc, int snext)
     {
-        advance<P>(qsrc, snext);
+        int qn; float nA[Shape<R, S>::C], nB[Shape<R, S>::C];
+        advance(qsrc, snext, qn, nA, nB);
         float fA = 0.0f, fB = 0.0f, fVA = STRQ_NINF, fVB = STRQ_NINF;
         if constexpr (HAS_IN) {
             fA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.sA), s));
@@ -437,8 +429,8 @@ struct Forward {
         if constexpr (PRED) act = (jA >= 1) && (jA <= tk.n);
         if (act) {
             float rsA[R], rsB[R];
-            expand_scores<R, S>(sc[P][0], pm, rsA);
-            expand_scores<R, S>(sc[P][1], pm, rsB);
+            expand_scores<R, S>(scA, pm, rsA);
+            expand_scores<R, S>(scB, pm, rsB);
             bool okB = true;
             if constexpr (PRED) okB = jB <= tk.n;
             if constexpr (HAS_OUT) {
@@ -468,6 +460,9 @@ struct Forward {
                 best = nb;
             }
         }
+        qq = qn;
+#pragma unroll
+        for (int c = 0; c < Shape<R, S>::C; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
     }
 };
 
@@ -498,20 +493,14 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
         const bool ckpt_here = ((t0 + 64) % STRQ_CKPT_STEPS) == 0 && (t0 + 64) < nsteps;
         const int send = nsteps - t0 < 64 ? nsteps - t0 : 64;
         if (full) {
-            // two steps per iteration on alternating register sets; 64 steps leave the roles where they were
-            for (int s = 0; s < 62; s += 2) {
-                f.template step<false, false, 0>(t0 + s + 1, s, qcur, s + 1);
-                f.template step<false, false, 1>(t0 + s + 2, s + 1, qcur, s + 2);
-            }
-            f.template step<false, false, 0>(t0 + 63, 62, qcur, 63);
-            if (ckpt_here) f.template step<false, true, 1>(t0 + 64, 63, qnext, 0);
-            else f.template step<false, false, 1>(t0 + 64, 63, qnext, 0);
+            for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, s, qcur, s + 1);
+            if (ckpt_here) f.template step<false, true>(t0 + 64, 63, qnext, 0);
+            else f.template step<false, false>(t0 + 64, 63, qnext, 0);
         } else {
             for (int s = 0; s < send; ++s) {
                 const int qsrc = s == 63 ? qnext : qcur, snext = (s + 1) & 63;
-                if (ckpt_here && s == 63) f.template step<true, true, 0>(t0 + s + 1, s, qsrc, snext);
-                else f.template step<true, false, 0>(t0 + s + 1, s, qsrc, snext);
-                f.rotate();
+                if (ckpt_here && s == 63) f.template step<true, true>(t0 + s + 1, s, qsrc, snext);
+                else f.template step<true, false>(t0 + s + 1, s, qsrc, snext);
             }
         }
         if (ckpt_here)

@@ -174,6 +174,17 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     // and with it the tie rule, is unchanged.
     const int shape_base = vit_shape_of(m) & ~VIT_SHAPE_SS;
     const bool silent_in_last_column = shape_base == 5 || shape_base == 7;
+    if (silent_in_last_column) {
+        // the kernels of these shapes take their column counts at compile time (6, 5, 3, 3): lay the slots out on exactly
+        // those, so that "the last column" means the same thing here and there
+        static const int cols[4] = {6, 5, 3, 3};
+        rows = 0;
+        for (int s = 0; s < epl; ++s) { m.e_deg[s] = cols[s]; m.e_base[s] = rows; rows += cols[s]; }
+        for (int s = 0; s < spl2; ++s) { m.s_base[s] = rows; rows += m.s_deg[s]; }
+        m.n_edge_rows = rows;
+        src.assign((size_t)std::max(rows, 1) * 64, m.n_cells - 1);
+        lp.assign((size_t)std::max(rows, 1) * 64, 0.0);
+    }
     auto fill = [&](int state, int base, int lane, int last_col) {
         for (int e = in_ptr[state], j = 0; e < in_ptr[state + 1]; ++e) {
             if (state >= ne && is_chain_edge(state, in_src[e])) continue;

@@ -66,8 +66,10 @@ struct VitResult {
 #define VIT_SHAPE_SS 16                            // flag in the shape id: single-stage model
 int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fits
 int vit_shape_silent_slots(int shape);             // silent slots per lane of that kernel shape
+// pair_ok: every window of the launch is a detect window (affine int16 / float64 source) whose clip range lies inside all
+// uniform emission supports of its model -- the two-waves-per-window kernel may take the launch (shape 7, count / MARK mode)
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
-                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);
+                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr, int pair_ok = 0);
 // want_bp: 0 = count only, 1 = back-pointers, 2 = repeat-section marks (flanked model), 3 = hub records (modification model)
 int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order);   // order by descending T (n <= 8192)
 int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResult* results,

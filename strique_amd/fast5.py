@@ -271,6 +271,11 @@ class H5File(object):
             raise NotImplementedError("only 1-D chunked datasets")
         out = np.zeros(n, dtype)
         csize = layout[2][0]
+        fids = [fid for fid, _ in filters]
+        if fids and set(fids) <= {1, 2} and fids.count(1) == 1 and (2 not in fids or fids.index(2) < fids.index(1)):
+            # deflate (after an optional shuffle): all chunks of the dataset in one native call, outside the interpreter lock
+            if self._native_inflate(layout[1], len(shape), out, csize, 2 in fids):
+                return out
         for off, data in self._chunks(layout[1], len(shape)):
             for fid, cd in reversed(filters):
                 if fid == 1:
@@ -286,6 +291,53 @@ class H5File(object):
             k = min(len(vals), csize, n - off)
             out[off:off + k] = vals[:k]
         return out
+
+    def _chunk_table(self, addr, rank, rows):
+        """Leaf entries of the chunk B-tree as (element offset, file address, stored size) rows, without touching the chunks."""
+        b = self.buf
+        if addr == UNDEF:
+            return
+        if bytes(b[addr:addr + 4]) != b"TREE":
+            raise ValueError("bad chunk B-tree node")
+        level = b[addr + 5]
+        n, = struct.unpack_from("<H", b, addr + 6)
+        keysz = 8 + 8 * (rank + 1)
+        ent = np.dtype({"names": ["csize", "fmask", "off0", "child"], "formats": ["<u4", "<u4", "<u8", "<u8"],
+                        "offsets": [0, 4, 8, keysz], "itemsize": keysz + 8})
+        tab = np.frombuffer(b, ent, n, addr + 24)
+        if level == 0:
+            if tab["fmask"].any():
+                raise NotImplementedError("chunk with skipped filters")
+            rows.append(tab)
+        else:
+            for child in tab["child"]:
+                self._chunk_table(int(child), rank, rows)
+
+    def _native_inflate(self, addr, rank, out, chunk_elems, shuffle):
+        """strq_inflate_chunks (csrc/h5_chunks.hip).  False when the library is not built: the Python loop takes over."""
+        import ctypes
+        try:
+            from . import ffi
+            lib = ffi.load_library()
+            fn = lib.strq_inflate_chunks
+        except (ImportError, OSError, AttributeError):
+            return False
+        rows = []
+        self._chunk_table(addr, rank, rows)
+        if not rows:
+            return True
+        tab = np.concatenate(rows) if len(rows) > 1 else rows[0]
+        caddr = np.ascontiguousarray(tab["child"], np.int64); csz = np.ascontiguousarray(tab["csize"], np.int32)
+        eoff = np.ascontiguousarray(tab["off0"], np.int64)
+        base = np.frombuffer(self.buf, np.uint8)
+        fn.restype = ctypes.c_int64
+        rc = fn(ctypes.c_void_p(base.ctypes.data), ctypes.c_int64(base.size), ctypes.c_int64(len(caddr)),
+                ctypes.c_void_p(caddr.ctypes.data), ctypes.c_void_p(csz.ctypes.data), ctypes.c_void_p(eoff.ctypes.data),
+                ctypes.c_int32(out.dtype.itemsize), ctypes.c_int32(1 if shuffle else 0), ctypes.c_int64(chunk_elems),
+                ctypes.c_int64(out.size), ctypes.c_void_p(out.ctypes.data))
+        if rc != 0:
+            raise ValueError("chunk %d of a deflate-compressed dataset is damaged" % (-rc - 2) if rc < -1 else "bad chunk table")
+        return True
 
     def _chunks(self, addr, rank):
         b = self.buf

@@ -267,3 +267,55 @@ def test_vbz_chunks(tmp_path):
     p.write_bytes(h5write.multi_read_fast5(reads, compression="gzip"))
     got = dict(fast5.read_raw(str(p)))
     assert all(np.array_equal(got[r], s) for r, s in reads)
+
+
+def test_deflate_chunks_native_and_python_paths(tmp_path, monkeypatch):
+    """Chunked deflate datasets (what h5py / MinKNOW write; the bundled c9orf72.fast5 is one) are inflated by the
+    library's host helper strq_inflate_chunks in one call per dataset; the per-chunk Python loop stays as the fallback.
+    Both must return the samples exactly: plain deflate, shuffle + deflate, ragged last chunk, a dataset shorter than a
+    chunk, a damaged chunk."""
+    import zlib
+    import numpy as np
+    from strique_amd import fast5, h5write
+    rng = np.random.default_rng(3)
+
+    def shuffled(part):
+        return np.frombuffer(part.astype("<i2").tobytes(), np.uint8).reshape(-1, 2).T.tobytes()
+
+    def bulk(signals, shuffle):
+        f = h5write._File()
+        top = {}
+        for i, sig in enumerate(signals):
+            if shuffle:
+                ds = h5write._chunked_dataset(f, sig, 4096, [(2, "shuffle", (2,)), (1, "deflate", (4,))],
+                                              lambda part: zlib.compress(shuffled(part), 4))
+            else:
+                ds = h5write._deflate_dataset(f, sig)
+            raw = h5write._group(f, {"Signal": ds}, attrs=[("read_id", "r%d" % i)])
+            top["read_r%d" % i] = h5write._group(f, {"Raw": raw})
+        return h5write._finish(f, h5write._group(f, top))
+
+    signals = [rng.integers(-3000, 3000, n).astype(np.int16) for n in (1, 17, 4096, 8192, 8193, 50001, 375013)]
+    for shuffle in (False, True):
+        path = tmp_path / ("bulk%d.fast5" % shuffle)
+        path.write_bytes(bulk(signals, shuffle))
+        f = fast5.H5File(str(path))
+        native = [f.dataset("/read_r%d/Raw/Signal" % i) for i in range(len(signals))]
+        calls = []
+        orig = fast5.H5File._native_inflate
+        monkeypatch.setattr(fast5.H5File, "_native_inflate", lambda self, *a: calls.append(1) and False)
+        python = [f.dataset("/read_r%d/Raw/Signal" % i) for i in range(len(signals))]
+        monkeypatch.setattr(fast5.H5File, "_native_inflate", orig)
+        assert len(calls) == len(signals)
+        for s, a, b in zip(signals, native, python):
+            assert np.array_equal(s, a) and np.array_equal(s, b)
+    # the reference's own data file goes through the same path
+    rid, sig = fast5.read_raw(os.path.join(GOLDEN, "c9orf72.fast5"))[0]
+    assert rid == "ce47b364-ed6e-4409-808a-1041c0b5aac2" and len(sig) == 284184 and int(sig.min()) == -4096 and int(sig.max()) == 3008
+    # a damaged chunk is reported, not returned as zeros
+    blob = bytearray(bulk([signals[-1]], False))
+    pos = bytes(blob).find(zlib.compress(signals[-1][:8192].tobytes(), 4)[:16])
+    assert pos > 0
+    blob[pos + 20] ^= 0xFF; blob[pos + 21] ^= 0xFF; blob[pos + 40] ^= 0xFF
+    with pytest.raises(Exception):
+        fast5.H5File(bytes(blob)).dataset("/read_r0/Raw/Signal")
