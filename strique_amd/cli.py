@@ -214,6 +214,7 @@ def count(argv):
         if not args.algn:
             log("Main: --algn FILE is required when running on several GPUs (stdin cannot be shared).", 'error'); raise SystemExit(1)
         sdist.init_process_group(backend=args.backend)
+    _tune_allocator()
     from .counter import repeatCounter
     device = args.device if (world == 1 or args.share_device) else local
     counter = repeatCounter(args.model, mod_model_file=args.mod_model, align_config=config['align'],
@@ -261,6 +262,21 @@ def count(argv):
         log("Main: %d read(s) could not be processed (see warnings above)." % stats["failed"], 'error')
         if args.strict:
             raise SystemExit(2)
+
+
+def _tune_allocator():
+    """The reader threads allocate one array per read (0.2 ... 8 MB).  glibc serves such sizes with a fresh mmap each time:
+    every read then costs a map, a page fault per 4 KB while it is filled and an unmap, all under the process-wide mm lock,
+    and the readers stop scaling beyond a few threads.  Raise the mmap threshold to its maximum (32 MB) and keep freed memory:
+    the arrays come out of the per-thread arenas and their pages are reused."""
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        M_TRIM_THRESHOLD, M_MMAP_THRESHOLD = -1, -3
+        libc.mallopt(M_MMAP_THRESHOLD, 32 << 20)
+        libc.mallopt(M_TRIM_THRESHOLD, (1 << 31) - 1)
+    except (OSError, AttributeError):
+        pass
 
 
 class DeviceFault(Exception):

@@ -873,6 +873,15 @@ int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
     static const bool no14 = getenv("STRQ_NO_R14") != nullptr;
     const int single[] = {6, 7, 8, 12, 14, 15};
     const int two[] = {6, 7, 8, 12};
+    // 14 or 15 rows per lane (flanks of 129 ... 149 classes fit both): the forward kernel reads the last flank row from a
+    // register it knows at compile time when that row is the lane's last one (m % R == 0) or, at R = 14, when m = 870
+    // (STRique's own flanks); otherwise a runtime-indexed pick costs ~40 instructions per step -- more than the idle
+    // lanes of the other shape.  Measured VALU instructions per step: 152 (R = 14) / 157 (R = 15), 191 / ~197 with the pick.
+    if (!force_two && !no14 && m > 64 * 12 && m <= 64 * 14) {
+        const bool fast14 = m % 14 == 0 || m == 870, fast15 = m % 15 == 0;
+        const int r = (fast14 || !fast15) ? 14 : 15;
+        *rows_per_lane = r; *n_strips = 1; return r;
+    }
     if (!force_two)
         for (int r : single) if (64 * r >= m && !(r == 14 && no14)) { *rows_per_lane = r; *n_strips = 1; return r; }
     for (int r : two) if (64 * r < m && 128 * r >= m) { *rows_per_lane = r; *n_strips = 2; return r; }

@@ -426,18 +426,13 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         by_shape[shape].push_back(i);
     }
     std::vector<int32_t> vit_slot(nr);
-    struct VL { int shape, first, count, max_states, pair_ok; };
+    struct VL { int shape, first, count, max_states; };
     std::vector<VL> vls;
     { int sl = 0;
       for (auto& g : by_shape) {
-        int mx = 0, pair_ok = 1;
-        for (int i : g.second) {
-            const VitModel& hm = c->models[d->targets[B.target[r0 + i]].model_id]->h;
-            mx = std::max(mx, hm.n_cells);
-            // the clipped observations of a detect window (STRique.py:178-179) cannot leave any uniform emission's support
-            if (!(d->ps.clip_lo >= hm.uni_lo_max && d->ps.clip_hi <= hm.uni_hi_min)) pair_ok = 0;
-        }
-        vls.push_back({g.first, sl, (int)g.second.size(), mx, pair_ok});
+        int mx = 0;
+        for (int i : g.second) mx = std::max(mx, c->models[d->targets[B.target[r0 + i]].model_id]->h.n_cells);
+        vls.push_back({g.first, sl, (int)g.second.size(), mx});
         for (int i : g.second) vit_slot[i] = sl++;
       } }
     const size_t idx_ints = (size_t)nr * 5;        // task_of (2 per read), trim (2 per read), vit_slot
@@ -529,7 +524,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
             if (launch_vit_sort(st, d->vit.as<VitTask>() + v.first, v.count, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
         }
         const int rc2 = launch_viterbi(st, v.shape, v.max_states, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
-                                       c->queue.as<int>() + qi, c->n_cu, any_mod ? 2 : 0, d_order, v.pair_ok);
+                                       c->queue.as<int>() + qi, c->n_cu, any_mod ? 2 : 0, d_order);
         if (rc2) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
       } }

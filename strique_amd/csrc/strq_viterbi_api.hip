@@ -37,8 +37,6 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     VitModel& m = hm->h;
     std::memset(&m, 0, sizeof(m));
     m.n_states = n_states; m.n_emit = ne; m.n_silent = ns; m.start = start; m.end = end; m.epl = epl; m.spl = spl;
-    m.sil_last = 1;
-    for (int l = 0; l < ne; ++l) { int nsil = 0; for (int e = in_ptr[l]; e < in_ptr[l + 1]; ++e) if (in_src[e] >= ne) ++nsil; if (nsil > 1) m.sil_last = 0; }
     // emitting states: dealt to slots by descending in-degree (slot 0 takes the 64 busiest, ...)
     auto deg_of = [&](int st) { return in_ptr[st + 1] - in_ptr[st]; };
     std::vector<int> eord(ne);
@@ -168,34 +166,16 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     m.start_cell = cell_of[start]; m.end_cell = cell_of[end];
     std::vector<int32_t> src((size_t)std::max(rows, 1) * 64, m.n_cells - 1);   // padding -> the -inf cell
     std::vector<double> lp((size_t)std::max(rows, 1) * 64, 0.0);
-    // Flanked-model shapes: the one silent in-edge of an emitting state -- its last in-edge, silent states are numbered
-    // after the emitting ones -- goes into the last edge column of the slot, padding in front of it: the kernel reduces the
-    // other columns (emitting cells only) one phase ahead (viterbi_kernels.hip, PIPE).  The order of the real candidates,
-    // and with it the tie rule, is unchanged.
-    const int shape_base = vit_shape_of(m) & ~VIT_SHAPE_SS;
-    const bool silent_in_last_column = shape_base == 5 || shape_base == 7;
-    if (silent_in_last_column) {
-        // the kernels of these shapes take their column counts at compile time (6, 5, 3, 3): lay the slots out on exactly
-        // those, so that "the last column" means the same thing here and there
-        static const int cols[4] = {6, 5, 3, 3};
-        rows = 0;
-        for (int s = 0; s < epl; ++s) { m.e_deg[s] = cols[s]; m.e_base[s] = rows; rows += cols[s]; }
-        for (int s = 0; s < spl2; ++s) { m.s_base[s] = rows; rows += m.s_deg[s]; }
-        m.n_edge_rows = rows;
-        src.assign((size_t)std::max(rows, 1) * 64, m.n_cells - 1);
-        lp.assign((size_t)std::max(rows, 1) * 64, 0.0);
-    }
-    auto fill = [&](int state, int base, int lane, int last_col) {
+    auto fill = [&](int state, int base, int lane) {
         for (int e = in_ptr[state], j = 0; e < in_ptr[state + 1]; ++e) {
             if (state >= ne && is_chain_edge(state, in_src[e])) continue;
-            const int col = (last_col >= 0 && in_src[e] >= ne) ? last_col : j++;
-            src[(size_t)(base + col) * 64 + lane] = cell_of[in_src[e]];
-            lp[(size_t)(base + col) * 64 + lane] = in_logp[e];
+            src[(size_t)(base + j) * 64 + lane] = cell_of[in_src[e]];
+            lp[(size_t)(base + j) * 64 + lane] = in_logp[e];
+            ++j;
         }
     };
-    for (int s = 0; s < epl; ++s) for (int lane = 0; lane < 64; ++lane) if (own_e[s * 64 + lane] >= 0)
-        fill(own_e[s * 64 + lane], m.e_base[s], lane, silent_in_last_column ? m.e_deg[s] - 1 : -1);
-    for (int s = 0; s < spl2; ++s) for (int lane = 0; lane < 64; ++lane) if (own_s[s * 64 + lane] >= 0) fill(own_s[s * 64 + lane], m.s_base[s], lane, -1);
+    for (int s = 0; s < epl; ++s) for (int lane = 0; lane < 64; ++lane) if (own_e[s * 64 + lane] >= 0) fill(own_e[s * 64 + lane], m.e_base[s], lane);
+    for (int s = 0; s < spl2; ++s) for (int lane = 0; lane < 64; ++lane) if (own_s[s * 64 + lane] >= 0) fill(own_s[s * 64 + lane], m.s_base[s], lane);
     std::vector<int32_t> kind((size_t)epl * 64, 0); std::vector<double> a((size_t)epl * 64, 0.0), b(a), cc(a);
     for (int i = 0; i < epl * 64; ++i) if (own_e[i] >= 0) { const int e = own_e[i]; kind[i] = emis_kind[e]; a[i] = emis_a[e]; b[i] = emis_b[e]; cc[i] = emis_c[e]; }
     m.uni_lo_max = -INFINITY; m.uni_hi_min = INFINITY;

@@ -37,8 +37,7 @@ struct VitModel {
     const int32_t* count_inc;         // n_states + 1, by state
     const int32_t* state_tag;         // n_states + 1, by state
     double uni_lo_max, uni_hi_min;    // tightest bounds of the uniform emissions: observations inside them need no range test
-    int32_t rec_state;                // the hub state (tag 2) with an edge into `end` (e0 of the modification model), or -1
-    int32_t sil_last;                 // 1: no emitting state has more than one silent in-edge (it then sits in the last edge column of its slot on the flanked-model shapes)
+    int32_t rec_state, pad2_;         // the hub state (tag 2) with an edge into `end` (e0 of the modification model), or -1
     int32_t e_flat[8];                // emitting slot without a Normal emission (uniform inserts, padding): its emission is a constant per lane
 };
 
@@ -66,10 +65,8 @@ struct VitResult {
 #define VIT_SHAPE_SS 16                            // flag in the shape id: single-stage model
 int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fits
 int vit_shape_silent_slots(int shape);             // silent slots per lane of that kernel shape
-// pair_ok: every window of the launch is a detect window (affine int16 / float64 source) whose clip range lies inside all
-// uniform emission supports of its model -- the two-waves-per-window kernel may take the launch (shape 7, count / MARK mode)
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
-                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr, int pair_ok = 0);
+                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);
 // want_bp: 0 = count only, 1 = back-pointers, 2 = repeat-section marks (flanked model), 3 = hub records (modification model)
 int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order);   // order by descending T (n <= 8192)
 int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResult* results,

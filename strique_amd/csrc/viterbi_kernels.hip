@@ -492,330 +492,6 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Two waves per window (flanked-repeat models on the (4, 2) layout with flat insert slots: kernel shape 7).
-//
-// A time step of the one-wave kernel is a chain of ~150 dependent float64 instructions and four LDS round trips:
-// ~0.8 us even for a wave alone on its SIMD, and the longest windows of a batch (91 k steps) set the launch time.
-// Here a workgroup of two waves decodes one window: wave 0 owns the match slots (0, 1: Normal emissions, the
-// observations), wave 1 the insert slots (2, 3: constant emissions) and the silent states with their chain sweeps; half
-// the registers per wave, so four waves per SIMD and the same eight windows per CU.  The host puts the one silent
-// in-edge of an emitting state in the last edge column of its slot (strq_viterbi_api.hip), which makes every other
-// column ready as soon as the emitting cells of a time step are written:
-//
-//     phase A(t)   wave 1: silent states of step t (gather, chain sweeps)    wave 0: tournament over the emitting-
-//                                                                              sourced columns of the match slots for t + 1
-//     -- barrier: silent cells of step t visible --
-//     phase B(t)   wave 0: last column, emission of x[t], match cells of t + 1   wave 1: insert slots of t + 1 (all columns)
-//     -- barrier: emitting cells of step t + 1 visible --
-//
-// Same candidates, same order, same float64 operations as viterbi_kernel (a tournament over columns [0, k) followed by
-// the strict-'>' merge of column k equals the tournament over [0, k]: the first of equal candidates survives either
-// way), so the results are bit-identical to it and to the oracle.  Count mode and MARK mode; windows whose clipped
-// observations can leave a uniform emission's support never come here (launch_viterbi_pair checks the model), a window
-// of NaNs (missing values) runs with every emission replaced by 0.
-template <bool MARK>
-__global__ void __attribute__((amdgpu_flat_work_group_size(128, 128), amdgpu_waves_per_eu(4, 4)))
-viterbi_pair_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
-                    int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
-{
-    constexpr int EPL = 4, SPL = 2, D0 = 6, D1 = 5, DI = 3, DS = 2;
-    constexpr int TRASH = VitLds<EPL, SPL>::TRASH, BUF = VitLds<EPL, SPL>::BUF;
-    extern __shared__ double lds_d[];
-    __shared__ int next_task;
-    const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    char* const vbase = reinterpret_cast<char*>(lds_d);
-    const double NEGINF = -__builtin_inf();
-    using Pay = std::conditional_t<MARK, uint64_t, int>;
-    struct alignas(16) Cell { double v; Pay c; };
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    auto ldcell = [](const char* p, int boff) {
-        const v4u q = *reinterpret_cast<const v4u*>(p + boff);
-        Cell x; x.v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
-        if constexpr (MARK) x.c = ((uint64_t)q.w << 32) | q.z; else x.c = (int)q.z;
-        return x;
-    };
-    auto stcell = [](char* p, int boff, double v, Pay c) {
-        const uint64_t u = __builtin_bit_cast(uint64_t, v);
-        v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32);
-        if constexpr (MARK) { q.z = (unsigned)c; q.w = (unsigned)((uint64_t)c >> 32); } else { q.z = (unsigned)c; q.w = 0u; }
-        *reinterpret_cast<v4u*>(p + boff) = q;
-    };
-    auto pay_add = [](Pay v, int inc) -> Pay {
-        if constexpr (MARK) return ((uint64_t)v & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)v + (uint32_t)inc);
-        else return v + inc;
-    };
-    auto shr1_pay = [](Pay v) -> Pay {
-        if constexpr (MARK) return ((uint64_t)(uint32_t)dpp_shr1_i32((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)dpp_shr1_i32((int)(uint32_t)v);
-        else return dpp_shr1_i32(v);
-    };
-    // first of equal candidates survives: the right-hand side wins only with a strict '>'
-    auto merge = [](double& v, Pay& c, double v2, Pay c2) {
-        const bool gt = v2 > v;
-        c = gt ? c2 : c;
-        v = __builtin_fmax(v, v2);
-    };
-
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) next_task = atomicAdd(queue, 1);
-        __syncthreads();
-        const int tq = __builtin_amdgcn_readfirstlane(next_task);
-        if (tq >= n_tasks) break;
-        const int ti = order ? __builtin_amdgcn_readfirstlane(order[tq]) : tq;
-        const VitTask tk = tasks[ti];
-        const VitModel& M = *tk.model;
-        const int NP = M.n_cells, m_start = M.start_cell, m_end = M.end_cell, scell0 = M.epl * 64, dummy = M.n_cells - 1, start_state = M.start;
-        const int64_t T = tk.T;
-        // a window normalised with NaN constants is all NaN: every emission is that of a missing value, 0 (viterbi_kernel)
-        const bool nanwin = __builtin_amdgcn_readfirstlane((int)(!(tk.c1 == tk.c1) || !(tk.h1 == tk.h1))) != 0;
-        for (int i = threadIdx.x; i < NP; i += 128) { stcell(vbase, 16 * i, NEGINF, 0); stcell(vbase, BUF + 16 * i, NEGINF, 0); }
-        __syncthreads();
-
-        if (role == 0) {
-            // ---------------- wave 0: match slots 0 (six in-edge columns) and 1 (five)
-            const char* src0[D0]; double lp0[D0]; const char* src1[D1]; double lp1[D1];
-            double ea[2], ebf[2], ecf[2]; int einc[2]; bool etag[2]; char* dst[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bool on = s < M.epl;
-                const int st = on ? M.own_e[s * 64 + lane] : -1;
-                const int kind = on ? M.emis_kind[s * 64 + lane] : 0;
-                ea[s] = (kind && !nanwin) ? M.emis_a[s * 64 + lane] : 0.0;
-                ebf[s] = (kind == 1 && !nanwin) ? M.emis_b[s * 64 + lane] : 0.0;
-                ecf[s] = kind ? (nanwin ? 0.0 : M.emis_c[s * 64 + lane]) : NEGINF;
-                einc[s] = st >= 0 ? M.count_inc[st] : 0;
-                etag[s] = st >= 0 && M.state_tag[st] == 1;
-                dst[s] = vbase + 16 * (st >= 0 ? s * 64 + lane : TRASH);
-            }
-#pragma unroll
-            for (int j = 0; j < D0; ++j) {
-                const bool ej = j < M.e_deg[0];
-                src0[j] = vbase + 16 * (ej ? M.edge_src[(M.e_base[0] + j) * 64 + lane] : dummy);
-                lp0[j] = ej ? M.edge_logp[(M.e_base[0] + j) * 64 + lane] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                const bool ej = 1 < M.epl && j < M.e_deg[1];
-                src1[j] = vbase + 16 * (ej ? M.edge_src[(M.e_base[1] + j) * 64 + lane] : dummy);
-                lp1[j] = ej ? M.edge_logp[(M.e_base[1] + j) * 64 + lane] : 0.0;
-            }
-            // The host lays every slot out on its padded degree (the silent edge in column e_deg - 1); the kernel's column
-            // counts are the compile-time maxima: a slot of lower degree has its last column at e_deg - 1 < D - 1, so the
-            // columns are re-based here so that the model's last column is the kernel's last column.
-            // (launch_viterbi_pair admits only models with e_deg[0] == 6 and e_deg[1] == 5: nothing to re-base.)
-            double pv[2]; Pay pc[2];
-            auto partial = [&](auto off_c) {
-                constexpr int OFF = decltype(off_c)::value;
-                Cell c0[D0 - 1], c1[D1 - 1];
-#pragma unroll
-                for (int j = 0; j < D0 - 1; ++j) c0[j] = ldcell(src0[j], OFF);
-#pragma unroll
-                for (int j = 0; j < D1 - 1; ++j) c1[j] = ldcell(src1[j], OFF);
-                double v0[D0 - 1], v1[D1 - 1];
-#pragma unroll
-                for (int j = 0; j < D0 - 1; ++j) v0[j] = c0[j].v + lp0[j];
-#pragma unroll
-                for (int j = 0; j < D1 - 1; ++j) v1[j] = c1[j].v + lp1[j];
-                // slot 0: ((0,1),(2,3)),4     slot 1: (0,1),(2,3)
-                { double a = v0[0]; Pay ac = c0[0].c; merge(a, ac, v0[1], c0[1].c);
-                  double b = v0[2]; Pay bc = c0[2].c; merge(b, bc, v0[3], c0[3].c);
-                  merge(a, ac, b, bc); merge(a, ac, v0[4], c0[4].c); pv[0] = a; pc[0] = ac; }
-                { double a = v1[0]; Pay ac = c1[0].c; merge(a, ac, v1[1], c1[1].c);
-                  double b = v1[2]; Pay bc = c1[2].c; merge(b, bc, v1[3], c1[3].c);
-                  merge(a, ac, b, bc); pv[1] = a; pc[1] = ac; }
-            };
-            auto finish = [&](auto rd_c, double x, int64_t t) {      // cells of step t at RD -> match cells of step t + 1 at the other buffer
-                constexpr int RD = decltype(rd_c)::value, WR = RD ? 0 : BUF;
-                const Cell l0 = ldcell(src0[D0 - 1], RD), l1 = ldcell(src1[D1 - 1], RD);
-                const uint32_t tt1 = (uint32_t)(t + 1);
-                const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
-                (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    double best = pv[s]; Pay bc = pc[s];
-                    const Cell& l = s == 0 ? l0 : l1;
-                    merge(best, bc, l.v + (s == 0 ? lp0[D0 - 1] : lp1[D1 - 1]), l.c);
-                    const double d = x - ea[s];
-                    const double em = ecf[s] - (d * d) * ebf[s];
-                    Pay nc;
-                    if constexpr (MARK) {
-                        uint32_t lo = (uint32_t)bc + (uint32_t)einc[s], hi = (uint32_t)((uint64_t)bc >> 32);
-                        const bool entered = ((lo >> 20) | (hi & 0x3FFu)) != 0, left = (hi >> 10) != 0;
-                        const bool set_e = etag[s] && !entered, set_l = !etag[s] && entered && !left;
-                        lo |= set_e ? mark_e_lo : 0u;
-                        hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
-                        nc = ((uint64_t)hi << 32) | lo;
-                    } else nc = bc + einc[s];
-                    stcell(dst[s], WR, best + em, nc);
-                }
-            };
-
-            partial(std::integral_constant<int, 0>{});      // emitting cells of step 0: all -inf
-            __syncthreads();                                 // (wave 1: silent states of step 0)
-            double xchunk = 0.0;
-            for (int64_t t0 = 0; t0 < T; t0 += 64) {
-                {
-                    const int64_t idx = t0 + lane;
-                    double xv = 0.0;
-                    if (idx < T && !nanwin) {
-                        double sv = tk.src_kind == VIT_SRC_I16_AFFINE ? (double)reinterpret_cast<const int16_t*>(tk.sig)[idx]
-                                                                      : reinterpret_cast<const double*>(tk.sig)[idx];
-                        sv = (sv - tk.c1) / tk.h1;
-                        sv = sv * tk.h2 + tk.c2;
-                        sv = sv < tk.lo ? tk.lo : sv;
-                        sv = sv > tk.hi ? tk.hi : sv;
-                        xv = sv;
-                    }
-                    xchunk = xv;
-                }
-                const int send = (int)((T - t0) < 64 ? (T - t0) : 64);
-                for (int s0 = 0; s0 < send; s0 += 2) {
-                    finish(std::integral_constant<int, 0>{}, readlane_f64(xchunk, s0), t0 + s0);
-                    __syncthreads();                                         // emitting cells of the odd step complete
-                    partial(std::integral_constant<int, BUF>{});
-                    __syncthreads();                                         // silent cells of the odd step complete
-                    if (s0 + 1 < send) {
-                        finish(std::integral_constant<int, BUF>{}, readlane_f64(xchunk, s0 + 1), t0 + s0 + 1);
-                        __syncthreads();
-                        partial(std::integral_constant<int, 0>{});
-                        __syncthreads();
-                    }
-                }
-            }
-            const Cell fin = ldcell(vbase + 16 * m_end, (T & 1) ? BUF : 0);
-            const double lp = fin.v;
-            VitResult r; r.logp = lp; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
-            r.dbg[0] = r.dbg[1] = r.dbg[2] = r.dbg[3] = 0;
-            if constexpr (MARK) {
-                const uint32_t plo = (uint32_t)fin.c, phi = (uint32_t)((uint64_t)fin.c >> 32);
-                r.counted = (lp > NEGINF) ? (int64_t)(plo & 0xFFFFFu) : 0;
-                r.dbg[0] = (plo >> 20) | ((phi & 0x3FFu) << 12);
-                r.dbg[1] = phi >> 10;
-                if (tk.T >= VIT_MARK_T_MAX) r.status = 2;
-            } else r.counted = (lp > NEGINF) ? (int64_t)fin.c : 0;
-            results[ti] = r;
-        } else {
-            // ---------------- wave 1: insert slots 2, 3 (three in-edge columns, constant emission) and the silent slots
-            const char* isrc[2][DI]; double ilp[2][DI]; double iec[2]; int iinc[2]; bool itag[2]; char* idst[2];
-            const char* ssrc[SPL][DS]; double slp[SPL][DS], clp[SPL]; int sinc[SPL]; int own_s[SPL]; char* sdst[SPL];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int s = 2 + k;
-                const bool on = s < M.epl;
-                const int st = on ? M.own_e[s * 64 + lane] : -1;
-                const int kind = on ? M.emis_kind[s * 64 + lane] : 0;
-                iec[k] = kind ? (nanwin ? 0.0 : M.emis_c[s * 64 + lane]) : NEGINF;
-                iinc[k] = st >= 0 ? M.count_inc[st] : 0;
-                itag[k] = st >= 0 && M.state_tag[st] == 1;
-                idst[k] = vbase + 16 * (st >= 0 ? s * 64 + lane : TRASH);
-#pragma unroll
-                for (int j = 0; j < DI; ++j) {
-                    const bool ej = on && j < M.e_deg[s];
-                    isrc[k][j] = vbase + 16 * (ej ? M.edge_src[(M.e_base[s] + j) * 64 + lane] : dummy);
-                    ilp[k][j] = ej ? M.edge_logp[(M.e_base[s] + j) * 64 + lane] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < SPL; ++s) {
-                const bool on = s < M.spl;
-                own_s[s] = on ? M.own_s[s * 64 + lane] : -1;
-                sinc[s] = own_s[s] >= 0 ? M.count_inc[own_s[s]] : 0;
-                const bool has_chain = on && M.chain_src[s * 64 + lane] >= 0;
-                clp[s] = has_chain ? M.chain_logp[s * 64 + lane] : NEGINF;
-                sdst[s] = vbase + 16 * (own_s[s] >= 0 ? scell0 + lane * SPL + s : TRASH);
-#pragma unroll
-                for (int j = 0; j < DS; ++j) {
-                    const bool ej = on && j < M.s_deg[s];
-                    ssrc[s][j] = vbase + 16 * (ej ? M.edge_src[(M.s_base[s] + j) * 64 + lane] : dummy);
-                    slp[s][j] = ej ? M.edge_logp[(M.s_base[s] + j) * 64 + lane] : 0.0;
-                }
-            }
-            auto silent = [&](auto pin_c, auto off_c) {      // silent states of the step whose emitting cells sit at OFF
-                constexpr bool PIN = decltype(pin_c)::value;
-                constexpr int OFF = decltype(off_c)::value;
-                Cell spc[SPL][DS];
-#pragma unroll
-                for (int s = 0; s < SPL; ++s)
-#pragma unroll
-                    for (int j = 0; j < DS; ++j) spc[s][j] = ldcell(ssrc[s][j], OFF);
-                double y[SPL]; Pay yc[SPL];
-#pragma unroll
-                for (int s = 0; s < SPL; ++s) {
-                    double best = spc[s][0].v + slp[s][0]; Pay bc = spc[s][0].c;
-                    merge(best, bc, spc[s][1].v + slp[s][1], spc[s][1].c);
-                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = pay_add((Pay)0, -sinc[s]); }
-                    y[s] = best; yc[s] = pay_add(bc, sinc[s]);
-                }
-                for (;;) {
-                    bool win_any = false;
-#pragma unroll
-                    for (int s = 0; s < SPL; ++s) {
-                        double tin; Pay cin;
-                        if (s == 0) { tin = dpp_shr1_f64(y[SPL - 1]) + clp[0]; cin = pay_add(shr1_pay(yc[SPL - 1]), sinc[0]); }
-                        else { tin = y[s - 1] + clp[s]; cin = pay_add(yc[s - 1], sinc[s]); }
-                        const bool win = tin > y[s];
-                        y[s] = max_f64_raw(y[s], tin);
-                        yc[s] = win ? cin : yc[s];
-                        if (s == SPL - 1) win_any = win;
-                    }
-                    if (!__any(win_any)) break;
-                }
-#pragma unroll
-                for (int s = 0; s < SPL; ++s) stcell(sdst[s], OFF, y[s], yc[s]);
-            };
-            auto inserts = [&](auto rd_c, int64_t t) {
-                constexpr int RD = decltype(rd_c)::value, WR = RD ? 0 : BUF;
-                Cell c[2][DI];
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int j = 0; j < DI; ++j) c[k][j] = ldcell(isrc[k][j], RD);
-                const uint32_t tt1 = (uint32_t)(t + 1);
-                const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
-                (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    double best = c[k][0].v + ilp[k][0]; Pay bc = c[k][0].c;
-                    merge(best, bc, c[k][1].v + ilp[k][1], c[k][1].c);
-                    merge(best, bc, c[k][2].v + ilp[k][2], c[k][2].c);
-                    Pay nc;
-                    if constexpr (MARK) {
-                        uint32_t lo = (uint32_t)bc + (uint32_t)iinc[k], hi = (uint32_t)((uint64_t)bc >> 32);
-                        const bool entered = ((lo >> 20) | (hi & 0x3FFu)) != 0, left = (hi >> 10) != 0;
-                        const bool set_e = itag[k] && !entered, set_l = !itag[k] && entered && !left;
-                        lo |= set_e ? mark_e_lo : 0u;
-                        hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
-                        nc = ((uint64_t)hi << 32) | lo;
-                    } else nc = bc + iinc[k];
-                    stcell(idst[k], WR, best + iec[k], nc);
-                }
-            };
-
-            if (lane == 0) stcell(vbase, 16 * m_start, 0.0, 0);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            silent(std::true_type{}, std::integral_constant<int, 0>{});
-            __syncthreads();
-            for (int64_t t0 = 0; t0 < T; t0 += 64) {
-                const int send = (int)((T - t0) < 64 ? (T - t0) : 64);
-                for (int s0 = 0; s0 < send; s0 += 2) {
-                    inserts(std::integral_constant<int, 0>{}, t0 + s0);
-                    __syncthreads();
-                    silent(std::false_type{}, std::integral_constant<int, BUF>{});
-                    __syncthreads();
-                    if (s0 + 1 < send) {
-                        inserts(std::integral_constant<int, BUF>{}, t0 + s0 + 1);
-                        __syncthreads();
-                        silent(std::false_type{}, std::integral_constant<int, 0>{});
-                        __syncthreads();
-                    }
-                }
-            }
-        }
-    }
-}
-
 // order[] = task indices by descending T (bitonic sort in LDS, one workgroup; n <= 8192)
 __global__ void __launch_bounds__(1024)
 vit_sort_kernel(const VitTask* __restrict__ tasks, int n, int* __restrict__ order)
@@ -911,7 +587,7 @@ static int vit_shape_base(const VitModel& mh)
     for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
     for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
     // flanked-repeat models: six-edge states in slot 0, two in-edges per delete state besides its chain
-    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2 && mh.sil_last) {
+    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2) {
         bool flat = true;
         for (int i = (e + 1) / 2; i < e; ++i) flat = flat && mh.e_flat[i];
         if (flat && e == 4) return 7;          // ... and only uniform emissions (the inserts) in the last two slots
@@ -967,33 +643,11 @@ static int vit_launch_shape(hipStream_t stream, int max_cells, const VitTask* ta
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// Two waves per window: flanked-repeat models on kernel shape 7, single stage, count or MARK mode, every window of the
-// launch with clipped observations inside all uniform supports (the caller's promise: `pair_ok`).  STRQ_VIT_PAIR=0: off.
-static int launch_viterbi_pair(hipStream_t stream, int max_cells, const VitTask* tasks, VitResult* results, int n_tasks,
-                               int* queue, int n_cu, int want_bp, const int* order)
-{
-    if (max_cells > VitLds<4, 2>::TRASH) return 3;
-    const size_t lds = (size_t)2 * VitLds<4, 2>::BUF;
-    const dim3 grid(8 * n_cu), block(128);
-    if (want_bp == 2) {
-        (void)hipFuncSetAttribute((const void*)viterbi_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((viterbi_pair_kernel<true>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);
-    } else {
-        (void)hipFuncSetAttribute((const void*)viterbi_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((viterbi_pair_kernel<false>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);
-    }
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-
 // `shape` as returned by vit_shape_of: kernel shape | VIT_SHAPE_SS for single-stage models
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
-                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order, int pair_ok)
+                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
 {
     const int ss = (shape & VIT_SHAPE_SS) ? 1 : 0;
-    const char* pe = getenv("STRQ_VIT_PAIR");
-    const bool pair_off = pe && pe[0] == '0';
-    if (pair_ok && !pair_off && ss && (shape & ~VIT_SHAPE_SS) == 7 && (want_bp == 0 || want_bp == 2))
-        return launch_viterbi_pair(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
     switch (shape & ~VIT_SHAPE_SS) {
         case 0: return vit_launch_shape<4, 2, 6, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 1: return vit_launch_shape<1, 1, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);

@@ -269,9 +269,9 @@ class H5File(object):
             return np.frombuffer(b, dtype, n, layout[1]).reshape(shape)      # a read-only view of the mapped file (it keeps the mapping alive)
         if len(shape) != 1:
             raise NotImplementedError("only 1-D chunked datasets")
-        out = np.zeros(n, dtype)
         csize = layout[2][0]
         fids = [fid for fid, _ in filters]
+        out = np.zeros(n, dtype)          # chunks that were never written read as the fill value
         if fids and set(fids) <= {1, 2} and fids.count(1) == 1 and (2 not in fids or fids.index(2) < fids.index(1)):
             # deflate (after an optional shuffle): all chunks of the dataset in one native call, outside the interpreter lock
             if self._native_inflate(layout[1], len(shape), out, csize, 2 in fids):

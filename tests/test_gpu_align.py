@@ -60,8 +60,9 @@ def test_general_affine_parameters(ctx, orc, params):
 
 @pytest.mark.parametrize("k", [1, 40, 64, 100, 128, 129, 140, 145, 149, 150, 158])
 def test_flank_shapes(ctx, orc, k):
-    """6 / 7 / 8 / 12 / 14 / 15 rows per lane (k = 129 ... 149 classes: 14; STRique's 145-class flanks are the k = 145
-    case), last flank row in an interior register or not."""
+    """6 / 7 / 8 / 12 / 14 / 15 rows per lane (k = 129 ... 149 classes: 14 or 15, whichever keeps the last flank row in a
+    register known at compile time; STRique's 145-class flanks are the k = 145 case at 14), last flank row in an
+    interior register or not."""
     rng = np.random.default_rng(k)
     params = orc.align_params(None)
     ctx.set_align_params(*[float(v) for v in params])

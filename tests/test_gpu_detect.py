@@ -464,37 +464,3 @@ def test_filtered_signal_without_tails_is_decoded_as_missing_values(gpu_counter,
     assert tuple(g) == tuple(w), (g, w)
     rc.ctx.close()
 
-
-def test_two_waves_per_window_viterbi_equals_the_one_wave_kernel(pm, pm_mod, cfg, targets, want, monkeypatch):
-    """The flanked-model Viterbi of `detect` runs two waves per window (viterbi_pair_kernel: match slots on one wave,
-    insert slots + silent states on the other); STRQ_VIT_PAIR=0 sends the same windows through the one-wave kernel.
-    Rows must be identical -- count mode and, with the modification model, MARK mode -- and equal the oracle's,
-    including windows of NaNs, a window shorter than a chunk and windows with an odd number of observations."""
-    from strique_amd.counter import repeatCounter
-    rng = np.random.default_rng(77)
-    items = []
-    for k in range(14):
-        name = ["c9orf72", "fmr1", "htt"][k % 3]; strand = "+-"[(k // 3) % 2]
-        nrep = [1, 2, 3, 9, 30, 77, 150][k % 7]
-        items.append((name, _read(pm, targets, name, strand, 3000 + 997 * k, nrep, 8100 + k), strand))
-    s = items[3][1].copy()                                   # NaN window: filtered tails empty (see the test above)
-    n = len(s); floor, ceil_ = int(s.min()) - 40, int(s.max()) + 40
-    for pos in rng.choice(np.arange(10, n - 10, 12), size=n // 100, replace=False):
-        s[pos:pos + 3] = floor
-    for pos in rng.choice(np.arange(16, n - 10, 12), size=n // 100, replace=False):
-        s[pos:pos + 3] = ceil_
-    items.append((items[3][0], s, items[3][2]))
-    for with_mod in (False, True):
-        rc = repeatCounter(pm, mod_model_file=pm_mod if with_mod else None, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
-        for name, t in targets.items():
-            rc.add_target(name, *t)
-        monkeypatch.delenv("STRQ_VIT_PAIR", raising=False)
-        pair = rc.detect_batch(items)
-        monkeypatch.setenv("STRQ_VIT_PAIR", "0")
-        single = rc.detect_batch(items)
-        monkeypatch.delenv("STRQ_VIT_PAIR", raising=False)
-        assert pair == single
-        if not with_mod:
-            for (name, sig, strand), g in zip(items, pair):
-                assert tuple(g[:6]) == tuple(want(name, sig, strand)[:6]), (name, strand, g)
-        rc.ctx.close()
