@@ -9,8 +9,8 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH_KT="bench.py --steps 2 --warmup 1 --reads 4096 --no-cpu-baseline --no-host-leg --check 0"
-BENCH_PMC="bench.py --steps 1 --warmup 0 --reads 1024 --no-cpu-baseline --no-host-leg --check 0"
+BENCH_KT="bench.py --steps 2 --warmup 1 --reads 4096 --batches 1 --synth-workers 1 --no-cpu-baseline --no-host-leg --check 0"
+BENCH_PMC="bench.py --steps 1 --warmup 0 --reads 1024 --batches 1 --synth-workers 1 --no-cpu-baseline --no-host-leg --check 0"
 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o "$TAG" -- python3 $BENCH_KT > "$OUT/bench_kt.log" 2>&1
 echo "kernel-trace pass rc=$?"

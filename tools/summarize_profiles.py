@@ -60,7 +60,7 @@ def main():
     with open(os.path.join(out, tag + "_kernel_stats.md"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats (%s)\n\n" % tag)
         f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s/kt -o %s -- "
-                "python3 bench.py --steps 2 --warmup 1 --reads 4096 --no-cpu-baseline --no-host-leg --check 0`\n"
+                "python3 bench.py --steps 2 --warmup 1 --reads 4096 --batches 1 --synth-workers 1 --no-cpu-baseline --no-host-leg --check 0`\n"
                 "(3 passes over 4096 reads of 50 kb: 1 warm-up + 2 timed; the warm-up pass cuts the column segments with the initial 8192-column overlap, the timed ones with "
                 "the overlap chosen from its scores, so the forward DP's average here sits ~2 ms above bench.py's timed average).  Raw table: `%s_kernel_stats.csv`.\n\n" % (tag, tag, tag))
         f.write("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n")
@@ -78,7 +78,7 @@ def main():
     with open(os.path.join(out, tag + "_pmc.md"), "w") as f:
         f.write("# HBM traffic per kernel, rocprofv3 PMC (%s)\n\n" % tag)
         f.write("Two separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, no trace domain) of\n"
-                "`python3 bench.py --steps 1 --warmup 0 --reads %d --no-cpu-baseline --no-host-leg --check 0` (%d reads of 50 kb = %d alignments).\n"
+                "`python3 bench.py --steps 1 --warmup 0 --reads %d --batches 1 --synth-workers 1 --no-cpu-baseline --no-host-leg --check 0` (%d reads of 50 kb = %d alignments).\n"
                 "Counter unit: KB.  On gfx950 FETCH_SIZE under-counts wide coalesced streams by 2x (MI355X_MICROARCH.md, HBM\n"
                 "section): the x2 column applies that correction as an upper bound; WRITE_SIZE is used as reported.\n"
                 "Values are per-dispatch averages.\n\n" % (pmc_reads, pmc_reads, 2 * pmc_reads))
@@ -155,6 +155,7 @@ def sq_summary(tag, src, out, pmc_reads, consts):
             targs = [x.strip() for x in k.split("<", 1)[1].rstrip(">").split(",")]
             kind = "packed" if (targs[2] if "seg_kernel" in k else targs[-1]) == "true" else "float32"
             consts.setdefault("valu_insts_per_wave_step", {})[kind] = sum(iv[k]) / len(iv[k]) / steps
+            consts.setdefault("valu_insts_per_wave_step_by_kernel", {})[k.replace("strq::", "")] = sum(iv[k]) / len(iv[k]) / steps      # bench.py looks the launched instance up by name
             consts.setdefault("kernels", {})[kind] = k
             consts.setdefault("issue_utilisation_counters", {})[kind] = {
                 "SQ_INSTS_VALU": sum(iv[k]) / len(iv[k]), "wave_steps": steps,
