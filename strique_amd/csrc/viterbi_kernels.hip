@@ -57,6 +57,15 @@ static __device__ __forceinline__ double readlane_f64(double v, int l)
 
 #define VIT_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
+// -DSTRQ_VIT_TIMING (diagnostic build, tools/vit_timing.py): shader cycles spent in the four parts of a time step, summed
+// over all waves -- [0] emitting phase up to its stores, [1] silent gather + tournament, [2] chain sweeps, [3] stores and loop
+// overhead, [4] time steps.  s_memtime drains the wave's LDS / scalar queues, so the split perturbs what it measures (the
+// parts add up to more than an uninstrumented step); it shows where a step's time goes, not how long a step takes.
+#ifdef STRQ_VIT_TIMING
+__device__ unsigned long long vit_timing_acc[8];
+#define VIT_CLOCK() __builtin_readcyclecounter()
+#endif
+
 // wave_shr:1 -- lane l receives lane l-1; lane 0 receives +0.0 / 0 (bound_ctrl).  The chain sweeps add the
 // chain log-probability afterwards, which is -inf for every lane without a chain predecessor (lane 0
 // never has one), so the filler value cannot survive.
@@ -221,6 +230,9 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             }
         }
         const int64_t T = tk.T;
+#ifdef STRQ_VIT_TIMING
+        unsigned long long tm_emit = 0, tm_gather = 0, tm_sweep = 0, tm_rest = 0, tm_steps = 0, tm_mark = 0;
+#endif
 #ifdef STRQ_VIT_STATS
         uint32_t stat_sweeps = 0;      // debug build (-DSTRQ_VIT_STATS): chain sweeps of the whole window, reported in place of the count
 #endif
@@ -299,7 +311,14 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     if (PIN && own_s[s] == start_state) { best = 0.0; bc = pay_add((Pay)0, -sinc[s]); a = dummy; }
                     y[s] = best; yc[s] = pay_add(bc, sinc[s]); arg[s] = a;
                 }
+#ifdef STRQ_VIT_TIMING
+                const unsigned long long tc_a = VIT_CLOCK();
+#endif
                 chain_sweeps(y, yc, arg);
+#ifdef STRQ_VIT_TIMING
+                const unsigned long long tc_b = VIT_CLOCK();
+                tm_sweep += tc_b - tc_a; tm_mark = tc_a;
+#endif
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) stcell(sdst[s], OFF, y[s], yc[s]);
                 VIT_FENCE();
@@ -373,6 +392,9 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         auto step = [&](auto rd_c, double x, int64_t t) {
             constexpr int RD = decltype(rd_c)::value, WR = RD ? 0 : BUF;
             double nv[EPL]; Pay nc[EPL]; int na[EPL];
+#ifdef STRQ_VIT_TIMING
+            const unsigned long long tc0 = VIT_CLOCK();
+#endif
             const uint32_t tt1 = (uint32_t)(t + 1);                       // wave-uniform: scalar registers
             const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
             (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
@@ -436,7 +458,17 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 for (int s = 0; s < SPL; ++s) stcell(sdst[s], WR, NEGINF, 0);
             }
             VIT_FENCE();
+#ifdef STRQ_VIT_TIMING
+            const unsigned long long tc1 = VIT_CLOCK();
+            tm_emit += tc1 - tc0;
+#endif
             relax_silent(std::false_type{}, std::integral_constant<int, WR>{}, t + 1);
+#ifdef STRQ_VIT_TIMING
+            const unsigned long long tc2 = VIT_CLOCK();
+            tm_gather += tm_mark - tc1;           // silent gather + tournament: up to the first sweep
+            tm_rest += tc2 - tm_mark;             // (includes the sweeps; subtracted on the host)
+            ++tm_steps;
+#endif
         };
 
         relax_silent(std::true_type{}, std::integral_constant<int, 0>{}, 0);
@@ -488,6 +520,12 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         r.counted = stat_sweeps;
 #endif
         results[ti] = r;     // every lane stores the same value
+#ifdef STRQ_VIT_TIMING
+        if (lane == 0) {
+            atomicAdd(&vit_timing_acc[0], tm_emit); atomicAdd(&vit_timing_acc[1], tm_gather); atomicAdd(&vit_timing_acc[2], tm_sweep);
+            atomicAdd(&vit_timing_acc[3], tm_rest - tm_sweep); atomicAdd(&vit_timing_acc[4], tm_steps);
+        }
+#endif
         VIT_FENCE();
     }
 }
@@ -670,3 +708,13 @@ int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResu
 }
 
 }  // namespace strq
+
+#ifdef STRQ_VIT_TIMING
+// diagnostic build only: read and clear the per-phase cycle sums (tools/vit_timing.py)
+extern "C" int strq_debug_vit_timing(unsigned long long out[8])
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(strq::vit_timing_acc), 64) != hipSuccess) return 2;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(strq::vit_timing_acc), z, 64) == hipSuccess ? 0 : 2;
+}
+#endif

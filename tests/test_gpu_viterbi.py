@@ -1,4 +1,10 @@
-"""HIP Viterbi vs the CPU oracle through the C ABI: identical log-probability bits, counts, paths."""
+"""HIP Viterbi vs the CPU oracle through the C ABI: identical log-probability bits, counts, paths.
+
+Both sides of THIS file decode the same baked arrays (the product's `hmm.bake()` output, or random models): it pins
+the kernel against the oracle's decode, not the bake.  That `hmm.bake()` itself equals the reference's model is the
+business of tests/test_oracle_independent.py (three-way decode: graph recorded from the reference's classes, the
+oracle's own un-baked construction, the product's baked arrays) and of every detect-level GPU test, whose
+expectations are built inside oracle/ from sequences, never from product objects."""
 import numpy as np
 import pytest
 
