@@ -190,7 +190,8 @@ def count(argv):
     parser.add_argument("--algn", default=None, help="Alignment in sam format, if not given read from stdin")
     parser.add_argument("--mod_model", default=None, help="Base modification pore model")
     parser.add_argument("--config", help="Config file with HMM transition probabilities")
-    parser.add_argument("--t", type=int, default=1, help="Reader threads that fetch and inflate raw signals ahead of the GPU batches (the reference's worker-process count)")
+    parser.add_argument("--t", type=int, default=0, help="Reader threads that fetch and inflate raw signals ahead of the GPU batches (the reference's worker-process count); "
+                                                          "0 (default): a share of the host's cores, at most 16 per rank")
     parser.add_argument("--log_level", default='warning', choices=LEVELS, help="Log level")
     parser.add_argument("--batch", type=int, default=2048, help="Reads per GPU batch")
     parser.add_argument("--device", type=int, default=0, help="HIP device")
@@ -232,7 +233,12 @@ def count(argv):
     f5 = Fast5Index(args.f5Index)
     stream = open(args.algn) if args.algn else sys.stdin
     out = (open(args.out, 'w') if args.out else sys.stdout) if rank == 0 else None
-    readers = max(1, args.t)
+    readers = args.t
+    if readers <= 0:
+        # one process per GPU: every rank takes its share of the cores (LOCAL_WORLD_SIZE is set by torchrun), half of it for the
+        # readers -- the staging threads of the library and the engine thread want the rest
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        readers = max(1, min(16, (os.cpu_count() or 1) // local_world // 2))
     stats = {}
     fault = 0
     try:
