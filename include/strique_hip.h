@@ -104,7 +104,8 @@ int strq_align_batch(strq_ctx* ctx, int64_t n_align, int64_t n_reads,
  *              wave -- states of one profile column type in one slot, lane = profile position -- so
  *              that the LDS reads of neighbouring lanes are contiguous.  Purely a performance hint:
  *              an invalid or missing hint falls back to an automatic placement, results are identical.
- * Limits: <= 512 emitting and <= 256 silent states, <= 8 in-edges per state.
+ * Models of up to 512 emitting and 256 silent states with at most 8 in-edges per state run on the wave-per-window
+ * kernels; anything beyond, up to 4096 states, on a general (slower) kernel; larger ones return STRQ_ERR_UNSUPPORTED.
  */
 int strq_model_create(strq_ctx* ctx, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                       const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,

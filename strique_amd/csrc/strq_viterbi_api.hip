@@ -221,6 +221,69 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     return STRQ_OK;
 }
 
+// The baked arrays as they are, for viterbi_csr_kernel (models the lane layouts do not cover).
+int build_vit_model_csr(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
+                        const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
+                        const int32_t* emis_kind, const double* emis_a, const double* emis_b, const double* emis_c,
+                        const int32_t* count_inc, const int32_t* state_tag, HostModel** out)
+{
+    const int ne = silent_start, ns = n_states - silent_start;
+    if (n_states > VIT_CSR_MAX_STATES) { c->err = "model too large: more than 4096 states"; return STRQ_ERR_UNSUPPORTED; }
+    HostModel* hm = new HostModel();
+    VitModel& m = hm->h;
+    std::memset(&m, 0, sizeof(m));
+    m.n_states = n_states; m.n_emit = ne; m.n_silent = ns; m.start = start; m.end = end; m.epl = 0; m.spl = 0;
+    m.csr = 1; m.n_cells = n_states + 1; m.start_cell = start; m.end_cell = end; m.rec_state = -1; m.single_stage = 0;
+    // level of a silent state: length of its longest chain of silent predecessors (they are in topological order)
+    std::vector<int> level(n_states, 0); int nlev = 0;
+    for (int l = ne; l < n_states; ++l) {
+        int lv = 0;
+        for (int e = in_ptr[l]; e < in_ptr[l + 1]; ++e) if (in_src[e] >= ne) lv = std::max(lv, level[in_src[e]] + 1);
+        level[l] = lv; nlev = std::max(nlev, lv + 1);
+    }
+    std::vector<int32_t> level_ptr((size_t)nlev + 1, 0), level_state((size_t)std::max(ns, 1), 0);
+    for (int l = ne; l < n_states; ++l) ++level_ptr[(size_t)level[l] + 1];
+    for (int v = 0; v < nlev; ++v) level_ptr[(size_t)v + 1] += level_ptr[v];
+    { std::vector<int32_t> pos(level_ptr.begin(), level_ptr.end() - 1);
+      for (int l = ne; l < n_states; ++l) level_state[(size_t)pos[level[l]]++] = l; }
+    m.n_levels = nlev;
+    m.uni_lo_max = -INFINITY; m.uni_hi_min = INFINITY;
+    for (int e = 0; e < ne; ++e) if (emis_kind[e] == 2) { m.uni_lo_max = std::max(m.uni_lo_max, emis_a[e]); m.uni_hi_min = std::min(m.uni_hi_min, emis_b[e]); }
+    std::vector<int32_t> inc((size_t)n_states + 1, 0), tagv((size_t)n_states + 1, 0);
+    if (count_inc) std::copy(count_inc, count_inc + n_states, inc.begin());
+    if (state_tag) std::copy(state_tag, state_tag + n_states, tagv.begin());
+    const int n_edges = in_ptr[n_states];
+    struct Part { const void* p; size_t bytes; size_t off; };
+    std::vector<Part> parts = {
+        {in_logp, (size_t)n_edges * 8, 0}, {emis_a, (size_t)ne * 8, 0}, {emis_b, (size_t)ne * 8, 0}, {emis_c, (size_t)ne * 8, 0},
+        {in_ptr, ((size_t)n_states + 1) * 4, 0}, {in_src, (size_t)n_edges * 4, 0}, {emis_kind, (size_t)ne * 4, 0},
+        {inc.data(), inc.size() * 4, 0}, {tagv.data(), tagv.size() * 4, 0},
+        {level_ptr.data(), level_ptr.size() * 4, 0}, {level_state.data(), level_state.size() * 4, 0}};
+    size_t total = 0;
+    for (auto& pt : parts) { pt.off = total; total += (pt.bytes + 15) & ~(size_t)15; }
+    const size_t o_m = total; total += sizeof(VitModel);
+    if (hm->blob.reserve(total) != hipSuccess) { delete hm; c->err = "out of device memory"; return STRQ_ERR_NOMEM; }
+    char* d = hm->blob.as<char>();
+    m.csr_in_logp = reinterpret_cast<const double*>(d + parts[0].off);
+    m.csr_a = reinterpret_cast<const double*>(d + parts[1].off);
+    m.csr_b = reinterpret_cast<const double*>(d + parts[2].off);
+    m.csr_c = reinterpret_cast<const double*>(d + parts[3].off);
+    m.csr_in_ptr = reinterpret_cast<const int32_t*>(d + parts[4].off);
+    m.csr_in_src = reinterpret_cast<const int32_t*>(d + parts[5].off);
+    m.csr_kind = reinterpret_cast<const int32_t*>(d + parts[6].off);
+    m.count_inc = reinterpret_cast<const int32_t*>(d + parts[7].off);
+    m.state_tag = reinterpret_cast<const int32_t*>(d + parts[8].off);
+    m.csr_level_ptr = reinterpret_cast<const int32_t*>(d + parts[9].off);
+    m.csr_level_state = reinterpret_cast<const int32_t*>(d + parts[10].off);
+    hm->dev = reinterpret_cast<const VitModel*>(d + o_m);
+    std::vector<char> host(total, 0);
+    for (auto& pt : parts) if (pt.bytes) std::memcpy(&host[pt.off], pt.p, pt.bytes);
+    std::memcpy(&host[o_m], &m, sizeof(VitModel));
+    if (hipMemcpy(d, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) { delete hm; c->err = "model upload failed"; return STRQ_ERR_DEVICE; }
+    *out = hm;
+    return STRQ_OK;
+}
+
 }  // namespace strq
 
 extern "C" {
@@ -235,7 +298,9 @@ int strq_model_create(strq_ctx* c, int32_t n_states, int32_t silent_start, int32
     if (!in_ptr || !in_src || !in_logp || !emis_kind || !emis_a || !emis_b || !emis_c || !model_id) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
     HostModel* hm = nullptr;
-    const int rc = build_vit_model(c, n_states, silent_start, start, end, in_ptr, in_src, in_logp, emis_kind, emis_a, emis_b, emis_c, count_inc, state_tag, hint_slot, hint_lane, &hm);
+    int rc = build_vit_model(c, n_states, silent_start, start, end, in_ptr, in_src, in_logp, emis_kind, emis_a, emis_b, emis_c, count_inc, state_tag, hint_slot, hint_lane, &hm);
+    if (rc == STRQ_ERR_UNSUPPORTED)      // no lane layout: the model runs on the general (slow) kernel
+        rc = build_vit_model_csr(c, n_states, silent_start, start, end, in_ptr, in_src, in_logp, emis_kind, emis_a, emis_b, emis_c, count_inc, state_tag, &hm);
     if (rc) return rc;
     c->models.push_back(hm);
     *model_id = (int32_t)c->models.size() - 1;

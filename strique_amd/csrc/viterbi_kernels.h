@@ -39,7 +39,21 @@ struct VitModel {
     double uni_lo_max, uni_hi_min;    // tightest bounds of the uniform emissions: observations inside them need no range test
     int32_t rec_state, pad2_;         // the hub state (tag 2) with an edge into `end` (e0 of the modification model), or -1
     int32_t e_flat[8];                // emitting slot without a Normal emission (uniform inserts, padding): its emission is a constant per lane
+    // Models no lane layout covers (more than 512 emitting / 256 silent states, more than 8 in-edges): the baked arrays as
+    // they are, for viterbi_csr_kernel -- one workgroup per window, a cell per state, silent states level by level.
+    int32_t csr, n_levels;            // csr = 1: the fields above that describe a lane layout are unused (epl = spl = 0, cell = state)
+    const int32_t* csr_in_ptr;        // n_states + 1
+    const int32_t* csr_in_src;        // in-edges by ascending source
+    const double* csr_in_logp;
+    const int32_t* csr_kind;          // n_emit: 1 Normal, 2 Uniform
+    const double* csr_a;
+    const double* csr_b;
+    const double* csr_c;
+    const int32_t* csr_level_ptr;     // n_levels + 1: silent states by the length of their longest silent predecessor chain
+    const int32_t* csr_level_state;   // n_silent
 };
+#define VIT_SHAPE_CSR 8              // launch_viterbi shape id of those models
+#define VIT_CSR_MAX_STATES 4096      // two buffers of 16-byte cells in 160 KB of LDS
 
 enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };
 

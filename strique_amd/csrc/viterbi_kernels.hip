@@ -530,6 +530,139 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Any baked model (up to VIT_CSR_MAX_STATES states, any in-degree): the recurrence of the oracle written down as it stands.
+// One workgroup of 256 threads per window, one 16-byte {value, payload} cell per state in two LDS buffers; emitting states
+// are dealt to the threads, every state walks its in-edges in baked order with a strict '>' (the first of equal
+// candidates wins, like the lane kernels and pomegranate); silent states go level by level -- a state's level is the
+// length of its longest chain of silent predecessors, so the states of one level only read emitting cells and lower
+// levels -- with a workgroup barrier in between.  Not a throughput path (a flank profile has ~50 levels: ~100 barriers
+// per time step); it exists so that a target whose HMM exceeds the lane layouts (repeat units beyond ~50 nt, states with
+// more than eight in-edges) runs instead of being refused -- the reference takes whatever pomegranate takes
+// (scripts/STRique.py:553-579).  MODE 0: count, 1: back-pointers (predecessor state per (time step, state)), 2: MARK.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+viterbi_csr_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
+                   int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
+{
+    extern __shared__ double lds_d[];
+    __shared__ int next_task;
+    struct alignas(16) Cell { double v; uint64_t c; };
+    const double NEGINF = -__builtin_inf();
+    constexpr bool MARK = MODE == 2, BP = MODE == 1;
+    auto count_add = [](uint64_t v, int inc) -> uint64_t { return (v & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)v + (uint32_t)inc); };
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_task = atomicAdd(queue, 1);
+        __syncthreads();
+        const int tq = next_task;
+        if (tq >= n_tasks) break;
+        const int ti = order ? order[tq] : tq;
+        const VitTask tk = tasks[ti];
+        const VitModel& M = *tk.model;
+        const int n = M.n_states, ne = M.n_emit, start = M.start, nlev = M.n_levels;
+        Cell* buf0 = reinterpret_cast<Cell*>(lds_d); Cell* buf1 = buf0 + n;
+        const int32_t* in_ptr = M.csr_in_ptr; const int32_t* in_src = M.csr_in_src; const double* in_lp = M.csr_in_logp;
+        for (int i = threadIdx.x; i < 2 * n; i += 256) { buf0[i].v = NEGINF; buf0[i].c = 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) buf0[start].v = 0.0;
+        __syncthreads();
+        // silent states of one time step, level by level, in `cur`; t = 0 keeps the start state at 0
+        auto silent = [&](Cell* cur, bool pin, int64_t trow) {
+            for (int lev = 0; lev < nlev; ++lev) {
+                for (int i = M.csr_level_ptr[lev] + threadIdx.x; i < M.csr_level_ptr[lev + 1]; i += 256) {
+                    const int l = M.csr_level_state[i];
+                    if (pin && l == start) { if (BP && tk.bp) tk.bp[(size_t)trow * n + l] = 0xFFFF; continue; }
+                    double best = NEGINF; uint64_t bc = 0; int arg = 0xFFFF;
+                    for (int e = in_ptr[l]; e < in_ptr[l + 1]; ++e) {
+                        const int k = in_src[e];
+                        const double c = cur[k].v + in_lp[e];
+                        if (c > best) { best = c; bc = cur[k].c; arg = k; }
+                    }
+                    cur[l].v = best; cur[l].c = count_add(bc, M.count_inc[l]);
+                    if (BP && tk.bp) tk.bp[(size_t)trow * n + l] = (uint16_t)arg;
+                }
+                __syncthreads();
+            }
+        };
+        silent(buf0, true, 0);
+        const int64_t T = tk.T;
+        for (int64_t t = 0; t < T; ++t) {
+            Cell* prev = (t & 1) ? buf1 : buf0; Cell* cur = (t & 1) ? buf0 : buf1;
+            double x;
+            if (tk.src_kind == VIT_SRC_F64) x = reinterpret_cast<const double*>(tk.sig)[t];
+            else {
+                double sv = tk.src_kind == VIT_SRC_I16_AFFINE ? (double)reinterpret_cast<const int16_t*>(tk.sig)[t] : reinterpret_cast<const double*>(tk.sig)[t];
+                sv = (sv - tk.c1) / tk.h1;
+                sv = sv * tk.h2 + tk.c2;
+                sv = sv < tk.lo ? tk.lo : sv;
+                sv = sv > tk.hi ? tk.hi : sv;
+                x = sv;
+            }
+            const uint32_t tt1 = (uint32_t)(t + 1);
+            const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
+            (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
+            for (int l = threadIdx.x; l < ne; l += 256) {
+                double best = NEGINF; uint64_t bc = 0; int arg = 0xFFFF;
+                for (int e = in_ptr[l]; e < in_ptr[l + 1]; ++e) {
+                    const int k = in_src[e];
+                    const double c = prev[k].v + in_lp[e];
+                    if (c > best) { best = c; bc = prev[k].c; arg = k; }
+                }
+                double em;
+                if (x != x) em = 0.0;                                   // missing observation (viterbi_kernel)
+                else if (M.csr_kind[l] == 1) { const double d = x - M.csr_a[l]; em = M.csr_c[l] - (d * d) * M.csr_b[l]; }
+                else em = (x >= M.csr_a[l] && x <= M.csr_b[l]) ? M.csr_c[l] : NEGINF;
+                uint64_t nc;
+                if constexpr (MARK) {
+                    const bool etag = M.state_tag[l] == 1;
+                    uint32_t lo = (uint32_t)bc + (uint32_t)M.count_inc[l], hi = (uint32_t)(bc >> 32);
+                    const bool entered = ((lo >> 20) | (hi & 0x3FFu)) != 0, left = (hi >> 10) != 0;
+                    const bool set_e = etag && !entered, set_l = !etag && entered && !left;
+                    lo |= set_e ? mark_e_lo : 0u;
+                    hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
+                    nc = ((uint64_t)hi << 32) | lo;
+                } else nc = count_add(bc, M.count_inc[l]);
+                cur[l].v = best + em; cur[l].c = nc;
+                if (BP && tk.bp) tk.bp[(size_t)(t + 1) * n + l] = (uint16_t)arg;
+            }
+            __syncthreads();
+            silent(cur, false, t + 1);
+        }
+        if (threadIdx.x == 0) {
+            const Cell fin = ((T & 1) ? buf1 : buf0)[M.end];
+            const double lp = fin.v;
+            VitResult r; r.logp = lp; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
+            r.dbg[0] = r.dbg[1] = r.dbg[2] = r.dbg[3] = 0;
+            if constexpr (MARK) {
+                const uint32_t plo = (uint32_t)fin.c, phi = (uint32_t)(fin.c >> 32);
+                r.counted = (lp > NEGINF) ? (int64_t)(plo & 0xFFFFFu) : 0;
+                r.dbg[0] = (plo >> 20) | ((phi & 0x3FFu) << 12);
+                r.dbg[1] = phi >> 10;
+                if (tk.T >= VIT_MARK_T_MAX) r.status = 2;
+            } else r.counted = (lp > NEGINF) ? (int64_t)(uint32_t)fin.c : 0;
+            results[ti] = r;
+        }
+    }
+}
+
+static int launch_viterbi_csr(hipStream_t stream, int max_cells, const VitTask* tasks, VitResult* results, int n_tasks,
+                              int* queue, int n_cu, int want_bp, const int* order)
+{
+    if (max_cells - 1 > VIT_CSR_MAX_STATES || want_bp == 3) return 2;
+    const size_t lds = (size_t)2 * (size_t)(max_cells - 1) * 16;
+    int per_cu = (int)((160 * 1024 - 64) / (lds ? lds : 1)); if (per_cu > 4) per_cu = 4; if (per_cu < 1) per_cu = 1;
+    const dim3 grid(per_cu * n_cu), block(256);
+#define VIT_CSR_GO(MODE_)                                                                                                 \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)viterbi_csr_kernel<MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((viterbi_csr_kernel<MODE_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order);  \
+    } while (0)
+    if (want_bp == 2) VIT_CSR_GO(2); else if (want_bp == 1) VIT_CSR_GO(1); else VIT_CSR_GO(0);
+#undef VIT_CSR_GO
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // order[] = task indices by descending T (bitonic sort in LDS, one workgroup; n <= 8192)
 __global__ void __launch_bounds__(1024)
 vit_sort_kernel(const VitTask* __restrict__ tasks, int n, int* __restrict__ order)
@@ -584,10 +717,11 @@ vit_traceback_kernel(const VitTask* __restrict__ tasks, const VitResult* __restr
     const VitModel& M = *tk.model;
     if (results[i].status != 0 || !tk.bp || !paths[i]) return;
     const int n = M.n_states, ne = M.n_emit, start = M.start, ncell = M.n_cells;
-    if (n > VIT_TB_ROWS_U16 || ncell > VIT_TB_CELLS) return;      // cannot happen with the compiled kernel shapes
+    const bool ident = M.csr != 0;          // viterbi_csr_kernel writes predecessor states, not cells
+    if (n > VIT_TB_ROWS_U16 || (!ident && ncell > VIT_TB_CELLS)) return;      // cannot happen with the compiled kernel shapes / the state limit of the csr kernel
     uint32_t* rows32 = rows_all[wave]; const uint16_t* rows = reinterpret_cast<const uint16_t*>(rows32);
     uint16_t* cs = cs_all[wave]; int32_t* pb = pb_all[wave];
-    for (int c = lane; c < ncell; c += 64) { const int st = M.cell_state[c]; cs[c] = (uint16_t)(st < 0 ? 0xFFFF : st); }
+    if (!ident) for (int c = lane; c < ncell; c += 64) { const int st = M.cell_state[c]; cs[c] = (uint16_t)(st < 0 ? 0xFFFF : st); }
     int RB = (VIT_TB_ROWS_U16 - 2) / n; if (RB > VIT_TB_MAXROWS) RB = VIT_TB_MAXROWS;
     int32_t* path = paths[i];
     int64_t t = tk.T; int l = M.end;
@@ -605,7 +739,7 @@ vit_traceback_kernel(const VitTask* __restrict__ tasks, const VitResult* __restr
         const int64_t t_hi = t;                                       // path entries tb-1 .. t_hi-1 may be produced here
         while (t >= tb && !(t == 0 && l == start)) {
             const int pcell = rows[(int)(t - tb) * n + l + shift];
-            const int prev = pcell < ncell ? cs[pcell] : 0xFFFF;
+            const int prev = ident ? (pcell < n ? pcell : 0xFFFF) : (pcell < ncell ? cs[pcell] : 0xFFFF);
             if (prev == 0xFFFF || prev >= n) { bad = true; break; }
             if (l < ne) { if (lane == 0) pb[(int)(t - tb)] = l; --t; guard = 0; }      // path[t-1] <- l, kept at slot (t-1) - (tb-1)
             else if (++guard > n) { bad = true; break; }
@@ -650,6 +784,7 @@ int vit_shape_silent_slots(int shape)
 
 int vit_shape_of(const VitModel& mh)
 {
+    if (mh.csr) return VIT_SHAPE_CSR;
     const int b = vit_shape_base(mh);
     return b < 0 ? b : (b | (mh.single_stage ? VIT_SHAPE_SS : 0));
 }
@@ -686,6 +821,7 @@ int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* 
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
 {
     const int ss = (shape & VIT_SHAPE_SS) ? 1 : 0;
+    if ((shape & ~VIT_SHAPE_SS) == VIT_SHAPE_CSR) return launch_viterbi_csr(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
     switch (shape & ~VIT_SHAPE_SS) {
         case 0: return vit_launch_shape<4, 2, 6, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 1: return vit_launch_shape<1, 1, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);

@@ -308,7 +308,8 @@ def test_odd_signals_against_the_oracle(gpu_counter, want, pm, targets):
 def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
     """repeat_config.tsv rows are the user's: flanks shorter than the 50 nt the HMM takes (no trim), much longer
     than the bundled 150 nt (a flank of more than 960 samples runs as strips of 768 rows, up to 64 of them), a two-letter
-    and a twelve-letter repeat.  Every field equals the oracle's on both strands."""
+    and a twelve-letter repeat; repeat units of 70 and 120 nt, whose HMMs exceed every lane layout and run on the general
+    kernel (viterbi_csr_kernel).  Every field equals the oracle's on both strands."""
     from strique_amd import synth
     from strique_amd.counter import repeatCounter
     rng = np.random.default_rng(31337)
@@ -316,7 +317,8 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
     custom = {"short": ("CAG", nt(30), nt(44)), "long": ("GGCCTG", nt(230), nt(201)), "uneven": ("CA", nt(64), nt(170)),
               "dodeca": ("CCCCGCCCCGCG", nt(120), nt(98)), "longer": ("CTG", nt(300), nt(415)), "longest": ("GAA", nt(1029), nt(163)),
               "vntr33": (nt(33), nt(150), nt(150)), "vntr48": (nt(48), nt(150), nt(150)),      # larger HMMs: other kernel shapes
-              "kb3": ("CAG", nt(3000), nt(260))}                                               # 24 strips of 768 flank rows
+              "kb3": ("CAG", nt(3000), nt(260)),                                               # 24 strips of 768 flank rows
+              "vntr70": (nt(70), nt(150), nt(150)), "vntr120": (nt(120), nt(150), nt(150))}    # 600 / 800 emitting states: no lane layout, the general kernel
     rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
     for name, t in custom.items():
         rc.add_target(name, *t)
@@ -325,7 +327,10 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
     items = []
     for k, name in enumerate(custom):
         for strand in "+-":
-            sig = synth.make_read(table, 9, 7000 + 2 * k + (strand == "-"), 6500 + 700 * k, custom[name], 12 + 9 * k, strand=strand)[0]
+            unit, pre, suf = custom[name]
+            total = 6500 + 700 * k
+            nrep = min(12 + 9 * k, (total - len(pre) - len(suf) - 2100) // len(unit))       # leave 2 kb of backbone around the locus
+            sig = synth.make_read(table, 9, 7000 + 2 * k + (strand == "-"), total, custom[name], nrep, strand=strand)[0]
             items.append((name, sig, strand))
     got = rc.detect_batch(items)
     for (name, sig, strand), g in zip(items, got):
@@ -334,8 +339,8 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
         assert g[0] > 0, (name, strand, g)
     with pytest.raises(Exception, match="flank shape"):
         rc.add_target("too_long", "CAG", nt(8198), nt(100))
-    with pytest.raises(Exception, match="model too large"):      # 600 emitting states: more than 8 per lane
-        rc.add_target("vntr70", nt(70), nt(150), nt(150))
+    with pytest.raises(Exception, match="more than 4096 states"):      # beyond the LDS of the general kernel
+        rc.add_target("vntr2000", nt(2000), nt(150), nt(150))
 
 
 @pytest.mark.parametrize("samples", [4, 8, 9, 12])

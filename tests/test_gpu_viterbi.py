@@ -148,3 +148,40 @@ def test_missing_observations(ctx, orc, pm, cfg):
         assert np.array_equal(po, pg)
         lg2, cg2, _, _ = ctx.viterbi(mid, xn, want_path=False)
         assert lg2 == lg and cg2 == cg
+
+
+@pytest.mark.parametrize("ne,ns,multi,fan", [(600, 300, True, 4), (1500, 700, False, 4), (40, 12, True, 14), (2600, 1400, True, 5)])
+def test_models_beyond_the_lane_layouts_run_on_the_general_kernel(ctx, orc, ne, ns, multi, fan):
+    """More than 512 emitting / 256 silent states, or more than eight in-edges per state: no lane layout exists and the
+    model goes to viterbi_csr_kernel (one workgroup per window, silent states level by level).  Log-probability bits,
+    counts and full state paths equal the oracle's; a model beyond 4096 states is refused when it is registered."""
+    from strique_amd import ffi
+    rng = np.random.default_rng(7000 + ne)
+    baked = _random_model(rng, ne, ns, multi)
+    if fan > 8:                                   # widen the in-degree of some emitting states beyond 8
+        in_ptr = [0]; src = []; lp = []
+        for l in range(baked.n_states):
+            ks = list(baked.in_src[baked.in_ptr[l]:baked.in_ptr[l + 1]]); ps = list(baked.in_logp[baked.in_ptr[l]:baked.in_ptr[l + 1]])
+            if l < ne and l % 3 == 0:
+                extra = [int(k) for k in rng.choice(ne, size=fan, replace=False) if int(k) not in ks]
+                ks += extra; ps += [float(np.log(rng.uniform(0.05, 0.9))) for _ in extra]
+                order = np.argsort(ks); ks = [ks[i] for i in order]; ps = [ps[i] for i in order]
+            src += ks; lp += ps; in_ptr.append(len(src))
+        baked = baked._replace(in_ptr=np.array(in_ptr, np.int32), in_src=np.array(src, np.int32), in_logp=np.array(lp))
+    mid = ctx.model_create(baked)
+    for T in (1, 9, 120):
+        x = rng.uniform(55, 125, T)
+        if T == 120:
+            x[::7] = np.nan                       # missing observations as well
+        lo, po, co = orc.viterbi(baked, x)
+        lg, cg, sg, pg = ctx.viterbi(mid, x, want_path=True)
+        if po is None:
+            assert sg == 1 and lg == -np.inf
+            continue
+        assert np.float64(lo).tobytes() == np.float64(lg).tobytes() and sg == 0 and co == cg
+        assert np.array_equal(po, pg)
+        lg2, cg2, _, _ = ctx.viterbi(mid, x, want_path=False)
+        assert lg2 == lg and cg2 == cg
+    if ne == 2600:
+        with pytest.raises(ffi.StriqueHipError, match="more than 4096 states"):
+            ctx.model_create(_random_model(rng, 3000, 1200, False))
