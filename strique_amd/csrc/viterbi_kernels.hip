@@ -389,8 +389,11 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         };
 
         // one observation: emitting states from the buffer at RD into the buffer at WR, then its silent states
-        auto step = [&](auto rd_c, double x, int64_t t) {
+        // FAST: the window's clipped observations cannot leave a uniform emission's support (and are numbers): decided once
+        // per window, outside the time loop -- inside it the choice costs ~20 scalar instructions of exec-mask bookkeeping per step
+        auto step = [&](auto rd_c, auto fast_c, double x, int64_t t) {
             constexpr int RD = decltype(rd_c)::value, WR = RD ? 0 : BUF;
+            constexpr bool FAST = decltype(fast_c)::value;
             double nv[EPL]; Pay nc[EPL]; int na[EPL];
 #ifdef STRQ_VIT_TIMING
             const unsigned long long tc0 = VIT_CLOCK();
@@ -412,7 +415,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                 tournament(cv, cc, ca, de_of(s));
                 const double best = cv[0]; const Pay bc = cc[0]; const int a = ca[0];
                 double em;
-                if (fast_em) {          // every observation of this window lies inside all uniform emissions
+                if constexpr (FAST) {          // every observation of this window lies inside all uniform emissions
                     if constexpr (LO_FLAT) {
                         if (s >= (EPL + 1) / 2) em = ecf[s];
                         else { const double d = x - ea[s]; em = ecf[s] - (d * d) * ebf[s]; }
@@ -473,6 +476,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 
         relax_silent(std::true_type{}, std::integral_constant<int, 0>{}, 0);
 
+        auto run_window = [&](auto fast_c) {
         double xchunk = 0.0;
         for (int64_t t0 = 0; t0 < T; t0 += 64) {
             // observations t0 .. t0+63, one per lane
@@ -496,10 +500,13 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
             const int send = (int)((T - t0) < 64 ? (T - t0) : 64);
             // chunks start at even t, so the buffer roles alternate A->B, B->A inside every pair
             for (int s0 = 0; s0 < send; s0 += 2) {
-                step(std::integral_constant<int, 0>{}, readlane_f64(xchunk, s0), t0 + s0);
-                if (s0 + 1 < send) step(std::integral_constant<int, BUF>{}, readlane_f64(xchunk, s0 + 1), t0 + s0 + 1);
+                step(std::integral_constant<int, 0>{}, fast_c, readlane_f64(xchunk, s0), t0 + s0);
+                if (s0 + 1 < send) step(std::integral_constant<int, BUF>{}, fast_c, readlane_f64(xchunk, s0 + 1), t0 + s0 + 1);
             }
         }
+        };
+        if (__builtin_amdgcn_readfirstlane((int)fast_em) != 0) run_window(std::true_type{});
+        else run_window(std::false_type{});
         const Cell fin = ldcell(vbase + 16 * m_end, (T & 1) ? BUF : 0);
         const double lp = fin.v;
         VitResult r; r.logp = lp; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
