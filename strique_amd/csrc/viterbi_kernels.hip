@@ -152,11 +152,17 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         if constexpr (WIDE) x.c = ((uint64_t)q.w << 32) | q.z; else x.c = (int)q.z;
         return x;
     };
-    auto stcell = [](char* p, int boff, double v, Pay c) {      // one ds_write_b128
+    typedef unsigned v3u __attribute__((ext_vector_type(3)));
+    auto stcell = [](char* p, int boff, double v, Pay c) {      // one ds_write_b128, or ds_write_b96 when the payload is 32 bits
         const uint64_t u = __builtin_bit_cast(uint64_t, v);
-        v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32);
-        if constexpr (WIDE) { q.z = (unsigned)c; q.w = (unsigned)((uint64_t)c >> 32); } else { q.z = (unsigned)c; q.w = 0u; }
-        *reinterpret_cast<v4u*>(p + boff) = q;
+        if constexpr (WIDE) {
+            v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = (unsigned)c; q.w = (unsigned)((uint64_t)c >> 32);
+            *reinterpret_cast<v4u*>(p + boff) = q;
+        } else {
+            // the fourth dword of a cell is never read as data: no register to fill, and the store moves 12 instead of 16 bytes per lane
+            v3u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = (unsigned)c;
+            *reinterpret_cast<v3u*>(p + boff) = q;
+        }
     };
     auto pay_add = [](Pay v, int inc) -> Pay {       // count += inc (the count field never carries out of the low half)
         if constexpr (HUB) return v;          // the modification model counts nothing
@@ -398,6 +404,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #ifdef STRQ_VIT_TIMING
             const unsigned long long tc0 = VIT_CLOCK();
 #endif
+
             const uint32_t tt1 = (uint32_t)(t + 1);                       // wave-uniform: scalar registers
             const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
             (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
