@@ -14,6 +14,7 @@
 // These kernels are byte/short streaming: coalesced 2-byte loads, LDS tiles for the four sliding
 // min/max passes, histograms accumulated in an LDS window per tile and flushed bin by bin.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <type_traits>
 #include "cond_kernels.h"
@@ -157,6 +158,101 @@ medfilt_hist16_kernel(const int16_t* __restrict__ raw_all, int16_t* __restrict__
             const int v = m[k], w = v - lo;
             if (w < HIST_WIN) atomicAdd(&bins[w], 1u);
             else atomicAdd(&hist[v + 32768], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < HIST_WIN; b += 256) { const uint32_t c = bins[b]; if (c) atomicAdd(&hist[lo + b + 32768], c); }
+}
+
+// The same, 16 bytes per lane: every thread takes eight consecutive samples with one aligned 16-byte load and stores the
+// eight filtered samples with one 16-byte store (2-byte accesses -- 128 bytes per wave instruction -- leave the kernel
+// waiting on memory latency at a quarter of the HBM rate).  Reads sit back to back in the batch, so a read starts anywhere
+// inside a 16-byte line: tiles are laid out in aligned vector space, `a0` samples before the read's first sample, and the
+// vectors that straddle the read's ends are masked (loads stay inside the batch buffer, which has slack at both ends of a
+// sub-batch; stores of partial vectors go sample by sample -- the bytes next to them belong to the neighbouring read).
+// `raw` and `flt` must have the same alignment phase (strq_detect_api.hip shifts the filtered buffer accordingly).
+__global__ void __launch_bounds__(256)
+medfilt_hist16_vec_kernel(const int16_t* __restrict__ raw_all, int16_t* __restrict__ flt_all, const ReadCond* __restrict__ rc_all,
+                          uint32_t* __restrict__ hist_all, uint32_t* __restrict__ range_all, int range_stride)
+{
+    __shared__ uint32_t bins[HIST_WIN];
+    __shared__ int tmin, tmax;
+    const ReadCond rc = rc_all[blockIdx.y];
+    const int n = rc.n;
+    const int16_t* raw = raw_all + rc.off;
+    int16_t* flt = flt_all + rc.off;
+    const int a0 = (int)((reinterpret_cast<uintptr_t>(raw) >> 1) & 7);      // samples between the 16-byte boundary in front of the read and its first sample
+    const int v_base = blockIdx.x * (HIST_TILE / 8);                        // first vector of the tile (vector v holds samples 8v - a0 ... 8v - a0 + 7)
+    if (8 * v_base - a0 >= n) return;
+    const int4* raw_al = reinterpret_cast<const int4*>(raw - a0);
+    int4* flt_al = reinterpret_cast<int4*>(flt - a0);
+    uint32_t* hist = hist_all + (size_t)blockIdx.y * 65536;
+    if (threadIdx.x == 0) { tmin = 32767; tmax = -32768; }
+    for (int b = threadIdx.x; b < HIST_WIN; b += 256) bins[b] = 0;
+    constexpr int PER = HIST_TILE / 8 / 256;      // vectors per thread
+    int16_t m[PER][8];
+    int mn = 32767, mx = -32768;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int v = v_base + k * 256 + threadIdx.x;
+        const int i0 = 8 * v - a0;
+        if (i0 + 7 >= 0 && i0 < n) {
+            const int4 w = raw_al[v];
+            int sx[10];      // sx[e + 1] = sample i0 + e; sx[0], sx[9]: the neighbours
+            const int ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sx[e + 1] = (int)(int16_t)((uint32_t)ww[e >> 1] >> (16 * (e & 1)));
+            sx[0] = i0 - 1 >= 0 ? (int)raw[i0 - 1] : 0;
+            sx[9] = i0 + 8 < n ? (int)raw[i0 + 8] : 0;
+            const bool whole = i0 >= 0 && i0 + 7 < n;
+            int o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = i0 + e;
+                // zero padding at the ends of the read (scipy medfilt): what lies beyond belongs to another read
+                const int a = idx - 1 >= 0 ? sx[e] : 0, c = sx[e + 1], b = idx + 1 < n ? sx[e + 2] : 0;
+                o[e] = med3<int>(a, c, b);
+            }
+            if (whole) {
+                int4 q;
+                q.x = (o[0] & 0xffff) | (o[1] << 16); q.y = (o[2] & 0xffff) | (o[3] << 16);
+                q.z = (o[4] & 0xffff) | (o[5] << 16); q.w = (o[6] & 0xffff) | (o[7] << 16);
+                flt_al[v] = q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { m[k][e] = (int16_t)o[e]; mn = o[e] < mn ? o[e] : mn; mx = o[e] > mx ? o[e] : mx; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int idx = i0 + e;
+                    m[k][e] = (int16_t)o[e];
+                    if (idx >= 0 && idx < n) { flt[idx] = (int16_t)o[e]; mn = o[e] < mn ? o[e] : mn; mx = o[e] > mx ? o[e] : mx; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[k][e] = 0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(mn, o, 64); mn = x < mn ? x : mn; const int y = __shfl_xor(mx, o, 64); mx = y > mx ? y : mx; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicMin(&tmin, mn); atomicMax(&tmax, mx); }
+    __syncthreads();
+    const int lo = tmin;
+    if (threadIdx.x == 0 && range_all && tmax >= tmin) {
+        atomicMax(&range_all[(size_t)blockIdx.y * range_stride], (uint32_t)(tmax + 32768));
+        atomicMax(&range_all[(size_t)blockIdx.y * range_stride + 1], (uint32_t)(65535 - (tmin + 32768)));
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i0 = 8 * (v_base + k * 256 + threadIdx.x) - a0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = i0 + e;
+            if (idx >= 0 && idx < n) {
+                const int v = m[k][e], w = v - lo;
+                if (w < HIST_WIN) atomicAdd(&bins[w], 1u);
+                else atomicAdd(&hist[v + 32768], 1u);
+            }
         }
     }
     __syncthreads();
@@ -438,7 +534,12 @@ int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, con
 {
     if (n_reads <= 0 || max_n <= 0) return 0;
     const dim3 hgrid((max_n + HIST_TILE - 1) / HIST_TILE, n_reads);
-    if (hist_flt) hipLaunchKernelGGL(medfilt_hist16_kernel, hgrid, dim3(256), 0, s, raw, flt, rc, hist_flt, range4, 4);
+    // 16 bytes per lane when the raw and the filtered buffer have the same alignment phase (the caller arranges that);
+    // its tiles start up to seven samples in front of a read: one more tile covers the longest read
+    const bool same_phase = ((reinterpret_cast<uintptr_t>(raw) ^ reinterpret_cast<uintptr_t>(flt)) & 15) == 0 && !getenv("STRQ_COND_SCALAR");
+    const dim3 vgrid((max_n + 7 + HIST_TILE - 1) / HIST_TILE, n_reads);
+    if (hist_flt && same_phase) hipLaunchKernelGGL(medfilt_hist16_vec_kernel, vgrid, dim3(256), 0, s, raw, flt, rc, hist_flt, range4, 4);
+    else if (hist_flt) hipLaunchKernelGGL(medfilt_hist16_kernel, hgrid, dim3(256), 0, s, raw, flt, rc, hist_flt, range4, 4);
     else hipLaunchKernelGGL((medfilt_kernel<int16_t>), tile_grid(max_n, n_reads), dim3(256), 0, s, raw, flt, rc, hist_flt, hist_raw);
     if (hist_raw) hipLaunchKernelGGL(hist16_kernel, hgrid, dim3(256), 0, s, raw, rc, hist_raw, range4 ? range4 + 2 : nullptr, 4);
     return hipGetLastError() == hipSuccess ? 0 : 1;

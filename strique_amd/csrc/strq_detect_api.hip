@@ -390,7 +390,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         }
     }
     loff[nr] = tot;
-    STRQ_HIP(c, d->flt.reserve((size_t)tot * esz + 64));
+    STRQ_HIP(c, d->flt.reserve((size_t)tot * esz + 64 + 16));
     STRQ_HIP(c, c->levels.reserve((size_t)tot + 64));
     STRQ_HIP(c, c->level_val.reserve((size_t)nr * 256 * 4));
     STRQ_HIP(c, d->rc.reserve((size_t)nr * sizeof(ReadCond)));
@@ -400,6 +400,9 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     STRQ_HIP(c, hipMemcpyAsync(d_rc, rc.data(), (size_t)nr * sizeof(ReadCond), hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemsetAsync(d->hist8.p, 0, (size_t)nr * 256 * 4, st));
     const char* raw = d->batch.raw.as<char>() + (size_t)s0 * esz;
+    // the filtered signal of the sub-batch starts at the same offset inside a 16-byte line as its raw signal, so that the
+    // conditioning kernels can move both with aligned 16-byte accesses
+    char* const flt_base = d->flt.as<char>() + (reinterpret_cast<uintptr_t>(raw) & 15);
     bool any_mod = false;
     for (int i = 0; i < nr; ++i) any_mod |= d->targets[B.target[r0 + i]].mod_model_id >= 0;
     uint32_t* d_hist_raw = nullptr; uint32_t* d_range = nullptr;
@@ -468,13 +471,13 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
             uint32_t* h16 = d->hist16.as<uint32_t>() + (size_t)i0 * 65536;
             uint32_t* hraw = d_hist_raw ? d_hist_raw + (size_t)i0 * 65536 : nullptr;
             uint32_t* rng = d_range + (size_t)i0 * 4;
-            bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), d->flt.as<int16_t>(), d_rc + i0, np_, max_n, h16, hraw, rng);
+            bad |= launch_medfilt_hist_i16(st, reinterpret_cast<const int16_t*>(raw), reinterpret_cast<int16_t*>(flt_base), d_rc + i0, np_, max_n, h16, hraw, rng);
             bad |= launch_hist_stats(st, h16, 65536, -32768, d_rc + i0, np_, d->ps, 0, nullptr, rng, 4);
             if (any_mod) bad |= launch_hist_stats(st, hraw, 65536, -32768, d_rc + i0, np_, d->ps, 2, nullptr, rng + 2, 4);
-            bad |= launch_quant_morph_i16(st, d->flt.as<int16_t>(), levels, d_rc + i0, np_, max_n, hist8);
+            bad |= launch_quant_morph_i16(st, reinterpret_cast<const int16_t*>(flt_base), levels, d_rc + i0, np_, max_n, hist8);
         } else {
-            bad |= launch_medfilt_f64(st, reinterpret_cast<const double*>(raw), d->flt.as<double>(), d_rc + i0, np_, max_n);
-            bad |= launch_quant_morph_f64(st, d->flt.as<double>(), levels, d_rc + i0, np_, max_n, hist8);
+            bad |= launch_medfilt_f64(st, reinterpret_cast<const double*>(raw), reinterpret_cast<double*>(flt_base), d_rc + i0, np_, max_n);
+            bad |= launch_quant_morph_f64(st, reinterpret_cast<const double*>(flt_base), levels, d_rc + i0, np_, max_n, hist8);
         }
         bad |= launch_hist_stats(st, hist8, 256, 0, d_rc + i0, np_, d->ps, 1, level_val, nullptr, 0);
         if (bad) { c->err = "conditioning launch failed"; return STRQ_ERR_DEVICE; }
@@ -509,7 +512,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         STRQ_HIP(c, hipMemcpyAsync(d_trim + 2 * (size_t)i0, trim.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
         FinalizeArgs fa;
         fa.tasks = co.d_tasks; fa.results = co.d_results; fa.task_of = d_task_of + 2 * (size_t)i0; fa.trim = d_trim + 2 * (size_t)i0; fa.vit_slot = d_slot + i0;
-        fa.rc = d_rc + i0; fa.model_of = d_model_of + i0; fa.flt = d->flt.p; fa.is_f64 = B.dtype; fa.ps = d->ps;
+        fa.rc = d_rc + i0; fa.model_of = d_model_of + i0; fa.flt = flt_base; fa.is_f64 = B.dtype; fa.ps = d->ps;
         fa.geom = d->geom.as<ReadGeom>() + i0; fa.vit = d->vit.as<VitTask>(); fa.n_reads = np_;
         hipLaunchKernelGGL(finalize_kernel, dim3((np_ + 127) / 128), dim3(128), 0, st, fa);
         STRQ_HIP(c, hipGetLastError());

@@ -469,3 +469,28 @@ def test_filtered_signal_without_tails_is_decoded_as_missing_values(gpu_counter,
     assert tuple(g) == tuple(w), (g, w)
     rc.ctx.close()
 
+
+
+def test_large_repeat_unit_with_the_modification_model(pm, pm_mod, cfg, orc, opm, opm_mod):
+    """A 70-nt repeat unit with CpGs: the flanked HMM (600 emitting states) runs on the general kernel in MARK mode
+    (the stretch decoded as `repeat*` is carried along the best path there as well), the dual base / mCpG model of
+    such a unit on the lane kernels with back-pointers or hub records.  Whole tuple, pattern string included."""
+    from strique_amd import synth
+    from strique_amd.counter import repeatCounter
+    rng = np.random.default_rng(707)
+    unit = "".join(rng.choice(list("ACGT"), 70))
+    unit = unit[:10] + "CG" + unit[12:40] + "CG" + unit[42:]
+    target = (unit, "".join(rng.choice(list("ACGT"), 150)), "".join(rng.choice(list("ACGT"), 150)))
+    rc = repeatCounter(pm, mod_model_file=pm_mod, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    rc.add_target("big", *target)
+    params = orc.align_params(cfg["align"])
+    items = []
+    for k, (table, strand) in enumerate(((synth.KmerTable(pm), "+"), (synth.KmerTable(pm_mod), "-"))):
+        items.append(("big", synth.make_read(table, 12, 70 + k, 9000, target, 40 + 15 * k, strand=strand)[0], strand))
+    got = rc.detect_batch(items)
+    for (name, sig, strand), g in zip(items, got):
+        tc = orc.classifier(*target, strand, opm, opm_mod, cfg["HMM"])
+        w = orc.detect(sig, tc, opm, params, pm_mod=opm_mod)[0]
+        assert tuple(g) == tuple(w), (strand, g, w)
+        assert g[0] > 0 and set(g[6]) <= set("01") and len(g[6]) > 0
+    rc.ctx.close()
