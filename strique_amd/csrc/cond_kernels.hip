@@ -414,9 +414,12 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
     __shared__ uint32_t h8[256];
     const ReadCond rc = rc_all[blockIdx.y];
     const int n = rc.n;
-    const int t0 = blockIdx.x * COND_TILE;
-    if (t0 >= n || !(rc.mad > 0.0)) return;      // constant signal: z-score undefined, no levels (hist_stats reports NaN level values)
     const T* flt = flt_all + rc.off;
+    // int16: tiles start `a0` samples in front of the read, on a 16-byte boundary of the filtered signal, so that an interior
+    // tile reads it with aligned 16-byte loads (a read starts anywhere inside a line: the reads of a batch sit back to back)
+    const int a0 = sizeof(T) == 2 ? (int)((reinterpret_cast<uintptr_t>(flt) >> 1) & 7) : 0;
+    const int t0 = blockIdx.x * COND_TILE - a0;
+    if (t0 >= n || !(rc.mad > 0.0)) return;      // constant signal: z-score undefined, no levels (hist_stats reports NaN level values)
     const int lo = t0 - COND_HALO, span = COND_TILE + 2 * COND_HALO;
     h8[threadIdx.x] = 0;
     uint8_t* levels = levels_all + rc.off;
@@ -425,8 +428,8 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
         // samples per thread, the sliding 8-wide min / max of a stage from 16 input bytes in registers
         // (suffix extrema of bytes 0..7, prefix extrema of bytes 8..15, one combine per output)
         constexpr int NG = (COND_TILE + 2 * COND_HALO) / 8;      // groups of 8 samples
-        auto quant = [&](int i) -> uint32_t {
-            double z = ((double)flt[i] - rc.med) / rc.mad;
+        auto quantv = [&](double f) -> uint32_t {
+            double z = (f - rc.med) / rc.mad;
             z = z * 24.0 + 127.0;
             z = z < 0.0 ? 0.0 : z;
             z = z > 255.0 ? 255.0 : z;
@@ -434,8 +437,18 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
         };
         for (int g = threadIdx.x; g < NG; g += 256) {
             const int i = lo + 8 * g;
-            const uint32_t w0 = quant(i) | (quant(i + 1) << 8) | (quant(i + 2) << 16) | (quant(i + 3) << 24);
-            const uint32_t w1 = quant(i + 4) | (quant(i + 5) << 8) | (quant(i + 6) << 16) | (quant(i + 7) << 24);
+            double f[8];
+            if constexpr (sizeof(T) == 2) {
+                const int4 w = *reinterpret_cast<const int4*>(flt + i);          // aligned: lo + a0 is a multiple of 8
+                const int ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (double)(int16_t)((uint32_t)ww[e >> 1] >> (16 * (e & 1)));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (double)flt[i + e];
+            }
+            const uint32_t w0 = quantv(f[0]) | (quantv(f[1]) << 8) | (quantv(f[2]) << 16) | (quantv(f[3]) << 24);
+            const uint32_t w1 = quantv(f[4]) | (quantv(f[5]) << 8) | (quantv(f[6]) << 16) | (quantv(f[7]) << 24);
             reinterpret_cast<uint32_t*>(bufA)[2 * g] = w0; reinterpret_cast<uint32_t*>(bufA)[2 * g + 1] = w1;
         }
         __syncthreads();
@@ -475,8 +488,17 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
         stage8(bufB, bufA, std::integral_constant<int, 0>{}, std::false_type{});      // dilation  (opening, second stage)
         stage8(bufA, bufB, std::integral_constant<int, 1>{}, std::false_type{});      // dilation  (closing, first stage)
         stage8(bufB, bufA, std::integral_constant<int, 0>{}, std::true_type{});       // erosion   (closing, second stage)
-        for (int x = threadIdx.x; x < COND_TILE; x += 256) {
-            const uint8_t v = bufA[x + COND_HALO]; levels[t0 + x] = v; atomicAdd(&h8[v], 1u);
+        if ((reinterpret_cast<uintptr_t>(levels + t0) & 7) == 0) {
+            // eight levels per thread, one 8-byte store (the caller gives the level buffer the phase that makes this hold)
+            static_assert(COND_TILE == 8 * 256, "one group of eight per thread");
+            const uint2 q = *reinterpret_cast<const uint2*>(bufA + COND_HALO + 8 * threadIdx.x);
+            *reinterpret_cast<uint2*>(levels + t0 + 8 * threadIdx.x) = q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&h8[((e < 4 ? q.x : q.y) >> (8 * (e & 3))) & 255u], 1u);
+        } else {
+            for (int x = threadIdx.x; x < COND_TILE; x += 256) {
+                const uint8_t v = bufA[x + COND_HALO]; levels[t0 + x] = v; atomicAdd(&h8[v], 1u);
+            }
         }
         __syncthreads();
         if (h8[threadIdx.x]) atomicAdd(&hist8[(size_t)blockIdx.y * 256 + threadIdx.x], h8[threadIdx.x]);
@@ -521,13 +543,13 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
     stage(bufB, bufA, -4, 3, true);      // erosion   (closing, second stage)
     for (int x = threadIdx.x; x < COND_TILE; x += 256) {
         const int i = t0 + x;
-        if (i < n) { const uint8_t v = bufA[x + COND_HALO]; levels[i] = v; atomicAdd(&h8[v], 1u); }
+        if (i >= 0 && i < n) { const uint8_t v = bufA[x + COND_HALO]; levels[i] = v; atomicAdd(&h8[v], 1u); }
     }
     __syncthreads();
     if (h8[threadIdx.x]) atomicAdd(&hist8[(size_t)blockIdx.y * 256 + threadIdx.x], h8[threadIdx.x]);
 }
 
-static inline dim3 tile_grid(int max_n, int n_reads) { return dim3((max_n + COND_TILE - 1) / COND_TILE, n_reads); }
+static inline dim3 tile_grid(int max_n, int n_reads) { return dim3((max_n + 7 + COND_TILE - 1) / COND_TILE, n_reads); }      // + 7: tiles may start up to seven samples in front of a read
 
 int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, const ReadCond* rc, int n_reads, int max_n,
                             uint32_t* hist_flt, uint32_t* hist_raw, uint32_t* range4)

@@ -140,6 +140,7 @@ struct DetectState {
     DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
+    int levels_shift = 0;                // bytes the level stream of the current sub-batch starts behind the buffer's base (alignment phase)
     hipStream_t copy_stream = nullptr;   // host -> HBM uploads that overlap the kernels of the previous sub-batch
     static constexpr int N_STAGE = 4;    // pinned staging ring of upload_reads
     void* stage[N_STAGE] = {}; hipEvent_t stage_ev[N_STAGE] = {}; bool stage_busy[N_STAGE] = {};
@@ -391,7 +392,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     }
     loff[nr] = tot;
     STRQ_HIP(c, d->flt.reserve((size_t)tot * esz + 64 + 16));
-    STRQ_HIP(c, c->levels.reserve((size_t)tot + 64));
+    STRQ_HIP(c, c->levels.reserve((size_t)tot + 64 + 8));
     STRQ_HIP(c, c->level_val.reserve((size_t)nr * 256 * 4));
     STRQ_HIP(c, d->rc.reserve((size_t)nr * sizeof(ReadCond)));
     STRQ_HIP(c, d->hist8.reserve((size_t)nr * 256 * 4));
@@ -464,7 +465,9 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         if (part == 0) STRQ_HIP(c, hipEventRecord(d->ev[0], st));
         // ---- conditioning (STRique.py:590-597)
         int bad = 0;
-        uint8_t* levels = c->levels.as<uint8_t>();
+        // levels: the same sample phase as the raw / filtered signal, so that a tile's eight-level groups are 8-byte aligned
+        d->levels_shift = (int)((reinterpret_cast<uintptr_t>(raw) & 15) >> (esz == 2 ? 1 : 4));
+        uint8_t* levels = c->levels.as<uint8_t>() + d->levels_shift;
         float* level_val = c->level_val.as<float>() + (size_t)i0 * 256;
         uint32_t* hist8 = d->hist8.as<uint32_t>() + (size_t)i0 * 256;
         if (B.dtype == 0) {
@@ -789,7 +792,7 @@ int strq_debug_conditioning(strq_ctx* c, int64_t read, uint8_t* levels, int64_t 
     DetectState* d = dstate(c);
     ReadCond rc;
     STRQ_HIP(c, hipMemcpy(&rc, d->rc.as<ReadCond>() + read, sizeof(rc), hipMemcpyDeviceToHost));
-    if (levels) STRQ_HIP(c, hipMemcpy(levels, c->levels.as<uint8_t>() + rc.off, (size_t)std::min<int64_t>(n, rc.n), hipMemcpyDeviceToHost));
+    if (levels) STRQ_HIP(c, hipMemcpy(levels, c->levels.as<uint8_t>() + d->levels_shift + rc.off, (size_t)std::min<int64_t>(n, rc.n), hipMemcpyDeviceToHost));
     if (level_val) STRQ_HIP(c, hipMemcpy(level_val, c->level_val.as<float>() + read * 256, 1024, hipMemcpyDeviceToHost));
     if (scalars10) {
         const double v[10] = {rc.med, rc.mad, rc.f_c1, rc.f_h1, rc.m_c1, rc.m_h1, rc.r_c1, rc.r_h1, rc.h2, rc.c2};
