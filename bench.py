@@ -400,6 +400,12 @@ def main():
             "stage_ms_per_step": {"conditioning": float(stage_ms[5]) / args.steps, "score_tables": float(stage_ms[0]) / args.steps,
                                   "forward_dp": float(stage_ms[1]) / args.steps, "trace": float(stage_ms[2]) / args.steps,
                                   "viterbi": float(stage_ms[6]) / args.steps},
+            # the HBM-bound part of the pipeline (median filter + histogram, quantise + morphology): algorithmic bytes per sample --
+            # int16 raw read, int16 filtered written and read again, uint8 levels written = 7 B -- over the stage's kernel time
+            "conditioning_hbm": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                 "achieved": 7.0 * n_samples / (float(stage_ms[5]) / args.steps * 1e-3) / 1e9 if stage_ms[5] > 0 else None,
+                                 "frac": 7.0 * n_samples / (float(stage_ms[5]) / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[5] > 0 else None,
+                                 "bytes_per_sample": 7, "note": "three streaming kernels + per-read statistics; no per-cell work"},
             "viterbi": {"time_steps_per_step": counters[7] / args.steps,
                         "us_per_time_step_per_wave_slot": (float(stage_ms[6]) / args.steps * 1e3) / max(1.0, counters[7] / args.steps / (8 * N_SIMD / 4))},
             "host": {"synth_s": t_gen, "synth_workers": synth_workers, "upload_s": t_up, "upload_GBs": int(off[-1]) * 2 / t_up / 1e9 if t_up > 0 else None},
