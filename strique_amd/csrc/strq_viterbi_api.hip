@@ -211,6 +211,8 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     m.state_tag = reinterpret_cast<const int32_t*>(d + parts[11].off);
     m.rec_state = -1;
     for (int e = in_ptr[end]; e < in_ptr[end + 1]; ++e) if (in_src[e] < ne && state_tag && state_tag[in_src[e]] == 2) m.rec_state = in_src[e];
+    m.silent_counted = 0;
+    for (int s2 = ne; s2 < n_states; ++s2) if (count_inc && count_inc[s2] != 0) m.silent_counted = 1;
     m.cell_state = reinterpret_cast<const int32_t*>(d + parts[12].off);
     hm->dev = reinterpret_cast<const VitModel*>(d + o_m);
     std::vector<char> host(total, 0);

@@ -37,7 +37,8 @@ struct VitModel {
     const int32_t* count_inc;         // n_states + 1, by state
     const int32_t* state_tag;         // n_states + 1, by state
     double uni_lo_max, uni_hi_min;    // tightest bounds of the uniform emissions: observations inside them need no range test
-    int32_t rec_state, pad2_;         // the hub state (tag 2) with an edge into `end` (e0 of the modification model), or -1
+    int32_t rec_state;                // the hub state (tag 2) with an edge into `end` (e0 of the modification model), or -1
+    int32_t silent_counted;           // 1: some silent state has a non-zero count_inc (STRique counts emitting states only: dummy1 / dummy2)
     int32_t e_flat[8];                // emitting slot without a Normal emission (uniform inserts, padding): its emission is a constant per lane
     // Models no lane layout covers (more than 512 emitting / 256 silent states, more than 8 in-edges): the baked arrays as
     // they are, for viterbi_csr_kernel -- one workgroup per window, a cell per state, silent states level by level.

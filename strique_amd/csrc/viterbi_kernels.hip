@@ -80,6 +80,23 @@ static __device__ __forceinline__ int dpp_shr1_i32(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
 }
+// (tin > y) ? value of `prev` in lane l-1 : keep -- compare and select with the lane shift folded into the select's first operand
+// (v_cndmask_b32 picks src0 when the condition is clear, and only src0 takes a DPP control: hence the inverted compare).
+// The s_nop gives the two wait states a DPP read needs after a VALU write of the same register, whatever the compiler put in front.
+static __device__ __forceinline__ int sel_shr1_i32(double tin, double y, int prev, int keep)
+{
+    asm("v_cmp_ngt_f64 vcc, %2, %3\n\ts_nop 0\n\tv_cndmask_b32_dpp %0, %1, %0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(keep) : "v"(prev), "v"(tin), "v"(y) : "vcc");
+    return keep;
+}
+static __device__ __forceinline__ uint64_t sel_shr1_u64(double tin, double y, uint64_t prev, uint64_t keep)
+{
+    int klo = (int)(uint32_t)keep, khi = (int)(uint32_t)(keep >> 32);
+    asm("v_cmp_ngt_f64 vcc, %4, %5\n\ts_nop 0\n\tv_cndmask_b32_dpp %0, %2, %0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %1, %3, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(klo), "+v"(khi) : "v"((int)(uint32_t)prev), "v"((int)(uint32_t)(prev >> 32)), "v"(tin), "v"(y) : "vcc");
+    return ((uint64_t)(uint32_t)khi << 32) | (uint32_t)klo;
+}
 // max of two non-NaN doubles in one instruction (__builtin_fmax makes the compiler canonicalise a
 // loop-carried operand first: a second v_max_f64 per sweep)
 static __device__ __forceinline__ double max_f64_raw(double a, double b)
@@ -103,7 +120,11 @@ template <int EPL, int SPL> struct VitLds {
     // waves per CU: two per SIMD.  (Three fit shape (4,2) at 168 VGPRs and raise the throughput of
     // large uniform batches by ~8%, but a 4096-read batch is bound by its longest window, whose
     // per-step latency gets worse -- measured 176 ms vs 164 ms per bench step.)
+#ifdef STRQ_VIT_WAVES12
+    static constexpr int WAVES = (160 * 1024) / (2 * BUF) >= 12 ? 12 : ((160 * 1024) / (2 * BUF) >= 8 ? 8 : ((160 * 1024) / (2 * BUF) >= 4 ? 4 : 2));
+#else
     static constexpr int WAVES = (160 * 1024) / (2 * BUF) >= 8 ? 8 : ((160 * 1024) / (2 * BUF) >= 4 ? 4 : 2);
+#endif
 };
 
 // SS: every model of the launch is single-stage (no silent state has a silent predecessor outside
@@ -139,6 +160,9 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     // a profile: uniform) -- with clipped observations inside every uniform support their emission is the constant ecf
     constexpr int LO = DE_LO > 10 ? DE_LO % 10 : DE_LO;
     constexpr bool LO_FLAT = DE_LO > 10;
+    // the packed shapes are chosen for models without counted silent states (vit_shape_base): the payload of a silent state is
+    // then its predecessor's as it is -- one VALU instruction less per chain hop (the lane shift folds into the select)
+    constexpr bool SILENT_COUNTED = DE_HI <= 16;
     constexpr int DEMAX = HI0 > LO ? HI0 : LO;
     auto de_of = [](int s) constexpr { return s == 0 ? HI0 : (s < (EPL + 1) / 2 ? HI1 : LO); };
     const double NEGINF = -__builtin_inf();
@@ -146,7 +170,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
     using Pay = std::conditional_t<WIDE, uint64_t, int>;      // what rides along the best path
     struct alignas(16) Cell { double v; Pay c; };
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    auto ldcell = [](const char* p, int boff) {      // one ds_read_b128
+    auto ldcell = [](const char* p, int boff) {      // one ds_read_b128 (a 96-bit read of the three dwords in use measures 40 % slower: profiles/r03_dead_ends.md)
         const v4u q = *reinterpret_cast<const v4u*>(p + boff);
         Cell x; x.v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
         if constexpr (WIDE) x.c = ((uint64_t)q.w << 32) | q.z; else x.c = (int)q.z;
@@ -169,6 +193,7 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         else if constexpr (MARK) return ((uint64_t)v & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)v + (uint32_t)inc);
         else return v + inc;
     };
+    auto spay_add = [&](Pay v, int inc) -> Pay { if constexpr (SILENT_COUNTED) return pay_add(v, inc); else return v; };
     auto shr1_pay = [](Pay v) -> Pay {               // payload of lane l-1
         if constexpr (WIDE) return ((uint64_t)(uint32_t)dpp_shr1_i32((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)dpp_shr1_i32((int)(uint32_t)v);
         else return dpp_shr1_i32(v);
@@ -190,6 +215,10 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
         const int tq = vit_next_task(queue, lane);
         if (tq >= n_tasks) break;
         const int ti = order ? order[tq] : tq;        // longest observation windows first
+#ifdef STRQ_VIT_PRIO
+        // experiment: the longest windows of a launch are its critical path -- let their waves issue ahead of the wave they share a SIMD with
+        if (tq < n_tasks / STRQ_VIT_PRIO) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
         const VitTask tk = tasks[ti];
         if (tk.model != cur_model) {
             cur_model = tk.model;
@@ -284,11 +313,13 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
                     double tin; Pay cin;
-                    if (s == 0) { tin = dpp_shr1_f64(y[SPL - 1]) + clp[0]; cin = pay_add(shr1_pay(yc[SPL - 1]), sinc[0]); }
-                    else { tin = y[s - 1] + clp[s]; cin = pay_add(yc[s - 1], sinc[s]); }
+                    if (s == 0) { tin = dpp_shr1_f64(y[SPL - 1]) + clp[0]; if constexpr (SILENT_COUNTED) cin = pay_add(shr1_pay(yc[SPL - 1]), sinc[0]); }
+                    else { tin = y[s - 1] + clp[s]; cin = spay_add(yc[s - 1], sinc[s]); }
                     const bool win = tin > y[s];     // the chain edge is the last in-edge: strict (clp = -inf without one)
+                    if (s == 0 && !SILENT_COUNTED) {      // payload of the previous lane's last slot, taken as it is
+                        if constexpr (WIDE) yc[0] = sel_shr1_u64(tin, y[0], yc[SPL - 1], yc[0]); else yc[0] = sel_shr1_i32(tin, y[0], yc[SPL - 1], yc[0]);
+                    } else yc[s] = win ? cin : yc[s];
                     y[s] = max_f64_raw(y[s], tin);
-                    yc[s] = win ? cin : yc[s];
                     if (BP) arg[s] = win ? scell0 + lane * SPL + s - 1 : arg[s];     // the chain predecessor's cell
                     if (s == SPL - 1) win_any = win;     // wins in the earlier slots were carried on inside this sweep already
                 }
@@ -314,8 +345,8 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                     for (int j = 0; j < DS; ++j) { cv[j] = spc[s][j].v + slp[s][j]; cc[j] = spc[s][j].c; ca[j] = BP ? (int)(ssrc[s][j] - vbase) >> 4 : 0; }
                     tournament(cv, cc, ca, DS);
                     double best = cv[0]; Pay bc = cc[0]; int a = ca[0];
-                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = pay_add((Pay)0, -sinc[s]); a = dummy; }
-                    y[s] = best; yc[s] = pay_add(bc, sinc[s]); arg[s] = a;
+                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = spay_add((Pay)0, -sinc[s]); a = dummy; }
+                    y[s] = best; yc[s] = spay_add(bc, sinc[s]); arg[s] = a;
                 }
 #ifdef STRQ_VIT_TIMING
                 const unsigned long long tc_a = VIT_CLOCK();
@@ -355,8 +386,8 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
                         if (BP) a = gt ? (int)(ssrc[s][j] - vbase) >> 4 : a;
                         best = __builtin_fmax(best, c);
                     }
-                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = pay_add((Pay)0, -sinc[s]); a = dummy; }
-                    base[s] = best; basec[s] = pay_add(bc, sinc[s]); basea[s] = a;
+                    if (PIN && own_s[s] == start_state) { best = 0.0; bc = spay_add((Pay)0, -sinc[s]); a = dummy; }
+                    base[s] = best; basec[s] = spay_add(bc, sinc[s]); basea[s] = a;
                     if (!(best == base_prev[s]) && !(best != best)) base_changed = true;
                 }
                 bool changed = false;
@@ -471,6 +502,32 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 #ifdef STRQ_VIT_TIMING
             const unsigned long long tc1 = VIT_CLOCK();
             tm_emit += tc1 - tc0;
+#endif
+#if defined(STRQ_X_ST) || defined(STRQ_X_RD) || defined(STRQ_X_VALU)
+            // sensitivity probes (tools/build_variant.sh, never in the product build): redundant work of one kind per time step --
+            // what a step's time does in response tells which unit it waits for (profiles/r03_vit_sensitivity.md)
+#ifdef STRQ_X_ST
+#pragma unroll
+            for (int k = 0; k < STRQ_X_ST; ++k)      // the cell just stored, stored again (same bytes)
+                asm volatile("ds_write_b96 %0, %1 offset:%2" :: "v"((unsigned)(uintptr_t)edst[k & 3]), "v"(v3u{(unsigned)__builtin_bit_cast(uint64_t, nv[k & 3]), (unsigned)(__builtin_bit_cast(uint64_t, nv[k & 3]) >> 32), (unsigned)nc[k & 3]}), "n"(WR) : "memory");
+#endif
+#ifdef STRQ_X_RD
+#pragma unroll
+            for (int k = 0; k < STRQ_X_RD; ++k)      // reads nobody uses, into registers the kernel does not allocate
+                asm volatile("ds_read_b128 v[248:251], %0 offset:%1" :: "v"((unsigned)(uintptr_t)edst[k & 3]), "n"(RD) : "v248", "v249", "v250", "v251", "memory");
+#endif
+#ifdef STRQ_X_VALU
+            {
+                double acc0 = x, acc1 = x, acc2 = x, acc3 = x;
+#pragma unroll
+                for (int k = 0; k < STRQ_X_VALU; k += 4) {
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc0) : "v"(nv[0]));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc1) : "v"(nv[1]));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc2) : "v"(nv[2]));
+                    asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc3) : "v"(nv[3]));
+                }
+            }
+#endif
 #endif
             relax_silent(std::false_type{}, std::integral_constant<int, WR>{}, t + 1);
 #ifdef STRQ_VIT_TIMING
@@ -773,7 +830,8 @@ static int vit_shape_base(const VitModel& mh)
     for (int i = 0; i < e; ++i) { if (i < (e + 1) / 2) hi = hi > mh.e_deg[i] ? hi : mh.e_deg[i]; else lo = lo > mh.e_deg[i] ? lo : mh.e_deg[i]; }
     for (int i = 0; i < s; ++i) ds = ds > mh.s_deg[i] ? ds : mh.s_deg[i];
     // flanked-repeat models: six-edge states in slot 0, two in-edges per delete state besides its chain
-    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2) {
+    // (their kernels leave the count increments of silent states out: STRique counts the emitting dummy states, STRique.py:341-342,375-377)
+    if (e <= 4 && s <= 2 && e > 2 && mh.e_deg[0] <= 6 && mh.e_deg[1] <= 5 && lo <= 3 && ds <= 2 && !mh.silent_counted) {
         bool flat = true;
         for (int i = (e + 1) / 2; i < e; ++i) flat = flat && mh.e_flat[i];
         if (flat && e == 4) return 7;          // ... and only uniform emissions (the inserts) in the last two slots

@@ -40,6 +40,37 @@ def test_flanked_model_parity(ctx, orc, pm, cfg, name):
         assert lg2 == lg and cg2 == cg
 
 
+def test_flanked_model_with_counted_silent_states(ctx, orc, pm, cfg):
+    """The kernels picked for STRique's flanked models carry a silent state's payload on unchanged (STRique counts the
+    emitting dummy states only, scripts/STRique.py:341-342,375-377).  The same model with some delete states counted must
+    run on a kernel that adds their increments: count, log-probability and path against the oracle."""
+    from strique_amd import hmm
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    fm = hmm.FlankedRepeatModel(repeat, prefix[-50:], suffix[:50], pm, cfg["HMM"])
+    rng = np.random.default_rng(31)
+    inc = fm.baked.count_inc.copy()
+    silent = np.arange(fm.baked.silent_start, fm.baked.n_states)
+    inc[silent[::2]] = 1
+    baked = fm.baked._replace(count_inc=inc)
+    mid = ctx.model_create(baked)
+    mid0 = ctx.model_create(fm.baked)
+    differs = False
+    for nrep, k in ((5, 0), (40, 6), (90, 13)):
+        seq = prefix[-50:] + repeat * nrep + suffix[:50]
+        seq = seq[:30] + seq[30 + k:]          # a deletion in the prefix: the best path goes through delete states
+        x = _signal(pm, rng, seq)
+        lo, po, co = orc.viterbi(baked, x)
+        lg, cg, sg, pg = ctx.viterbi(mid, x, want_path=True)
+        assert np.float64(lo).tobytes() == np.float64(lg).tobytes() and co == cg and sg == 0
+        assert np.array_equal(po, pg)
+        lg2, cg2, _, _ = ctx.viterbi(mid, x, want_path=False)
+        assert lg2 == lg and cg2 == cg
+        l0, c0, _, _ = ctx.viterbi(mid0, x, want_path=False)
+        assert l0 == lg and c0 == orc.viterbi(fm.baked, x, want_path=False)[2]
+        differs = differs or c0 != cg
+    assert differs, "the counted silent states never lay on a best path: the test checks nothing"
+
+
 def test_mod_model_and_edge_cases(ctx, orc, pm, pm_mod, cfg):
     from strique_amd import hmm
     mm = hmm.RepeatModModel("GGCCCC", pm, pm_mod, cfg["HMM"])
