@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 7 (5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 8 (8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -112,6 +112,17 @@ int strq_model_create(strq_ctx* ctx, int32_t n_states, int32_t silent_start, int
                       const int32_t* emis_kind, const double* emis_a, const double* emis_b,
                       const double* emis_c, const int32_t* count_inc, const int32_t* state_tag,
                       const int32_t* hint_slot, const int32_t* hint_lane, int32_t* model_id);
+
+/*
+ * Optional, after strq_model_create: where every emitting state of a profile-HMM chain sits along the chain --
+ * kind[e] 0 for a match-type state, 1 for an insert-type state, pos[e] >= 0 its position (prefix profile, repeat unit,
+ * the two dummy states at one position, suffix profile: scripts/STRique.py:236-300,313-354,401-417 laid end to end).
+ * A model that is such a chain (every in-edge joins a position with itself or the one before, plus the two edges that close
+ * the repeat loop) additionally gets a register-resident image: count / mark decodes then keep the value vector in VGPRs
+ * and touch no LDS.  Purely a performance hint: results are identical; STRQ_ERR_UNSUPPORTED (strq_last_error says why)
+ * when the model is not such a chain -- it stays valid and runs on its lane layout.
+ */
+int strq_model_set_positions(strq_ctx* ctx, int32_t model_id, const int32_t* kind, const int32_t* pos);
 
 /*
  * HiddenMarkovModel.viterbi(x) (scripts/STRique.py:434,493).

@@ -609,7 +609,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 
 extern "C" {
 
-int strq_abi_version(void) { return 7; }
+int strq_abi_version(void) { return 8; }
 
 int strq_ctx_create(int device_id, strq_ctx** out)
 {

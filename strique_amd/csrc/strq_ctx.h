@@ -60,6 +60,11 @@ struct HostModel {
     VitModel h;              // host copy (pointers are device pointers)
     const VitModel* dev = nullptr;
     DevBuf blob;
+    DevBuf g2_blob;          // register-resident image of the same model (strq_model_set_positions), if any
+    // the baked arrays as they were handed to strq_model_create (strq_model_set_positions lays them out once more)
+    int32_t n_states = 0, silent_start = 0, start = 0, end = 0;
+    std::vector<int32_t> in_ptr, in_src, emis_kind, count_inc, state_tag;
+    std::vector<double> in_logp, emis_a, emis_b, emis_c;
 };
 
 }  // namespace strq

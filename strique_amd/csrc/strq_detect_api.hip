@@ -425,7 +425,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     for (int i = 0; i < nr; ++i) {
         HostModel* hm = c->models[d->targets[B.target[r0 + i]].model_id];
         model_of[i] = hm->dev;
-        const int shape = vit_shape_of(hm->h);
+        const int shape = vit_shape_for(hm->h, any_mod ? 2 : 0);
         if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
         by_shape[shape].push_back(i);
     }

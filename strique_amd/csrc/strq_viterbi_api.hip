@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
+#include <string>
 #include "../../include/strique_hip.h"
 #include "strq_ctx.h"
 #include "viterbi_kernels.h"
@@ -286,6 +287,154 @@ int build_vit_model_csr(strq_ctx* c, int32_t n_states, int32_t silent_start, int
     return STRQ_OK;
 }
 
+// Register-resident image of a profile chain (VitG2, viterbi_kernels.h) from the position of every emitting state along the
+// chain: kind 0 = match-type, 1 = insert-type, pos >= 0.  Silent states take the position after their emitting / silent
+// predecessors (a silent state without predecessors -- start -- the position before its match-type successor).  Every
+// in-edge must fall into a column of the layout, in ascending column order (= ascending source state, the order ties are
+// broken in); the states that need the even-position columns (a broadcast source, an insert-type state fed by the previous
+// delete state) decide the parity of the whole chain.  Returns STRQ_ERR_UNSUPPORTED when the model is not such a chain:
+// it then keeps running on its lane layout.
+struct G2Host {
+    std::vector<double> lp, em; std::vector<int32_t> knd, own, inc, tag;
+    VitG2 G;
+    int odd = 0;
+};
+
+// host part: the tables of the image (no device involved), or the reason there is none
+static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32_t* pos_hint, G2Host& out, std::string& why_out)
+{
+    const int n = hm->n_states, ne = hm->silent_start;
+    const std::vector<int32_t>& in_ptr = hm->in_ptr; const std::vector<int32_t>& in_src = hm->in_src; const std::vector<double>& in_logp = hm->in_logp;
+    auto unsupported = [&](const char* why) { why_out = why; return false; };
+    for (int b = ne; b < n; ++b) if (!hm->count_inc.empty() && hm->count_inc[b] != 0) return unsupported("a silent state is counted");
+    for (int e = 0; e < ne; ++e) {
+        if ((kind_hint[e] != 0 && kind_hint[e] != 1) || pos_hint[e] < 0 || pos_hint[e] > 125) return unsupported("an emitting state has no position");
+        if (kind_hint[e] == 1 && hm->emis_kind[e] == 1) return unsupported("an insert-type state has a Normal emission");
+    }
+    const double NEG = -INFINITY;
+    std::string why = "?";
+    for (int off = 0; off < 2; ++off) {
+        std::vector<int> g(n, -1), kind(n, 2);
+        for (int e = 0; e < ne; ++e) { g[e] = pos_hint[e] + 1 + off; kind[e] = kind_hint[e]; }
+        bool ok = true;
+        for (int b = ne; b < n && ok; ++b) {
+            int gp = -1;
+            for (int e = in_ptr[b]; e < in_ptr[b + 1]; ++e) {
+                const int k = in_src[e];
+                if (g[k] < 0) { ok = false; why = "a silent state precedes its predecessor"; break; }
+                if (gp < 0) gp = g[k] + 1; else if (gp != g[k] + 1) { ok = false; why = "a silent state has predecessors at two positions"; break; }
+            }
+            if (ok && gp < 0) {      // no predecessors: the position before its match-type successor (else that of its insert-type successor)
+                int gm = -1, gi = -1;
+                for (int l = 0; l < ne; ++l) for (int e = in_ptr[l]; e < in_ptr[l + 1]; ++e) if (in_src[e] == b) { if (kind[l] == 0) gm = g[l] - 1; else gi = g[l]; }
+                gp = gm >= 0 ? gm : gi;
+                if (gp < 0) {      // only silent successors: right before the first of them is decided below -- take position 0
+                    gp = 0;
+                }
+            }
+            g[b] = gp;
+        }
+        if (!ok) continue;
+        // one state per (kind, position), positions below 128
+        std::vector<int> at(3 * 128, -1);
+        for (int l = 0; l < n && ok; ++l) {
+            if (g[l] < 0 || g[l] > 127) { ok = false; why = "the chain has more than 128 positions"; break; }
+            int& slot = at[kind[l] * 128 + g[l]];
+            if (slot >= 0) { ok = false; why = "two states of one type at one position"; break; }
+            slot = l;
+        }
+        if (!ok) continue;
+        std::vector<double> lp((size_t)G2_ROWS * 64, NEG), em((size_t)12 * 64, 0.0);
+        std::vector<int32_t> knd((size_t)4 * 64, 0), own((size_t)6 * 64, -1), inc((size_t)4 * 64, 0), tag((size_t)4 * 64, 0);
+        int bc_state[2] = {-1, -1};
+        for (int l = 0; l < n && ok; ++l) {
+            const int gl = g[l], par = gl & 1, lane = gl >> 1;
+            int last_col = -1;
+            for (int e = in_ptr[l]; e < in_ptr[l + 1] && ok; ++e) {
+                const int k = in_src[e], kk = kind[k], dg = gl - g[k];
+                int col = -1, row = -1;
+                if (kind[l] == 0) {          // match-type
+                    row = par ? G2_ROW_MO : G2_ROW_ME;
+                    if (kk == 0 && dg == 2) col = 0; else if (kk == 1 && dg == 1) col = 1; else if (kk == 0 && dg == 1) col = 2;
+                    else if (kk == 1 && dg == 0) col = 3; else if (k == l) col = 4;
+                    else if (kk == 2 && dg == 1) col = par ? 5 : 6;
+                    else if (!par && kk == 0 && k < ne && (bc_state[0] < 0 || bc_state[0] == k)) { col = 5; bc_state[0] = k; }
+                } else if (kind[l] == 1) {   // insert-type
+                    row = par ? G2_ROW_IO : G2_ROW_IE;
+                    if (kk == 1 && dg == 1) col = 0; else if (kk == 0 && dg == 1) col = 1; else if (k == l) col = 2; else if (kk == 0 && dg == 0) col = 3;
+                    else if (kk == 2 && dg == 0) col = par ? 4 : 6;
+                    else if (!par && kk == 2 && dg == 1) col = 5;
+                    else if (!par && kk == 1 && k < ne && (bc_state[1] < 0 || bc_state[1] == k)) { col = 4; bc_state[1] = k; }
+                } else {                     // delete-type: two gathers, then the chain edge
+                    if (kk == 1 && dg == 1) { row = par ? G2_ROW_DO : G2_ROW_DE; col = 0; }
+                    else if (kk == 0 && dg == 1) { row = par ? G2_ROW_DO : G2_ROW_DE; col = 1; }
+                    else if (kk == 2 && dg == 1) { row = G2_ROW_CHAIN + par; col = 2; }
+                }
+                if (col < 0) { ok = false; why = "an edge outside the columns of the layout (parity " + std::to_string(off) + ")"; break; }
+                if (col <= last_col) { ok = false; why = "in-edges not in column order"; break; }
+                last_col = col;
+                lp[(size_t)(row + (kind[l] == 2 && col == 2 ? 0 : col)) * 64 + lane] = in_logp[e];
+            }
+            if (!ok) break;
+            if (kind[l] < 2) {
+                const int slot = kind[l] * 2 + par;
+                own[(size_t)slot * 64 + lane] = l; knd[(size_t)slot * 64 + lane] = hm->emis_kind[l];
+                em[((size_t)slot * 3 + 0) * 64 + lane] = hm->emis_a[l]; em[((size_t)slot * 3 + 1) * 64 + lane] = hm->emis_b[l]; em[((size_t)slot * 3 + 2) * 64 + lane] = hm->emis_c[l];
+                inc[(size_t)slot * 64 + lane] = hm->count_inc.empty() ? 0 : hm->count_inc[l];
+                tag[(size_t)slot * 64 + lane] = (!hm->state_tag.empty() && hm->state_tag[l] == 1) ? 1 : 0;
+            } else own[(size_t)(4 + par) * 64 + lane] = l;
+        }
+        if (!ok) continue;
+        if (in_ptr[hm->start + 1] != in_ptr[hm->start]) { why = "the start state has in-edges"; continue; }
+        VitG2& G = out.G; std::memset(&G, 0, sizeof(G));
+        for (int i = 0; i < 2; ++i) {
+            G.bc_slot[i] = 2 * i; G.bc_lane[i] = -1;
+            if (bc_state[i] >= 0) { G.bc_slot[i] = kind[bc_state[i]] * 2 + (g[bc_state[i]] & 1); G.bc_lane[i] = g[bc_state[i]] >> 1; }
+        }
+        G.start_slot = g[hm->start] & 1; G.start_lane = g[hm->start] >> 1; G.end_slot = g[hm->end] & 1; G.end_lane = g[hm->end] >> 1;
+        // one kernel variant per parity of the broadcast sources; the odd one also evaluates the first two insert columns at odd positions
+        int par_bc = -1; bool bad_par = false;
+        for (int i = 0; i < 2; ++i) if (bc_state[i] >= 0) { const int pb = g[bc_state[i]] & 1; if (par_bc >= 0 && par_bc != pb) bad_par = true; par_bc = pb; }
+        bool io_front = false;
+        for (int lane = 0; lane < 64; ++lane) if (lp[(size_t)(G2_ROW_IO + 0) * 64 + lane] > NEG || lp[(size_t)(G2_ROW_IO + 1) * 64 + lane] > NEG) io_front = true;
+        if (bad_par || (io_front && par_bc == 0)) { why = "broadcast sources at positions of both parities"; continue; }
+        out.odd = (par_bc == 1 || io_front) ? 1 : 0;
+        out.lp.swap(lp); out.em.swap(em); out.knd.swap(knd); out.own.swap(own); out.inc.swap(inc); out.tag.swap(tag);
+        return true;
+    }
+    return unsupported(why.c_str());
+}
+
+int build_vit_g2(strq_ctx* c, HostModel* hm, const int32_t* kind_hint, const int32_t* pos_hint)
+{
+    if (hm->h.csr) { c->err = "no register-resident layout: the model runs on the general kernel"; return STRQ_ERR_UNSUPPORTED; }
+    G2Host L; std::string why;
+    if (!g2_layout(hm, kind_hint, pos_hint, L, why)) { c->err = "no register-resident layout: " + why; return STRQ_ERR_UNSUPPORTED; }
+    {
+        VitG2& G = L.G;
+        std::vector<double>& lp = L.lp; std::vector<double>& em = L.em;
+        std::vector<int32_t>& knd = L.knd; std::vector<int32_t>& own = L.own; std::vector<int32_t>& inc = L.inc; std::vector<int32_t>& tag = L.tag;
+        struct Part { const void* p; size_t bytes; size_t off; };
+        std::vector<Part> parts = {{lp.data(), lp.size() * 8, 0}, {em.data(), em.size() * 8, 0}, {knd.data(), knd.size() * 4, 0},
+                                   {own.data(), own.size() * 4, 0}, {inc.data(), inc.size() * 4, 0}, {tag.data(), tag.size() * 4, 0}};
+        size_t total = 0;
+        for (auto& pt : parts) { pt.off = total; total += (pt.bytes + 15) & ~(size_t)15; }
+        const size_t o_g = total; total += sizeof(VitG2);
+        if (hm->g2_blob.reserve(total) != hipSuccess) { c->err = "out of device memory"; return STRQ_ERR_NOMEM; }
+        char* d = hm->g2_blob.as<char>();
+        G.lp = reinterpret_cast<const double*>(d + parts[0].off); G.em = reinterpret_cast<const double*>(d + parts[1].off);
+        G.kind = reinterpret_cast<const int32_t*>(d + parts[2].off); G.own = reinterpret_cast<const int32_t*>(d + parts[3].off);
+        G.inc = reinterpret_cast<const int32_t*>(d + parts[4].off); G.tag = reinterpret_cast<const int32_t*>(d + parts[5].off);
+        std::vector<char> host(total, 0);
+        for (auto& pt : parts) std::memcpy(&host[pt.off], pt.p, pt.bytes);
+        std::memcpy(&host[o_g], &G, sizeof(VitG2));
+        if (hipMemcpy(d, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) { c->err = "model upload failed"; return STRQ_ERR_DEVICE; }
+        hm->h.g2 = reinterpret_cast<const VitG2*>(d + o_g); hm->h.g2_odd = L.odd;
+        if (hipMemcpy(const_cast<VitModel*>(hm->dev), &hm->h, sizeof(VitModel), hipMemcpyHostToDevice) != hipSuccess) { hm->h.g2 = nullptr; c->err = "model upload failed"; return STRQ_ERR_DEVICE; }
+        return STRQ_OK;
+    }
+}
+
 }  // namespace strq
 
 extern "C" {
@@ -304,9 +453,46 @@ int strq_model_create(strq_ctx* c, int32_t n_states, int32_t silent_start, int32
     if (rc == STRQ_ERR_UNSUPPORTED)      // no lane layout: the model runs on the general (slow) kernel
         rc = build_vit_model_csr(c, n_states, silent_start, start, end, in_ptr, in_src, in_logp, emis_kind, emis_a, emis_b, emis_c, count_inc, state_tag, &hm);
     if (rc) return rc;
+    hm->n_states = n_states; hm->silent_start = silent_start; hm->start = start; hm->end = end;
+    hm->in_ptr.assign(in_ptr, in_ptr + n_states + 1);
+    hm->in_src.assign(in_src, in_src + in_ptr[n_states]); hm->in_logp.assign(in_logp, in_logp + in_ptr[n_states]);
+    hm->emis_kind.assign(emis_kind, emis_kind + silent_start); hm->emis_a.assign(emis_a, emis_a + silent_start);
+    hm->emis_b.assign(emis_b, emis_b + silent_start); hm->emis_c.assign(emis_c, emis_c + silent_start);
+    if (count_inc) hm->count_inc.assign(count_inc, count_inc + n_states);
+    if (state_tag) hm->state_tag.assign(state_tag, state_tag + n_states);
     c->models.push_back(hm);
     *model_id = (int32_t)c->models.size() - 1;
     return STRQ_OK;
+}
+
+// Host-only (no context, no device): the tables strq_model_set_positions would upload, for tests of the layout.
+// out_lp[G2_ROWS * 64], out_own[6 * 64], out_meta[8] = {bc_slot0, bc_lane0, bc_slot1, bc_lane1, start_slot, start_lane, end_slot, end_lane}.
+int strq_debug_g2_layout(int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
+                         const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
+                         const int32_t* emis_kind, const int32_t* count_inc, const int32_t* kind, const int32_t* pos,
+                         double* out_lp, int32_t* out_own, int32_t* out_meta, char* why, int32_t why_len)
+{
+    HostModel hm;
+    hm.n_states = n_states; hm.silent_start = silent_start; hm.start = start; hm.end = end;
+    hm.in_ptr.assign(in_ptr, in_ptr + n_states + 1); hm.in_src.assign(in_src, in_src + in_ptr[n_states]); hm.in_logp.assign(in_logp, in_logp + in_ptr[n_states]);
+    hm.emis_kind.assign(emis_kind, emis_kind + silent_start); hm.emis_a.assign(silent_start, 0.0); hm.emis_b.assign(silent_start, 0.0); hm.emis_c.assign(silent_start, 0.0);
+    if (count_inc) hm.count_inc.assign(count_inc, count_inc + n_states);
+    for (int e = 0; e < silent_start; ++e) if ((kind[e] != 0 && kind[e] != 1) || pos[e] < 0 || pos[e] > 125) { if (why && why_len > 0) snprintf(why, why_len, "an emitting state has no position"); return STRQ_ERR_UNSUPPORTED; }
+    for (int e = 0; e < silent_start; ++e) if (kind[e] == 1 && emis_kind[e] == 1) { if (why && why_len > 0) snprintf(why, why_len, "an insert-type state has a Normal emission"); return STRQ_ERR_UNSUPPORTED; }
+    G2Host L; std::string w;
+    if (!g2_layout(&hm, kind, pos, L, w)) { if (why && why_len > 0) snprintf(why, why_len, "%s", w.c_str()); return STRQ_ERR_UNSUPPORTED; }
+    std::memcpy(out_lp, L.lp.data(), L.lp.size() * 8); std::memcpy(out_own, L.own.data(), L.own.size() * 4);
+    const int32_t meta[8] = {L.G.bc_slot[0], L.G.bc_lane[0], L.G.bc_slot[1], L.G.bc_lane[1], L.G.start_slot, L.G.start_lane, L.G.end_slot, L.G.end_lane};
+    std::memcpy(out_meta, meta, sizeof(meta));
+    return STRQ_OK;
+}
+
+int strq_model_set_positions(strq_ctx* c, int32_t model_id, const int32_t* kind, const int32_t* pos)
+{
+    if (!c) return STRQ_ERR_ARG;
+    if (model_id < 0 || model_id >= (int32_t)c->models.size() || !c->models[model_id] || !kind || !pos) { c->err = "bad argument"; return STRQ_ERR_ARG; }
+    STRQ_HIP(c, hipSetDevice(c->device));
+    return build_vit_g2(c, c->models[model_id], kind, pos);
 }
 
 int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const double* x, const int64_t* x_off,
@@ -347,7 +533,7 @@ int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const doubl
     STRQ_HIP(c, c->queue.reserve(1024));
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
     STRQ_HIP(c, hipEventRecord(c->ev[0], st));
-    const int shape = vit_shape_of(hm->h);
+    const int shape = vit_shape_for(hm->h, paths ? 1 : 0);
     if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
     int rc = launch_viterbi(st, shape, hm->h.n_cells, d_tasks, d_res, (int)n_seq, c->queue.as<int>(), c->n_cu, paths ? 1 : 0);
     if (rc) { c->err = "viterbi launch failed"; return rc == 2 || rc == 3 ? STRQ_ERR_UNSUPPORTED : STRQ_ERR_DEVICE; }

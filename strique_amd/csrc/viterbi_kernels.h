@@ -15,6 +15,29 @@ namespace strq {
 // chain_logp).  A chain zig-zags through the silent slots: position p sits in lane p / spl, slot p % spl.
 // In-edge j of the state owned by (slot, lane) is entry (base[slot] + j) * 64 + lane of
 // edge_src / edge_logp; padding edges point at the extra cell v[n_states] == -inf.
+// Register-resident layout of a profile chain (viterbi_g2_kernel): the model's states as ONE chain of positions g, two
+// positions per lane (g = 2 * lane + parity), every position holding at most a match-type state M_g, an insert-type state
+// I_g (both emitting) and a delete-type silent state D_g.  All in-edges of the regular part connect a position with itself
+// or its predecessor, so a time step needs the lane's own previous values and those of lane - 1 (one DPP shift) -- no LDS:
+//   M_g <- M_{g-2}, I_{g-1}, M_{g-1}, I_g, M_g, [B0], D_{g-1}             (B0 only at even g)
+//   I_g <- [I_{g-1}, M_{g-1}], I_g, M_g, [B1], [D_{g-1}], D_g             (B1 and D_{g-1} only at even g; the first two at odd g
+//                                                                          only in images flagged g2_odd)
+//   D_g <- I_{g-1}, M_{g-1} (this time step's values), then its chain predecessor D_{g-1}
+// in this order -- which must be the ascending order of the source states, the order the oracle breaks ties in; B0 / B1 are
+// two designated states (STRique: the dummy states that close the repeat loop) whose previous values are broadcast.
+// Rows of `lp` (64 doubles each, -inf where a lane has no such edge): see G2_ROW_* below.
+struct VitG2 {
+    const double* lp;            // G2_ROWS x 64
+    const double* em;            // [slot][a | b | c][lane]: emission parameters of the emitting slots (Me, Mo, Ie, Io), as in VitModel
+    const int32_t* kind;         // [slot][lane]: 0 none, 1 Normal, 2 Uniform
+    const int32_t* own;          // [6][lane]: state of Me, Mo, Ie, Io, De, Do or -1
+    const int32_t* inc;          // [4][lane]: count_inc of the emitting states
+    const int32_t* tag;          // [4][lane]: state_tag == 1
+    int32_t bc_slot[2], bc_lane[2];      // broadcast sources B0 (slot 0 / 1) and B1 (slot 2 / 3); lane -1: none
+    int32_t start_slot, start_lane, end_slot, end_lane;      // silent slots 0 (even g) / 1 (odd g)
+};
+enum { G2_ROW_ME = 0, G2_ROW_MO = 7, G2_ROW_IE = 13, G2_ROW_IO = 20, G2_ROW_DE = 25, G2_ROW_DO = 27, G2_ROW_CHAIN = 29, G2_ROWS = 31 };
+
 struct VitModel {
     int32_t n_states, n_emit, n_silent, start, end;
     int32_t epl, spl;                 // slots per lane (emitting / silent)
@@ -52,8 +75,11 @@ struct VitModel {
     const double* csr_c;
     const int32_t* csr_level_ptr;     // n_levels + 1: silent states by the length of their longest silent predecessor chain
     const int32_t* csr_level_state;   // n_silent
+    const VitG2* g2;                  // register-resident profile layout of the same model, or null (strq_model_set_positions)
+    int32_t g2_odd, pad3_;            // that image has its broadcast sources (and the states they feed directly) at odd positions
 };
 #define VIT_SHAPE_CSR 8              // launch_viterbi shape id of those models
+#define VIT_SHAPE_G2 9               // ... of models with a VitG2 image, for count / mark launches (want_bp 0 or 2); + 1 when g2_odd
 #define VIT_CSR_MAX_STATES 4096      // two buffers of 16-byte cells in 160 KB of LDS
 
 enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };
@@ -79,6 +105,7 @@ struct VitResult {
 // (`shape_of`); `max_cells` = largest n_cells among them (checked against the shape's LDS buffers).
 #define VIT_SHAPE_SS 16                            // flag in the shape id: single-stage model
 int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fits
+int vit_shape_for(const VitModel& model_host, int want_bp);      // the same, or VIT_SHAPE_G2 when the model has a register-resident image and the mode allows it
 int vit_shape_silent_slots(int shape);             // silent slots per lane of that kernel shape
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
                    int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);

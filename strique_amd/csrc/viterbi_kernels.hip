@@ -602,6 +602,263 @@ viterbi_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ result
 }
 
 // ------------------------------------------------------------------------------------------
+// Register-resident profile chain (VitG2, viterbi_kernels.h): one wave per window, two chain positions per lane, the value
+// vector of the previous time step in VGPRs.  What the lane layouts above fetch through LDS -- 21 ds_read_b128 and 6
+// ds_write_b96 per time step, the unit the step was found to wait for (profiles/r03_vit_sensitivity.md) -- is here the lane's
+// own registers, one wave_shr:1 DPP shift of four previous values, and two v_readlane broadcasts for the edges that close the
+// repeat loop.  Same recurrence, same candidate order (ascending source state, first of equal candidates wins), same chain
+// sweeps as viterbi_kernel; count and mark modes (no back-pointers: models keep their lane layout for those).
+template <int N, typename P>
+static __device__ __forceinline__ void g2_tournament(double (&cv)[8], P (&cc)[8])
+{
+#pragma unroll
+    for (int stride = 1; stride < 8; stride *= 2) {
+#pragma unroll
+        for (int j = 0; j + stride < 8; j += 2 * stride) {
+            if (j + stride < N) {
+                const bool gt = cv[j + stride] > cv[j];          // strict: the lower index -- the earlier in-edge -- survives a tie
+                cc[j] = gt ? cc[j + stride] : cc[j];
+                cv[j] = __builtin_fmax(cv[j], cv[j + stride]);
+            }
+        }
+    }
+}
+
+template <bool MARK, int WAVES, bool ODD>
+__global__ void __launch_bounds__(64 * WAVES)
+viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
+                  int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
+{
+    const int lane = threadIdx.x & 63;
+    const double NEGINF = -__builtin_inf();
+    using Pay = std::conditional_t<MARK, uint64_t, int>;
+    auto shr1_pay = [](Pay v) -> Pay {
+        if constexpr (MARK) return ((uint64_t)(uint32_t)dpp_shr1_i32((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)dpp_shr1_i32((int)(uint32_t)v);
+        else return dpp_shr1_i32(v);
+    };
+    auto readlane_pay = [](Pay v, int l) -> Pay {
+        if constexpr (MARK) return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+        else return __builtin_amdgcn_readlane(v, l);
+    };
+    const VitModel* cur_model = nullptr;
+    const VitG2* G = nullptr;
+    double la[7], lb[6], lc[7], ld[5], sg[2][2], clp[2];
+    double ea[2], ebf[2], ecf[4];
+    int einc[4]; bool etag[4];
+    double uni_lo_max = 0.0, uni_hi_min = 0.0;
+    // ODD: the two broadcast sources sit at an odd position (a repeat profile of odd length), and insert-type states at odd
+    // positions may be fed by the match / insert of the position before (the dummy state behind such a profile)
+    constexpr int B0 = ODD ? 1 : 0, B1 = ODD ? 3 : 2;
+    int bc0_lane = 0, bc1_lane = 0, start_slot = 0, start_lane = 0, end_slot = 0, end_lane = 0;
+
+    for (;;) {
+        const int tq = vit_next_task(queue, lane);
+        if (tq >= n_tasks) break;
+        const int ti = order ? order[tq] : tq;        // longest observation windows first
+        const VitTask tk = tasks[ti];
+        if (tk.model != cur_model) {
+            cur_model = tk.model;
+            G = cur_model->g2;
+            uni_lo_max = cur_model->uni_lo_max; uni_hi_min = cur_model->uni_hi_min;
+            const double* lp = G->lp;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) la[j] = lp[(G2_ROW_ME + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) lb[j] = lp[(G2_ROW_MO + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) lc[j] = lp[(G2_ROW_IE + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ld[j] = lp[(G2_ROW_IO + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { sg[0][j] = lp[(G2_ROW_DE + j) * 64 + lane]; sg[1][j] = lp[(G2_ROW_DO + j) * 64 + lane]; clp[j] = lp[(G2_ROW_CHAIN + j) * 64 + lane]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kind = G->kind[k * 64 + lane];
+                const double a = G->em[(k * 3 + 0) * 64 + lane], b = G->em[(k * 3 + 1) * 64 + lane], c = G->em[(k * 3 + 2) * 64 + lane];
+                if (k < 2) { ea[k] = kind ? a : 0.0; ebf[k] = kind == 1 ? b : 0.0; }
+                ecf[k] = kind ? c : NEGINF;          // branch-free emission  ecf - (x - ea)^2 * ebf  (uniform: ebf = 0; no state: -inf)
+                einc[k] = G->inc[k * 64 + lane]; etag[k] = G->tag[k * 64 + lane] != 0;
+            }
+            bc0_lane = G->bc_lane[0] < 0 ? 0 : G->bc_lane[0];
+            bc1_lane = G->bc_lane[1] < 0 ? 0 : G->bc_lane[1];
+            start_slot = G->start_slot; start_lane = G->start_lane; end_slot = G->end_slot; end_lane = G->end_lane;
+        }
+        const int64_t T = tk.T;
+        const bool fast_em = tk.src_kind != VIT_SRC_F64 && tk.lo >= uni_lo_max && tk.hi <= uni_hi_min && tk.c1 == tk.c1 && tk.h1 == tk.h1;
+
+        // chain sweeps: De (slot 0) takes from lane - 1's Do, Do (slot 1) from the lane's own De -- as in viterbi_kernel
+        auto chain_sweeps = [&](double (&y)[2], Pay (&yc)[2]) {
+            for (;;) {
+                double tin = dpp_shr1_f64(y[1]) + clp[0];
+                if constexpr (MARK) yc[0] = sel_shr1_u64(tin, y[0], yc[1], yc[0]); else yc[0] = sel_shr1_i32(tin, y[0], yc[1], yc[0]);
+                y[0] = max_f64_raw(y[0], tin);
+                tin = y[0] + clp[1];
+                const bool win = tin > y[1];
+                y[1] = max_f64_raw(y[1], tin);
+                yc[1] = win ? yc[0] : yc[1];
+                if (!__any(win)) break;
+            }
+        };
+
+        double pv[4]; Pay pc[4]; double dv[2]; Pay dc[2];      // Me, Mo, Ie, Io of the previous time step; De, Do
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pv[k] = NEGINF; pc[k] = 0; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { dv[s] = (lane == start_lane && s == start_slot) ? 0.0 : NEGINF; dc[s] = 0; }
+        chain_sweeps(dv, dc);          // t = 0: the silent states reachable from start (start itself has no chain edge: it stays 0)
+
+        auto step = [&](auto fast_c, double x, int64_t t) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            const uint32_t tt1 = (uint32_t)(t + 1);
+            const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
+            (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
+            // previous values of lane - 1 (lane 0 receives 0.0: every column that uses them is -inf there)
+            const double sMe = dpp_shr1_f64(pv[0]), sMo = dpp_shr1_f64(pv[1]), sIo = dpp_shr1_f64(pv[3]), sDo = dpp_shr1_f64(dv[1]);
+            const Pay cMe = shr1_pay(pc[0]), cMo = shr1_pay(pc[1]), cIo = shr1_pay(pc[3]), cDo = shr1_pay(dc[1]);
+            // the two broadcast sources
+            const double b0v = readlane_f64(pv[B0], bc0_lane), b1v = readlane_f64(pv[B1], bc1_lane);
+            const Pay b0c = readlane_pay(pc[B0], bc0_lane), b1c = readlane_pay(pc[B1], bc1_lane);
+            double nv[4]; Pay nc[4];
+            double best[4]; Pay bcnt[4];
+            {   // Me
+                double cv[8]; Pay cc[8];
+                cv[0] = sMe + la[0]; cc[0] = cMe;  cv[1] = sIo + la[1]; cc[1] = cIo;  cv[2] = sMo + la[2]; cc[2] = cMo;
+                cv[3] = pv[2] + la[3]; cc[3] = pc[2];  cv[4] = pv[0] + la[4]; cc[4] = pc[0];  cv[5] = b0v + la[5]; cc[5] = b0c;
+                cv[6] = sDo + la[6]; cc[6] = cDo;
+                g2_tournament<7>(cv, cc); best[0] = cv[0]; bcnt[0] = cc[0];
+            }
+            {   // Mo
+                double cv[8]; Pay cc[8];
+                cv[0] = sMo + lb[0]; cc[0] = cMo;  cv[1] = pv[2] + lb[1]; cc[1] = pc[2];  cv[2] = pv[0] + lb[2]; cc[2] = pc[0];
+                cv[3] = pv[3] + lb[3]; cc[3] = pc[3];  cv[4] = pv[1] + lb[4]; cc[4] = pc[1];  cv[5] = dv[0] + lb[5]; cc[5] = dc[0];
+                g2_tournament<6>(cv, cc); best[1] = cv[0]; bcnt[1] = cc[0];
+            }
+            {   // Ie
+                double cv[8]; Pay cc[8];
+                cv[0] = sIo + lc[0]; cc[0] = cIo;  cv[1] = sMo + lc[1]; cc[1] = cMo;  cv[2] = pv[2] + lc[2]; cc[2] = pc[2];
+                cv[3] = pv[0] + lc[3]; cc[3] = pc[0];  cv[4] = b1v + lc[4]; cc[4] = b1c;  cv[5] = sDo + lc[5]; cc[5] = cDo;
+                cv[6] = dv[0] + lc[6]; cc[6] = dc[0];
+                g2_tournament<7>(cv, cc); best[2] = cv[0]; bcnt[2] = cc[0];
+            }
+            {   // Io
+                double cv[8]; Pay cc[8];
+                if constexpr (ODD) {
+                    cv[0] = pv[2] + ld[0]; cc[0] = pc[2];  cv[1] = pv[0] + ld[1]; cc[1] = pc[0];  cv[2] = pv[3] + ld[2]; cc[2] = pc[3];
+                    cv[3] = pv[1] + ld[3]; cc[3] = pc[1];  cv[4] = dv[1] + ld[4]; cc[4] = dc[1];
+                    g2_tournament<5>(cv, cc);
+                } else {
+                    cv[0] = pv[3] + ld[2]; cc[0] = pc[3];  cv[1] = pv[1] + ld[3]; cc[1] = pc[1];  cv[2] = dv[1] + ld[4]; cc[2] = dc[1];
+                    g2_tournament<3>(cv, cc);
+                }
+                best[3] = cv[0]; bcnt[3] = cc[0];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double em;
+                if constexpr (FAST) {
+                    if (k < 2) { const double d = x - ea[k]; em = ecf[k] - (d * d) * ebf[k]; }
+                    else em = ecf[k];          // insert-type states carry no Normal emission (checked when the image is built)
+                } else {
+                    // general emission (observations outside a uniform support, NaN): parameters from memory, every step (rare path)
+                    const volatile int32_t* kp = G->kind; const volatile double* ep = G->em;
+                    const int kind = kp[k * 64 + lane];
+                    const double a = ep[(k * 3 + 0) * 64 + lane], b = ep[(k * 3 + 1) * 64 + lane], c = ep[(k * 3 + 2) * 64 + lane];
+                    const double d = x - a;
+                    const double en = c - (d * d) * b;
+                    const double eu = (x >= a && x <= b) ? c : NEGINF;
+                    em = kind == 1 ? en : (kind == 2 ? eu : NEGINF);
+                    if (x != x) em = kind ? 0.0 : NEGINF;          // missing observation: log-probability 0 under every distribution
+                }
+                nv[k] = best[k] + em;
+                const Pay bc = bcnt[k];
+                if constexpr (MARK) {
+                    uint32_t lo = (uint32_t)bc + (uint32_t)einc[k], hi = (uint32_t)((uint64_t)bc >> 32);
+                    const bool entered = ((lo >> 20) | (hi & 0x3FFu)) != 0, left = (hi >> 10) != 0;
+                    const bool set_e = etag[k] && !entered, set_l = !etag[k] && entered && !left;
+                    lo |= set_e ? mark_e_lo : 0u;
+                    hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
+                    nc[k] = ((uint64_t)hi << 32) | lo;
+                } else nc[k] = bc + einc[k];
+            }
+            // silent states of this time step: De from lane - 1's new Io, Mo; Do from the lane's own new Ie, Me; then the chains
+            double y[2]; Pay yc[2];
+            {
+                const double tI = dpp_shr1_f64(nv[3]) + sg[0][0], tM = dpp_shr1_f64(nv[1]) + sg[0][1];
+                const Pay cI = shr1_pay(nc[3]), cM = shr1_pay(nc[1]);
+                const bool gt = tM > tI;
+                y[0] = __builtin_fmax(tI, tM); yc[0] = gt ? cM : cI;
+            }
+            {
+                const double tI = nv[2] + sg[1][0], tM = nv[0] + sg[1][1];
+                const bool gt = tM > tI;
+                y[1] = __builtin_fmax(tI, tM); yc[1] = gt ? nc[0] : nc[2];
+            }
+            chain_sweeps(y, yc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pv[k] = nv[k]; pc[k] = nc[k]; }
+            dv[0] = y[0]; dv[1] = y[1]; dc[0] = yc[0]; dc[1] = yc[1];
+        };
+
+        auto run_window = [&](auto fast_c) {
+            double xchunk = 0.0;
+            for (int64_t t0 = 0; t0 < T; t0 += 64) {
+                {
+                    const int64_t idx = t0 + lane;
+                    double xv = 0.0;
+                    if (idx < T) {
+                        if (tk.src_kind == VIT_SRC_F64) xv = reinterpret_cast<const double*>(tk.sig)[idx];
+                        else {
+                            double sv = tk.src_kind == VIT_SRC_I16_AFFINE ? (double)reinterpret_cast<const int16_t*>(tk.sig)[idx]
+                                                                          : reinterpret_cast<const double*>(tk.sig)[idx];
+                            sv = (sv - tk.c1) / tk.h1;
+                            sv = sv * tk.h2 + tk.c2;
+                            sv = sv < tk.lo ? tk.lo : sv;          // np.clip
+                            sv = sv > tk.hi ? tk.hi : sv;
+                            xv = sv;
+                        }
+                    }
+                    xchunk = xv;
+                }
+                const int send = (int)((T - t0) < 64 ? (T - t0) : 64);
+                for (int s0 = 0; s0 < send; ++s0) step(fast_c, readlane_f64(xchunk, s0), t0 + s0);
+            }
+        };
+        if (__builtin_amdgcn_readfirstlane((int)fast_em) != 0) run_window(std::true_type{});
+        else run_window(std::false_type{});
+
+        double lp; Pay fc;
+        if (__builtin_amdgcn_readfirstlane(end_slot)) { lp = readlane_f64(dv[1], end_lane); fc = readlane_pay(dc[1], end_lane); }
+        else { lp = readlane_f64(dv[0], end_lane); fc = readlane_pay(dc[0], end_lane); }
+        VitResult r; r.logp = lp; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
+        r.dbg[0] = r.dbg[1] = r.dbg[2] = r.dbg[3] = 0;
+        if constexpr (MARK) {
+            const uint32_t plo = (uint32_t)fc, phi = (uint32_t)((uint64_t)fc >> 32);
+            r.counted = (lp > NEGINF) ? (int64_t)(plo & 0xFFFFFu) : 0;
+            r.dbg[0] = (plo >> 20) | ((phi & 0x3FFu) << 12);
+            r.dbg[1] = phi >> 10;
+            if (tk.T >= VIT_MARK_T_MAX) r.status = 2;
+        } else {
+            r.counted = (lp > NEGINF) ? (int64_t)fc : 0;
+        }
+        results[ti] = r;     // every lane stores the same value
+    }
+}
+
+static int launch_viterbi_g2(hipStream_t stream, bool odd, const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
+{
+    if (want_bp != 0 && want_bp != 2) return 2;
+    int nw = 8;
+    if (const char* e = getenv("STRQ_VIT_G2_WAVES")) { const int v = atoi(e); if (v == 12 || v == 8 || v == 4) nw = v; }
+    const dim3 grid(n_cu), block(64 * nw);
+#define G2_GO(MK_, W_) do { if (odd) hipLaunchKernelGGL((viterbi_g2_kernel<MK_, W_, true>), grid, block, 0, stream, tasks, results, n_tasks, queue, order); \
+                            else hipLaunchKernelGGL((viterbi_g2_kernel<MK_, W_, false>), grid, block, 0, stream, tasks, results, n_tasks, queue, order); } while (0)
+    if (want_bp == 2) { if (nw == 12) G2_GO(true, 12); else if (nw == 4) G2_GO(true, 4); else G2_GO(true, 8); }
+    else { if (nw == 12) G2_GO(false, 12); else if (nw == 4) G2_GO(false, 4); else G2_GO(false, 8); }
+#undef G2_GO
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // Any baked model (up to VIT_CSR_MAX_STATES states, any in-degree): the recurrence of the oracle written down as it stands.
 // One workgroup of 256 threads per window, one 16-byte {value, payload} cell per state in two LDS buffers; emitting states
 // are dealt to the threads, every state walks its in-edges in baked order with a strict '>' (the first of equal
@@ -854,6 +1111,13 @@ int vit_shape_silent_slots(int shape)
     return b >= 0 && b < 8 ? spl[b] : 0;
 }
 
+int vit_shape_for(const VitModel& mh, int want_bp)
+{
+    static const bool no_g2 = getenv("STRQ_VIT_NO_G2") != nullptr;      // A/B: the lane layout for every mode
+    if (mh.g2 && !no_g2 && (want_bp == 0 || want_bp == 2)) return VIT_SHAPE_G2 + (mh.g2_odd ? 1 : 0);
+    return vit_shape_of(mh);
+}
+
 int vit_shape_of(const VitModel& mh)
 {
     if (mh.csr) return VIT_SHAPE_CSR;
@@ -894,6 +1158,8 @@ int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* 
 {
     const int ss = (shape & VIT_SHAPE_SS) ? 1 : 0;
     if ((shape & ~VIT_SHAPE_SS) == VIT_SHAPE_CSR) return launch_viterbi_csr(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
+    if ((shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 || (shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 + 1)
+        return launch_viterbi_g2(stream, (shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 + 1, tasks, results, n_tasks, queue, n_cu, want_bp, order);
     switch (shape & ~VIT_SHAPE_SS) {
         case 0: return vit_launch_shape<4, 2, 6, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 1: return vit_launch_shape<1, 1, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);

@@ -36,6 +36,7 @@ class Graph(object):
         self.names, self.kinds, self.params = [], [], []
         self.edges = []                       # (src, dst, probability)
         self.layout = {}                      # optional: state -> (slot, lane) placement hint for the GPU kernel
+        self.positions = {}                   # optional: emitting state -> (0 match-type | 1 insert-type, position along the profile chain)
         self.start = self.add_state("start", SILENT)
         self.end = self.add_state("end", SILENT)
 
@@ -186,6 +187,18 @@ class FlankedRepeatModel(object):
         lay[rep.d2] = (0, b0 + len(rep.profile.match)); lay[rep.d1] = (1, b1 + len(rep.profile.insert))
         if max(l for _, l in lay.values()) < 64:
             g.layout = lay
+        # the same states as one chain of positions: prefix profile, repeat unit, the two dummy states (match-type dummy2,
+        # insert-type dummy1: they feed suffix00m / suffix00d the way a match / insert feeds the next position), suffix profile
+        pos = {}
+        P, R = len(pre.match), len(rep.profile.match)
+        for p_, st in enumerate(pre.match): pos[st] = (0, p_)
+        for p_, st in enumerate(pre.insert): pos[st] = (1, p_)
+        for q_, st in enumerate(rep.profile.match): pos[st] = (0, P + q_)
+        for q_, st in enumerate(rep.profile.insert): pos[st] = (1, P + q_)
+        pos[rep.d2] = (0, P + R); pos[rep.d1] = (1, P + R)
+        for p_, st in enumerate(suf.match): pos[st] = (0, P + R + 1 + p_)
+        for p_, st in enumerate(suf.insert): pos[st] = (1, P + R + 1 + p_)
+        g.positions = pos
         self.graph = g
         self.repeat_offset = rep.repeat_offset
         # visits of the two dummy states count repeat units (STRique.py:374-378)
@@ -243,7 +256,8 @@ BakedHMM = namedtuple("BakedHMM", [
     "tag",                                  # 1 for states whose name contains `tag_substring`
     "names", "orig_index",
     "hint_slot", "hint_lane",               # placement hints (-1 = none), see strq_model_create
-])
+    "pos_kind", "pos_index",                # position of every emitting state along the profile chain (None = unknown), see strq_model_set_positions
+], defaults=(None, None))
 
 
 def bake(g, count_states=(), tag_substring=None, tag2_states=()):
@@ -364,6 +378,11 @@ def bake(g, count_states=(), tag_substring=None, tag2_states=()):
     if g.layout and all(old in g.layout for old in emitting):
         for old in emitting:
             hint_slot[new[old]], hint_lane[new[old]] = g.layout[old]
+    pos_kind = pos_index = None
+    if getattr(g, 'positions', None) and all(old in g.positions for old in emitting):
+        pos_kind = np.zeros(m, np.int32); pos_index = np.zeros(m, np.int32)
+        for old in emitting:
+            pos_kind[new[old]], pos_index[new[old]] = g.positions[old]
     return BakedHMM(m, ne, new[g.start], new[g.end], in_ptr, np.array(in_src, np.int32),
                     np.array(in_logp, np.float64), kind, ea, eb, ec, count_inc, tag,
-                    [g.names[i] for i in final], np.array(final, np.int32), hint_slot, hint_lane)
+                    [g.names[i] for i in final], np.array(final, np.int32), hint_slot, hint_lane, pos_kind, pos_index)
