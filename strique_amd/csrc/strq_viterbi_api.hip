@@ -399,6 +399,10 @@ static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32
         for (int lane = 0; lane < 64; ++lane) if (lp[(size_t)(G2_ROW_IO + 0) * 64 + lane] > NEG || lp[(size_t)(G2_ROW_IO + 1) * 64 + lane] > NEG) io_front = true;
         if (bad_par || (io_front && par_bc == 0)) { why = "broadcast sources at positions of both parities"; continue; }
         out.odd = (par_bc == 1 || io_front) ? 1 : 0;
+        // the kernel adds count increments only in the two slots of that parity (STRique counts the two dummy states: the broadcast sources)
+        bool inc_elsewhere = false;
+        for (int k = 0; k < 4; ++k) if ((k & 1) != out.odd) for (int lane = 0; lane < 64; ++lane) if (inc[(size_t)k * 64 + lane] != 0) inc_elsewhere = true;
+        if (inc_elsewhere) { why = "a counted state at a position of the other parity"; continue; }
         out.lp.swap(lp); out.em.swap(em); out.knd.swap(knd); out.own.swap(own); out.inc.swap(inc); out.tag.swap(tag);
         return true;
     }

@@ -624,13 +624,29 @@ static __device__ __forceinline__ void g2_tournament(double (&cv)[8], P (&cc)[8]
     }
 }
 
-template <bool MARK, int WAVES, bool ODD>
+// LX: the three values a lane needs from lane - 1 on every time step (its odd-position match, insert and delete state) travel
+// through LDS -- one 16-byte cell per lane and kind, written by the owner, read by the right neighbour -- instead of three DPP
+// shifts of three registers each: the kernel is VALU-bound without it (177 VALU instructions per step), and the new Mo / Io
+// read for the delete gather of this step are next step's shifted previous values for free.  The rarely used neighbours (the
+// even match for the skip edges of a repeat profile) and the two broadcast sources stay on DPP / v_readlane.
+#define G2_LDS_CELLS 65              // cell 0 stays -inf: lane 0's left neighbour
+#define G2_LDS_WAVE_BYTES (5 * G2_LDS_CELLS * 16)
+template <bool MARK, int WAVES, bool ODD, int LXL>
 __global__ void __launch_bounds__(64 * WAVES)
 viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
                   int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
 {
+    extern __shared__ double lds_d[];
     const int lane = threadIdx.x & 63;
     const double NEGINF = -__builtin_inf();
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef unsigned v3u __attribute__((ext_vector_type(3)));
+    // LXL 1: Mo, Io, Do through LDS; 2: also the even match (skip edges) and the two broadcast sources (uniform-address reads)
+    constexpr bool LX = LXL >= 1, LX2 = LXL >= 2;
+    // this wave's cells: [Mo | Io | Do | Me | Ie][65]; the owner lane l writes cell l + 1, lane l reads cell l
+    char* const xbase = reinterpret_cast<char*>(lds_d) + (size_t)(threadIdx.x >> 6) * G2_LDS_WAVE_BYTES;
+    char* const xst = xbase + 16 * (lane + 1);
+    const char* const xld = xbase + 16 * lane;
     using Pay = std::conditional_t<MARK, uint64_t, int>;
     auto shr1_pay = [](Pay v) -> Pay {
         if constexpr (MARK) return ((uint64_t)(uint32_t)dpp_shr1_i32((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)dpp_shr1_i32((int)(uint32_t)v);
@@ -639,6 +655,21 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
     auto readlane_pay = [](Pay v, int l) -> Pay {
         if constexpr (MARK) return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
         else return __builtin_amdgcn_readlane(v, l);
+    };
+    auto xstore = [&](int kind, double v, Pay c) {          // ds_write_b96 / b128 at a compile-time offset
+        const uint64_t u = __builtin_bit_cast(uint64_t, v);
+        if constexpr (MARK) { v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = (unsigned)c; q.w = (unsigned)((uint64_t)c >> 32); *reinterpret_cast<v4u*>(xst + kind * (G2_LDS_CELLS * 16)) = q; }
+        else { v3u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = (unsigned)c; *reinterpret_cast<v3u*>(xst + kind * (G2_LDS_CELLS * 16)) = q; }
+    };
+    auto xload = [&](int kind, double& v, Pay& c) {         // ds_read_b128
+        const v4u q = *reinterpret_cast<const v4u*>(xld + kind * (G2_LDS_CELLS * 16));
+        v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
+        if constexpr (MARK) c = ((uint64_t)q.w << 32) | q.z; else c = (int)q.z;
+    };
+    auto xload_at = [&](int kind, int src_lane, double& v, Pay& c) {      // the cell of one lane, read by all (same address: one LDS cycle)
+        const v4u q = *reinterpret_cast<const v4u*>(xbase + kind * (G2_LDS_CELLS * 16) + 16 * (src_lane + 1));
+        v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
+        if constexpr (MARK) c = ((uint64_t)q.w << 32) | q.z; else c = (int)q.z;
     };
     const VitModel* cur_model = nullptr;
     const VitG2* G = nullptr;
@@ -706,6 +737,15 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
 #pragma unroll
         for (int s = 0; s < 2; ++s) { dv[s] = (lane == start_lane && s == start_slot) ? 0.0 : NEGINF; dc[s] = 0; }
         chain_sweeps(dv, dc);          // t = 0: the silent states reachable from start (start itself has no chain edge: it stays 0)
+        double rMo = NEGINF, rIo = NEGINF, rDo = NEGINF; Pay qMo = 0, qIo = 0, qDo = 0;      // LX: lane - 1's Mo, Io, Do of the previous time step
+        double rMe = NEGINF, rB0 = NEGINF, rB1 = NEGINF; Pay qMe = 0, qB0 = 0, qB1 = 0;      // LX2: lane - 1's Me, the two broadcast sources
+        if constexpr (LX) {
+            if (lane < 5) { const uint64_t u = __builtin_bit_cast(uint64_t, NEGINF); v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = 0; q.w = 0; *reinterpret_cast<v4u*>(xbase + lane * (G2_LDS_CELLS * 16)) = q; }
+            VIT_FENCE();
+            xstore(2, dv[1], dc[1]);
+            VIT_FENCE();
+            xload(2, rDo, qDo);
+        }
 
         auto step = [&](auto fast_c, double x, int64_t t) {
             constexpr bool FAST = decltype(fast_c)::value;
@@ -713,11 +753,15 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
             (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
             // previous values of lane - 1 (lane 0 receives 0.0: every column that uses them is -inf there)
-            const double sMe = dpp_shr1_f64(pv[0]), sMo = dpp_shr1_f64(pv[1]), sIo = dpp_shr1_f64(pv[3]), sDo = dpp_shr1_f64(dv[1]);
-            const Pay cMe = shr1_pay(pc[0]), cMo = shr1_pay(pc[1]), cIo = shr1_pay(pc[3]), cDo = shr1_pay(dc[1]);
+            double sMe; Pay cMe;
+            if constexpr (LX2) { sMe = rMe; cMe = qMe; } else { sMe = dpp_shr1_f64(pv[0]); cMe = shr1_pay(pc[0]); }
+            double sMo, sIo, sDo; Pay cMo, cIo, cDo;
+            if constexpr (LX) { sMo = rMo; sIo = rIo; sDo = rDo; cMo = qMo; cIo = qIo; cDo = qDo; }
+            else { sMo = dpp_shr1_f64(pv[1]); sIo = dpp_shr1_f64(pv[3]); sDo = dpp_shr1_f64(dv[1]); cMo = shr1_pay(pc[1]); cIo = shr1_pay(pc[3]); cDo = shr1_pay(dc[1]); }
             // the two broadcast sources
-            const double b0v = readlane_f64(pv[B0], bc0_lane), b1v = readlane_f64(pv[B1], bc1_lane);
-            const Pay b0c = readlane_pay(pc[B0], bc0_lane), b1c = readlane_pay(pc[B1], bc1_lane);
+            double b0v, b1v; Pay b0c, b1c;
+            if constexpr (LX2) { b0v = rB0; b1v = rB1; b0c = qB0; b1c = qB1; }
+            else { b0v = readlane_f64(pv[B0], bc0_lane); b1v = readlane_f64(pv[B1], bc1_lane); b0c = readlane_pay(pc[B0], bc0_lane); b1c = readlane_pay(pc[B1], bc1_lane); }
             double nv[4]; Pay nc[4];
             double best[4]; Pay bcnt[4];
             {   // Me
@@ -772,19 +816,30 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 nv[k] = best[k] + em;
                 const Pay bc = bcnt[k];
                 if constexpr (MARK) {
-                    uint32_t lo = (uint32_t)bc + (uint32_t)einc[k], hi = (uint32_t)((uint64_t)bc >> 32);
+                    uint32_t lo = (k == B0 || k == B1) ? (uint32_t)bc + (uint32_t)einc[k] : (uint32_t)bc, hi = (uint32_t)((uint64_t)bc >> 32);
                     const bool entered = ((lo >> 20) | (hi & 0x3FFu)) != 0, left = (hi >> 10) != 0;
                     const bool set_e = etag[k] && !entered, set_l = !etag[k] && entered && !left;
                     lo |= set_e ? mark_e_lo : 0u;
                     hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
                     nc[k] = ((uint64_t)hi << 32) | lo;
-                } else nc[k] = bc + einc[k];
+                } else nc[k] = (k == B0 || k == B1) ? bc + einc[k] : bc;          // counted states sit in the slots of the broadcast sources (checked when the image is built)
             }
             // silent states of this time step: De from lane - 1's new Io, Mo; Do from the lane's own new Ie, Me; then the chains
             double y[2]; Pay yc[2];
             {
-                const double tI = dpp_shr1_f64(nv[3]) + sg[0][0], tM = dpp_shr1_f64(nv[1]) + sg[0][1];
-                const Pay cI = shr1_pay(nc[3]), cM = shr1_pay(nc[1]);
+                double nI, nM; Pay cI, cM;      // lane - 1's new Io, Mo
+                if constexpr (LX) {
+                    xstore(0, nv[1], nc[1]); xstore(1, nv[3], nc[3]);
+                    if constexpr (LX2) { xstore(3, nv[0], nc[0]); if constexpr (!ODD) xstore(4, nv[2], nc[2]); }
+                    VIT_FENCE();
+                    xload(0, nM, cM); xload(1, nI, cI);
+                    rMo = nM; rIo = nI; qMo = cM; qIo = cI;          // ... which are next step's shifted previous values
+                    if constexpr (LX2) {      // for the next time step
+                        xload(3, rMe, qMe);
+                        xload_at(ODD ? 0 : 3, bc0_lane, rB0, qB0); xload_at(ODD ? 1 : 4, bc1_lane, rB1, qB1);
+                    }
+                } else { nI = dpp_shr1_f64(nv[3]); nM = dpp_shr1_f64(nv[1]); cI = shr1_pay(nc[3]); cM = shr1_pay(nc[1]); }
+                const double tI = nI + sg[0][0], tM = nM + sg[0][1];
                 const bool gt = tM > tI;
                 y[0] = __builtin_fmax(tI, tM); yc[0] = gt ? cM : cI;
             }
@@ -794,6 +849,12 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 y[1] = __builtin_fmax(tI, tM); yc[1] = gt ? nc[0] : nc[2];
             }
             chain_sweeps(y, yc);
+            if constexpr (LX) {
+                VIT_FENCE();
+                xstore(2, y[1], yc[1]);
+                VIT_FENCE();
+                xload(2, rDo, qDo);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) { pv[k] = nv[k]; pc[k] = nc[k]; }
             dv[0] = y[0]; dv[1] = y[1]; dc[0] = yc[0]; dc[1] = yc[1];
@@ -847,14 +908,18 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
 static int launch_viterbi_g2(hipStream_t stream, bool odd, const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
 {
     if (want_bp != 0 && want_bp != 2) return 2;
-    int nw = 8;
-    if (const char* e = getenv("STRQ_VIT_G2_WAVES")) { const int v = atoi(e); if (v == 12 || v == 8 || v == 4) nw = v; }
+    int nw = 8, lx = 2;
+    if (const char* e = getenv("STRQ_VIT_G2_WAVES")) { const int v = atoi(e); if (v == 12 || v == 8 || v == 4) nw = v; }      // experiments
+    if (const char* e = getenv("STRQ_VIT_G2_LDS")) { const int v = atoi(e); if (v >= 0 && v <= 2) lx = v; }
     const dim3 grid(n_cu), block(64 * nw);
-#define G2_GO(MK_, W_) do { if (odd) hipLaunchKernelGGL((viterbi_g2_kernel<MK_, W_, true>), grid, block, 0, stream, tasks, results, n_tasks, queue, order); \
-                            else hipLaunchKernelGGL((viterbi_g2_kernel<MK_, W_, false>), grid, block, 0, stream, tasks, results, n_tasks, queue, order); } while (0)
+    const size_t lds = lx ? (size_t)nw * G2_LDS_WAVE_BYTES : 0;
+#define G2_GO2(MK_, W_, OD_, LX_) hipLaunchKernelGGL((viterbi_g2_kernel<MK_, W_, OD_, LX_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order)
+#define G2_GO(MK_, W_) do { if (odd) { if (lx == 2) G2_GO2(MK_, W_, true, 2); else if (lx == 1) G2_GO2(MK_, W_, true, 1); else G2_GO2(MK_, W_, true, 0); } \
+                            else { if (lx == 2) G2_GO2(MK_, W_, false, 2); else if (lx == 1) G2_GO2(MK_, W_, false, 1); else G2_GO2(MK_, W_, false, 0); } } while (0)
     if (want_bp == 2) { if (nw == 12) G2_GO(true, 12); else if (nw == 4) G2_GO(true, 4); else G2_GO(true, 8); }
     else { if (nw == 12) G2_GO(false, 12); else if (nw == 4) G2_GO(false, 4); else G2_GO(false, 8); }
 #undef G2_GO
+#undef G2_GO2
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -1113,7 +1178,7 @@ int vit_shape_silent_slots(int shape)
 
 int vit_shape_for(const VitModel& mh, int want_bp)
 {
-    static const bool no_g2 = getenv("STRQ_VIT_NO_G2") != nullptr;      // A/B: the lane layout for every mode
+    const bool no_g2 = getenv("STRQ_VIT_NO_G2") != nullptr;      // A/B: the lane layout for every mode
     if (mh.g2 && !no_g2 && (want_bp == 0 || want_bp == 2)) return VIT_SHAPE_G2 + (mh.g2_odd ? 1 : 0);
     return vit_shape_of(mh);
 }

@@ -151,7 +151,8 @@ class Context(object):
         self._check(self._lib.strq_model_create(self._h, ctypes.c_int32(baked.n_states), ctypes.c_int32(baked.silent_start),
                                                 ctypes.c_int32(baked.start), ctypes.c_int32(baked.end),
                                                 *[_ptr(a) for a in arrs], ctypes.byref(mid)))
-        if getattr(baked, 'pos_kind', None) is not None and os.environ.get("STRQ_VIT_NO_G2") is None:
+        self.last_positions_rc = None
+        if getattr(baked, 'pos_kind', None) is not None:
             # optional register-resident image (profile chains); a model that is no such chain keeps its lane layout
             rc = self._lib.strq_model_set_positions(self._h, mid, _ptr(_c(baked.pos_kind, np.int32)), _ptr(_c(baked.pos_index, np.int32)))
             self.last_positions_rc = rc

@@ -40,6 +40,33 @@ def test_flanked_model_parity(ctx, orc, pm, cfg, name):
         assert lg2 == lg and cg2 == cg
 
 
+def test_register_resident_kernel_variants_agree(ctx, orc, pm, cfg, monkeypatch):
+    """Count-only decodes of a flanked model run on viterbi_g2_kernel (strq_model_set_positions accepted the chain): its
+    three exchange levels (all DPP / odd-slot neighbours through LDS / skip and broadcast sources too) and the lane-layout
+    kernel must give the oracle's log-probability and count on the same windows -- even and odd repeat profiles, ragged
+    lengths, a window of missing observations."""
+    from strique_amd import hmm
+    rng = np.random.default_rng(77)
+    for name, rep_override in (("c9orf72", None), ("fmr1", None), ("c9orf72", "CAGCA")):
+        chrom, b, e, repeat, prefix, suffix = cfg["repeat"][name]
+        repeat = rep_override or repeat
+        fm = hmm.FlankedRepeatModel(repeat, prefix[-50:], suffix[:50], pm, cfg["HMM"])
+        mid = ctx.model_create(fm.baked)
+        assert ctx.last_positions_rc == 0
+        seqs = [_signal(pm, rng, prefix[-50:] + repeat * int(k) + suffix[:50]) for k in (1, 2, 7, 33, 90)]
+        seqs.append(np.full(57, np.nan)); seqs.append(seqs[2][:1])
+        want = [orc.viterbi(fm.baked, s, want_path=False) for s in seqs]
+        for env in ({"STRQ_VIT_G2_LDS": "0"}, {"STRQ_VIT_G2_LDS": "1"}, {"STRQ_VIT_G2_LDS": "2"}, {"STRQ_VIT_NO_G2": "1"}, {"STRQ_VIT_G2_WAVES": "4"}):
+            with monkeypatch.context() as mp:
+                for k, v in env.items():
+                    mp.setenv(k, v)
+                lg, cg, sg, _ = ctx.viterbi_batch(mid, seqs)
+            for i, (lo, _, co) in enumerate(want):
+                if len(seqs[i]) == 1 and not np.isfinite(lo):
+                    assert not np.isfinite(lg[i]); continue
+                assert np.float64(lo).tobytes() == np.float64(lg[i]).tobytes() and co == cg[i], (name, env, i)
+
+
 def test_flanked_model_with_counted_silent_states(ctx, orc, pm, cfg):
     """The kernels picked for STRique's flanked models carry a silent state's payload on unchanged (STRique counts the
     emitting dummy states only, scripts/STRique.py:341-342,375-377).  The same model with some delete states counted must
