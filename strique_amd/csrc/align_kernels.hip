@@ -48,6 +48,11 @@ static __device__ __forceinline__ float dpp_shr1_f(float v, float fill)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
                               __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
 }
+static __device__ __forceinline__ float dpp_shr1_f0(float v)
+{
+    // ... lane 0 receives +0.0 (bound_ctrl): no register to preload with the fill value
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
 static __device__ __forceinline__ int dpp_shr1_i(int v, int fill)
 {
     return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false);
@@ -420,8 +425,14 @@ struct Forward {
                 fVB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bcur.vB), s));
             }
         }
+#ifdef STRQ_DP_ZFILL
+        // experiment (13 % SLOWER, profiles/r03_dead_ends.md 7): without a strip above, lane 0 takes the DPP's own zero fill -- two v_mov less per step
+        const float upA = HAS_IN ? dpp_shr1_f(st.SbotA, fA) : dpp_shr1_f0(st.SbotA);
+        const float upB = HAS_IN ? dpp_shr1_f(st.S[R - 1], fB) : dpp_shr1_f0(st.S[R - 1]);
+#else
         const float upA = dpp_shr1_f(st.SbotA, fA);
         const float upB = dpp_shr1_f(st.S[R - 1], fB);
+#endif
         float upVA = STRQ_NINF, upVB = STRQ_NINF;
         if constexpr (!LV) { upVA = dpp_shr1_f(st.VbotA, fVA); upVB = dpp_shr1_f(st.VbotB, fVB); }
         const int jB = 2 * (t - lane), jA = jB - 1;
