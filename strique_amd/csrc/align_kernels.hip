@@ -37,6 +37,8 @@ namespace strq {
 
 #define STRQ_NINF (-3.4028234663852886e38f / 2)
 
+#define STRQ_STR2(x) #x
+#define STRQ_STR(x) STRQ_STR2(x)
 // tie rules -- keep identical to oracle/align_oracle.c
 #define STRQ_TIE_EXT(ext, opn)  ((ext) >= (opn))
 #define STRQ_TIE_H_OVER_V(h, v) ((h) >= (v))
@@ -504,6 +506,10 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
         const bool ckpt_here = ((t0 + 64) % STRQ_CKPT_STEPS) == 0 && (t0 + 64) < nsteps;
         const int send = nsteps - t0 < 64 ? nsteps - t0 : 64;
         if (full) {
+#ifdef STRQ_DP_PAD
+            // placement experiment (profiles/r03_dead_ends.md 9): the steady-state loop STRQ_DP_PAD dwords behind a 64-byte boundary
+            asm volatile(".p2align 6\n\t.rept " STRQ_STR(STRQ_DP_PAD) "\n\ts_nop 0\n\t.endr");
+#endif
             for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, s, qcur, s + 1);
             if (ckpt_here) f.template step<false, true>(t0 + 64, 63, qnext, 0);
             else f.template step<false, false>(t0 + 64, 63, qnext, 0);
