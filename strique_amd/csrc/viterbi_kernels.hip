@@ -764,27 +764,27 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             else { b0v = readlane_f64(pv[B0], bc0_lane); b1v = readlane_f64(pv[B1], bc1_lane); b0c = readlane_pay(pc[B0], bc0_lane); b1c = readlane_pay(pc[B1], bc1_lane); }
             double nv[4]; Pay nc[4];
             double best[4]; Pay bcnt[4];
-            {   // Me
+            auto tour_me = [&]() {
                 double cv[8]; Pay cc[8];
                 cv[0] = sMe + la[0]; cc[0] = cMe;  cv[1] = sIo + la[1]; cc[1] = cIo;  cv[2] = sMo + la[2]; cc[2] = cMo;
                 cv[3] = pv[2] + la[3]; cc[3] = pc[2];  cv[4] = pv[0] + la[4]; cc[4] = pc[0];  cv[5] = b0v + la[5]; cc[5] = b0c;
                 cv[6] = sDo + la[6]; cc[6] = cDo;
                 g2_tournament<7>(cv, cc); best[0] = cv[0]; bcnt[0] = cc[0];
-            }
-            {   // Mo
+            };
+            auto tour_mo = [&]() {
                 double cv[8]; Pay cc[8];
                 cv[0] = sMo + lb[0]; cc[0] = cMo;  cv[1] = pv[2] + lb[1]; cc[1] = pc[2];  cv[2] = pv[0] + lb[2]; cc[2] = pc[0];
                 cv[3] = pv[3] + lb[3]; cc[3] = pc[3];  cv[4] = pv[1] + lb[4]; cc[4] = pc[1];  cv[5] = dv[0] + lb[5]; cc[5] = dc[0];
                 g2_tournament<6>(cv, cc); best[1] = cv[0]; bcnt[1] = cc[0];
-            }
-            {   // Ie
+            };
+            auto tour_ie = [&]() {
                 double cv[8]; Pay cc[8];
                 cv[0] = sIo + lc[0]; cc[0] = cIo;  cv[1] = sMo + lc[1]; cc[1] = cMo;  cv[2] = pv[2] + lc[2]; cc[2] = pc[2];
                 cv[3] = pv[0] + lc[3]; cc[3] = pc[0];  cv[4] = b1v + lc[4]; cc[4] = b1c;  cv[5] = sDo + lc[5]; cc[5] = cDo;
                 cv[6] = dv[0] + lc[6]; cc[6] = dc[0];
                 g2_tournament<7>(cv, cc); best[2] = cv[0]; bcnt[2] = cc[0];
-            }
-            {   // Io
+            };
+            auto tour_io = [&]() {
                 double cv[8]; Pay cc[8];
                 if constexpr (ODD) {
                     cv[0] = pv[2] + ld[0]; cc[0] = pc[2];  cv[1] = pv[0] + ld[1]; cc[1] = pc[0];  cv[2] = pv[3] + ld[2]; cc[2] = pc[3];
@@ -795,12 +795,13 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                     g2_tournament<3>(cv, cc);
                 }
                 best[3] = cv[0]; bcnt[3] = cc[0];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            };
+            // emission and payload of slot k
+            auto finish = [&](auto k_c) {
+                constexpr int k = decltype(k_c)::value;
                 double em;
                 if constexpr (FAST) {
-                    if (k < 2) { const double d = x - ea[k]; em = ecf[k] - (d * d) * ebf[k]; }
+                    if constexpr (k < 2) { const double d = x - ea[k]; em = ecf[k] - (d * d) * ebf[k]; }
                     else em = ecf[k];          // insert-type states carry no Normal emission (checked when the image is built)
                 } else {
                     // general emission (observations outside a uniform support, NaN): parameters from memory, every step (rare path)
@@ -823,22 +824,39 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                     hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
                     nc[k] = ((uint64_t)hi << 32) | lo;
                 } else nc[k] = (k == B0 || k == B1) ? bc + einc[k] : bc;          // counted states sit in the slots of the broadcast sources (checked when the image is built)
-            }
+            };
+            using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+            using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
             // silent states of this time step: De from lane - 1's new Io, Mo; Do from the lane's own new Ie, Me; then the chains
             double y[2]; Pay yc[2];
             {
                 double nI, nM; Pay cI, cM;      // lane - 1's new Io, Mo
                 if constexpr (LX) {
+#ifdef STRQ_G2_EARLY
+                    // experiment: the odd slots first -- their cells are on their way through LDS while the even slots (the larger tournaments) are evaluated
+                    tour_mo(); tour_io(); finish(K1{}); finish(K3{});
+                    xstore(0, nv[1], nc[1]); xstore(1, nv[3], nc[3]);
+                    VIT_FENCE();
+                    xload(0, nM, cM); xload(1, nI, cI);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tour_me(); tour_ie(); finish(K0{}); finish(K2{});
+                    if constexpr (LX2) { xstore(3, nv[0], nc[0]); if constexpr (!ODD) xstore(4, nv[2], nc[2]); VIT_FENCE(); }
+#else
+                    tour_me(); tour_mo(); tour_ie(); tour_io(); finish(K0{}); finish(K1{}); finish(K2{}); finish(K3{});
                     xstore(0, nv[1], nc[1]); xstore(1, nv[3], nc[3]);
                     if constexpr (LX2) { xstore(3, nv[0], nc[0]); if constexpr (!ODD) xstore(4, nv[2], nc[2]); }
                     VIT_FENCE();
                     xload(0, nM, cM); xload(1, nI, cI);
+#endif
                     rMo = nM; rIo = nI; qMo = cM; qIo = cI;          // ... which are next step's shifted previous values
                     if constexpr (LX2) {      // for the next time step
                         xload(3, rMe, qMe);
                         xload_at(ODD ? 0 : 3, bc0_lane, rB0, qB0); xload_at(ODD ? 1 : 4, bc1_lane, rB1, qB1);
                     }
-                } else { nI = dpp_shr1_f64(nv[3]); nM = dpp_shr1_f64(nv[1]); cI = shr1_pay(nc[3]); cM = shr1_pay(nc[1]); }
+                } else {
+                    tour_me(); tour_mo(); tour_ie(); tour_io(); finish(K0{}); finish(K1{}); finish(K2{}); finish(K3{});
+                    nI = dpp_shr1_f64(nv[3]); nM = dpp_shr1_f64(nv[1]); cI = shr1_pay(nc[3]); cM = shr1_pay(nc[1]);
+                }
                 const double tI = nI + sg[0][0], tM = nM + sg[0][1];
                 const bool gt = tM > tI;
                 y[0] = __builtin_fmax(tI, tM); yc[0] = gt ? cM : cI;
