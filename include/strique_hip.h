@@ -224,6 +224,15 @@ int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, int64_t n_chu
  * last sub-batch processed by strq_batch_run. */
 int strq_debug_conditioning(strq_ctx* ctx, int64_t read, uint8_t* levels, int64_t n, float* level_val,
                             double* scalars10);
+/* Test hook, host only (no context, no device): the tables strq_model_set_positions would upload for this model --
+ * out_lp[31 * 64] (log-probability of every column of the layout per lane, -inf where a lane has no such edge),
+ * out_own[6 * 64] (state of every slot and lane, -1 if none), out_meta[8] = {slot, lane of the two broadcast sources,
+ * of start and of end}.  STRQ_ERR_UNSUPPORTED and the reason in `why` when the model is no profile chain.
+ * tests/test_g2_layout.py drives a plain restatement of the kernel's time step with them. */
+int strq_debug_g2_layout(int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
+                         const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
+                         const int32_t* emis_kind, const int32_t* count_inc, const int32_t* kind, const int32_t* pos,
+                         double* out_lp, int32_t* out_own, int32_t* out_meta, char* why, int32_t why_len);
 
 /* Kernel timing of the last batched call, milliseconds (HIP events on the library's stream):
  * [0] table build  [1] forward DP  [2] trace pass  [3] total  [4] table entries re-evaluated on
