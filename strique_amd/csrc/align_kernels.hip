@@ -174,6 +174,29 @@ static __device__ __forceinline__ float pick_row(const float (&x)[R], int rM)
 
 struct TraceWords { uint64_t a[2], b[2]; };
 
+// Trace codes, one nibble per cell: bit 0 the diagonal won (D >= G), bit 1 H won over V, bit 2 H extended, bit 3 V extended.
+// A cell's four tie-rule compares are shifted into a 32-bit accumulator as they are made -- acc = 2 * acc + (a >= b), one
+// v_cmp + one v_addc_co_u32 (the compare's lane mask is the carry) -- instead of four selects and the ors that merged them:
+// eight rows per accumulator, two accumulators per 64-bit trace word, the first row of a half in its highest nibble.
+#ifndef STRQ_TRACE_SELECT
+static __device__ __forceinline__ void trace_push_ge(uint32_t& acc, float a, float b)
+{
+    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+#endif
+// position (bit offset in the 64-bit word r / 16) of the nibble of row r
+template <int R> static __device__ __forceinline__ int trace_shift(int r)
+{
+#ifndef STRQ_TRACE_SELECT
+    const int in_word = r % 16, half = in_word / 8;
+    const int rows_word = R - 16 * (r / 16) < 16 ? R - 16 * (r / 16) : 16;
+    const int rows_half = rows_word - 8 * half < 8 ? rows_word - 8 * half : 8;
+    return 32 * half + 4 * (rows_half - 1 - (in_word % 8));
+#else
+    return 4 * (r % 16);
+#endif
+}
+
 // Two DP columns (jA, jB) for this lane.
 // LH / LV: open == extend in that direction, where the affine recurrence collapses exactly
 // (H[i][j-1] <= S[i][j-1] always and x -> x+e is monotone in IEEE arithmetic, so
@@ -190,6 +213,8 @@ static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[
     float HA[R], HB[R];
     float vA = upVA, vB = upVB;
     if constexpr (TRACE) { tw->a[0] = tw->a[1] = tw->b[0] = tw->b[1] = 0; }
+    uint32_t accA[4] = {0u, 0u, 0u, 0u}, accB[4] = {0u, 0u, 0u, 0u};
+    (void)accA; (void)accB;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         // ---- column A, row r
@@ -199,17 +224,28 @@ static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[
             const float D = diag + rsA[r];
             if constexpr (TRACE) {
                 const float hext = st.H[r] + p.ext_h, hopn = st.S[r] + p.open_h;
+                const float vext = vA + p.ext_v, vopn = up + p.open_v;
+#ifndef STRQ_TRACE_SELECT
+                // every tie rule is a '>=' and the winner of each is the larger value: the values come from max, the rules from the compares
+                uint32_t& acc = accA[(r / 16) * 2 + (r % 16) / 8];
+                trace_push_ge(acc, vext, vopn); trace_push_ge(acc, hext, hopn);
+                const float Hn = __builtin_fmaxf(hext, hopn), Vn = __builtin_fmaxf(vext, vopn);
+                trace_push_ge(acc, Hn, Vn);
+                const float Gm = __builtin_fmaxf(Hn, Vn);
+                trace_push_ge(acc, D, Gm);
+                SA[r] = __builtin_fmaxf(D, Gm); HA[r] = Hn; vA = Vn;
+#else
                 const bool he = STRQ_TIE_EXT(hext, hopn);
                 const float Hn = he ? hext : hopn;
-                const float vext = vA + p.ext_v, vopn = up + p.open_v;
                 const bool ve = STRQ_TIE_EXT(vext, vopn);
                 const float Vn = ve ? vext : vopn;
                 const bool gh = STRQ_TIE_H_OVER_V(Hn, Vn);
                 const float Gm = gh ? Hn : Vn;
                 const bool dd = STRQ_TIE_D_OVER_G(D, Gm);
                 SA[r] = dd ? D : Gm; HA[r] = Hn; vA = Vn;
-                const uint64_t code = (dd ? 0u : (gh ? 1u : 2u)) | (he ? 4u : 0u) | (ve ? 8u : 0u);
+                const uint64_t code = (dd ? 1u : 0u) | (gh ? 2u : 0u) | (he ? 4u : 0u) | (ve ? 8u : 0u);
                 tw->a[r / 16] |= code << (4 * (r % 16));
+#endif
             } else {
                 float Hn, Vn;
                 if constexpr (LH) Hn = st.S[r] + p.ext_h;
@@ -227,17 +263,27 @@ static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[
             const float D = diag + rsB[r];
             if constexpr (TRACE) {
                 const float hext = HA[r] + p.ext_h, hopn = SA[r] + p.open_h;
+                const float vext = vB + p.ext_v, vopn = up + p.open_v;
+#ifndef STRQ_TRACE_SELECT
+                uint32_t& acc = accB[(r / 16) * 2 + (r % 16) / 8];
+                trace_push_ge(acc, vext, vopn); trace_push_ge(acc, hext, hopn);
+                const float Hn = __builtin_fmaxf(hext, hopn), Vn = __builtin_fmaxf(vext, vopn);
+                trace_push_ge(acc, Hn, Vn);
+                const float Gm = __builtin_fmaxf(Hn, Vn);
+                trace_push_ge(acc, D, Gm);
+                SB[r] = __builtin_fmaxf(D, Gm); HB[r] = Hn; vB = Vn;
+#else
                 const bool he = STRQ_TIE_EXT(hext, hopn);
                 const float Hn = he ? hext : hopn;
-                const float vext = vB + p.ext_v, vopn = up + p.open_v;
                 const bool ve = STRQ_TIE_EXT(vext, vopn);
                 const float Vn = ve ? vext : vopn;
                 const bool gh = STRQ_TIE_H_OVER_V(Hn, Vn);
                 const float Gm = gh ? Hn : Vn;
                 const bool dd = STRQ_TIE_D_OVER_G(D, Gm);
                 SB[r] = dd ? D : Gm; HB[r] = Hn; vB = Vn;
-                const uint64_t code = (dd ? 0u : (gh ? 1u : 2u)) | (he ? 4u : 0u) | (ve ? 8u : 0u);
+                const uint64_t code = (dd ? 1u : 0u) | (gh ? 2u : 0u) | (he ? 4u : 0u) | (ve ? 8u : 0u);
                 tw->b[r / 16] |= code << (4 * (r % 16));
+#endif
             } else {
                 float Hn, Vn;
                 if constexpr (LH) Hn = SA[r] + p.ext_h;
@@ -249,6 +295,15 @@ static __device__ __forceinline__ void dp_step2(Lane<R>& st, const float (&rsA)[
             }
         }
     }
+#ifndef STRQ_TRACE_SELECT
+    if constexpr (TRACE) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            tw->a[x] = (uint64_t)accA[2 * x] | ((uint64_t)accA[2 * x + 1] << 32);
+            tw->b[x] = (uint64_t)accB[2 * x] | ((uint64_t)accB[2 * x + 1] << 32);
+        }
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) st.S[r] = SB[r];
     if constexpr (TRACE || !LH || KEEP) {
@@ -751,11 +806,10 @@ align_trace_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict_
                 const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pf, src);
                 const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pf >> 32), src);
                 const uint64_t w = ((uint64_t)whi << 32) | wlo;
-                const uint32_t code = (uint32_t)(w >> (4 * (r % 16))) & 15u;
+                const uint32_t code = (uint32_t)(w >> trace_shift<R>(r)) & 15u;
                 if (state == 0) {
-                    const uint32_t d = code & 3u;
-                    if (d == 0) { rec[ci - 1] = (cj + col_off) << 1; --ci; --cj; }
-                    else state = (int)d;
+                    if (code & 1u) { rec[ci - 1] = (cj + col_off) << 1; --ci; --cj; }      // the diagonal won
+                    else state = (code & 2u) ? 1 : 2;                                      // H over V
                 } else if (state == 1) {
                     --cj; if (!(code & 4u)) state = 0;
                 } else {
