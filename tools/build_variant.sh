@@ -15,7 +15,7 @@ else
   file=$root/strique_amd/csrc/$base; inc=""
 fi
 extra=""
-[[ "$base" == viterbi_kernels.hip ]] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"
+[[ "$base" == viterbi_kernels.hip && -z "${NOILP:-}" ]] && extra="-mllvm -amdgpu-sched-strategy=max-ilp"      # NOILP=1: the default scheduler
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-fast-math -Wall -Wno-unused-function $extra $inc "$@" -c $file -o $root/tools/bin/obj_$name/${base%.hip}.o
 objs=""
 for o in $root/strique_amd/lib/obj/*.o; do
