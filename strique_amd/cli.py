@@ -25,12 +25,19 @@ LEVELS = ['error', 'warning', 'info', 'debug']
 
 
 class Log(object):
+    """Messages to stderr.  The engine thread of `run_count` logs while the main thread does: one write per message,
+    under a lock, so that lines never interleave."""
+
     def __init__(self, level='warning'):
+        import threading
         self.level = LEVELS.index(level)
+        self._lock = threading.Lock()
 
     def __call__(self, message, level='info'):
         if LEVELS.index(level) <= self.level:
-            print("[%s] %s" % (level.upper(), message), file=sys.stderr)
+            with self._lock:
+                sys.stderr.write("[%s] %s\n" % (level.upper(), message))
+                sys.stderr.flush()
 
 
 def parse_config(repeat_config_file, param_config_file=None, log=None):
@@ -215,6 +222,7 @@ def count(argv):
         if not args.algn:
             log("Main: --algn FILE is required when running on several GPUs (stdin cannot be shared).", 'error'); raise SystemExit(1)
         sdist.init_process_group(backend=args.backend)
+        sdist.pin_rank_cpus()                 # this rank's share of the host's CPUs: reader, upload and statistics threads follow
     _tune_allocator()
     from .counter import repeatCounter
     device = args.device if (world == 1 or args.share_device) else local
@@ -238,7 +246,10 @@ def count(argv):
         # one process per GPU: every rank takes its share of the cores (LOCAL_WORLD_SIZE is set by torchrun), half of it for the
         # readers -- the staging threads of the library and the engine thread want the rest
         local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-        readers = max(1, min(16, (os.cpu_count() or 1) // local_world // 2))
+        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if share == (os.cpu_count() or 1):          # not pinned: an equal share by count
+            share //= local_world
+        readers = max(1, min(16, share // 2))
     stats = {}
     fault = 0
     try:
@@ -378,16 +389,22 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
         mine_set = set(int(i) for i in sdist.shard_indices(len(items), rank, world, cost))
         stats["items"] = items
 
+    import threading
+    faulted = threading.Event()
+
     def run_batch(batch):
         """Engine thread: one batch through the GPU pipeline (the library releases the GIL for the whole call), its rows
         formatted; returns (rows, number of failed reads)."""
         failed = 0
         results = None
+        if faulted.is_set():                                      # queued behind the batch that faulted: the device is not touched again
+            raise DeviceFault("not run: the device failed in an earlier batch")
         try:
             results = counter.detect_batch([(t, raw, s) for _, _, t, s, raw in batch])
         except StriqueHipError as e:
             if e.code not in (STRQ_ERR_ARG, STRQ_ERR_UNSUPPORTED):
                 # a device fault or an out-of-memory condition will not go away read by read
+                faulted.set()
                 log("Detector: device error, giving up: %s" % e, 'error')
                 raise DeviceFault(str(e))
             log("Detector: batch rejected (%s), retrying read by read" % e, 'warning')
@@ -400,6 +417,7 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
                     results.append(counter.detect(t, raw, s))
                 except StriqueHipError as e1:
                     if e1.code not in (STRQ_ERR_ARG, STRQ_ERR_UNSUPPORTED):
+                        faulted.set()
                         log("Detector: device error, giving up: %s" % e1, 'error')
                         raise DeviceFault(str(e1))
                     log("Detector: read failed: %s" % e1, 'warning'); results.append(None); failed += 1
@@ -478,6 +496,7 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
 
     seq = 0
     lookahead = max(1, 2 * batch_size // CHUNK) if pool is not None else 0
+    finished = False
     try:
         for qname, strand, targets, _qlen in records:
             mine = [(seq + i, t) for i, t in enumerate(targets) if mine_set is None or (seq + i) in mine_set]
@@ -492,10 +511,21 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
         drain(0)
         flush(batch)
         collect(0)
+        finished = True
     finally:
-        engine.shutdown(wait=True)
-        if pool is not None:
-            pool.shutdown()
+        if finished:
+            engine.shutdown(wait=True)
+            if pool is not None:
+                pool.shutdown()
+        else:
+            # an exception is on its way out (a DeviceFault from the engine thread, a broken input): the batch queued behind
+            # the failed one must not be handed to a device that may be hung, and nobody waits for it -- the caller exits,
+            # or tells the other ranks (dist.any_rank), right away
+            for fut in in_flight:
+                fut.cancel()
+            engine.shutdown(wait=False, cancel_futures=True)
+            if pool is not None:
+                pool.shutdown(wait=False, cancel_futures=True)
     return rows
 
 
@@ -511,8 +541,8 @@ def index(argv):
 
 
 def plot(argv):
-    """Signal plots over STR expansions: the reference's `plot` command (scripts/STRique.py:948-1024),
-    same arguments, same three panels (whole repeat region, prefix and suffix boundaries).  Host code."""
+    """The `plot` command (argument contract of scripts/STRique.py:948-960).  The figures themselves are this
+    package's own: strique_amd/plotting.py draws them from the TSV columns `offset` / `ticks` / scores."""
     parser = argparse.ArgumentParser(description="Signal plots over STR expansions")
     parser.add_argument("f5Index", help="Fast5 index")
     parser.add_argument("--counts", default=None, help="Repeat count output from STRique, if not given read from stdin")
@@ -528,57 +558,31 @@ def plot(argv):
     log = Log(args.log_level)
     if not os.path.isfile(args.f5Index):
         log("Main: Fast5 index file does not exist.", 'error'); raise SystemExit(1)
+    from . import plotting
     import matplotlib
     if args.output:
         matplotlib.use("Agg")
-    import matplotlib.pyplot as plt
-    import scipy.signal as sp
-    f5 = Fast5Index(args.f5Index)
-    if args.output:
         os.makedirs(args.output, exist_ok=True)
-    stream = open(args.counts) if args.counts else sys.stdin
-    for line in stream:
-        if line.startswith('ID') or not line.strip():
-            continue
-        ID, target, strand, count, score_prefix, score_suffix, _, offset, ticks = line.strip().split('\t')[:9]
-        offset, ticks = int(offset), int(ticks)
-        score_prefix, score_suffix = float(score_prefix), float(score_suffix)
-        raw_signal = f5.get_raw(ID)
-        if raw_signal is None:
-            log("Plot: No fast5 for ID %s" % ID, 'warning'); continue
-        flt = sp.medfilt(raw_signal, kernel_size=3)
-        flt = (flt - np.median(flt)) / np.std(flt)
-        prefix_extend = max(0, offset - int(ticks * args.extension))
-        suffix_extend = min(len(flt), offset + ticks + int(ticks * args.extension))
-        prefix_begin = max(offset - args.zoom, 0)
-        prefix_end = prefix_begin + args.zoom * 2
-        suffix_begin = max(offset + ticks - args.zoom, 0)
-        suffix_end = min(len(flt), suffix_begin + args.zoom * 2)
-        plt.figure(num=None, figsize=(args.width, args.height), dpi=args.dpi, facecolor='w', edgecolor='k')
-        plt.subplot(2, 1, 1)
-        plt.plot(flt[prefix_extend:suffix_extend], 'k-', linewidth=0.5, label='genome')
-        plt.plot(np.arange(len(flt[offset:offset + ticks])) + (offset - prefix_extend), flt[offset:offset + ticks], 'b-', linewidth=1.0, label='STR')
-        plt.legend()
-        plt.title("Read {} with {} repeats".format(ID, count))
-        plt.subplot(2, 2, 3)
-        plt.plot(flt[prefix_begin:prefix_end], 'k-', label='prefix')
-        seg = flt[prefix_begin + args.zoom:prefix_end]
-        plt.plot(np.arange(args.zoom, args.zoom + len(seg)), seg, 'b-')
-        plt.axvline(args.zoom, color='red', label='STR begin')
-        plt.legend()
-        plt.title("Prefix region with score {:.2f}".format(score_prefix))
-        plt.subplot(2, 2, 4)
-        plt.plot(flt[suffix_begin:suffix_end], 'k-', label='suffix')
-        plt.plot(flt[suffix_begin:max(suffix_begin, suffix_end - args.zoom)], 'b-')
-        plt.axvline(args.zoom, color='red', label='STR end')
-        plt.legend()
-        plt.title("Suffix region with score {:.2f}".format(score_suffix))
-        plt.tight_layout()
-        if args.output:
-            plt.savefig(os.path.join(args.output, '_'.join([target, count, ID]) + '.' + args.format))
-            plt.close()
-        else:
-            plt.show()
+    from matplotlib.figure import Figure
+    reads = Fast5Index(args.f5Index)
+    made = []
+    with (open(args.counts) if args.counts else sys.stdin) as stream:
+        for row in plotting.parse_counts(stream):
+            raw = reads.get_raw(row.read_id)
+            if raw is None:
+                log("Plot: No fast5 for ID %s" % row.read_id, 'warning'); continue
+            if args.output:
+                fig = Figure(figsize=(args.width, args.height), dpi=args.dpi, layout="constrained")
+            else:
+                import matplotlib.pyplot as plt
+                fig = plt.figure(figsize=(args.width, args.height), dpi=args.dpi, layout="constrained")
+            plotting.draw(fig, raw, row, extension=args.extension, zoom=args.zoom)
+            if args.output:
+                path = os.path.join(args.output, plotting.figure_name(row, args.format))
+                fig.savefig(path); made.append(path)
+            else:
+                plt.show()
+    return made
 
 
 def main(argv=None):

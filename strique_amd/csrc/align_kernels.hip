@@ -941,7 +941,7 @@ int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
     const bool force_two = e && e[0] == '2';
     // 14 rows per lane: STRique's 870-row flanks keep 63 of 64 lanes busy (15 rows: 58).  STRQ_NO_R14 leaves the shape
     // out (A/B runs).
-    static const bool no14 = getenv("STRQ_NO_R14") != nullptr;
+    const bool no14 = getenv("STRQ_NO_R14") != nullptr;          // read on every call, like STRQ_STRIPS
     const int single[] = {6, 7, 8, 12, 14, 15};
     const int two[] = {6, 7, 8, 12};
     // 14 or 15 rows per lane (flanks of 129 ... 149 classes fit both): the forward kernel reads the last flank row from a

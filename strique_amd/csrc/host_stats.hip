@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <limits>
+#include <sched.h>
 #include <thread>
 #include <vector>
 #include "../../include/strique_hip.h"
@@ -137,10 +138,15 @@ void host_read_stats(const double* raw, int64_t n, bool want_raw, double* out)
 void host_stats_batch(const double* signals, const int64_t* offsets, int64_t n_reads, bool want_raw, double* out,
                       const double* const* reads)
 {
-    int threads = (int)std::thread::hardware_concurrency();
+    // the CPUs this process may run on: a rank pinned to its share of the host (strique_amd.dist.pin_rank_cpus, taskset,
+    // a container's cpuset) sizes its pool by that share, not by the machine
+    int threads = 0;
+    { cpu_set_t set; CPU_ZERO(&set); if (sched_getaffinity(0, sizeof(set), &set) == 0) threads = CPU_COUNT(&set); }
+    const int machine = (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = machine;
     if (threads < 1) threads = 1;
-    // one process per GPU under torchrun: every rank takes its share of the host's cores
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int w = atoi(e); if (w > 1) threads = threads / w > 0 ? threads / w : 1; }
+    // one process per GPU under torchrun and not pinned: every rank still takes only its share of the host's cores
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int w = atoi(e); if (w > 1 && threads == machine) threads = threads / w > 0 ? threads / w : 1; }
     if (threads > 64) threads = 64;          // 9 ms per 375 k-sample read and core: 64 threads ~ 7 k reads/s of float64 input
     if (const char* e = getenv("STRQ_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }
     if ((int64_t)threads > n_reads) threads = (int)n_reads;

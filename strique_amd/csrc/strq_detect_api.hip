@@ -258,7 +258,11 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
             d_order = d->order.as<int>() + first;
             if (launch_vit_sort(st, d_tb + first, sidx - first, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
         }
-        if (launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, use_hub ? 3 : 1, d_order)) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
+        if (const int vrc = launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, use_hub ? 3 : 1, d_order)) {
+            // 2 / 3: this kernel shape has no such decode mode -- the caller's input, not a device fault (strq_viterbi_batch maps them the same way)
+            c->err = (vrc == 2 || vrc == 3) ? "viterbi: decode mode not available for this model's kernel shape" : "viterbi launch failed";
+            return (vrc == 2 || vrc == 3) ? STRQ_ERR_UNSUPPORTED : STRQ_ERR_DEVICE;
+        }
         ++qi;
       } }
     int64_t* d_plen = d_len;
@@ -545,7 +549,10 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         }
         const int rc2 = launch_viterbi(st, v.shape, v.max_states, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
                                        c->queue.as<int>() + qi, c->n_cu, any_mod ? 2 : 0, d_order);
-        if (rc2) { c->err = "viterbi launch failed"; return STRQ_ERR_DEVICE; }
+        if (rc2) {
+            c->err = (rc2 == 2 || rc2 == 3) ? "viterbi: decode mode not available for this model's kernel shape" : "viterbi launch failed";
+            return (rc2 == 2 || rc2 == 3) ? STRQ_ERR_UNSUPPORTED : STRQ_ERR_DEVICE;
+        }
         ++qi;
       } }
     STRQ_HIP(c, hipEventRecord(d->ev[3], st));

@@ -15,6 +15,24 @@ using namespace strq;
 
 namespace strq {
 
+// What every builder relies on: in_ptr monotone from 0, sources in range, silent states in topological order, the in-edges
+// of a state sorted by ascending source (the order ties are broken in), emitting states Normal (1) or Uniform (2).
+// Returns the reason, or null.
+static const char* validate_vit_model(int32_t n_states, int32_t silent_start, const int32_t* in_ptr, const int32_t* in_src, const int32_t* emis_kind)
+{
+    if (in_ptr[0] != 0) return "in_ptr must start at 0";
+    for (int l = 0; l < n_states; ++l) if (in_ptr[l + 1] < in_ptr[l]) return "in_ptr must not decrease";
+    for (int l = 0; l < n_states; ++l)
+        for (int e = in_ptr[l]; e < in_ptr[l + 1]; ++e) {
+            const int k = in_src[e];
+            if (k < 0 || k >= n_states) return "edge source out of range";
+            if (l >= silent_start && k >= l) return "silent states are not in topological order";
+            if (e > in_ptr[l] && in_src[e - 1] >= k) return "in-edges must be sorted by source";
+        }
+    for (int e = 0; e < silent_start; ++e) if (emis_kind[e] != 1 && emis_kind[e] != 2) return "emission kind must be 1 (Normal) or 2 (Uniform)";
+    return nullptr;
+}
+
 int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                     const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                     const int32_t* emis_kind, const double* emis_a, const double* emis_b, const double* emis_c,
@@ -25,15 +43,11 @@ int build_vit_model(strq_ctx* c, int32_t n_states, int32_t silent_start, int32_t
     if (n_states < 2 || ne < 1 || ns < 2 || start < ne || end < ne || start >= n_states || end >= n_states) {
         c->err = "bad model dimensions"; return STRQ_ERR_ARG;
     }
+    // the edge lists are validated before any size decision: a model too large for the lane layouts goes on to the general
+    // kernel's builder, which indexes host arrays with these sources
+    if (const char* bad = validate_vit_model(n_states, silent_start, in_ptr, in_src, emis_kind)) { c->err = bad; return STRQ_ERR_ARG; }
     const int epl = (ne + 63) / 64, spl = (ns + 63) / 64;
     if (epl > 8 || spl > 4 || n_states >= 65535) { c->err = "model too large for the compiled Viterbi kernels"; return STRQ_ERR_UNSUPPORTED; }
-    for (int l = 0; l < n_states; ++l)
-        for (int e = in_ptr[l]; e < in_ptr[l + 1]; ++e) {
-            const int k = in_src[e];
-            if (k < 0 || k >= n_states) { c->err = "edge source out of range"; return STRQ_ERR_ARG; }
-            if (l >= ne && k >= l) { c->err = "silent states are not in topological order"; return STRQ_ERR_ARG; }
-            if (e > in_ptr[l] && in_src[e - 1] >= k) { c->err = "in-edges must be sorted by source"; return STRQ_ERR_ARG; }
-        }
     HostModel* hm = new HostModel();
     VitModel& m = hm->h;
     std::memset(&m, 0, sizeof(m));

@@ -21,6 +21,62 @@ def shard_indices(n_items, rank, world, cost=None):
     return np.sort(order[rank::world])
 
 
+def _core_groups(allowed):
+    """Logical CPUs of `allowed` grouped by physical core (hyper-thread siblings together), cores in ascending order of
+    their first CPU.  /sys topology when readable, one CPU per core otherwise."""
+    groups, seen = [], set()
+    for cpu in sorted(allowed):
+        if cpu in seen:
+            continue
+        sib = {cpu}
+        try:
+            txt = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu).read().strip()
+            for part in txt.split(","):
+                lo, _, hi = part.partition("-")
+                sib.update(range(int(lo), int(hi or lo) + 1))
+        except (OSError, ValueError):
+            pass
+        sib = sorted(sib & set(allowed))
+        seen.update(sib)
+        groups.append(sib)
+    return groups
+
+
+def rank_cpu_share(local, local_world, allowed=None):
+    """The CPUs of rank `local` out of `local_world` ranks on this host: a contiguous block of physical cores (ranks
+    0 .. w/2-1 land on the first socket of a two-socket host, next to GPUs 0 .. w/2-1) with their siblings.
+    Every allowed CPU belongs to exactly one rank; a host with fewer cores than ranks shares them round-robin."""
+    if allowed is None:
+        allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    groups = _core_groups(allowed)
+    if local_world <= 1 or not groups:
+        return sorted(allowed)
+    if len(groups) < local_world:
+        return groups[local % len(groups)]
+    lo, hi = len(groups) * local // local_world, len(groups) * (local + 1) // local_world
+    return sorted(c for g in groups[lo:hi] for c in g)
+
+
+def pin_rank_cpus(local=None, local_world=None):
+    """Pin this rank process -- and with it the library's upload, order-statistic and reader threads -- to its share of
+    the host's CPUs (256 CPUs / 8 ranks on the MI355X box: without it eight ranks size their pools for the whole
+    machine and migrate across sockets).  STRQ_NO_PIN=1 leaves the affinity alone.  Returns the CPUs, or None."""
+    if os.environ.get("STRQ_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    if local is None:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if local_world <= 1:
+        return None
+    cpus = rank_cpu_share(local, local_world)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return cpus
+
+
 def init_process_group(backend=None):
     import torch
     import torch.distributed as dist

@@ -22,6 +22,55 @@ class StriqueHipError(RuntimeError):
         self.code = code
 
 
+def _torch_hip_runtime():
+    """Path of the HIP runtime a PyTorch-ROCm wheel bundles (torch/lib/libamdhip64.so), found WITHOUT importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    return cand if os.path.exists(cand) else None
+
+
+def mapped_hip_runtimes():
+    """Files of every HIP runtime mapped into this process (diagnostics, tests): there must never be two."""
+    seen = set()
+    try:
+        for line in open("/proc/self/maps"):
+            f = line.split()[-1]
+            if "libamdhip64" in os.path.basename(f):
+                seen.add(os.path.realpath(f))
+    except OSError:
+        pass
+    return sorted(seen)
+
+
+def _pin_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    libstrique_hip.so needs `libamdhip64.so.7`; a PyTorch-ROCm wheel brings its own copy with the SAME soname.  If torch is
+    imported first, the dynamic linker resolves the library's dependency to torch's already-loaded copy (soname match) and
+    the process has one runtime.  The other order used to load /opt/rocm's copy here and torch's copy later -- two
+    runtimes, and torch.cuda could no longer initialise (round 3's README note).  So the decision is taken here, before
+    the library is opened: when a torch wheel with a bundled runtime is installed, that copy is loaded first (by path,
+    RTLD_GLOBAL; torch itself is not imported), and both this library and a later `import torch` -- for RCCL through
+    torch.distributed -- bind to it.  STRQ_HIP_RUNTIME=system keeps /opt/rocm's runtime (a process that never imports
+    torch), STRQ_HIP_RUNTIME=/path/to/libamdhip64.so names one."""
+    choice = os.environ.get("STRQ_HIP_RUNTIME", "auto")
+    if choice == "system" or mapped_hip_runtimes():
+        return None
+    path = _torch_hip_runtime() if choice in ("auto", "torch") else choice
+    if path is None:
+        if choice == "torch":
+            raise ImportError("STRQ_HIP_RUNTIME=torch: no torch wheel with a bundled libamdhip64.so found")
+        return None
+    ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    return path
+
+
 def load_library(path=None):
     """Load the shared library (building nothing: see strique_amd.build / __graft_entry__.build)."""
     global _lib
@@ -29,6 +78,7 @@ def load_library(path=None):
         path = path or LIB_PATH
         if not os.path.exists(path):
             raise ImportError("%s not found: run `python -m strique_amd.build` (hipcc, gfx950) first" % path)
+        _pin_hip_runtime()
         lib = ctypes.CDLL(path)
         lib.strq_last_error.restype = ctypes.c_char_p
         lib.strq_last_error.argtypes = [ctypes.c_void_p]

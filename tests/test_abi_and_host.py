@@ -115,3 +115,57 @@ def test_host_stats_equal_numpy():
             want = [med, np.mean(np.absolute(np.subtract(flt, med)))] + list(tails(flt)) + list(tails(s))
             assert np.array_equal(np.asarray(want), g, equal_nan=True), (len(s), want, g)
     assert np.array_equal(ffi.host_stats(np.concatenate(sigs), off)[:, 4:], np.tile([0.0, 1.0], (len(sigs), 1)))
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libstrique_hip.so and a PyTorch-ROCm wheel both need `libamdhip64.so.7`; strique_amd.ffi decides which copy serves the
+    process BEFORE it opens the library, so that a later `import torch` (RCCL through torch.distributed) binds to the same
+    one.  Either order must leave exactly one HIP runtime mapped (round 3: library first, torch second = two runtimes and
+    a torch.cuda that could not initialise).  No GPU needed: this is the dynamic linker's doing."""
+    import subprocess
+    import sys
+    prog = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "order = sys.argv[1]\n"
+        "if order == 'torch_first': import torch\n"
+        "from strique_amd import ffi\n"
+        "ffi.load_library()\n"
+        "before = ffi.mapped_hip_runtimes()\n"
+        "import torch\n"
+        "after = ffi.mapped_hip_runtimes()\n"
+        "assert len(before) == 1 and after == before, (order, before, after)\n"
+        "print(order, after[0])\n") % ROOT
+    env = dict(os.environ); env.pop("STRQ_HIP_RUNTIME", None)
+    seen = []
+    for order in ("lib_first", "torch_first"):
+        r = subprocess.run([sys.executable, "-c", prog, order], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        seen.append(r.stdout.split()[-1])
+    assert seen[0] == seen[1]
+
+
+def test_rank_cpu_share_partitions_the_host():
+    """strique_amd.dist.rank_cpu_share: every CPU belongs to exactly one rank, hyper-thread siblings stay together, the
+    blocks are contiguous in core order (ranks 0..3 of 8 on the first socket)."""
+    from strique_amd import dist as sdist
+    allowed = set(range(256))
+    import builtins
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):          # a 2 x 64-core host with SMT: cpu c and c + 128 share a core
+        if isinstance(path, str) and path.startswith("/sys/devices/system/cpu/cpu") and path.endswith("thread_siblings_list"):
+            c = int(path.split("/cpu")[-1].split("/")[0]) % 128
+            import io
+            return io.StringIO("%d,%d\n" % (c, c + 128))
+        return real_open(path, *a, **k)
+
+    builtins.open = fake_open
+    try:
+        shares = [sdist.rank_cpu_share(r, 8, allowed) for r in range(8)]
+    finally:
+        builtins.open = real_open
+    assert sorted(c for s in shares for c in s) == list(range(256))
+    for r, s in enumerate(shares):
+        assert s == list(range(16 * r, 16 * r + 16)) + list(range(128 + 16 * r, 128 + 16 * r + 16))
+    assert sdist.rank_cpu_share(0, 1, {3, 4}) == [3, 4]
+    assert sdist.rank_cpu_share(5, 8, {0, 1}) in ([0], [1])          # fewer cores than ranks: shared round-robin

@@ -114,6 +114,40 @@ def test_reader_threads_keep_the_row_order(cfg):
     assert outs[0] == outs[1] and len(outs[0].splitlines()) == 1 + 38
 
 
+def test_device_fault_stops_the_engine_without_running_the_queued_batch(cfg):
+    """A device fault in batch k: `run_count` raises DeviceFault at once -- the batch already queued behind k is cancelled,
+    not handed to the faulted device, and nobody waits for it (the caller has to tell the other ranks, dist.any_rank)."""
+    import io
+    import threading
+    import time
+    import numpy as np
+    import pytest
+    from strique_amd import cli, ffi
+    loci = {}
+    for name, (chrom, b, e, *_r) in cfg["repeat"].items():
+        loci.setdefault(chrom, []).append((name, b, e))
+    lines = ["\t".join(["read%d" % i, "0", "chr9", "27570000", "60", "8000M", "*", "0", "0", "ACGT", "*"]) for i in range(60)]
+    calls = []
+
+    class FaultyCounter(object):
+        def detect_batch(self, items):
+            calls.append(len(items))
+            if len(calls) == 2:
+                time.sleep(0.3)                      # batch 2 is running while batch 3 is prepared and queued behind it
+                raise ffi.StriqueHipError(ffi.STRQ_ERR_DEVICE, "hipErrorLaunchFailure")
+            return [(1, 1.0, 2.0, -1.0, 0, 3, "-") for _ in items]
+
+    def get_raw(qname):
+        return np.arange(100)
+
+    t0 = time.time()
+    with pytest.raises(cli.DeviceFault):
+        cli.run_count(iter(lines), loci, get_raw, FaultyCounter(), cli.Log("error"), 7, 0, 1, io.StringIO(), readers=0)
+    assert time.time() - t0 < 5.0
+    time.sleep(0.2)
+    assert calls == [7, 7], calls                    # nothing ran on the device after the fault
+
+
 def test_vlen_read_id_and_user_block(tmp_path):
     """read_id stored as a variable-length string (global heap), and a file with a user block in front of
     the superblock (non-zero base address): both forms real fast5 writers produce."""
@@ -198,6 +232,26 @@ def test_fast5_masker_and_plot(tmp_path):
     cli.main(["plot", str(src / "reads.fofn"), "--counts", str(counts), "--output", str(plots), "--zoom", "200", "--width", "6", "--height", "4"])
     made = sorted(p.name for p in plots.glob("*.png"))
     assert made == sorted("c9orf72_17_%s.png" % r for r in ids) and all((plots / m).stat().st_size > 2000 for m in made)
+    # what the figures shade is the TSV's [offset, offset + ticks), panel by panel (strique_amd/plotting.py)
+    from matplotlib.figure import Figure
+    from strique_amd import plotting
+    with open(counts) as fh:
+        rows_ = {r.read_id: r for r in plotting.parse_counts(fh)}
+    assert sorted(rows_) == sorted(ids + ["not-in-the-index"])
+    for rid, (off, ticks) in plan.items():
+        n = len(sigs[rid])
+        axes = plotting.draw(Figure(figsize=(6, 4)), sigs[rid], rows_[rid], extension=0.1, zoom=200)
+        assert axes["overview"].strique_span == (off, off + ticks)
+        assert axes["left"].strique_span == (off, min(off + ticks, off + 200, n))
+        assert axes["right"].strique_span == (max(off, off + ticks - 200), off + ticks)
+        for name, ax in axes.items():
+            spans = [p for p in ax.patches]
+            assert len(spans) == 1
+            x0 = float(spans[0].get_x())          # axvspan draws a Rectangle in data x-coordinates
+            assert (x0, x0 + float(spans[0].get_width())) == tuple(float(v) for v in ax.strique_span)
+        assert [l.get_xdata()[0] for l in axes["left"].lines[1:]] == [off] and [l.get_xdata()[0] for l in axes["right"].lines[1:]] == [off + ticks]
+    w = plotting.Windows(1000, 950, 400, 0.1, 100)          # a repeat that runs past the end of the signal is clipped
+    assert w.repeat == (950, 1000) and w.overview == (910, 1000) and w.right == (900, 1000) and w.shaded("left") == (950, 1000)
 
 
 def test_sam_edge_cases_equal_the_reference():

@@ -243,3 +243,28 @@ def test_models_beyond_the_lane_layouts_run_on_the_general_kernel(ctx, orc, ne, 
     if ne == 2600:
         with pytest.raises(ffi.StriqueHipError, match="more than 4096 states"):
             ctx.model_create(_random_model(rng, 3000, 1200, False))
+    # a model of this size with a broken edge list is refused as a bad argument before any builder indexes with it
+    # (round-3 advisor finding: the general kernel's builder used to receive such models unvalidated)
+    if ne >= 600:
+        big = baked
+        e0 = int(big.in_ptr[big.silent_start + 5])                # first in-edge of a silent state
+        assert big.in_ptr[big.silent_start + 6] > e0
+        for what, breaker in (("edge source out of range", lambda a: a.__setitem__(e0, big.n_states + 3)),
+                              ("topological order", lambda a: a.__setitem__(e0, big.n_states - 1))):
+            src = big.in_src.copy(); breaker(src)
+            with pytest.raises(ffi.StriqueHipError, match=what) as ei:
+                ctx.model_create(big._replace(in_src=src))
+            assert ei.value.code == ffi.STRQ_ERR_ARG
+        deg = np.diff(big.in_ptr); l2 = int(np.argmax(deg >= 2))      # a state with two in-edges: swap them
+        src = big.in_src.copy(); a0 = int(big.in_ptr[l2]); src[a0], src[a0 + 1] = src[a0 + 1], src[a0]
+        with pytest.raises(ffi.StriqueHipError, match="sorted by source") as ei:
+            ctx.model_create(big._replace(in_src=src))
+        assert ei.value.code == ffi.STRQ_ERR_ARG
+        ptr = big.in_ptr.copy(); ptr[10] = ptr[11] + 1
+        with pytest.raises(ffi.StriqueHipError, match="in_ptr") as ei:
+            ctx.model_create(big._replace(in_ptr=ptr))
+        assert ei.value.code == ffi.STRQ_ERR_ARG
+        kinds = big.emis_kind.copy(); kinds[3] = 0
+        with pytest.raises(ffi.StriqueHipError, match="emission kind") as ei:
+            ctx.model_create(big._replace(emis_kind=kinds))
+        assert ei.value.code == ffi.STRQ_ERR_ARG
