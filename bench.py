@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=0, help="cap on the worker processes of the CPU baseline (0: one per physical core)")
     ap.add_argument("--cpu-sweep", default="32,64,128", help="worker counts of the CPU baseline; the best one is reported as cpu_baseline.value")
     ap.add_argument("--gather-every-step", action="store_true", help="N > 1: run the result gather after every step instead of once after the last one")
+    ap.add_argument("--dump-rows", default=None, help="testing: rank 0 saves the gathered table of the timed steps (numpy .npy) here")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive strq_detect_batch measurement")
     ap.add_argument("--host-leg-batches", type=int, default=3, help="sub-batches of the PCIe-inclusive leg")
     ap.add_argument("--check", type=int, default=2, help="reads verified against the CPU oracle, all six fields (LUT variant: same bits)")
@@ -239,10 +240,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     n_batches = max(1, args.batches)
+    pinned = None
     if world > 1:
         # every rank on its share of the host's CPUs (synthesis workers, upload and statistics threads inherit it)
         from strique_amd import dist as _sd
-        _sd.pin_rank_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        pinned = _sd.pin_rank_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     # ---- synthetic reads (before anything touches the GPU): `batches` distinct batches per rank
     t_gen = time.time()
@@ -322,18 +324,44 @@ def main():
         fwd_ms += float(tm[1]); fwd_launches += int(tm[7]); stage_ms += tm
         counters[:3] += cn[:3]; counters[3:7] = cn[3:7]; counters[7] += cn[7]
         geoms.append(ctx.last_geometry())
+    table = None
     if dist is not None and not args.gather_every_step:
         table = gather(mine)                    # ONE gather of all steps' records, inside the timed region
-        if rank == 0:
-            gathered_rows = len(table)
-            # rank 0's own rows must have arrived at their positions
-            k0 = mine[0][0]
-            for k, r in (mine[0], mine[-1]):
-                p0 = ((k - k0) * world + rank) * args.reads
-                if not np.array_equal(table[p0:p0 + len(r)], r):
-                    raise SystemExit("bench.py: the gathered table does not hold rank 0's rows at their positions")
     barrier()
     elapsed = time.time() - t0
+    rank_report = None
+    if dist is not None:
+        # after the clock: every rank's digest of its own rows, its peak host memory and its CPU share to rank 0 (a second, tiny
+        # collective), which checks the gathered table against the digests -- every rank's rows arrived intact, at their positions
+        import hashlib
+        import resource
+        import torch
+        digest = hashlib.sha256(np.concatenate([r for _, r in mine]).tobytes()).digest()[:8]
+        mine_info = np.zeros(4, np.int64)
+        mine_info[0] = int.from_bytes(digest, "little", signed=True)
+        mine_info[1] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss          # KiB
+        mine_info[2] = len(pinned) if pinned else 0
+        mine_info[3] = device
+        t = torch.from_numpy(mine_info).to(coll_dev)
+        infos = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(infos, t)
+        if rank == 0:
+            infos = [i.cpu().numpy() for i in infos]
+            rows_ok = None
+            if table is not None:
+                gathered_rows = len(table)
+                rows_ok = True
+                k0 = mine[0][0]
+                for r_ in range(world):
+                    part = np.concatenate([table[((k - k0) * world + r_) * args.reads:((k - k0) * world + r_ + 1) * args.reads] for k, _ in mine])
+                    d = int.from_bytes(hashlib.sha256(part.tobytes()).digest()[:8], "little", signed=True)
+                    rows_ok = rows_ok and d == int(infos[r_][0])
+                if not rows_ok:
+                    raise SystemExit("bench.py: the gathered table differs from what the ranks computed")
+                if args.dump_rows:
+                    np.save(args.dump_rows, table)
+            rank_report = {"rows_equal_every_ranks_digest": rows_ok, "peak_host_rss_gb_per_rank": [round(float(i[1]) / 1048576.0, 3) for i in infos],
+                           "cpus_pinned_per_rank": [int(i[2]) for i in infos], "hip_device_per_rank": [int(i[3]) for i in infos]}
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -441,7 +469,7 @@ def main():
             "world_size_seen_by_the_collective": world_seen[0],
             "collective": None if world == 1 else {"what": "all_gather of the result records to rank 0 (%s)" % ("RCCL" if args.backend == "nccl" else args.backend),
                                                    "when": "after every step" if args.gather_every_step else "once, after the last timed step, inside the timed region",
-                                                   "rows_on_rank_0": gathered_rows},
+                                                   "rows_on_rank_0": gathered_rows, "ranks": rank_report},
             "resident_reads_per_s": value,
             "roofline": roof,
             "stage_ms_per_step": {"conditioning": float(stage_ms[5]) / args.steps, "score_tables": float(stage_ms[0]) / args.steps,

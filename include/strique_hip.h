@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 8 (8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -251,6 +251,10 @@ int strq_last_counters(const strq_ctx* ctx, double out[8]);
  * [4] 1 = 24-bit tables   [5] overlap (columns) the pieces were cut with first   [6] the worst-case overlap
  * [7] forward launch groups of the last sub-batch. */
 int strq_last_geometry(const strq_ctx* ctx, int32_t out[8]);
+/* Viterbi launches of the flanked-model decode (scripts/STRique.py:603) of the last sub-batch of the last batched call:
+ * [0] launches   [1] of them on the register-resident kernel (viterbi_g2_kernel: one launch serves repeat profiles of
+ * either parity)   [2] on the lane-layout kernels   [3] on the general kernel (viterbi_csr_kernel). */
+int strq_last_viterbi_launches(const strq_ctx* ctx, int32_t out[4]);
 
 #ifdef __cplusplus
 }

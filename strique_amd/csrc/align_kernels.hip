@@ -32,6 +32,8 @@
 #include <stdint.h>
 #include "align_kernels.h"
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace strq {
 
@@ -468,7 +470,9 @@ struct Forward {
 
     // PRED: lanes may be idle (before their first / after their last column).
     // s: position of this step inside its 64-step chunk; (qsrc, snext): where the next step's levels come from.
-    template <bool PRED, bool KEEP>
+    // RMX: the register of its lane the last flank row sits in, when the caller knows it at compile time (forward_one
+    // switches its steady-state loop on (m - 1) % R); -1: read through the runtime index rM
+    template <bool PRED, bool KEEP, int RMX = RMC>
     __device__ __forceinline__ void step(int t, int s, int qsrc, int snext)
     {
         int qn; float nA[Shape<R, S>::C], nB[Shape<R, S>::C];
@@ -512,11 +516,11 @@ struct Forward {
                 }
             } else {
                 float candA, candB;
-                if constexpr (RM_LAST) {
+                if constexpr (RM_LAST || RMX == R - 1) {
                     dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, 0, nullptr, nullptr);
                     candA = st.SbotA; candB = st.S[R - 1];
-                } else if constexpr (RMC >= 0) {
-                    dp_step2<R, LH, LV, KEEP, false, RMC>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, rM, &candA, &candB);
+                } else if constexpr (RMX >= 0) {
+                    dp_step2<R, LH, LV, KEEP, false, RMX>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, rM, &candA, &candB);
                 } else {
                     dp_step2<R, LH, LV, KEEP, false>(st, rsA, rsB, upA, upB, upVA, upVB, p, nullptr, rM, &candA, &candB);
                 }
@@ -534,7 +538,28 @@ struct Forward {
     }
 };
 
-template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK, bool STAGE = true, int RMC = -1>
+// The registers (m - 1) % R can be for a flank of m = k * S rows: x with x + 1 a multiple of gcd(R, S).  `f` runs for the
+// one that equals rM, as a compile-time constant; returns false when none does (a flank that is no whole number of runs).
+template <int R, int S, int X, class F>
+static __device__ __forceinline__ void rm_case(int rM, bool& hit, F& f)
+{
+    if constexpr ((X + 1) % Shape<R, S>::G == 0) {
+        if (!hit && rM == X) { f(std::integral_constant<int, X>{}); hit = true; }
+    }
+}
+template <int R, int S, class F, int... X>
+static __device__ __forceinline__ bool rm_dispatch(int rM, F& f, std::integer_sequence<int, X...>)
+{
+    bool hit = false;
+    (rm_case<R, S, X>(rM, hit, f), ...);
+    return hit;
+}
+
+// RMSW: the steady-state loop (every lane busy for the 64 steps of a chunk -- all but the first and last chunks of a piece)
+// is compiled once per possible register of the last flank row and chosen by a wave-uniform branch outside the loop, so
+// that EVERY flank length runs the 152-instruction step of STRique's own 870 rows (round 3 knew that register at compile
+// time for m = 870 and m % R == 0 only; any other flank read it through pick_row, ~40 instructions per step more).
+template <int R, int S, bool LH, bool LV, int MODE, bool RM_LAST, bool PK, bool STAGE = true, int RMC = -1, bool RMSW = false>
 static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignResult* res, const AlignParams& p,
                                                    float* lds, int lds_base, const char* ldsb, int lane)
 {
@@ -549,6 +574,8 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
     __builtin_amdgcn_s_waitcnt(0);   // LDS table written by this wave is visible to it
 
     const int nsteps = (tk.n + 1) / 2 + 63;
+    const int rM_u = __builtin_amdgcn_readfirstlane(rM);      // in an SGPR: the switch over it is a scalar branch around the loops, not an exec mask inside them
+    (void)rM_u;
     int qcur = load_chunk<PK>(tk, 0, lane);
     f.prime(qcur);
     Bnd4 bnext{0.0f, STRQ_NINF, 0.0f, STRQ_NINF};
@@ -565,9 +592,15 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
             // placement experiment (profiles/r03_dead_ends.md 9): the steady-state loop STRQ_DP_PAD dwords behind a 64-byte boundary
             asm volatile(".p2align 6\n\t.rept " STRQ_STR(STRQ_DP_PAD) "\n\ts_nop 0\n\t.endr");
 #endif
-            for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, s, qcur, s + 1);
-            if (ckpt_here) f.template step<false, true>(t0 + 64, 63, qnext, 0);
-            else f.template step<false, false>(t0 + 64, 63, qnext, 0);
+            auto chunk = [&](auto rmx) {
+                constexpr int X = decltype(rmx)::value;
+                for (int s = 0; s < 63; ++s) f.template step<false, false, X>(t0 + s + 1, s, qcur, s + 1);
+                if (ckpt_here) f.template step<false, true, X>(t0 + 64, 63, qnext, 0);
+                else f.template step<false, false, X>(t0 + 64, 63, qnext, 0);
+            };
+            bool hit = false;
+            if constexpr (RMSW && !HAS_OUT && !RM_LAST) hit = rm_dispatch<R, S>(rM_u, chunk, std::make_integer_sequence<int, R>{});
+            if (!hit) chunk(std::integral_constant<int, RMC>{});
         } else {
             for (int s = 0; s < send; ++s) {
                 const int qsrc = s == 63 ? qnext : qcur, snext = (s + 1) & 63;
@@ -652,11 +685,17 @@ align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __res
         const int ti = gi * SEG + wave;
         const AlignTask& tk = tasks[ti];
         if (tk.n <= 0) continue;               // unused piece of a short read (wave-uniform)
-        // STRique's own flanks (145 k-mer classes, 870 rows) at 14 rows per lane end in register 1 of lane 62
+        // the last flank row sits in register (m - 1) % R of its lane: STRique's own flanks (145 k-mer classes, 870 rows) at 14
+        // rows per lane in register 1 of lane 62.  One forward pass, its steady-state loop switched on that register (RMSW).
+#ifdef STRQ_DP_NO_RMSW
+        // round 3's dispatch (A/B builds): the register known at compile time for m % R == 0 and m = 870 only
         constexpr int RMC870 = R == 14 ? (870 - 1) % 14 : -1;
         if ((tk.m - 1) % R == R - 1) forward_one<R, S, true, true, 0, true, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
         else if (RMC870 >= 0 && (tk.m - 1) % R == RMC870) forward_one<R, S, true, true, 0, false, PK, false, RMC870>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
         else forward_one<R, S, true, true, 0, false, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+#else
+        forward_one<R, S, true, true, 0, false, PK, false, -1, true>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+#endif
     }
 }
 
@@ -944,15 +983,9 @@ int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
     const bool no14 = getenv("STRQ_NO_R14") != nullptr;          // read on every call, like STRQ_STRIPS
     const int single[] = {6, 7, 8, 12, 14, 15};
     const int two[] = {6, 7, 8, 12};
-    // 14 or 15 rows per lane (flanks of 129 ... 149 classes fit both): the forward kernel reads the last flank row from a
-    // register it knows at compile time when that row is the lane's last one (m % R == 0) or, at R = 14, when m = 870
-    // (STRique's own flanks); otherwise a runtime-indexed pick costs ~40 instructions per step -- more than the idle
-    // lanes of the other shape.  Measured VALU instructions per step: 152 (R = 14) / 157 (R = 15), 191 / ~197 with the pick.
-    if (!force_two && !no14 && m > 64 * 12 && m <= 64 * 14) {
-        const bool fast14 = m % 14 == 0 || m == 870, fast15 = m % 15 == 0;
-        const int r = (fast14 || !fast15) ? 14 : 15;
-        *rows_per_lane = r; *n_strips = 1; return r;
-    }
+    // Flanks of 129 ... 149 classes fit 14 and 15 rows per lane; 14 keeps more lanes busy, and since round 4 the register the
+    // last flank row sits in is a compile-time constant of the steady-state loop for every flank length (forward_one, RMSW),
+    // so nothing speaks for 15 any more (round 3 chose it when only 15 | m had the register: 191 against 157 instructions).
     if (!force_two)
         for (int r : single) if (64 * r >= m && !(r == 14 && no14)) { *rows_per_lane = r; *n_strips = 1; return r; }
     for (int r : two) if (64 * r < m && 128 * r >= m) { *rows_per_lane = r; *n_strips = 2; return r; }

@@ -609,7 +609,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 
 extern "C" {
 
-int strq_abi_version(void) { return 8; }
+int strq_abi_version(void) { return 9; }
 
 int strq_ctx_create(int device_id, strq_ctx** out)
 {
@@ -680,6 +680,13 @@ int strq_last_counters(const strq_ctx* c, double out[8])
 {
     if (!c || !out) return STRQ_ERR_ARG;
     std::memcpy(out, c->counters, sizeof(c->counters));
+    return STRQ_OK;
+}
+
+int strq_last_viterbi_launches(const strq_ctx* c, int32_t out[4])
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    std::memcpy(out, c->vit_launches, sizeof(c->vit_launches));
     return STRQ_OK;
 }
 

@@ -79,6 +79,7 @@ struct strq_ctx {
     float timing[8] = {};
     double counters[8] = {};
     int32_t geometry[8] = {};                 // strq_last_geometry
+    int32_t vit_launches[4] = {};             // strq_last_viterbi_launches
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd,

@@ -433,20 +433,6 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
         by_shape[shape].push_back(i);
     }
-    // The register-resident kernel has one variant per parity of the repeat profile (VIT_SHAPE_G2, + 1): a sub-batch whose targets
-    // need both would run two launches, each bound by its own longest windows, where the lane layout takes all of them in one
-    // (configs[3], C9orf72 / FMR1 / HTT mixed: 43 ms against 37 ms).  Such a sub-batch keeps the lane layout.
-    if (by_shape.count(VIT_SHAPE_G2) && by_shape.count(VIT_SHAPE_G2 + 1)) {
-        std::vector<int> mixed(by_shape[VIT_SHAPE_G2]);
-        mixed.insert(mixed.end(), by_shape[VIT_SHAPE_G2 + 1].begin(), by_shape[VIT_SHAPE_G2 + 1].end());
-        by_shape.erase(VIT_SHAPE_G2); by_shape.erase(VIT_SHAPE_G2 + 1);
-        for (int i : mixed) {
-            const int shape = vit_shape_of(c->models[d->targets[B.target[r0 + i]].model_id]->h);
-            if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
-            by_shape[shape].push_back(i);
-        }
-        for (auto& g : by_shape) std::sort(g.second.begin(), g.second.end());
-    }
     std::vector<int32_t> vit_slot(nr);
     struct VL { int shape, first, count, max_states; };
     std::vector<VL> vls;
@@ -541,7 +527,10 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
     STRQ_HIP(c, hipEventRecord(d->ev[2], st));
     { int qi = 0;
+      std::memset(c->vit_launches, 0, sizeof(c->vit_launches));
       for (auto& v : vls) {
+        ++c->vit_launches[0];
+        ++c->vit_launches[(v.shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 ? 1 : ((v.shape & ~VIT_SHAPE_SS) == VIT_SHAPE_CSR ? 3 : 2)];
         int* d_order = nullptr;
         if (v.count <= 8192) {
             d_order = d->order.as<int>() + v.first;

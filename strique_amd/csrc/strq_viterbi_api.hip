@@ -326,8 +326,10 @@ static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32
         if (kind_hint[e] == 1 && hm->emis_kind[e] == 1) return unsupported("an insert-type state has a Normal emission");
     }
     const double NEG = -INFINITY;
-    std::string why = "?";
+    std::string why = "?", why_all;
+    struct Edge { int src; double lp; };
     for (int off = 0; off < 2; ++off) {
+        if (off == 1) why_all = why + "; ";
         std::vector<int> g(n, -1), kind(n, 2);
         for (int e = 0; e < ne; ++e) { g[e] = pos_hint[e] + 1 + off; kind[e] = kind_hint[e]; }
         bool ok = true;
@@ -358,14 +360,53 @@ static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32
             slot = l;
         }
         if (!ok) continue;
+        // ---- in-edges per state, then the virtual relay states (see viterbi_kernels.h).  The in-edges of an insert-type state T
+        // at position g, in evaluation order, must read   F ++ mid ++ back   with
+        //   F    = sources among {I_{g-1}, M_{g-1}}                         (repeat0i, dummy1 <- e1 <- last insert / match before them)
+        //   mid  = the regular columns {I_g (T itself), M_g, D_g}
+        //   back = [one far emitting state], [D_{g-1}]                      (repeat0i <- s1 <- {dummy1, last prefix delete})
+        // F and back go to a virtual delete-type state V at T's own position (free in a profile without delete states): F in V's
+        // two gather columns, the far state in V's broadcast column, D_{g-1} as V's chain edge -- V evaluates them in exactly this
+        // order -- and T keeps mid ++ [V with 0.0].  V stands LAST in T's tournament although F stands first in T's list: the
+        // lane is flagged in `hub_mask`, and there the kernel lets V win a tie against mid when V's own winner came from F.
+        std::vector<std::vector<Edge>> edges(n);
+        for (int l = 0; l < n; ++l) for (int e = in_ptr[l]; e < in_ptr[l + 1]; ++e) edges[l].push_back({in_src[e], in_logp[e]});
+        const int n_real = n;
+        uint64_t hub_mask = 0;
+        for (int l = 0; l < ne && ok; ++l) {
+            if (kind[l] != 1) continue;
+            const std::vector<Edge> E = edges[l];
+            size_t i = 0;
+            std::vector<Edge> F, mid, back;
+            while (i < E.size() && E[i].src < ne && E[i].src != l && g[l] - g[E[i].src] == 1) F.push_back(E[i++]);
+            while (i < E.size() && (E[i].src == l || (kind[E[i].src] == 0 && g[E[i].src] == g[l]) || (kind[E[i].src] == 2 && g[E[i].src] == g[l]))) mid.push_back(E[i++]);
+            if (i < E.size() && E[i].src < ne && !(g[l] - g[E[i].src] == 1 || g[l] == g[E[i].src])) back.push_back(E[i++]);      // a far emitting state
+            if (i < E.size() && kind[E[i].src] == 2 && g[l] - g[E[i].src] == 1) back.push_back(E[i++]);                          // D_{g-1}
+            if (i != E.size()) { ok = false; why = "an insert-type state with in-edges no relay covers"; break; }
+            if (F.empty() && back.empty()) continue;
+            if (at[2 * 128 + g[l]] >= 0) { ok = false; why = "an insert-type state with irregular in-edges and a delete state at its position"; break; }
+            if (!F.empty() && !mid.empty()) {
+                // ties between F and mid are decided by the flag: only the even insert slot evaluates it
+                if (g[l] & 1) { ok = false; why = "a relayed insert-type state at an odd position (parity " + std::to_string(off) + ")"; break; }
+                hub_mask |= (uint64_t)1 << (g[l] >> 1);
+            }
+            const int v = (int)edges.size();
+            std::vector<Edge> ve(F); ve.insert(ve.end(), back.begin(), back.end());
+            mid.push_back({v, 0.0});
+            edges[l] = mid;                                   // before the push_back below: it may move the vectors
+            edges.push_back(ve); g.push_back(g[l]); kind.push_back(2);
+            at[2 * 128 + g[l]] = v;
+        }
+        if (!ok) continue;
+        const int n_all = (int)edges.size();
         std::vector<double> lp((size_t)G2_ROWS * 64, NEG), em((size_t)12 * 64, 0.0);
         std::vector<int32_t> knd((size_t)4 * 64, 0), own((size_t)6 * 64, -1), inc((size_t)4 * 64, 0), tag((size_t)4 * 64, 0);
         int bc_state[2] = {-1, -1};
-        for (int l = 0; l < n && ok; ++l) {
+        for (int l = 0; l < n_all && ok; ++l) {
             const int gl = g[l], par = gl & 1, lane = gl >> 1;
             int last_col = -1;
-            for (int e = in_ptr[l]; e < in_ptr[l + 1] && ok; ++e) {
-                const int k = in_src[e], kk = kind[k], dg = gl - g[k];
+            for (const Edge& ed : edges[l]) {
+                const int k = ed.src, kk = kind[k], dg = gl - g[k];
                 int col = -1, row = -1;
                 if (kind[l] == 0) {          // match-type
                     row = par ? G2_ROW_MO : G2_ROW_ME;
@@ -373,21 +414,21 @@ static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32
                     else if (kk == 1 && dg == 0) col = 3; else if (k == l) col = 4;
                     else if (kk == 2 && dg == 1) col = par ? 5 : 6;
                     else if (!par && kk == 0 && k < ne && (bc_state[0] < 0 || bc_state[0] == k)) { col = 5; bc_state[0] = k; }
-                } else if (kind[l] == 1) {   // insert-type
+                } else if (kind[l] == 1) {   // insert-type: itself, the match and the delete state of its position
                     row = par ? G2_ROW_IO : G2_ROW_IE;
-                    if (kk == 1 && dg == 1) col = 0; else if (kk == 0 && dg == 1) col = 1; else if (k == l) col = 2; else if (kk == 0 && dg == 0) col = 3;
-                    else if (kk == 2 && dg == 0) col = par ? 4 : 6;
-                    else if (!par && kk == 2 && dg == 1) col = 5;
-                    else if (!par && kk == 1 && k < ne && (bc_state[1] < 0 || bc_state[1] == k)) { col = 4; bc_state[1] = k; }
-                } else {                     // delete-type: two gathers, then the chain edge
-                    if (kk == 1 && dg == 1) { row = par ? G2_ROW_DO : G2_ROW_DE; col = 0; }
-                    else if (kk == 0 && dg == 1) { row = par ? G2_ROW_DO : G2_ROW_DE; col = 1; }
-                    else if (kk == 2 && dg == 1) { row = G2_ROW_CHAIN + par; col = 2; }
+                    if (k == l) col = 0; else if (kk == 0 && dg == 0) col = 1; else if (kk == 2 && dg == 0) col = 2;
+                } else {                     // delete-type: the gather columns, then the chain edge
+                    row = par ? G2_ROW_DO : G2_ROW_DE;
+                    if (kk == 1 && dg == 1) col = 0;
+                    else if (kk == 0 && dg == 1) col = 1;
+                    else if (kk == 2 && dg == 1) { row = G2_ROW_CHAIN + par; col = 3; }
+                    else if (!par && kk == 1 && k < ne && (bc_state[1] < 0 || bc_state[1] == k)) { col = 2; bc_state[1] = k; }
                 }
-                if (col < 0) { ok = false; why = "an edge outside the columns of the layout (parity " + std::to_string(off) + ")"; break; }
+                if (col < 0) { ok = false; why = "an edge outside the columns of the layout (parity " + std::to_string(off) + ": state " + std::to_string(l) + " at position " + std::to_string(gl) +
+                                                 " <- state " + std::to_string(k) + " of type " + std::to_string(kk) + " at position " + std::to_string(g[k]) + ")"; break; }
                 if (col <= last_col) { ok = false; why = "in-edges not in column order"; break; }
                 last_col = col;
-                lp[(size_t)(row + (kind[l] == 2 && col == 2 ? 0 : col)) * 64 + lane] = in_logp[e];
+                lp[(size_t)(row + (kind[l] == 2 && col == 3 ? 0 : col)) * 64 + lane] = ed.lp;
             }
             if (!ok) break;
             if (kind[l] < 2) {
@@ -396,7 +437,7 @@ static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32
                 em[((size_t)slot * 3 + 0) * 64 + lane] = hm->emis_a[l]; em[((size_t)slot * 3 + 1) * 64 + lane] = hm->emis_b[l]; em[((size_t)slot * 3 + 2) * 64 + lane] = hm->emis_c[l];
                 inc[(size_t)slot * 64 + lane] = hm->count_inc.empty() ? 0 : hm->count_inc[l];
                 tag[(size_t)slot * 64 + lane] = (!hm->state_tag.empty() && hm->state_tag[l] == 1) ? 1 : 0;
-            } else own[(size_t)(4 + par) * 64 + lane] = l;
+            } else own[(size_t)(4 + par) * 64 + lane] = l < n_real ? l : -2;
         }
         if (!ok) continue;
         if (in_ptr[hm->start + 1] != in_ptr[hm->start]) { why = "the start state has in-edges"; continue; }
@@ -406,13 +447,12 @@ static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32
             if (bc_state[i] >= 0) { G.bc_slot[i] = kind[bc_state[i]] * 2 + (g[bc_state[i]] & 1); G.bc_lane[i] = g[bc_state[i]] >> 1; }
         }
         G.start_slot = g[hm->start] & 1; G.start_lane = g[hm->start] >> 1; G.end_slot = g[hm->end] & 1; G.end_lane = g[hm->end] >> 1;
-        // one kernel variant per parity of the broadcast sources; the odd one also evaluates the first two insert columns at odd positions
+        G.hub_mask = hub_mask;
+        // one code path per parity of the broadcast sources (a repeat profile of odd length puts them at an odd position)
         int par_bc = -1; bool bad_par = false;
         for (int i = 0; i < 2; ++i) if (bc_state[i] >= 0) { const int pb = g[bc_state[i]] & 1; if (par_bc >= 0 && par_bc != pb) bad_par = true; par_bc = pb; }
-        bool io_front = false;
-        for (int lane = 0; lane < 64; ++lane) if (lp[(size_t)(G2_ROW_IO + 0) * 64 + lane] > NEG || lp[(size_t)(G2_ROW_IO + 1) * 64 + lane] > NEG) io_front = true;
-        if (bad_par || (io_front && par_bc == 0)) { why = "broadcast sources at positions of both parities"; continue; }
-        out.odd = (par_bc == 1 || io_front) ? 1 : 0;
+        if (bad_par) { why = "broadcast sources at positions of both parities"; continue; }
+        out.odd = par_bc == 1 ? 1 : 0;
         // the kernel adds count increments only in the two slots of that parity (STRique counts the two dummy states: the broadcast sources)
         bool inc_elsewhere = false;
         for (int k = 0; k < 4; ++k) if ((k & 1) != out.odd) for (int lane = 0; lane < 64; ++lane) if (inc[(size_t)k * 64 + lane] != 0) inc_elsewhere = true;
@@ -420,6 +460,7 @@ static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32
         out.lp.swap(lp); out.em.swap(em); out.knd.swap(knd); out.own.swap(own); out.inc.swap(inc); out.tag.swap(tag);
         return true;
     }
+    why = why_all + why;
     return unsupported(why.c_str());
 }
 
@@ -484,7 +525,7 @@ int strq_model_create(strq_ctx* c, int32_t n_states, int32_t silent_start, int32
 }
 
 // Host-only (no context, no device): the tables strq_model_set_positions would upload, for tests of the layout.
-// out_lp[G2_ROWS * 64], out_own[6 * 64], out_meta[8] = {bc_slot0, bc_lane0, bc_slot1, bc_lane1, start_slot, start_lane, end_slot, end_lane}.
+// out_lp[G2_ROWS * 64], out_own[6 * 64], out_meta[10] = {bc_slot0, bc_lane0, bc_slot1, bc_lane1, start_slot, start_lane, end_slot, end_lane, hub_mask lo, hub_mask hi}.
 int strq_debug_g2_layout(int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                          const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                          const int32_t* emis_kind, const int32_t* count_inc, const int32_t* kind, const int32_t* pos,
@@ -500,7 +541,8 @@ int strq_debug_g2_layout(int32_t n_states, int32_t silent_start, int32_t start, 
     G2Host L; std::string w;
     if (!g2_layout(&hm, kind, pos, L, w)) { if (why && why_len > 0) snprintf(why, why_len, "%s", w.c_str()); return STRQ_ERR_UNSUPPORTED; }
     std::memcpy(out_lp, L.lp.data(), L.lp.size() * 8); std::memcpy(out_own, L.own.data(), L.own.size() * 4);
-    const int32_t meta[8] = {L.G.bc_slot[0], L.G.bc_lane[0], L.G.bc_slot[1], L.G.bc_lane[1], L.G.start_slot, L.G.start_lane, L.G.end_slot, L.G.end_lane};
+    const int32_t meta[10] = {L.G.bc_slot[0], L.G.bc_lane[0], L.G.bc_slot[1], L.G.bc_lane[1], L.G.start_slot, L.G.start_lane, L.G.end_slot, L.G.end_lane,
+                              (int32_t)(uint32_t)L.G.hub_mask, (int32_t)(uint32_t)(L.G.hub_mask >> 32)};
     std::memcpy(out_meta, meta, sizeof(meta));
     return STRQ_OK;
 }

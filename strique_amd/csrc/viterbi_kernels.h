@@ -18,25 +18,32 @@ namespace strq {
 // Register-resident layout of a profile chain (viterbi_g2_kernel): the model's states as ONE chain of positions g, two
 // positions per lane (g = 2 * lane + parity), every position holding at most a match-type state M_g, an insert-type state
 // I_g (both emitting) and a delete-type silent state D_g.  All in-edges of the regular part connect a position with itself
-// or its predecessor, so a time step needs the lane's own previous values and those of lane - 1 (one DPP shift) -- no LDS:
+// or its predecessor, so a time step needs the lane's own previous values and those of lane - 1 -- no gathers:
 //   M_g <- M_{g-2}, I_{g-1}, M_{g-1}, I_g, M_g, [B0], D_{g-1}             (B0 only at even g)
-//   I_g <- [I_{g-1}, M_{g-1}], I_g, M_g, [B1], [D_{g-1}], D_g             (B1 and D_{g-1} only at even g; the first two at odd g
-//                                                                          only in images flagged g2_odd)
-//   D_g <- I_{g-1}, M_{g-1} (this time step's values), then its chain predecessor D_{g-1}
+//   I_g <- I_g, M_g, D_g
+//   D_g <- I_{g-1}, M_{g-1}, [B1] (this time step's values; B1 only at even g), then its chain predecessor D_{g-1}
 // in this order -- which must be the ascending order of the source states, the order the oracle breaks ties in; B0 / B1 are
-// two designated states (STRique: the dummy states that close the repeat loop) whose previous values are broadcast.
+// two designated emitting states (STRique: the dummy states that close the repeat loop) whose values are broadcast.
+// Round 4: an insert-type state has three columns, not seven.  What bake() splices out of STRique's graph -- the silent
+// hubs repeat.e1 (in front of dummy1) and repeat.s1 (in front of the first insert of the repeat unit), scripts/STRique.py:
+// 339-344 -- comes back in the IMAGE as a virtual delete-type state at a free position (the repeat unit has no delete
+// states): dummy1 <- V <- {last insert, last match of the unit}, and repeat0i <- {itself, repeat0m, V' <- {dummy1, last
+// prefix delete}}.  A virtual state forwards with log-probability 0.0: x + lp + 0.0 == x + lp bit for bit, the payload of a
+// silent state is its predecessor's, and the relayed sources are the LAST of their target's in-edges in evaluation order
+// and adjacent, so that every tie is broken as in the baked model (g2_layout checks all of it and refuses otherwise).
 // Rows of `lp` (64 doubles each, -inf where a lane has no such edge): see G2_ROW_* below.
 struct VitG2 {
     const double* lp;            // G2_ROWS x 64
     const double* em;            // [slot][a | b | c][lane]: emission parameters of the emitting slots (Me, Mo, Ie, Io), as in VitModel
     const int32_t* kind;         // [slot][lane]: 0 none, 1 Normal, 2 Uniform
-    const int32_t* own;          // [6][lane]: state of Me, Mo, Ie, Io, De, Do or -1
+    const int32_t* own;          // [6][lane]: state of Me, Mo, Ie, Io, De, Do; -1 none, -2 a virtual relay state
     const int32_t* inc;          // [4][lane]: count_inc of the emitting states
     const int32_t* tag;          // [4][lane]: state_tag == 1
-    int32_t bc_slot[2], bc_lane[2];      // broadcast sources B0 (slot 0 / 1) and B1 (slot 2 / 3); lane -1: none
+    int32_t bc_slot[2], bc_lane[2];      // broadcast sources B0 (slot 0 / 1: feeds match-type states) and B1 (slot 2 / 3: feeds delete-type states); lane -1: none
     int32_t start_slot, start_lane, end_slot, end_lane;      // silent slots 0 (even g) / 1 (odd g)
+    uint64_t hub_mask;           // lanes whose even delete slot is a virtual relay that lets its target win a tie when the relay's own winner was one of its gather columns
 };
-enum { G2_ROW_ME = 0, G2_ROW_MO = 7, G2_ROW_IE = 13, G2_ROW_IO = 20, G2_ROW_DE = 25, G2_ROW_DO = 27, G2_ROW_CHAIN = 29, G2_ROWS = 31 };
+enum { G2_ROW_ME = 0, G2_ROW_MO = 7, G2_ROW_IE = 13, G2_ROW_IO = 16, G2_ROW_DE = 19, G2_ROW_DO = 22, G2_ROW_CHAIN = 24, G2_ROWS = 26 };
 
 struct VitModel {
     int32_t n_states, n_emit, n_silent, start, end;
@@ -79,7 +86,7 @@ struct VitModel {
     int32_t g2_odd, pad3_;            // that image has its broadcast sources (and the states they feed directly) at odd positions
 };
 #define VIT_SHAPE_CSR 8              // launch_viterbi shape id of those models
-#define VIT_SHAPE_G2 9               // ... of models with a VitG2 image, for count / mark launches (want_bp 0 or 2); + 1 when g2_odd
+#define VIT_SHAPE_G2 9               // ... of models with a VitG2 image, for count / mark launches (want_bp 0 or 2); both parities (g2_odd) share the launch
 #define VIT_CSR_MAX_STATES 4096      // two buffers of 16-byte cells in 160 KB of LDS
 
 enum { VIT_SRC_F64 = 0, VIT_SRC_F64_AFFINE = 1, VIT_SRC_I16_AFFINE = 2 };

@@ -97,6 +97,13 @@ static __device__ __forceinline__ uint64_t sel_shr1_u64(double tin, double y, ui
         : "+v"(klo), "+v"(khi) : "v"((int)(uint32_t)prev), "v"((int)(uint32_t)(prev >> 32)), "v"(tin), "v"(y) : "vcc");
     return ((uint64_t)(uint32_t)khi << 32) | (uint32_t)klo;
 }
+// lane-mask select: the mask lives in an SGPR pair (the result of compares combined with scalar instructions)
+static __device__ __forceinline__ int sel_mask_i32(int if0, int if1, uint64_t mask)
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+    return r;
+}
 // max of two non-NaN doubles in one instruction (__builtin_fmax makes the compiler canonicalise a
 // loop-carried operand first: a second v_max_f64 per sweep)
 static __device__ __forceinline__ double max_f64_raw(double a, double b)
@@ -631,7 +638,10 @@ static __device__ __forceinline__ void g2_tournament(double (&cv)[8], P (&cc)[8]
 // even match for the skip edges of a repeat profile) and the two broadcast sources stay on DPP / v_readlane.
 #define G2_LDS_CELLS 65              // cell 0 stays -inf: lane 0's left neighbour
 #define G2_LDS_WAVE_BYTES (5 * G2_LDS_CELLS * 16)
-template <bool MARK, int WAVES, bool ODD, int LXL>
+// Both parities of the chain in one kernel: a repeat profile of odd length (CGG, CAG) puts the two broadcast sources at odd
+// positions, and which of the two code paths a window takes is decided per task -- wave-uniform, outside the time loop -- from
+// its model (VitModel::g2_odd).  A sub-batch that mixes such targets with even ones (C9orf72 + FMR1 + HTT) is one launch.
+template <bool MARK, int WAVES, int LXL>
 __global__ void __launch_bounds__(64 * WAVES)
 viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ results,
                   int n_tasks, int* __restrict__ queue, const int* __restrict__ order)
@@ -673,13 +683,12 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
     };
     const VitModel* cur_model = nullptr;
     const VitG2* G = nullptr;
-    double la[7], lb[6], lc[7], ld[5], sg[2][2], clp[2];
+    double la[7], lb[6], lc[3], ld[3], sg0[3], sg1[2], clp[2];
     double ea[2], ebf[2], ecf[4];
     int einc[4]; bool etag[4];
     double uni_lo_max = 0.0, uni_hi_min = 0.0;
-    // ODD: the two broadcast sources sit at an odd position (a repeat profile of odd length), and insert-type states at odd
-    // positions may be fed by the match / insert of the position before (the dummy state behind such a profile)
-    constexpr int B0 = ODD ? 1 : 0, B1 = ODD ? 3 : 2;
+    bool odd_model = false;
+    uint64_t hub_mask = 0;
     int bc0_lane = 0, bc1_lane = 0, start_slot = 0, start_lane = 0, end_slot = 0, end_lane = 0;
 
     for (;;) {
@@ -690,6 +699,9 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
         if (tk.model != cur_model) {
             cur_model = tk.model;
             G = cur_model->g2;
+            odd_model = cur_model->g2_odd != 0;
+            { const uint64_t hm = G->hub_mask;          // into SGPRs: the model pointer came through a vector load
+              hub_mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hm >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hm); }
             uni_lo_max = cur_model->uni_lo_max; uni_hi_min = cur_model->uni_hi_min;
             const double* lp = G->lp;
 #pragma unroll
@@ -697,11 +709,9 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
 #pragma unroll
             for (int j = 0; j < 6; ++j) lb[j] = lp[(G2_ROW_MO + j) * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) lc[j] = lp[(G2_ROW_IE + j) * 64 + lane];
+            for (int j = 0; j < 3; ++j) { lc[j] = lp[(G2_ROW_IE + j) * 64 + lane]; ld[j] = lp[(G2_ROW_IO + j) * 64 + lane]; sg0[j] = lp[(G2_ROW_DE + j) * 64 + lane]; }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) ld[j] = lp[(G2_ROW_IO + j) * 64 + lane];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { sg[0][j] = lp[(G2_ROW_DE + j) * 64 + lane]; sg[1][j] = lp[(G2_ROW_DO + j) * 64 + lane]; clp[j] = lp[(G2_ROW_CHAIN + j) * 64 + lane]; }
+            for (int j = 0; j < 2; ++j) { sg1[j] = lp[(G2_ROW_DO + j) * 64 + lane]; clp[j] = lp[(G2_ROW_CHAIN + j) * 64 + lane]; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int kind = G->kind[k * 64 + lane];
@@ -738,7 +748,11 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
         for (int s = 0; s < 2; ++s) { dv[s] = (lane == start_lane && s == start_slot) ? 0.0 : NEGINF; dc[s] = 0; }
         chain_sweeps(dv, dc);          // t = 0: the silent states reachable from start (start itself has no chain edge: it stays 0)
         double rMo = NEGINF, rIo = NEGINF, rDo = NEGINF; Pay qMo = 0, qIo = 0, qDo = 0;      // LX: lane - 1's Mo, Io, Do of the previous time step
-        double rMe = NEGINF, rB0 = NEGINF, rB1 = NEGINF; Pay qMe = 0, qB0 = 0, qB1 = 0;      // LX2: lane - 1's Me, the two broadcast sources
+        double rMe = NEGINF, rB0 = NEGINF; Pay qMe = 0, qB0 = 0;      // LX2: lane - 1's Me, the broadcast source of the match-type states
+        // hub lanes (VitG2::hub_mask) whose even delete slot -- a virtual relay -- took its value of the previous time step from one
+        // of its gather columns: there the relay wins a tie against the insert-type state's own columns (the relayed sources
+        // stand in front of them in the baked model's in-edge order; a relay whose winner is its broadcast / chain source stands behind)
+        uint64_t front_won = 0;
         if constexpr (LX) {
             if (lane < 5) { const uint64_t u = __builtin_bit_cast(uint64_t, NEGINF); v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = 0; q.w = 0; *reinterpret_cast<v4u*>(xbase + lane * (G2_LDS_CELLS * 16)) = q; }
             VIT_FENCE();
@@ -747,8 +761,12 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             xload(2, rDo, qDo);
         }
 
-        auto step = [&](auto fast_c, double x, int64_t t) {
+        auto step = [&](auto fast_c, auto odd_c, double x, int64_t t) {
             constexpr bool FAST = decltype(fast_c)::value;
+            // ODD: the two broadcast sources sit at an odd position (a repeat profile of odd length), and insert-type states at
+            // odd positions may be fed by the match / insert of the position before (the dummy state behind such a profile)
+            constexpr bool ODD = decltype(odd_c)::value;
+            constexpr int B0 = ODD ? 1 : 0, B1 = ODD ? 3 : 2;
             const uint32_t tt1 = (uint32_t)(t + 1);
             const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
             (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
@@ -758,10 +776,10 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             double sMo, sIo, sDo; Pay cMo, cIo, cDo;
             if constexpr (LX) { sMo = rMo; sIo = rIo; sDo = rDo; cMo = qMo; cIo = qIo; cDo = qDo; }
             else { sMo = dpp_shr1_f64(pv[1]); sIo = dpp_shr1_f64(pv[3]); sDo = dpp_shr1_f64(dv[1]); cMo = shr1_pay(pc[1]); cIo = shr1_pay(pc[3]); cDo = shr1_pay(dc[1]); }
-            // the two broadcast sources
-            double b0v, b1v; Pay b0c, b1c;
-            if constexpr (LX2) { b0v = rB0; b1v = rB1; b0c = qB0; b1c = qB1; }
-            else { b0v = readlane_f64(pv[B0], bc0_lane); b1v = readlane_f64(pv[B1], bc1_lane); b0c = readlane_pay(pc[B0], bc0_lane); b1c = readlane_pay(pc[B1], bc1_lane); }
+            // the broadcast source of the match-type states (previous time step); the one of the delete-type states is read below, from this step's values
+            double b0v; Pay b0c;
+            if constexpr (LX2) { b0v = rB0; b0c = qB0; }
+            else { b0v = readlane_f64(pv[B0], bc0_lane); b0c = readlane_pay(pc[B0], bc0_lane); }
             double nv[4]; Pay nc[4];
             double best[4]; Pay bcnt[4];
             auto tour_me = [&]() {
@@ -777,24 +795,22 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 cv[3] = pv[3] + lb[3]; cc[3] = pc[3];  cv[4] = pv[1] + lb[4]; cc[4] = pc[1];  cv[5] = dv[0] + lb[5]; cc[5] = dc[0];
                 g2_tournament<6>(cv, cc); best[1] = cv[0]; bcnt[1] = cc[0];
             };
+            // insert-type states: themselves, the match and the delete state of their position (what else feeds one in the
+            // baked model reaches it through a virtual delete state, viterbi_kernels.h)
             auto tour_ie = [&]() {
-                double cv[8]; Pay cc[8];
-                cv[0] = sIo + lc[0]; cc[0] = cIo;  cv[1] = sMo + lc[1]; cc[1] = cMo;  cv[2] = pv[2] + lc[2]; cc[2] = pc[2];
-                cv[3] = pv[0] + lc[3]; cc[3] = pc[0];  cv[4] = b1v + lc[4]; cc[4] = b1c;  cv[5] = sDo + lc[5]; cc[5] = cDo;
-                cv[6] = dv[0] + lc[6]; cc[6] = dc[0];
-                g2_tournament<7>(cv, cc); best[2] = cv[0]; bcnt[2] = cc[0];
+                const double c0 = pv[2] + lc[0], c1 = pv[0] + lc[1], c2 = dv[0] + lc[2];
+                const bool g1 = c1 > c0;
+                const double w = __builtin_fmax(c0, c1); const Pay pw = g1 ? pc[0] : pc[2];
+                // the delete column wins on '>' everywhere and on '==' in the flagged hub lanes
+                const uint64_t win = __builtin_amdgcn_ballot_w64(c2 > w) | (__builtin_amdgcn_ballot_w64(c2 == w) & front_won);
+                best[2] = __builtin_fmax(w, c2);
+                if constexpr (MARK) bcnt[2] = ((uint64_t)(uint32_t)sel_mask_i32((int)(uint32_t)(pw >> 32), (int)(uint32_t)(dc[0] >> 32), win) << 32) | (uint32_t)sel_mask_i32((int)(uint32_t)pw, (int)(uint32_t)dc[0], win);
+                else bcnt[2] = sel_mask_i32(pw, dc[0], win);
             };
             auto tour_io = [&]() {
                 double cv[8]; Pay cc[8];
-                if constexpr (ODD) {
-                    cv[0] = pv[2] + ld[0]; cc[0] = pc[2];  cv[1] = pv[0] + ld[1]; cc[1] = pc[0];  cv[2] = pv[3] + ld[2]; cc[2] = pc[3];
-                    cv[3] = pv[1] + ld[3]; cc[3] = pc[1];  cv[4] = dv[1] + ld[4]; cc[4] = dc[1];
-                    g2_tournament<5>(cv, cc);
-                } else {
-                    cv[0] = pv[3] + ld[2]; cc[0] = pc[3];  cv[1] = pv[1] + ld[3]; cc[1] = pc[1];  cv[2] = dv[1] + ld[4]; cc[2] = dc[1];
-                    g2_tournament<3>(cv, cc);
-                }
-                best[3] = cv[0]; bcnt[3] = cc[0];
+                cv[0] = pv[3] + ld[0]; cc[0] = pc[3];  cv[1] = pv[1] + ld[1]; cc[1] = pc[1];  cv[2] = dv[1] + ld[2]; cc[2] = dc[1];
+                g2_tournament<3>(cv, cc); best[3] = cv[0]; bcnt[3] = cc[0];
             };
             // emission and payload of slot k
             auto finish = [&](auto k_c) {
@@ -827,10 +843,11 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             };
             using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
             using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
-            // silent states of this time step: De from lane - 1's new Io, Mo; Do from the lane's own new Ie, Me; then the chains
+            // silent states of this time step: De from lane - 1's new Io, Mo and the broadcast source B1; Do from the lane's own new Ie, Me; then the chains
             double y[2]; Pay yc[2];
+            double gather01;      // what the even delete slot's two gather columns gave, before the broadcast source and the chain
             {
-                double nI, nM; Pay cI, cM;      // lane - 1's new Io, Mo
+                double nI, nM, nB; Pay cI, cM, cB;      // lane - 1's new Io, Mo; the new value of B1
                 if constexpr (LX) {
 #ifdef STRQ_G2_EARLY
                     // experiment: the odd slots first -- their cells are on their way through LDS while the even slots (the larger tournaments) are evaluated
@@ -849,24 +866,30 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                     xload(0, nM, cM); xload(1, nI, cI);
 #endif
                     rMo = nM; rIo = nI; qMo = cM; qIo = cI;          // ... which are next step's shifted previous values
-                    if constexpr (LX2) {      // for the next time step
-                        xload(3, rMe, qMe);
-                        xload_at(ODD ? 0 : 3, bc0_lane, rB0, qB0); xload_at(ODD ? 1 : 4, bc1_lane, rB1, qB1);
-                    }
+                    if constexpr (LX2) {
+                        xload_at(ODD ? 1 : 4, bc1_lane, nB, cB);
+                        xload(3, rMe, qMe); xload_at(ODD ? 0 : 3, bc0_lane, rB0, qB0);      // for the next time step
+                    } else { nB = readlane_f64(nv[B1], bc1_lane); cB = readlane_pay(nc[B1], bc1_lane); }
                 } else {
                     tour_me(); tour_mo(); tour_ie(); tour_io(); finish(K0{}); finish(K1{}); finish(K2{}); finish(K3{});
                     nI = dpp_shr1_f64(nv[3]); nM = dpp_shr1_f64(nv[1]); cI = shr1_pay(nc[3]); cM = shr1_pay(nc[1]);
+                    nB = readlane_f64(nv[B1], bc1_lane); cB = readlane_pay(nc[B1], bc1_lane);
                 }
-                const double tI = nI + sg[0][0], tM = nM + sg[0][1];
+                const double tI = nI + sg0[0], tM = nM + sg0[1], tB = nB + sg0[2];
                 const bool gt = tM > tI;
-                y[0] = __builtin_fmax(tI, tM); yc[0] = gt ? cM : cI;
+                const double v01 = __builtin_fmax(tI, tM); const Pay c01 = gt ? cM : cI;
+                const bool gb = tB > v01;
+                y[0] = __builtin_fmax(v01, tB); yc[0] = gb ? cB : c01;
+                gather01 = v01;
             }
             {
-                const double tI = nv[2] + sg[1][0], tM = nv[0] + sg[1][1];
+                const double tI = nv[2] + sg1[0], tM = nv[0] + sg1[1];
                 const bool gt = tM > tI;
                 y[1] = __builtin_fmax(tI, tM); yc[1] = gt ? nc[0] : nc[2];
             }
             chain_sweeps(y, yc);
+            // the broadcast source wins only on '>' and the chain only raises a value: the slot kept a gather column's value iff it still equals it
+            front_won = __builtin_amdgcn_ballot_w64(y[0] == gather01) & hub_mask;
             if constexpr (LX) {
                 VIT_FENCE();
                 xstore(2, y[1], yc[1]);
@@ -878,7 +901,7 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             dv[0] = y[0]; dv[1] = y[1]; dc[0] = yc[0]; dc[1] = yc[1];
         };
 
-        auto run_window = [&](auto fast_c) {
+        auto run_window = [&](auto fast_c, auto odd_c) {
             double xchunk = 0.0;
             for (int64_t t0 = 0; t0 < T; t0 += 64) {
                 {
@@ -899,11 +922,12 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                     xchunk = xv;
                 }
                 const int send = (int)((T - t0) < 64 ? (T - t0) : 64);
-                for (int s0 = 0; s0 < send; ++s0) step(fast_c, readlane_f64(xchunk, s0), t0 + s0);
+                for (int s0 = 0; s0 < send; ++s0) step(fast_c, odd_c, readlane_f64(xchunk, s0), t0 + s0);
             }
         };
-        if (__builtin_amdgcn_readfirstlane((int)fast_em) != 0) run_window(std::true_type{});
-        else run_window(std::false_type{});
+        const bool fast_u = __builtin_amdgcn_readfirstlane((int)fast_em) != 0, odd_u = __builtin_amdgcn_readfirstlane((int)odd_model) != 0;
+        if (fast_u) { if (odd_u) run_window(std::true_type{}, std::true_type{}); else run_window(std::true_type{}, std::false_type{}); }
+        else { if (odd_u) run_window(std::false_type{}, std::true_type{}); else run_window(std::false_type{}, std::false_type{}); }
 
         double lp; Pay fc;
         if (__builtin_amdgcn_readfirstlane(end_slot)) { lp = readlane_f64(dv[1], end_lane); fc = readlane_pay(dc[1], end_lane); }
@@ -923,7 +947,7 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
     }
 }
 
-static int launch_viterbi_g2(hipStream_t stream, bool odd, const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
+static int launch_viterbi_g2(hipStream_t stream, const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
 {
     if (want_bp != 0 && want_bp != 2) return 2;
     int nw = 8, lx = 2;
@@ -931,9 +955,8 @@ static int launch_viterbi_g2(hipStream_t stream, bool odd, const VitTask* tasks,
     if (const char* e = getenv("STRQ_VIT_G2_LDS")) { const int v = atoi(e); if (v >= 0 && v <= 2) lx = v; }
     const dim3 grid(n_cu), block(64 * nw);
     const size_t lds = lx ? (size_t)nw * G2_LDS_WAVE_BYTES : 0;
-#define G2_GO2(MK_, W_, OD_, LX_) hipLaunchKernelGGL((viterbi_g2_kernel<MK_, W_, OD_, LX_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order)
-#define G2_GO(MK_, W_) do { if (odd) { if (lx == 2) G2_GO2(MK_, W_, true, 2); else if (lx == 1) G2_GO2(MK_, W_, true, 1); else G2_GO2(MK_, W_, true, 0); } \
-                            else { if (lx == 2) G2_GO2(MK_, W_, false, 2); else if (lx == 1) G2_GO2(MK_, W_, false, 1); else G2_GO2(MK_, W_, false, 0); } } while (0)
+#define G2_GO2(MK_, W_, LX_) hipLaunchKernelGGL((viterbi_g2_kernel<MK_, W_, LX_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order)
+#define G2_GO(MK_, W_) do { if (lx == 2) G2_GO2(MK_, W_, 2); else if (lx == 1) G2_GO2(MK_, W_, 1); else G2_GO2(MK_, W_, 0); } while (0)
     if (want_bp == 2) { if (nw == 12) G2_GO(true, 12); else if (nw == 4) G2_GO(true, 4); else G2_GO(true, 8); }
     else { if (nw == 12) G2_GO(false, 12); else if (nw == 4) G2_GO(false, 4); else G2_GO(false, 8); }
 #undef G2_GO
@@ -1197,7 +1220,7 @@ int vit_shape_silent_slots(int shape)
 int vit_shape_for(const VitModel& mh, int want_bp)
 {
     const bool no_g2 = getenv("STRQ_VIT_NO_G2") != nullptr;      // A/B: the lane layout for every mode
-    if (mh.g2 && !no_g2 && (want_bp == 0 || want_bp == 2)) return VIT_SHAPE_G2 + (mh.g2_odd ? 1 : 0);
+    if (mh.g2 && !no_g2 && (want_bp == 0 || want_bp == 2)) return VIT_SHAPE_G2;          // either parity of the chain: decided per window inside the kernel
     return vit_shape_of(mh);
 }
 
@@ -1241,8 +1264,8 @@ int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* 
 {
     const int ss = (shape & VIT_SHAPE_SS) ? 1 : 0;
     if ((shape & ~VIT_SHAPE_SS) == VIT_SHAPE_CSR) return launch_viterbi_csr(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
-    if ((shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 || (shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 + 1)
-        return launch_viterbi_g2(stream, (shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 + 1, tasks, results, n_tasks, queue, n_cu, want_bp, order);
+    if ((shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2)
+        return launch_viterbi_g2(stream, tasks, results, n_tasks, queue, n_cu, want_bp, order);
     switch (shape & ~VIT_SHAPE_SS) {
         case 0: return vit_launch_shape<4, 2, 6, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 1: return vit_launch_shape<1, 1, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);

@@ -183,6 +183,12 @@ class Context(object):
         self._check(self._lib.strq_last_counters(self._h, _ptr(t)))
         return t
 
+    def last_viterbi_launches(self):
+        """strq_last_viterbi_launches as a dict (flanked-model decode of the last sub-batch)."""
+        g = np.zeros(4, np.int32)
+        self._check(self._lib.strq_last_viterbi_launches(self._h, _ptr(g)))
+        return dict(zip(("launches", "register_resident", "lane_layout", "general"), (int(v) for v in g)))
+
     def last_geometry(self):
         """strq_last_geometry as a dict: which forward-DP kernel instance the last batched call ran."""
         g = np.zeros(8, np.int32)

@@ -91,6 +91,43 @@ def test_bench_two_ranks_on_one_gpu():
     assert r["vs_baseline"] is None and "cpu_baseline" not in r
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_four_and_eight_ranks_on_one_gpu(world, tmp_path, pm, cfg):
+    """The N = 4 and N = 8 launches the driver's scaling run makes, on the one GPU of this box: rank processes sharing HIP
+    device 0, gloo for the collectives.  One JSON line; the single final gather saw N ranks and delivered steps x N x reads rows;
+    every rank's rows arrived intact (digests) and EQUAL what one process computes for the same reads; every rank is pinned to
+    its own share of the CPUs and stays within a bounded host footprint."""
+    import bench
+    dump = str(tmp_path / "rows.npy")
+    reads, steps, warmup, read_nt = 64, 2, 1, 10000
+    lines, recs = _run_bench(["--gpus", str(world), "--backend", "gloo", "--share-device", "--reads", str(reads), "--steps", str(steps), "--warmup", str(warmup),
+                              "--read-nt", str(read_nt), "--no-cpu-baseline", "--check", "1", "--synth-workers", "1", "--dump-rows", dump],
+                             world=world, port=str(29560 + world), timeout=1500)
+    assert [len(l) for l in lines] == [1] + [0] * (world - 1)
+    r = recs[0]
+    assert r["n_gpus"] == world and r["world_size_seen_by_the_collective"] == world and r["scaling"] == "weak" and r["check_ok"]
+    coll = r["collective"]
+    assert coll["rows_on_rank_0"] == steps * world * reads and "once" in coll["when"]
+    ranks = coll["ranks"]
+    assert ranks["rows_equal_every_ranks_digest"] is True and ranks["hip_device_per_rank"] == [0] * world
+    assert max(ranks["peak_host_rss_gb_per_rank"]) < 6.0, ranks
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= world:
+        assert sum(ranks["cpus_pinned_per_rank"]) == ncpu and min(ranks["cpus_pinned_per_rank"]) >= ncpu // world - 1, ranks
+    assert abs(r["value"] - world * reads * steps / (r["ms_per_step"] * steps / 1e3)) < 1e-6 * r["value"]
+    # the same reads through one process: rank k's batches are reads [k * 3 * reads, (k + 1) * 3 * reads) of the recipe
+    table = np.load(dump)
+    counter = _fresh_counter(pm, cfg, {"c9orf72": tuple(cfg["repeat"]["c9orf72"][3:6])})
+    for rank in range(world):
+        sigs, strands, _ = bench.make_batch(pm, cfg, 3 * reads, read_nt, rank * 3 * reads)
+        for j, k in enumerate(range(warmup, warmup + steps)):
+            bi = k % 3
+            got = counter.detect_batch([("c9orf72", s, st) for s, st in zip(sigs[bi * reads:(bi + 1) * reads], strands[bi * reads:(bi + 1) * reads])])
+            part = table[(j * world + rank) * reads:(j * world + rank + 1) * reads]
+            for g, t in zip(got, part):
+                assert (g[0], g[1], g[2], g[3], g[4], g[5]) == (int(t["count"]), float(t["score_prefix"]), float(t["score_suffix"]), float(t["log_p"]), int(t["offset"]), int(t["ticks"]))
+
+
 def test_bench_line_single_gpu_small():
     """The default single-GPU line at a reduced batch (512 reads so that four waves per alignment is what runs):
     roofline + host leg present, three distinct batches rotated, rows of the host-buffer leg equal the resident

@@ -199,7 +199,7 @@ def test_config1_ten_kb_thirty_repeats(gpu_counter, want, pm, targets):
     assert [g[0] for g in got] == [30, 30]
 
 
-def test_config3_three_targets_mixed(gpu_counter, want, pm, targets):
+def test_config3_three_targets_mixed(gpu_counter, want, pm, targets, monkeypatch):
     """configs[3]: C9orf72 / FMR1(CGG) / HTT(CAG) targets from repeat_config.tsv mixed in one batch,
     both strands, n ~ U{30..1000} scaled to short reads; every field equals the oracle's."""
     rng = np.random.default_rng(33)
@@ -212,6 +212,12 @@ def test_config3_three_targets_mixed(gpu_counter, want, pm, targets):
         items.append((name, _read(pm, targets, name, strand, nt, nrep, 600 + k), strand))
     got = _check(gpu_counter, want, items)
     assert all(g[0] > 0 for g in got)
+    # GGGGCC has a repeat profile of even length, CGG and CAG of odd length: both parities of the register-resident Viterbi
+    # in ONE launch (round 3 ran such a sub-batch on the lane layout); the lane layout must agree record by record
+    assert gpu_counter.ctx.last_viterbi_launches() == {"launches": 1, "register_resident": 1, "lane_layout": 0, "general": 0}
+    monkeypatch.setenv("STRQ_VIT_NO_G2", "1")
+    again = gpu_counter.detect_batch([(n, s, st) for n, s, st in items])
+    assert gpu_counter.ctx.last_viterbi_launches()["register_resident"] == 0 and again == got
 
 
 @pytest.mark.parametrize("name,nrep", [("c9orf72", 1000), ("fmr1", 1000), ("htt", 700)])
@@ -341,6 +347,40 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
         rc.add_target("too_long", "CAG", nt(8198), nt(100))
     with pytest.raises(Exception, match="more than 4096 states"):      # beyond the LDS of the general kernel
         rc.add_target("vntr2000", nt(2000), nt(150), nt(150))
+
+
+def test_every_flank_length_of_the_fourteen_row_shape(pm, cfg, orc, opm, monkeypatch):
+    """Flanks of 134 ... 154 nt (129 ... 149 k-mer classes, 774 ... 894 flank rows) all run at 14 rows per lane, and the last
+    flank row sits in register (m - 1) % 14 of its lane -- 1, 3, ..., 13 over this range.  Round 3 knew that register at
+    compile time for STRique's 870 rows only; now the steady-state loop of align_forward_seg_kernel is compiled once per
+    register and picked by a scalar branch (forward_one, RMSW).  One target per flank length, prefix and suffix of different
+    lengths, both strands, four waves per alignment on reads long enough for every piece to run full 64-step chunks: all
+    six fields against the oracle, and the geometry the library reports."""
+    from strique_amd import synth
+    from strique_amd.counter import repeatCounter
+    rng = np.random.default_rng(4141)
+    nt = lambda n: "".join(rng.choice(list("ACGT"), n))
+    lengths = list(range(134, 155))
+    custom = {"f%d" % L: ("GGCCCC" if L % 2 else "CAG", nt(L), nt(lengths[(i * 7 + 3) % len(lengths)])) for i, L in enumerate(lengths)}
+    monkeypatch.setenv("STRQ_SEG", "4"); monkeypatch.setenv("STRQ_CLASS_MIN", "1")
+    rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    for name, t in custom.items():
+        rc.add_target(name, *t)
+    table = synth.KmerTable(pm)
+    params = orc.align_params(cfg["align"])
+    items = []
+    for k, name in enumerate(custom):
+        strand = "+-"[k % 2]
+        sig = synth.make_read(table, 9, 8100 + k, 4200, custom[name], 20 + k, strand=strand)[0]      # ~31 k samples: pieces of ~8 k + overlap columns
+        items.append((name, sig, strand))
+    got = rc.detect_batch(items)
+    geo = rc.ctx.last_geometry()
+    assert geo["rows_per_lane"] == 14 and geo["waves_per_alignment"] == 4, geo
+    import oracle_pool          # the oracle on a few worker processes (31 k samples x 2 flanks cost it ~0.5 s each)
+    want = oracle_pool.detect_many([(sig, strand, custom[name]) for name, sig, strand in items])
+    for (name, sig, strand), g, w in zip(items, got, want):
+        assert tuple(g[:6]) == tuple(w[:6]), (name, strand, g, w)
+        assert g[0] > 0, (name, strand, g)
 
 
 @pytest.mark.parametrize("samples", [4, 8, 9, 12])

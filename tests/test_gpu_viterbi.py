@@ -67,6 +67,33 @@ def test_register_resident_kernel_variants_agree(ctx, orc, pm, cfg, monkeypatch)
                 assert np.float64(lo).tobytes() == np.float64(lg[i]).tobytes() and co == cg[i], (name, env, i)
 
 
+def test_register_resident_kernel_breaks_ties_like_the_oracle(ctx, orc, pm, cfg, monkeypatch):
+    """Integer log-probabilities and constant emissions (tests/test_g2_layout.py::tie_prone): equal candidates at almost every
+    state and time step, so the count depends on every tie going to the first in-edge in ascending source order -- including
+    the ties that the relay flag of the even insert slot settles (VitG2::hub_mask; the crafted seed-0 model reaches them at
+    every time step after the first round of the loop).  Every exchange level of viterbi_g2_kernel and the lane layout."""
+    from strique_amd import hmm
+    from test_g2_layout import tie_prone
+    for name, rep_override in (("c9orf72", None), ("fmr1", None), ("c9orf72", "CAGCA")):
+        chrom, b, e, repeat, prefix, suffix = cfg["repeat"][name]
+        repeat = rep_override or repeat
+        bk0 = hmm.FlankedRepeatModel(repeat, prefix[-30:], suffix[:30], pm, cfg["HMM"]).baked
+        for seed in range(4):
+            rng = np.random.default_rng(100 + seed)
+            bk = tie_prone(bk0, rng if seed else None)
+            mid = ctx.model_create(bk)
+            assert ctx.last_positions_rc == 0
+            seqs = [rng.uniform(10.0, 150.0, T) for T in (40, 75, 130, 333)]
+            want = [orc.viterbi(bk, s, want_path=False) for s in seqs]
+            for env in ({"STRQ_VIT_G2_LDS": "2"}, {"STRQ_VIT_G2_LDS": "1"}, {"STRQ_VIT_G2_LDS": "0"}, {"STRQ_VIT_NO_G2": "1"}):
+                with monkeypatch.context() as mp:
+                    for k, v in env.items():
+                        mp.setenv(k, v)
+                    lg, cg, sg, _ = ctx.viterbi_batch(mid, seqs)
+                for i, (lo, _, co) in enumerate(want):
+                    assert lo == lg[i] and co == cg[i] and sg[i] == 0, (name, seed, env, i, lo, lg[i], co, cg[i])
+
+
 def test_flanked_model_with_counted_silent_states(ctx, orc, pm, cfg):
     """The kernels picked for STRique's flanked models carry a silent state's payload on unchanged (STRique counts the
     emitting dummy states only, scripts/STRique.py:341-342,375-377).  The same model with some delete states counted must
