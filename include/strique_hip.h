@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_inflate_backend; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -219,6 +219,9 @@ int64_t strq_svb_decode(const uint8_t* stream, int64_t stream_len, int64_t n, in
 int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, int64_t n_chunks, const int64_t* addr,
                             const int32_t* csize, const int64_t* elem_off, int32_t elem_size, int32_t shuffle,
                             int64_t chunk_elems, int64_t n_total, void* out);
+/* 1 when libdeflate (dlopen of libdeflate.so.0) decodes the zlib streams of strq_inflate_chunks in this process, 0 when
+ * zlib does (library absent, or STRQ_NO_LIBDEFLATE=1).  Same bytes either way. */
+int strq_inflate_backend(void);
 /* Test hook: conditioning outputs (8-bit morphology levels, their 256 float32 values, and
  * {median, MAD, c1/h1 of the filtered, morphology and raw signal, h2, c2}) of read `read` of the
  * last sub-batch processed by strq_batch_run. */

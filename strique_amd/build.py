@@ -55,7 +55,7 @@ def build_lib(force=False, verbose=False):
         if p.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode(errors="replace")))
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]      # zlib: strq_inflate_chunks (fast5 reader)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-ldl"]      # zlib: strq_inflate_chunks (fast5 reader); dl: libdeflate.so.0 is resolved at run time
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))

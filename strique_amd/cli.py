@@ -114,8 +114,16 @@ class Fast5Index(object):
         with open(index_file) as fp:
             self.index = {rid: path for path, rid in (line.split('\t') for line in fp.read().split('\n') if line)}
         self.dir = os.path.dirname(index_file)
+        self._joined = {}
         self._open = {}                  # path -> H5File, the few most recently used (bulk files hold thousands of reads)
         self._lock = threading.Lock()
+
+    def _join(self, rel):
+        """os.path.join(self.dir, rel), memoised per file (thousands of reads share a bulk file)."""
+        full = self._joined.get(rel)
+        if full is None:
+            full = self._joined[rel] = os.path.join(self.dir, rel)
+        return full
 
     def _file(self, path):
         from . import fast5
@@ -130,9 +138,14 @@ class Fast5Index(object):
 
     def get_raw(self, read_id):
         from . import fast5
-        if read_id not in self.index:
+        where = self.index.get(read_id)
+        if where is None:
             return None
-        parts = re.split(r'(\.fast5|\.tar)/', self.index[read_id])
+        cut = where.find('.fast5/')          # the common case, a read of a bulk file, without the regular expression
+        if cut >= 0 and '.tar/' not in where:
+            f = self._file(self._join(where[:cut + 6]))
+            return f.dataset("/%s/Raw/Signal" % where[cut + 7:].strip('/'))
+        parts = re.split(r'(\.fast5|\.tar)/', where)
         if len(parts) == 1:
             f = self._file(os.path.join(self.dir, parts[0]))
             grp = "/Raw/Reads/" + f.listdir("/Raw/Reads")[0]

@@ -685,16 +685,18 @@ align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __res
         const int ti = gi * SEG + wave;
         const AlignTask& tk = tasks[ti];
         if (tk.n <= 0) continue;               // unused piece of a short read (wave-uniform)
-        // the last flank row sits in register (m - 1) % R of its lane: STRique's own flanks (145 k-mer classes, 870 rows) at 14
-        // rows per lane in register 1 of lane 62.  One forward pass, its steady-state loop switched on that register (RMSW).
-#ifdef STRQ_DP_NO_RMSW
-        // round 3's dispatch (A/B builds): the register known at compile time for m % R == 0 and m = 870 only
+        // the last flank row sits in register (m - 1) % R of its lane.  STRique's own flanks (145 k-mer classes, 870 rows: register 1
+        // of lane 62 at 14 rows per lane) and flanks that fill their last lane keep the forward pass round 3 compiled for them --
+        // the benchmarked instance, instruction for instruction; every other flank length runs the pass whose steady-state loop
+        // is switched on that register (RMSW: 151 VALU instructions per step for all of them, where round 3 read the row
+        // through a runtime index at 191; measured +1 ... +7 % against the 870-row instance, tools/flank_sweep.py).
         constexpr int RMC870 = R == 14 ? (870 - 1) % 14 : -1;
         if ((tk.m - 1) % R == R - 1) forward_one<R, S, true, true, 0, true, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
-        else if (RMC870 >= 0 && (tk.m - 1) % R == RMC870) forward_one<R, S, true, true, 0, false, PK, false, RMC870>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
-        else forward_one<R, S, true, true, 0, false, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+        else if (RMC870 >= 0 && tk.m == 870) forward_one<R, S, true, true, 0, false, PK, false, RMC870>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+#ifdef STRQ_DP_NO_RMSW
+        else forward_one<R, S, true, true, 0, false, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);          // round 3 (A/B builds)
 #else
-        forward_one<R, S, true, true, 0, false, PK, false, -1, true>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+        else forward_one<R, S, true, true, 0, false, PK, false, -1, true>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
 #endif
     }
 }

@@ -1,37 +1,113 @@
 // Host-side helper of the fast5 reader (strique_amd/fast5.py): the chunks of one 1-D chunked HDF5 dataset behind the
 // deflate (and optional shuffle) filter, inflated straight from the mapped file into the caller's array.
 // Replaces what the reference gets from h5py / libhdf5 when it reads /Raw/.../Signal (STRique_lib/fast5Index.py:76-84,
-// 220-233).  Pure C++ on the host (zlib); it lives in this library so that the `count` command's reader threads spend
+// 220-233).  Pure C++ on the host; it lives in this library so that the `count` command's reader threads spend
 // their time here, outside the interpreter lock, instead of in a per-chunk Python loop (46 chunks per 50 kb read).
+//
+// Round 4: the inflate itself was what bounded `count` on gzip-compressed files (4.8 of the 5.5 ms a 375 k-sample read took
+// its reader thread: zlib at ~160 MB/s of int16 signal).  libdeflate -- in the image as libdeflate.so.0, without headers:
+// its three entry points are declared here and resolved with dlopen -- decodes the same zlib streams about three times as
+// fast; zlib stays as the fallback when the library is absent (or STRQ_NO_LIBDEFLATE=1: A/B runs).  Same bytes either way
+// (tests/test_cli_host.py::test_deflate_chunks_native_and_python_paths).
+#include <dlfcn.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include <zlib.h>
 #include "../../include/strique_hip.h"
+
+namespace {
+
+// libdeflate's public C API (libdeflate.h, stable since 1.0): a decompressor object per thread, one call per zlib stream
+typedef struct libdeflate_decompressor* (*ld_alloc_fn)(void);
+typedef int (*ld_zlib_fn)(struct libdeflate_decompressor*, const void* in, size_t in_nbytes, void* out, size_t out_nbytes_avail,
+                          size_t* actual_out_nbytes_ret);          // 0 = LIBDEFLATE_SUCCESS
+typedef void (*ld_free_fn)(struct libdeflate_decompressor*);
+
+struct LibDeflate {
+    ld_alloc_fn alloc = nullptr; ld_zlib_fn zlib_decompress = nullptr; ld_free_fn release = nullptr;
+    bool ok = false;
+};
+
+const LibDeflate& libdeflate()
+{
+    static LibDeflate L;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("STRQ_NO_LIBDEFLATE")) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        L.alloc = reinterpret_cast<ld_alloc_fn>(dlsym(h, "libdeflate_alloc_decompressor"));
+        L.zlib_decompress = reinterpret_cast<ld_zlib_fn>(dlsym(h, "libdeflate_zlib_decompress"));
+        L.release = reinterpret_cast<ld_free_fn>(dlsym(h, "libdeflate_free_decompressor"));
+        L.ok = L.alloc && L.zlib_decompress && L.release;
+    });
+    return L;
+}
+
+// one decompressor per reader thread, freed with the thread
+struct ThreadDecompressor {
+    struct libdeflate_decompressor* d = nullptr;
+    ~ThreadDecompressor() { if (d) libdeflate().release(d); }
+};
+
+// inflate one zlib stream of at most `cap` bytes; returns the number of bytes produced or -1
+int64_t inflate_one(const uint8_t* src, size_t n, uint8_t* dst, size_t cap)
+{
+    const LibDeflate& L = libdeflate();
+    if (L.ok) {
+        static thread_local ThreadDecompressor td;
+        if (!td.d) td.d = L.alloc();
+        if (td.d) {
+            size_t got = 0;
+            if (L.zlib_decompress(td.d, src, n, dst, cap, &got) == 0) return (int64_t)got;
+            return -1;
+        }
+    }
+    uLongf got = (uLongf)cap;
+    if (uncompress(dst, &got, src, (uLong)n) != Z_OK) return -1;
+    return (int64_t)got;
+}
+
+}  // namespace
+
+// 1 when libdeflate serves strq_inflate_chunks in this process, 0 when zlib does
+extern "C" int strq_inflate_backend(void) { return libdeflate().ok ? 1 : 0; }
 
 extern "C" int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, int64_t n_chunks, const int64_t* addr,
                                        const int32_t* csize, const int64_t* elem_off, int32_t elem_size, int32_t shuffle,
                                        int64_t chunk_elems, int64_t n_total, void* out)
 {
-    if (!base || n_chunks < 0 || (n_chunks > 0 && (!addr || !csize || !elem_off)) || elem_size < 1 || elem_size > 8 ||
+    if (!base || base_len < 0 || n_chunks < 0 || (n_chunks > 0 && (!addr || !csize || !elem_off)) || elem_size < 1 || elem_size > 8 ||
         chunk_elems < 1 || n_total < 0 || !out) return -1;
     const size_t raw = (size_t)chunk_elems * (size_t)elem_size;          // edge chunks are stored whole
     std::vector<uint8_t> tmp(raw), tmp2(shuffle ? raw : 0);
     for (int64_t k = 0; k < n_chunks; ++k) {
-        if (addr[k] < 0 || csize[k] < 0 || addr[k] + csize[k] > base_len || elem_off[k] < 0) return -(k + 2);
-        uLongf got = (uLongf)raw;
-        if (uncompress(tmp.data(), &got, base + addr[k], (uLong)csize[k]) != Z_OK) return -(k + 2);
+        // addresses and sizes come from the file's B-tree: no arithmetic on them that could wrap
+        if (addr[k] < 0 || csize[k] < 0 || (int64_t)csize[k] > base_len || addr[k] > base_len - (int64_t)csize[k] || elem_off[k] < 0) return -(k + 2);
+        const bool direct = !shuffle && elem_off[k] < n_total && n_total - elem_off[k] >= chunk_elems;      // a whole chunk inside the array: no staging copy
+        uint8_t* dst = direct ? static_cast<uint8_t*>(out) + (size_t)elem_off[k] * elem_size : tmp.data();
+        const int64_t got = inflate_one(base + addr[k], (size_t)csize[k], dst, raw);
+        // libhdf5 stores every chunk whole, the last one of a dataset padded to the chunk size; other writers (the file the
+        // reference bundles, data/c9orf72.fast5) end the last chunk with the data.  Either way a chunk must deliver every
+        // element of the dataset that falls into it -- anything shorter is a damaged file, not zeros
+        int64_t need = elem_off[k] < n_total ? n_total - elem_off[k] : 0;
+        if (need > chunk_elems) need = chunk_elems;
+        if (got < 0 || got % elem_size != 0 || got < need * elem_size) return -(k + 2);
+        if (direct) continue;
         const uint8_t* src = tmp.data();
         if (shuffle) {
-            // HDF5 shuffle: byte b of element i sits at b * n + i
+            // HDF5 shuffle: byte b of element i sits at b * n + i, n = the elements the chunk holds
             const size_t ne = (size_t)got / (size_t)elem_size;
             for (size_t i = 0; i < ne; ++i)
                 for (int b = 0; b < elem_size; ++b) tmp2[i * elem_size + b] = tmp[(size_t)b * ne + i];
             src = tmp2.data();
         }
         if (elem_off[k] >= n_total) continue;
-        int64_t take = (int64_t)got / elem_size;
-        if (take > chunk_elems) take = chunk_elems;
+        int64_t take = chunk_elems;
         if (take > n_total - elem_off[k]) take = n_total - elem_off[k];
         memcpy(static_cast<uint8_t*>(out) + (size_t)elem_off[k] * elem_size, src, (size_t)take * elem_size);
     }

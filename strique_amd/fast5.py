@@ -89,11 +89,14 @@ class H5File(object):
             raise ValueError("bad local heap")
         data_addr, = struct.unpack_from("<Q", b, heap_addr + 24)
         p = data_addr + off
-        chunk = bytes(b[p:p + 1024])
-        e = chunk.find(b"\x00")
+        if hasattr(b, "find"):
+            e = b.find(b"\x00", p, p + 1024)           # mmap and bytes search in place: no 1 KB copy per name
+        else:                                          # a memoryview (file with a user block)
+            e = bytes(b[p:p + 1024]).find(b"\x00")
+            e = e + p if e >= 0 else e
         if e < 0:
             raise ValueError("unterminated heap string")
-        return chunk[:e].decode()
+        return bytes(b[p:e]).decode()
 
     def _group_entries(self, ohdr):
         """name -> object header address of a group (memoised: a bulk file's root group holds thousands of reads)."""
@@ -141,8 +144,8 @@ class H5File(object):
             n, = struct.unpack_from("<H", b, addr + 6)
             p = addr + 8
             for _ in range(n):
-                e = self._symbol_entry(p)
-                out[self._heap_string(heap, e["name_off"])] = e["ohdr"]
+                name_off, ohdr = struct.unpack_from("<QQ", b, p)          # symbol table entry: link name offset, object header address
+                out[self._heap_string(heap, name_off)] = ohdr
                 p += 40
             return
         if bytes(b[addr:addr + 4]) != b"TREE":
@@ -301,9 +304,13 @@ class H5File(object):
             raise ValueError("bad chunk B-tree node")
         level = b[addr + 5]
         n, = struct.unpack_from("<H", b, addr + 6)
-        keysz = 8 + 8 * (rank + 1)
-        ent = np.dtype({"names": ["csize", "fmask", "off0", "child"], "formats": ["<u4", "<u4", "<u8", "<u8"],
-                        "offsets": [0, 4, 8, keysz], "itemsize": keysz + 8})
+        ent = _CHUNK_ENTRY.get(rank)
+        if ent is None:
+            keysz = 8 + 8 * (rank + 1)
+            ent = _CHUNK_ENTRY[rank] = np.dtype({"names": ["csize", "fmask", "off0", "child"], "formats": ["<u4", "<u4", "<u8", "<u8"],
+                                                 "offsets": [0, 4, 8, keysz], "itemsize": keysz + 8})
+        if addr + 24 + n * ent.itemsize > len(b):
+            raise ValueError("chunk B-tree node runs past the end of the file")
         tab = np.frombuffer(b, ent, n, addr + 24)
         if level == 0:
             if tab["fmask"].any():
@@ -315,12 +322,8 @@ class H5File(object):
 
     def _native_inflate(self, addr, rank, out, chunk_elems, shuffle):
         """strq_inflate_chunks (csrc/h5_chunks.hip).  False when the library is not built: the Python loop takes over."""
-        import ctypes
-        try:
-            from . import ffi
-            lib = ffi.load_library()
-            fn = lib.strq_inflate_chunks
-        except (ImportError, OSError, AttributeError):
+        fn = _inflate_fn()
+        if fn is None:
             return False
         rows = []
         self._chunk_table(addr, rank, rows)
@@ -329,12 +332,12 @@ class H5File(object):
         tab = np.concatenate(rows) if len(rows) > 1 else rows[0]
         caddr = np.ascontiguousarray(tab["child"], np.int64); csz = np.ascontiguousarray(tab["csize"], np.int32)
         eoff = np.ascontiguousarray(tab["off0"], np.int64)
-        base = np.frombuffer(self.buf, np.uint8)
-        fn.restype = ctypes.c_int64
-        rc = fn(ctypes.c_void_p(base.ctypes.data), ctypes.c_int64(base.size), ctypes.c_int64(len(caddr)),
-                ctypes.c_void_p(caddr.ctypes.data), ctypes.c_void_p(csz.ctypes.data), ctypes.c_void_p(eoff.ctypes.data),
-                ctypes.c_int32(out.dtype.itemsize), ctypes.c_int32(1 if shuffle else 0), ctypes.c_int64(chunk_elems),
-                ctypes.c_int64(out.size), ctypes.c_void_p(out.ctypes.data))
+        base = self.__dict__.get("_base_u8")
+        if base is None:
+            base = self._base_u8 = np.frombuffer(self.buf, np.uint8)
+            self._base_ptr = base.ctypes.data
+        rc = fn(self._base_ptr, base.size, len(caddr), caddr.ctypes.data, csz.ctypes.data, eoff.ctypes.data,
+                out.dtype.itemsize, 1 if shuffle else 0, chunk_elems, out.size, out.ctypes.data)
         if rc != 0:
             raise ValueError("chunk %d of a deflate-compressed dataset is damaged" % (-rc - 2) if rc < -1 else "bad chunk table")
         return True
@@ -361,6 +364,26 @@ class H5File(object):
             else:
                 for x in self._chunks(child, rank):
                     yield x
+
+
+_CHUNK_ENTRY = {}          # rank -> numpy dtype of a chunk B-tree leaf entry
+_INFLATE = []
+
+
+def _inflate_fn():
+    """strq_inflate_chunks with its argument types set once (plain ints go in, no ctypes objects per call), or None."""
+    if not _INFLATE:
+        import ctypes
+        try:
+            from . import ffi
+            fn = ffi.load_library().strq_inflate_chunks
+            fn.restype = ctypes.c_int64
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+            _INFLATE.append(fn)
+        except (ImportError, OSError, AttributeError):
+            _INFLATE.append(None)
+    return _INFLATE[0]
 
 
 def read_raw(path):

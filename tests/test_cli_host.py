@@ -4,7 +4,7 @@ import os
 
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 
 def test_sam_decoding_matches_reference():
@@ -373,3 +373,38 @@ def test_deflate_chunks_native_and_python_paths(tmp_path, monkeypatch):
     blob[pos + 20] ^= 0xFF; blob[pos + 21] ^= 0xFF; blob[pos + 40] ^= 0xFF
     with pytest.raises(Exception):
         fast5.H5File(bytes(blob)).dataset("/read_r0/Raw/Signal")
+    # the helper itself, with libdeflate (when the image has libdeflate.so.0) and with zlib: same bytes; what the file's B-tree
+    # says is never trusted -- an address near INT64_MAX, a chunk that inflates to less than a whole chunk, a bad stream
+    import ctypes
+    import subprocess
+    import sys
+    from strique_amd import ffi
+    lib = ffi.load_library()
+    lib.strq_inflate_chunks.restype = ctypes.c_int64
+    sig = signals[-1]
+    chunks = [zlib.compress(np.pad(sig[i:i + 8192], (0, max(0, 8192 - len(sig[i:i + 8192])))).tobytes(), 4) for i in range(0, len(sig), 8192)]
+    base = np.frombuffer(b"".join(chunks), np.uint8)
+    csz = np.array([len(c) for c in chunks], np.int32); addr = np.concatenate([[0], np.cumsum(csz)[:-1]]).astype(np.int64)
+    eoff = np.arange(len(chunks), dtype=np.int64) * 8192
+
+    def call(addr_, csz_, n_chunks=len(chunks)):
+        out = np.zeros(len(sig), np.int16)
+        rc = lib.strq_inflate_chunks(ctypes.c_void_p(base.ctypes.data), ctypes.c_int64(base.size), ctypes.c_int64(n_chunks), ctypes.c_void_p(addr_.ctypes.data),
+                                     ctypes.c_void_p(csz_.ctypes.data), ctypes.c_void_p(eoff.ctypes.data), ctypes.c_int32(2), ctypes.c_int32(0), ctypes.c_int64(8192),
+                                     ctypes.c_int64(len(sig)), ctypes.c_void_p(out.ctypes.data))
+        return rc, out
+
+    rc, out = call(addr, csz)
+    assert rc == 0 and np.array_equal(out, sig)
+    bad = addr.copy(); bad[3] = np.iinfo(np.int64).max - 5
+    assert call(bad, csz)[0] == -(3 + 2)
+    short = zlib.compress(sig[:100].tobytes(), 4)                       # a valid stream of less than a chunk
+    base = np.frombuffer(b"".join(chunks) + short, np.uint8)
+    bad = addr.copy(); badsz = csz.copy(); bad[2] = int(np.sum(csz)); badsz[2] = len(short)
+    assert call(bad, badsz)[0] == -(2 + 2)
+    base = np.frombuffer(b"".join(chunks), np.uint8)
+    prog = ("import sys, ctypes; sys.path.insert(0, %r)\nfrom strique_amd import ffi\nprint(ffi.load_library().strq_inflate_backend())" % ROOT)
+    backends = {}
+    for name, env in (("default", {}), ("zlib", {"STRQ_NO_LIBDEFLATE": "1"})):
+        backends[name] = int(subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, **env), stdout=subprocess.PIPE, check=True).stdout.split()[-1])
+    assert backends["zlib"] == 0 and backends["default"] == (1 if os.path.exists("/usr/lib/x86_64-linux-gnu/libdeflate.so.0") else backends["default"])

@@ -99,7 +99,7 @@ def test_bench_four_and_eight_ranks_on_one_gpu(world, tmp_path, pm, cfg):
     its own share of the CPUs and stays within a bounded host footprint."""
     import bench
     dump = str(tmp_path / "rows.npy")
-    reads, steps, warmup, read_nt = 64, 2, 1, 10000
+    reads, steps, warmup, read_nt = 64, 2, 1, 50000
     lines, recs = _run_bench(["--gpus", str(world), "--backend", "gloo", "--share-device", "--reads", str(reads), "--steps", str(steps), "--warmup", str(warmup),
                               "--read-nt", str(read_nt), "--no-cpu-baseline", "--check", "1", "--synth-workers", "1", "--dump-rows", dump],
                              world=world, port=str(29560 + world), timeout=1500)
