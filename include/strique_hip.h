@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_inflate_backend; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -258,6 +258,10 @@ int strq_last_geometry(const strq_ctx* ctx, int32_t out[8]);
  * [0] launches   [1] of them on the register-resident kernel (viterbi_g2_kernel: one launch serves repeat profiles of
  * either parity)   [2] on the lane-layout kernels   [3] on the general kernel (viterbi_csr_kernel). */
 int strq_last_viterbi_launches(const strq_ctx* ctx, int32_t out[4]);
+/* Flank alignments of the last batched call whose first forward round -- column segments cut with the short, adaptive
+ * overlap -- did not reach the score that certifies it, and which therefore ran the second round with the worst-case
+ * overlap: [0] such alignments, [1] all alignments (two per read).  What a read that does not contain its flank costs. */
+int strq_last_second_round(const strq_ctx* ctx, int64_t out[2]);
 
 #ifdef __cplusplus
 }

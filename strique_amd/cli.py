@@ -136,7 +136,8 @@ class Fast5Index(object):
             self._open[path] = f         # most recently used last
             return f
 
-    def get_raw(self, read_id):
+    def get_raw(self, read_id, alloc=None):
+        """The raw signal of a read, or None.  `alloc`: see fast5.H5File.dataset (output arrays of compressed datasets)."""
         from . import fast5
         where = self.index.get(read_id)
         if where is None:
@@ -144,15 +145,15 @@ class Fast5Index(object):
         cut = where.find('.fast5/')          # the common case, a read of a bulk file, without the regular expression
         if cut >= 0 and '.tar/' not in where:
             f = self._file(self._join(where[:cut + 6]))
-            return f.dataset("/%s/Raw/Signal" % where[cut + 7:].strip('/'))
+            return f.dataset("/%s/Raw/Signal" % where[cut + 7:].strip('/'), alloc)
         parts = re.split(r'(\.fast5|\.tar)/', where)
         if len(parts) == 1:
             f = self._file(os.path.join(self.dir, parts[0]))
             grp = "/Raw/Reads/" + f.listdir("/Raw/Reads")[0]
-            return f.dataset(grp + "/Signal")
+            return f.dataset(grp + "/Signal", alloc)
         if parts[1] == '.fast5':
             f = self._file(os.path.join(self.dir, parts[0] + '.fast5'))
-            return f.dataset("/%s/Raw/Signal" % parts[2].strip('/'))
+            return f.dataset("/%s/Raw/Signal" % parts[2].strip('/'), alloc)
         with tarfile.open(os.path.join(self.dir, parts[0] + '.tar')) as tar:
             data = tar.extractfile(tar.getmember(parts[2])).read()
         f = fast5.H5File(data)
@@ -465,9 +466,15 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
         collect(1)                                               # at most one batch running and one waiting
         in_flight.append(engine.submit(run_batch, batch))
 
-    def fetch(qname):
+    import inspect
+    try:
+        takes_alloc = "alloc" in inspect.signature(get_raw).parameters
+    except (TypeError, ValueError):
+        takes_alloc = False
+
+    def fetch(qname, alloc=None):
         try:
-            return get_raw(qname)
+            return get_raw(qname, alloc) if takes_alloc else get_raw(qname)
         except NotImplementedError as e:          # a storage layout / filter the HDF5 subset reader does not cover
             log("Detector: cannot read %s: %s" % (qname, e), 'error'); stats["failed"] += 1
             return None
@@ -484,7 +491,10 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
     batch = []
 
     def fetch_many(qnames):
-        return [fetch(q) for q in qnames]
+        from .fast5 import SlabAllocator
+        # STRQ_READ_SLABS=1: the reads of a task share huge-page slabs instead of one numpy array each (tools/reader_probe.py)
+        alloc = SlabAllocator() if takes_alloc and os.environ.get("STRQ_READ_SLABS") else None
+        return [fetch(q, alloc) for q in qnames]
 
     def push_group():
         nonlocal group

@@ -58,7 +58,8 @@ int align_segment_overlap(const AlignParams& p, int m);
 // group_list / n_list (nullable): run only the alignments listed on the device (second round, see below).
 int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* seg_results,
                           int n_groups, int segs, int* queue, const AlignParams& p, int lds_dwords,
-                          int tables_per_cu, int n_cu, int packed, const int* group_list = nullptr, const int* n_list = nullptr);
+                          int tables_per_cu, int n_cu, int packed, const int* group_list = nullptr, const int* n_list = nullptr,
+                          bool known_last_row = false);
 int align_segments_wpe(int segs, int tables_per_cu);      // waves per SIMD the kernel instance of such a launch is compiled for
 // per alignment: best piece -> results[a] (j_end in read columns), pick[a] = pick_base + index of its task.
 // The pieces may be cut with less overlap than align_segment_overlap: the result is exact whenever the best
@@ -66,7 +67,8 @@ int align_segments_wpe(int segs, int tables_per_cu);      // waves per SIMD the 
 // (device list + counter) for a second round with the worst-case overlap (list / n_list select them).
 int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const AlignResult* seg_results, int n_align,
                          int segs, AlignResult* results, int32_t* pick, int pick_base = 0, const int* list = nullptr,
-                         const int* n_list = nullptr, const float* min_score = nullptr, int* redo = nullptr, int* redo_count = nullptr);
+                         const int* n_list = nullptr, const float* min_score = nullptr, int* redo = nullptr, int* redo_count = nullptr,
+                         unsigned int* redo_total = nullptr);
 float align_segment_min_score(const AlignParams& p, int m, int overlap_used);
 // phase 0 = forward, 1 = trace.  `queue`: one zero-initialised int per launch.
 // trace: task of alignment ti is tasks[pick[ti]] (pick may be null: identity), result slot is results[ti].

@@ -574,7 +574,8 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
     __builtin_amdgcn_s_waitcnt(0);   // LDS table written by this wave is visible to it
 
     const int nsteps = (tk.n + 1) / 2 + 63;
-    const int rM_u = __builtin_amdgcn_readfirstlane(rM);      // in an SGPR: the switch over it is a scalar branch around the loops, not an exec mask inside them
+    int rM_u = 0;
+    if constexpr (RMSW) rM_u = __builtin_amdgcn_readfirstlane(rM);      // in an SGPR: the switch over it is a scalar branch around the loops, not an exec mask inside them
     (void)rM_u;
     int qcur = load_chunk<PK>(tk, 0, lane);
     f.prime(qcur);
@@ -592,15 +593,19 @@ static __device__ __forceinline__ void forward_one(const AlignTask& tk, AlignRes
             // placement experiment (profiles/r03_dead_ends.md 9): the steady-state loop STRQ_DP_PAD dwords behind a 64-byte boundary
             asm volatile(".p2align 6\n\t.rept " STRQ_STR(STRQ_DP_PAD) "\n\ts_nop 0\n\t.endr");
 #endif
-            auto chunk = [&](auto rmx) {
-                constexpr int X = decltype(rmx)::value;
-                for (int s = 0; s < 63; ++s) f.template step<false, false, X>(t0 + s + 1, s, qcur, s + 1);
-                if (ckpt_here) f.template step<false, true, X>(t0 + 64, 63, qnext, 0);
-                else f.template step<false, false, X>(t0 + 64, 63, qnext, 0);
-            };
-            bool hit = false;
-            if constexpr (RMSW && !HAS_OUT && !RM_LAST) hit = rm_dispatch<R, S>(rM_u, chunk, std::make_integer_sequence<int, R>{});
-            if (!hit) chunk(std::integral_constant<int, RMC>{});
+            if constexpr (RMSW && !HAS_OUT && !RM_LAST) {
+                auto chunk = [&](auto rmx) {
+                    constexpr int X = decltype(rmx)::value;
+                    for (int s = 0; s < 63; ++s) f.template step<false, false, X>(t0 + s + 1, s, qcur, s + 1);
+                    if (ckpt_here) f.template step<false, true, X>(t0 + 64, 63, qnext, 0);
+                    else f.template step<false, false, X>(t0 + 64, 63, qnext, 0);
+                };
+                if (!rm_dispatch<R, S>(rM_u, chunk, std::make_integer_sequence<int, R>{})) chunk(std::integral_constant<int, -1>{});
+            } else {
+                for (int s = 0; s < 63; ++s) f.template step<false, false>(t0 + s + 1, s, qcur, s + 1);
+                if (ckpt_here) f.template step<false, true>(t0 + 64, 63, qnext, 0);
+                else f.template step<false, false>(t0 + 64, 63, qnext, 0);
+            }
         } else {
             for (int s = 0; s < send; ++s) {
                 const int qsrc = s == 63 ? qnext : qcur, snext = (s + 1) & 63;
@@ -650,7 +655,11 @@ align_forward_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restric
 // SIMD) caps the registers the compiler may use so that all of them are resident.
 // LISTED: the (normally empty) second round over the alignments the combine kernel listed -- a kernel of its
 // own so that profiles show the first round alone.
-template <int R, int S, bool PK, int SEG, int WPE, bool LISTED = false>
+// KNOWN: the launch holds only flanks whose last row sits in the lane's last register (m % R == 0) or, at 14 rows per lane,
+// STRique's own 870 rows: the forward passes round 3 compiled for exactly those (the benchmarked instance).  Otherwise the
+// pass whose steady-state loop is switched on that register (RMSW).  Two kernels instead of one body with all of them: together
+// they spill (10 ... 42 VGPRs at the 128 the four waves per SIMD allow) and the 870-row loop ran 17 % slower (gpurun_out/r4c).
+template <int R, int S, bool PK, int SEG, int WPE, bool LISTED = false, bool KNOWN = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64 * SEG, 64 * SEG), amdgpu_waves_per_eu(WPE, WPE)))
 align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __restrict__ results, int n_groups,
                          int* __restrict__ queue, AlignParams p, const int* __restrict__ group_list,
@@ -685,19 +694,16 @@ align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __res
         const int ti = gi * SEG + wave;
         const AlignTask& tk = tasks[ti];
         if (tk.n <= 0) continue;               // unused piece of a short read (wave-uniform)
-        // the last flank row sits in register (m - 1) % R of its lane.  STRique's own flanks (145 k-mer classes, 870 rows: register 1
-        // of lane 62 at 14 rows per lane) and flanks that fill their last lane keep the forward pass round 3 compiled for them --
-        // the benchmarked instance, instruction for instruction; every other flank length runs the pass whose steady-state loop
-        // is switched on that register (RMSW: 151 VALU instructions per step for all of them, where round 3 read the row
-        // through a runtime index at 191; measured +1 ... +7 % against the 870-row instance, tools/flank_sweep.py).
-        constexpr int RMC870 = R == 14 ? (870 - 1) % 14 : -1;
-        if ((tk.m - 1) % R == R - 1) forward_one<R, S, true, true, 0, true, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
-        else if (RMC870 >= 0 && tk.m == 870) forward_one<R, S, true, true, 0, false, PK, false, RMC870>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
-#ifdef STRQ_DP_NO_RMSW
-        else forward_one<R, S, true, true, 0, false, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);          // round 3 (A/B builds)
-#else
-        else forward_one<R, S, true, true, 0, false, PK, false, -1, true>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
-#endif
+        // the last flank row sits in register (m - 1) % R of its lane: STRique's own flanks (145 k-mer classes, 870 rows) at 14 rows
+        // per lane in register 1 of lane 62
+        if constexpr (KNOWN) {
+            constexpr int RMC870 = R == 14 ? (870 - 1) % 14 : -1;
+            if ((tk.m - 1) % R == R - 1) forward_one<R, S, true, true, 0, true, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+            else if (RMC870 >= 0 && (tk.m - 1) % R == RMC870) forward_one<R, S, true, true, 0, false, PK, false, RMC870>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+            else forward_one<R, S, true, true, 0, false, PK, false>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);      // not reached: the host launches this kernel for such flanks only
+        } else {
+            forward_one<R, S, true, true, 0, false, PK, false, -1, true>(tk, results + ti, p, lds_all, lds_base, ldsb, lane);
+        }
     }
 }
 
@@ -708,7 +714,8 @@ align_forward_seg_kernel(const AlignTask* __restrict__ tasks, AlignResult* __res
 __global__ void align_combine_kernel(const AlignTask* __restrict__ tasks, const AlignResult* __restrict__ seg, int n_align,
                                      int segs, AlignResult* __restrict__ out, int32_t* __restrict__ pick, int pick_base,
                                      const int* __restrict__ list, const int* __restrict__ n_list,
-                                     const float* __restrict__ min_score, int* __restrict__ redo, int* __restrict__ redo_count)
+                                     const float* __restrict__ min_score, int* __restrict__ redo, int* __restrict__ redo_count,
+                                     unsigned int* __restrict__ redo_total)
 {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= (n_list ? *n_list : n_align)) return;
@@ -725,7 +732,10 @@ __global__ void align_combine_kernel(const AlignTask* __restrict__ tasks, const 
     r.j_end += tasks[t].col_off;
     out[a] = r;
     pick[a] = pick_base + (int32_t)t;
-    if (min_score && !(best >= min_score[a])) redo[atomicAdd(redo_count, 1)] = a;
+    if (min_score && !(best >= min_score[a])) {
+        redo[atomicAdd(redo_count, 1)] = a;
+        if (redo_total) atomicAdd(redo_total, 1u);          // running total of second-round alignments (strq_last_second_round)
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1040,23 +1050,35 @@ int align_segment_overlap(const AlignParams& p, int m)
     return (int)L + 1;
 }
 
-template <int R, int S, bool PK, int SEG, int WPE>
-static int launch_seg1(hipStream_t stream, const AlignTask* tasks, AlignResult* seg_results, int n_groups, int* queue,
+template <int R, int S, bool PK, int SEG, int WPE, bool KNOWN>
+static int launch_seg2(hipStream_t stream, const AlignTask* tasks, AlignResult* seg_results, int n_groups, int* queue,
                        const AlignParams& p, int lds_dwords, int n_blocks, const int* group_list, const int* n_list)
 {
     const size_t lds_bytes = (size_t)lds_dwords * 4;
     if (group_list && n_list) {
-        (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE, true>,
+        (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE, true, KNOWN>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE, true>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
+        hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE, true, KNOWN>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
                            tasks, seg_results, n_groups, queue, p, group_list, n_list);
     } else {
-        (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE, false>,
+        (void)hipFuncSetAttribute((const void*)align_forward_seg_kernel<R, S, PK, SEG, WPE, false, KNOWN>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE, false>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
+        hipLaunchKernelGGL((align_forward_seg_kernel<R, S, PK, SEG, WPE, false, KNOWN>), dim3(n_blocks), dim3(64 * SEG), lds_bytes, stream,
                            tasks, seg_results, n_groups, queue, p, group_list, n_list);
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// known_last_row: every flank of the launch has m % R == 0 or (R == 14) m == 870 -- the round-3 kernel body; compiled for 14 rows
+// per lane only (STRique's flank length), every other shape runs the switched loop, which covers m % R == 0 as one of its cases
+template <int R, int S, bool PK, int SEG, int WPE>
+static int launch_seg1(hipStream_t stream, const AlignTask* tasks, AlignResult* seg_results, int n_groups, int* queue,
+                       const AlignParams& p, int lds_dwords, int n_blocks, const int* group_list, const int* n_list, bool known_last_row)
+{
+    if constexpr (R == 14) {
+        if (known_last_row) return launch_seg2<R, S, PK, SEG, WPE, true>(stream, tasks, seg_results, n_groups, queue, p, lds_dwords, n_blocks, group_list, n_list);
+    }
+    return launch_seg2<R, S, PK, SEG, WPE, false>(stream, tasks, seg_results, n_groups, queue, p, lds_dwords, n_blocks, group_list, n_list);
 }
 
 // compiled (segments, waves per SIMD) pairs
@@ -1077,16 +1099,17 @@ int align_segments_wpe(int segs, int tables_per_cu)
 
 int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tasks, AlignResult* seg_results,
                           int n_groups, int segs, int* queue, const AlignParams& p, int lds_dwords,
-                          int tables_per_cu, int n_cu, int packed, const int* group_list, const int* n_list)
+                          int tables_per_cu, int n_cu, int packed, const int* group_list, const int* n_list, bool known_last_row)
 {
     if (!(p.open_h == p.ext_h && p.open_v == p.ext_v)) return 2;
+    if (getenv("STRQ_DP_SWITCHED")) known_last_row = false;          // A/B: the switched loop for STRique's own flanks too
     AlignParams ps = p;
     if (packed) { ps.open_h *= STRQ_PK_SCALE; ps.ext_h *= STRQ_PK_SCALE; ps.open_v *= STRQ_PK_SCALE; ps.ext_v *= STRQ_PK_SCALE; }
     const int wpe = align_segments_wpe(segs, tables_per_cu);
     const int n_blocks = tables_per_cu * n_cu;
 #define STRQ_SEGCASE(R_, S_, PK_, SEG_, WPE_)                                                             \
     if (R == R_ && S == S_ && (packed != 0) == PK_ && segs == SEG_ && wpe == WPE_)                        \
-        return launch_seg1<R_, S_, PK_, SEG_, WPE_>(stream, tasks, seg_results, n_groups, queue, ps, lds_dwords, n_blocks, group_list, n_list);
+        return launch_seg1<R_, S_, PK_, SEG_, WPE_>(stream, tasks, seg_results, n_groups, queue, ps, lds_dwords, n_blocks, group_list, n_list, known_last_row);
 #define STRQ_SEGSHAPE(R_, S_) STRQ_SEG_CONFIGS(STRQ_SEGCASE, R_, S_, true) STRQ_SEG_CONFIGS(STRQ_SEGCASE, R_, S_, false)
     STRQ_SHAPES(STRQ_SEGSHAPE)
 #undef STRQ_SEGSHAPE
@@ -1096,11 +1119,11 @@ int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tas
 
 int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const AlignResult* seg_results, int n_align,
                          int segs, AlignResult* results, int32_t* pick, int pick_base, const int* list, const int* n_list,
-                         const float* min_score, int* redo, int* redo_count)
+                         const float* min_score, int* redo, int* redo_count, unsigned int* redo_total)
 {
     if (n_align <= 0) return 0;
     hipLaunchKernelGGL(align_combine_kernel, dim3((n_align + 255) / 256), dim3(256), 0, stream, tasks, seg_results, n_align, segs,
-                       results, pick, pick_base, list, n_list, min_score, redo, redo_count);
+                       results, pick, pick_base, list, n_list, min_score, redo, redo_count, redo_total);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -299,7 +299,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         }
     }
     out.order.clear(); out.order.reserve(nb);
-    struct Launch { int R, NS, tables, first, count, first_task, first_up, lds_floats, packed, segs; };
+    struct Launch { int R, NS, tables, first, count, first_task, first_up, lds_floats, packed, segs; bool known_last_row; };
     std::vector<Launch> launches;
     int n_up = 0; size_t n_tasks = 0;
     for (auto& g : groups) {
@@ -312,7 +312,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         const int segs = -std::get<2>(g.first);
         const int tables = std::min(-std::get<3>(g.first), tables_for(lds_floats, segs));       // members that joined from a smaller-slice group
         if (tables < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
-        launches.push_back({std::get<0>(g.first), NS, tables, (int)out.order.size(), (int)v.size(), (int)n_tasks, 0, lds_floats, pk, segs});
+        bool known = true;          // every flank of the launch ends in its lane's last register, or is STRique's own 870 rows at 14 per lane
+        for (int i : v) known = known && (in.m[i] % std::get<0>(g.first) == 0 || (std::get<0>(g.first) == 14 && in.m[i] == 870));
+        launches.push_back({std::get<0>(g.first), NS, tables, (int)out.order.size(), (int)v.size(), (int)n_tasks, 0, lds_floats, pk, segs, known});
         out.order.insert(out.order.end(), v.begin(), v.end());
         n_tasks += (size_t)v.size() * segs;
         if (NS > 1) n_up += (int)v.size() * (NS - 1);
@@ -470,7 +472,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             int rc;
             if (L.NS == 1 && collapsed) {
                 rc = launch_align_segments(st, L.R, S, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, c->queue.as<int>() + qi,
-                                           c->ap, L.lds_floats, L.tables, c->n_cu, L.packed);
+                                           c->ap, L.lds_floats, L.tables, c->n_cu, L.packed, nullptr, nullptr, L.known_last_row);
             } else {
                 const bool last = level == L.NS - 1;
                 const AlignTask* dt = last ? d_tasks + L.first_task : d_tasks + L.first_up + (size_t)level * L.count;
@@ -486,11 +488,12 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         auto& L = launches[li];
         int* redo = d_redo + L.first; int* cnt = d_redo_count + li;
         if (launch_align_combine(st, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, d_res + L.first, d_pick + L.first, L.first_task,
-                                 nullptr, nullptr, two_round[li] ? d_min_score + L.first : nullptr, redo, cnt)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
+                                 nullptr, nullptr, two_round[li] ? d_min_score + L.first : nullptr, redo, cnt,
+                                 c->redo_total.p ? c->redo_total.as<unsigned int>() : nullptr)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
         if (!two_round[li]) continue;
         // second round (normally empty): the listed alignments again, cut with the worst-case overlap
         if (launch_align_segments(st, L.R, S, d_tasks + safe0 + L.first_task, d_seg_safe + L.first_task, L.count, L.segs, c->queue.as<int>() + qi,
-                                  c->ap, L.lds_floats, L.tables, c->n_cu, L.packed, redo, cnt)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
+                                  c->ap, L.lds_floats, L.tables, c->n_cu, L.packed, redo, cnt, L.known_last_row)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
         ++qi;
         if (launch_align_combine(st, d_tasks + safe0 + L.first_task, d_seg_safe + L.first_task, L.count, L.segs, d_res + L.first, d_pick + L.first,
                                  (int)safe0 + L.first_task, redo, cnt, nullptr, nullptr, nullptr)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
@@ -637,7 +640,7 @@ void strq_ctx_destroy(strq_ctx* c)
     detect_state_free(c);
     for (DevBuf* b : {&c->levels, &c->level_val, &c->flank_cls, &c->tables, &c->tables3, &c->band_lo, &c->col0, &c->ckpt,
                       &c->rec, &c->tasks, &c->results, &c->queue, &c->scratch, &c->lutinfo, &c->hard, &c->misc,
-                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd, &c->gen_codes, &c->gen_table, &c->gen_bnd, &c->gen_trace, &c->gen_hard})
+                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd, &c->gen_codes, &c->gen_table, &c->gen_bnd, &c->gen_trace, &c->gen_hard, &c->redo_total})
         b->release();
     for (HostModel* m : c->models) if (m) { m->blob.release(); delete m; }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -680,6 +683,13 @@ int strq_last_counters(const strq_ctx* c, double out[8])
 {
     if (!c || !out) return STRQ_ERR_ARG;
     std::memcpy(out, c->counters, sizeof(c->counters));
+    return STRQ_OK;
+}
+
+int strq_last_second_round(const strq_ctx* c, int64_t out[2])
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    out[0] = c->second_round[0]; out[1] = c->second_round[1];
     return STRQ_OK;
 }
 

@@ -80,6 +80,8 @@ struct strq_ctx {
     double counters[8] = {};
     int32_t geometry[8] = {};                 // strq_last_geometry
     int32_t vit_launches[4] = {};             // strq_last_viterbi_launches
+    int64_t second_round[2] = {};             // strq_last_second_round: alignments that ran the second forward round / alignments, last batched call
+    strq::DevBuf redo_total;                  // device counter behind second_round[0]
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd,

@@ -554,7 +554,10 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     STRQ_HIP(c, hipMemcpyAsync(geom.data(), d->geom.p, (size_t)nr * sizeof(ReadGeom), hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(vres.data(), d->vres.p, (size_t)nr * sizeof(VitResult), hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipMemcpyAsync(rc_out.data(), d_rc, (size_t)nr * sizeof(ReadCond), hipMemcpyDeviceToHost, st));
+    unsigned int redo_so_far = 0;
+    if (c->redo_total.p) STRQ_HIP(c, hipMemcpyAsync(&redo_so_far, c->redo_total.p, 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
+    c->second_round[0] = redo_so_far; c->second_round[1] += 2 * (int64_t)nr;
     for (int i = 0; i < nr; ++i) {
         strq_result& o = B.results[r0 + i];
         std::memset(&o, 0, sizeof(o));
@@ -712,6 +715,9 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
     STRQ_HIP(c, hipSetDevice(c->device));
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
     std::fill(c->counters, c->counters + 8, 0.0);
+    c->second_round[0] = c->second_round[1] = 0;
+    STRQ_HIP(c, c->redo_total.reserve(64));
+    STRQ_HIP(c, hipMemsetAsync(c->redo_total.p, 0, 64, c->stream));
     // partition into sub-batches first, so that the upload of piece k + 1 can overlap the kernels of piece k
     std::vector<int64_t> cuts(1, first);
     int64_t r0 = first;

@@ -310,6 +310,7 @@ int build_vit_model_csr(strq_ctx* c, int32_t n_states, int32_t silent_start, int
 // it then keeps running on its lane layout.
 struct G2Host {
     std::vector<double> lp, em; std::vector<int32_t> knd, own, inc, tag;
+    std::vector<uint64_t> mark_add;      // empty: the tagged states are no contiguous stretch of the chain
     VitG2 G;
     int odd = 0;
 };
@@ -457,6 +458,24 @@ static bool g2_layout(const HostModel* hm, const int32_t* kind_hint, const int32
         bool inc_elsewhere = false;
         for (int k = 0; k < 4; ++k) if ((k & 1) != out.odd) for (int lane = 0; lane < 64; ++lane) if (inc[(size_t)k * 64 + lane] != 0) inc_elsewhere = true;
         if (inc_elsewhere) { why = "a counted state at a position of the other parity"; continue; }
+        // mark decodes: tagged emitting states must fill one stretch of positions [g_lo, g_hi] (every emitting state there is
+        // tagged), so that a path -- which only moves forward along the chain, the loop inside the stretch apart -- emits
+        // untagged / tagged / untagged in that order and two counters give the two boundaries (G2_MARK_*)
+        out.mark_add.clear();
+        if (!hm->state_tag.empty()) {
+            int g_lo = 1 << 30, g_hi = -1; bool any = false, holes = false;
+            for (int e = 0; e < ne; ++e) if (hm->state_tag[e] == 1) { any = true; g_lo = std::min(g_lo, g[e]); g_hi = std::max(g_hi, g[e]); }
+            for (int e = 0; e < ne; ++e) if (hm->state_tag[e] != 1 && g[e] >= g_lo && g[e] <= g_hi) holes = true;
+            if (any && !holes) {
+                out.mark_add.assign((size_t)4 * 64, 0);
+                for (int e = 0; e < ne; ++e) {
+                    const size_t at_ = (size_t)(kind[e] * 2 + (g[e] & 1)) * 64 + (size_t)(g[e] >> 1);
+                    uint64_t a = hm->state_tag[e] == 1 ? 1 : (g[e] > g_hi ? (uint64_t)1 << G2_MARK_BEHIND_SHIFT : 0);
+                    if (!hm->count_inc.empty()) a += (uint64_t)(uint32_t)hm->count_inc[e] << G2_MARK_COUNT_SHIFT;
+                    out.mark_add[at_] = a;
+                }
+            }
+        }
         out.lp.swap(lp); out.em.swap(em); out.knd.swap(knd); out.own.swap(own); out.inc.swap(inc); out.tag.swap(tag);
         return true;
     }
@@ -475,7 +494,8 @@ int build_vit_g2(strq_ctx* c, HostModel* hm, const int32_t* kind_hint, const int
         std::vector<int32_t>& knd = L.knd; std::vector<int32_t>& own = L.own; std::vector<int32_t>& inc = L.inc; std::vector<int32_t>& tag = L.tag;
         struct Part { const void* p; size_t bytes; size_t off; };
         std::vector<Part> parts = {{lp.data(), lp.size() * 8, 0}, {em.data(), em.size() * 8, 0}, {knd.data(), knd.size() * 4, 0},
-                                   {own.data(), own.size() * 4, 0}, {inc.data(), inc.size() * 4, 0}, {tag.data(), tag.size() * 4, 0}};
+                                   {own.data(), own.size() * 4, 0}, {inc.data(), inc.size() * 4, 0}, {tag.data(), tag.size() * 4, 0},
+                                   {L.mark_add.data(), L.mark_add.size() * 8, 0}};
         size_t total = 0;
         for (auto& pt : parts) { pt.off = total; total += (pt.bytes + 15) & ~(size_t)15; }
         const size_t o_g = total; total += sizeof(VitG2);
@@ -484,11 +504,12 @@ int build_vit_g2(strq_ctx* c, HostModel* hm, const int32_t* kind_hint, const int
         G.lp = reinterpret_cast<const double*>(d + parts[0].off); G.em = reinterpret_cast<const double*>(d + parts[1].off);
         G.kind = reinterpret_cast<const int32_t*>(d + parts[2].off); G.own = reinterpret_cast<const int32_t*>(d + parts[3].off);
         G.inc = reinterpret_cast<const int32_t*>(d + parts[4].off); G.tag = reinterpret_cast<const int32_t*>(d + parts[5].off);
+        G.mark_add = L.mark_add.empty() ? nullptr : reinterpret_cast<const uint64_t*>(d + parts[6].off);
         std::vector<char> host(total, 0);
         for (auto& pt : parts) std::memcpy(&host[pt.off], pt.p, pt.bytes);
         std::memcpy(&host[o_g], &G, sizeof(VitG2));
         if (hipMemcpy(d, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) { c->err = "model upload failed"; return STRQ_ERR_DEVICE; }
-        hm->h.g2 = reinterpret_cast<const VitG2*>(d + o_g); hm->h.g2_odd = L.odd;
+        hm->h.g2 = reinterpret_cast<const VitG2*>(d + o_g); hm->h.g2_odd = L.odd; hm->h.g2_mark = L.mark_add.empty() ? 0 : 1;
         if (hipMemcpy(const_cast<VitModel*>(hm->dev), &hm->h, sizeof(VitModel), hipMemcpyHostToDevice) != hipSuccess) { hm->h.g2 = nullptr; c->err = "model upload failed"; return STRQ_ERR_DEVICE; }
         return STRQ_OK;
     }

@@ -41,8 +41,15 @@ struct VitG2 {
     const int32_t* tag;          // [4][lane]: state_tag == 1
     int32_t bc_slot[2], bc_lane[2];      // broadcast sources B0 (slot 0 / 1: feeds match-type states) and B1 (slot 2 / 3: feeds delete-type states); lane -1: none
     int32_t start_slot, start_lane, end_slot, end_lane;      // silent slots 0 (even g) / 1 (odd g)
+    const uint64_t* mark_add;    // [4][lane] or null: what an emission of (slot, lane) adds to the 64-bit payload of a mark decode (see G2_MARK_*)
     uint64_t hub_mask;           // lanes whose even delete slot is a virtual relay that lets its target win a tie when the relay's own winner was one of its gather columns
 };
+// Payload of a mark decode on this layout (want_bp 2: the modification pass needs the stretch of the window decoded into the
+// repeat section, scripts/STRique.py:608): three counters in one 64-bit integer, every emission adds a per-(slot, lane) constant
+// with one 64-bit addition -- [0, 21) emissions from tagged states, [21, 43) visits of counted states, [43, 64) emissions from
+// untagged states BEHIND the tagged stretch of the chain.  The model is one-way (prefix -> repeat section -> suffix), so with
+// T observations the first tagged emission is observation T - behind - tagged and the first one after the section T - behind.
+enum { G2_MARK_COUNT_SHIFT = 21, G2_MARK_BEHIND_SHIFT = 43 };
 enum { G2_ROW_ME = 0, G2_ROW_MO = 7, G2_ROW_IE = 13, G2_ROW_IO = 16, G2_ROW_DE = 19, G2_ROW_DO = 22, G2_ROW_CHAIN = 24, G2_ROWS = 26 };
 
 struct VitModel {
@@ -83,7 +90,7 @@ struct VitModel {
     const int32_t* csr_level_ptr;     // n_levels + 1: silent states by the length of their longest silent predecessor chain
     const int32_t* csr_level_state;   // n_silent
     const VitG2* g2;                  // register-resident profile layout of the same model, or null (strq_model_set_positions)
-    int32_t g2_odd, pad3_;            // that image has its broadcast sources (and the states they feed directly) at odd positions
+    int32_t g2_odd, g2_mark;          // that image has its broadcast sources at odd positions; it can carry the repeat-section marks (mark_add)
 };
 #define VIT_SHAPE_CSR 8              // launch_viterbi shape id of those models
 #define VIT_SHAPE_G2 9               // ... of models with a VitG2 image, for count / mark launches (want_bp 0 or 2); both parities (g2_odd) share the launch

@@ -685,7 +685,7 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
     const VitG2* G = nullptr;
     double la[7], lb[6], lc[3], ld[3], sg0[3], sg1[2], clp[2];
     double ea[2], ebf[2], ecf[4];
-    int einc[4]; bool etag[4];
+    int einc[4]; uint64_t madd[4];
     double uni_lo_max = 0.0, uni_hi_min = 0.0;
     bool odd_model = false;
     uint64_t hub_mask = 0;
@@ -718,7 +718,8 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 const double a = G->em[(k * 3 + 0) * 64 + lane], b = G->em[(k * 3 + 1) * 64 + lane], c = G->em[(k * 3 + 2) * 64 + lane];
                 if (k < 2) { ea[k] = kind ? a : 0.0; ebf[k] = kind == 1 ? b : 0.0; }
                 ecf[k] = kind ? c : NEGINF;          // branch-free emission  ecf - (x - ea)^2 * ebf  (uniform: ebf = 0; no state: -inf)
-                einc[k] = G->inc[k * 64 + lane]; etag[k] = G->tag[k * 64 + lane] != 0;
+                einc[k] = G->inc[k * 64 + lane];
+                if constexpr (MARK) madd[k] = G->mark_add[k * 64 + lane]; else madd[k] = 0;
             }
             bc0_lane = G->bc_lane[0] < 0 ? 0 : G->bc_lane[0];
             bc1_lane = G->bc_lane[1] < 0 ? 0 : G->bc_lane[1];
@@ -767,9 +768,7 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             // odd positions may be fed by the match / insert of the position before (the dummy state behind such a profile)
             constexpr bool ODD = decltype(odd_c)::value;
             constexpr int B0 = ODD ? 1 : 0, B1 = ODD ? 3 : 2;
-            const uint32_t tt1 = (uint32_t)(t + 1);
-            const uint32_t mark_e_lo = (tt1 & 0xFFFu) << 20, mark_e_hi = tt1 >> 12, mark_l_hi = tt1 << 10;
-            (void)mark_e_lo; (void)mark_e_hi; (void)mark_l_hi;
+            (void)t;
             // previous values of lane - 1 (lane 0 receives 0.0: every column that uses them is -inf there)
             double sMe; Pay cMe;
             if constexpr (LX2) { sMe = rMe; cMe = qMe; } else { sMe = dpp_shr1_f64(pv[0]); cMe = shr1_pay(pc[0]); }
@@ -832,14 +831,8 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 }
                 nv[k] = best[k] + em;
                 const Pay bc = bcnt[k];
-                if constexpr (MARK) {
-                    uint32_t lo = (k == B0 || k == B1) ? (uint32_t)bc + (uint32_t)einc[k] : (uint32_t)bc, hi = (uint32_t)((uint64_t)bc >> 32);
-                    const bool entered = ((lo >> 20) | (hi & 0x3FFu)) != 0, left = (hi >> 10) != 0;
-                    const bool set_e = etag[k] && !entered, set_l = !etag[k] && entered && !left;
-                    lo |= set_e ? mark_e_lo : 0u;
-                    hi |= set_e ? mark_e_hi : (set_l ? mark_l_hi : 0u);
-                    nc[k] = ((uint64_t)hi << 32) | lo;
-                } else nc[k] = (k == B0 || k == B1) ? bc + einc[k] : bc;          // counted states sit in the slots of the broadcast sources (checked when the image is built)
+                if constexpr (MARK) nc[k] = bc + madd[k];          // the three counters of G2_MARK_* in one 64-bit addition
+                else nc[k] = (k == B0 || k == B1) ? bc + einc[k] : bc;          // counted states sit in the slots of the broadcast sources (checked when the image is built)
             };
             using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
             using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
@@ -935,10 +928,13 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
         VitResult r; r.logp = lp; r.status = (lp > NEGINF) ? 0 : 1; r.pad_ = 0;
         r.dbg[0] = r.dbg[1] = r.dbg[2] = r.dbg[3] = 0;
         if constexpr (MARK) {
-            const uint32_t plo = (uint32_t)fc, phi = (uint32_t)((uint64_t)fc >> 32);
-            r.counted = (lp > NEGINF) ? (int64_t)(plo & 0xFFFFFu) : 0;
-            r.dbg[0] = (plo >> 20) | ((phi & 0x3FFu) << 12);
-            r.dbg[1] = phi >> 10;
+            const uint64_t f = (uint64_t)fc;
+            const int64_t tagged = (int64_t)(f & 0x1FFFFFu), behind = (int64_t)(f >> G2_MARK_BEHIND_SHIFT);
+            r.counted = (lp > NEGINF) ? (int64_t)((f >> G2_MARK_COUNT_SHIFT) & 0x3FFFFFu) : 0;
+            // the same two numbers the lane-layout mark kernels report: time (1-based) of the first repeat-section emission and of
+            // the first emission after the section, 0 = none
+            r.dbg[0] = tagged > 0 ? (uint32_t)(T - behind - tagged + 1) : 0u;
+            r.dbg[1] = (tagged > 0 && behind > 0) ? (uint32_t)(T - behind + 1) : 0u;
             if (tk.T >= VIT_MARK_T_MAX) r.status = 2;
         } else {
             r.counted = (lp > NEGINF) ? (int64_t)fc : 0;
@@ -1220,7 +1216,7 @@ int vit_shape_silent_slots(int shape)
 int vit_shape_for(const VitModel& mh, int want_bp)
 {
     const bool no_g2 = getenv("STRQ_VIT_NO_G2") != nullptr;      // A/B: the lane layout for every mode
-    if (mh.g2 && !no_g2 && (want_bp == 0 || want_bp == 2)) return VIT_SHAPE_G2;          // either parity of the chain: decided per window inside the kernel
+    if (mh.g2 && !no_g2 && (want_bp == 0 || (want_bp == 2 && mh.g2_mark))) return VIT_SHAPE_G2;          // either parity of the chain: decided per window inside the kernel
     return vit_shape_of(mh);
 }
 

@@ -189,6 +189,12 @@ class Context(object):
         self._check(self._lib.strq_last_viterbi_launches(self._h, _ptr(g)))
         return dict(zip(("launches", "register_resident", "lane_layout", "general"), (int(v) for v in g)))
 
+    def last_second_round(self):
+        """strq_last_second_round: (alignments that ran the second forward round, alignments) of the last batched call."""
+        g = np.zeros(2, np.int64)
+        self._check(self._lib.strq_last_second_round(self._h, _ptr(g)))
+        return int(g[0]), int(g[1])
+
     def last_geometry(self):
         """strq_last_geometry as a dict: which forward-DP kernel instance the last batched call ran."""
         g = np.zeros(8, np.int32)

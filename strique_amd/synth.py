@@ -53,20 +53,52 @@ def make_sequence(rng, total_nt, prefix, repeat, n_repeat, suffix, strand="+"):
     return seq
 
 
-def make_signal(rng, table, seq_bytes, as_int16=True):
+def make_signal(rng, table, seq_bytes, as_int16=True, realism=0.0):
+    """realism = 0: the reference's generate_signal(noise=True) distribution (dwell U{6..9}, N(mean, stdv) per sample) -- the
+    easiest input the flank alignment will ever see.  realism in (0, 2] degrades the read the way real r9.4 signal differs
+    from the k-mer table, all of it scaled by `realism`:
+      * dwell: a share of the k-mers takes a geometric dwell with a long tail (stalls of tens of samples) or is skipped
+        down to one or two samples, instead of 6..9;
+      * levels: every k-mer occurrence is off its table mean by N(0, 2.5 pA x realism) (sequence context the 6-mer table
+        does not model), sample noise is wider by (1 + realism), and the whole read sits on a slow baseline drift of up to
+        +-4 pA x realism (a random walk smoothed over ~10^4 samples) with its own scale error of +-8 % x realism;
+      * spikes: 3 % x realism of the samples are outliers of +-15..45 pA.
+    realism = 1 brings the flank scores of the synthetic reads down to those of the read the reference bundles
+    (data/c9orf72.fast5: 0.67 / 0.70 of the maximum against 0.79 at realism 0; 0.5 gives 0.72; tools/realism_probe.py), values
+    up to 2 go below any real read seen here."""
     idx = table.indices(seq_bytes)
-    dwell = rng.integers(6, 10, len(idx))
-    pa = rng.normal(np.repeat(table.mean[idx], dwell), np.repeat(table.stdv[idx], dwell))
+    n_k = len(idx)
+    dwell = rng.integers(6, 10, n_k)
+    if realism > 0.0:
+        r = float(min(realism, 2.0))
+        u = rng.random(n_k)
+        stall = u < 0.18 * r
+        skip = (u >= 0.18 * r) & (u < 0.30 * r)
+        dwell = np.where(stall, 4 + rng.geometric(1.0 / 14.0, n_k), dwell)
+        dwell = np.where(skip, rng.integers(1, 3, n_k), dwell)
+        dwell = np.minimum(dwell, 120)
+        level = table.mean[idx] + rng.normal(0.0, 2.5 * r, n_k)
+        pa = rng.normal(np.repeat(level, dwell), np.repeat(table.stdv[idx] * (1.0 + r), dwell))
+        n = len(pa)
+        steps = rng.normal(0.0, 1.0, n // 512 + 2).cumsum()
+        steps -= np.linspace(steps[0], steps[-1], len(steps))          # a bridge: starts and ends on the baseline
+        amp = np.abs(steps).max()
+        drift = np.interp(np.arange(n), np.arange(len(steps)) * 512.0, steps * (4.0 * r / amp if amp > 0 else 0.0))
+        pa = (pa - 90.0) * (1.0 + rng.uniform(-0.08, 0.08) * r) + 90.0 + drift
+        spikes = rng.random(n) < 0.03 * r
+        pa = np.where(spikes, pa + rng.choice((-1.0, 1.0), n) * rng.uniform(15.0, 45.0, n), pa)
+    else:
+        pa = rng.normal(np.repeat(table.mean[idx], dwell), np.repeat(table.stdv[idx], dwell))
     if as_int16:
-        return np.round(pa * (8192 / 1400.0) - 10).astype(np.int16)
+        return np.clip(np.round(pa * (8192 / 1400.0) - 10), -32768, 32767).astype(np.int16)
     return pa
 
 
-def make_read(table, config_id, read_idx, total_nt, target, n_repeat, strand=None, as_int16=True):
-    """target = (repeat, prefix, suffix).  Returns (signal, strand)."""
+def make_read(table, config_id, read_idx, total_nt, target, n_repeat, strand=None, as_int16=True, realism=0.0):
+    """target = (repeat, prefix, suffix).  Returns (signal, strand).  `realism`: see make_signal (0 = the SURVEY.md 8d recipe)."""
     rng = np.random.Generator(np.random.PCG64(read_seed(config_id, read_idx)))
     if strand is None:
         strand = "+" if rng.random() < 0.5 else "-"
     repeat, prefix, suffix = target
     seq = make_sequence(rng, total_nt, prefix, repeat, n_repeat, suffix, strand)
-    return make_signal(rng, table, seq, as_int16), strand
+    return make_signal(rng, table, seq, as_int16, realism), strand

@@ -349,6 +349,34 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
         rc.add_target("vntr2000", nt(2000), nt(150), nt(150))
 
 
+def test_degraded_reads_equal_the_oracle(gpu_counter, pm, targets, monkeypatch):
+    """Reads synthesised with `realism` (strique_amd/synth.py): long-tailed dwell times, skipped k-mers, level jitter, baseline
+    drift, spikes -- at realism 1 the flank scores of the real read the reference bundles (0.67 of the maximum), at 1.5 below it.
+    Lower scores are what moves the column segments' overlap and sends alignments into the second forward round; whatever the
+    heuristic does, all six fields equal the oracle's.  Sixteen 10 kb reads at both levels, both strands and targets, first at
+    the initial overlap, then again after the library adapted to them, then with a short overlap pinned (second round for
+    most of them: strq_last_second_round counts it); two 50 kb reads at realism 1."""
+    import oracle_pool
+    from strique_amd import synth
+    table = synth.KmerTable(pm)
+    items = []
+    for i in range(16):
+        name = ("c9orf72", "fmr1")[i % 2]; strand = "+-"[(i // 2) % 2]
+        sig = synth.make_read(table, 41, i, 10000, targets[name], 20 + 3 * i, strand=strand, realism=(1.0, 1.5)[i // 8])[0]
+        items.append((name, sig, strand))
+    for i in range(2):
+        items.append(("c9orf72", synth.make_read(table, 41, 100 + i, 50000, targets["c9orf72"], 400 + 300 * i, strand="+-"[i], realism=1.0)[0], "+-"[i]))
+    want = oracle_pool.detect_many([(sig, strand, targets[name]) for name, sig, strand in items])
+    first = gpu_counter.detect_batch(items)
+    again = gpu_counter.detect_batch(items)
+    monkeypatch.setenv("STRQ_OVERLAP", "1200"); monkeypatch.setenv("STRQ_SEG", "4")
+    pinned = gpu_counter.detect_batch(items)
+    redo, total = gpu_counter.ctx.last_second_round()
+    assert total == 2 * len(items) and redo > 0
+    for (name, sig, strand), w, a, b, c in zip(items, want, first, again, pinned):
+        assert tuple(a[:6]) == tuple(w[:6]) and tuple(b[:6]) == tuple(w[:6]) and tuple(c[:6]) == tuple(w[:6]), (name, strand, w, a, b, c)
+
+
 def test_every_flank_length_of_the_fourteen_row_shape(pm, cfg, orc, opm, monkeypatch):
     """Flanks of 134 ... 154 nt (129 ... 149 k-mer classes, 774 ... 894 flank rows) all run at 14 rows per lane, and the last
     flank row sits in register (m - 1) % 14 of its lane -- 1, 3, ..., 13 over this range.  Round 3 knew that register at
