@@ -396,7 +396,10 @@ def main():
         prof = _profile_constants()
         geo = geoms[-1] if geoms else ctx.last_geometry()
         segs, tables, packed, R, wpe = geo["waves_per_alignment"], geo["tables_per_cu"], geo["packed"], geo["rows_per_lane"], geo["wpe"]
-        kname = "align_forward_seg_kernel<%d, 6, %s, %d, %d, false>" % (R, "true" if packed else "false", segs, wpe)      # the instance the library launched (strq_last_geometry)
+        # the instance the library launched (strq_last_geometry): the last template argument says which of the two kernel bodies --
+        # true = round 3's, kept for launches whose flanks are all 870 rows (or fill their last lane) at 14 rows per lane
+        known = R == 14 and FLANK_ROWS == 870
+        kname = "align_forward_seg_kernel<%d, 6, %s, %d, %d, false, %s>" % (R, "true" if packed else "false", segs, wpe, "true" if known else "false")
         by_kernel = prof.get("valu_insts_per_wave_step_by_kernel", {})
         ipstep = by_kernel.get(kname)
         ipstep_note = None

@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -219,6 +219,13 @@ int64_t strq_svb_decode(const uint8_t* stream, int64_t stream_len, int64_t n, in
 int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, int64_t n_chunks, const int64_t* addr,
                             const int32_t* csize, const int64_t* elem_off, int32_t elem_size, int32_t shuffle,
                             int64_t chunk_elems, int64_t n_total, void* out);
+/* The same for n_ds datasets in one call (one reader task of the `count` command): dataset i owns the chunks
+ * [chunk_first[i], chunk_first[i + 1]) of addr / csize / elem_off and has its own mapped file base[i].  status[i] receives what
+ * strq_inflate_chunks would return for it; the return value is the number of datasets that failed (-1: bad argument). */
+int64_t strq_inflate_many(int64_t n_ds, const uint8_t* const* base, const int64_t* base_len, const int64_t* chunk_first,
+                          const int64_t* addr, const int32_t* csize, const int64_t* elem_off, const int32_t* elem_size,
+                          const int32_t* shuffle, const int64_t* chunk_elems, const int64_t* n_total, void* const* out,
+                          int64_t* status);
 /* 1 when libdeflate (dlopen of libdeflate.so.0) decodes the zlib streams of strq_inflate_chunks in this process, 0 when
  * zlib does (library absent, or STRQ_NO_LIBDEFLATE=1).  Same bytes either way. */
 int strq_inflate_backend(void);

@@ -136,8 +136,9 @@ class Fast5Index(object):
             self._open[path] = f         # most recently used last
             return f
 
-    def get_raw(self, read_id, alloc=None):
-        """The raw signal of a read, or None.  `alloc`: see fast5.H5File.dataset (output arrays of compressed datasets)."""
+    def get_raw(self, read_id, alloc=None, defer=False):
+        """The raw signal of a read, or None.  `alloc`, `defer`: see fast5.H5File.dataset (compressed datasets: where the output
+        array comes from; an InflatePlan instead of the samples, for fast5.inflate_plans to fill a whole task's reads at once)."""
         from . import fast5
         where = self.index.get(read_id)
         if where is None:
@@ -145,15 +146,15 @@ class Fast5Index(object):
         cut = where.find('.fast5/')          # the common case, a read of a bulk file, without the regular expression
         if cut >= 0 and '.tar/' not in where:
             f = self._file(self._join(where[:cut + 6]))
-            return f.dataset("/%s/Raw/Signal" % where[cut + 7:].strip('/'), alloc)
+            return f.dataset("/%s/Raw/Signal" % where[cut + 7:].strip('/'), alloc, defer)
         parts = re.split(r'(\.fast5|\.tar)/', where)
         if len(parts) == 1:
             f = self._file(os.path.join(self.dir, parts[0]))
             grp = "/Raw/Reads/" + f.listdir("/Raw/Reads")[0]
-            return f.dataset(grp + "/Signal", alloc)
+            return f.dataset(grp + "/Signal", alloc, defer)
         if parts[1] == '.fast5':
             f = self._file(os.path.join(self.dir, parts[0] + '.fast5'))
-            return f.dataset("/%s/Raw/Signal" % parts[2].strip('/'), alloc)
+            return f.dataset("/%s/Raw/Signal" % parts[2].strip('/'), alloc, defer)
         with tarfile.open(os.path.join(self.dir, parts[0] + '.tar')) as tar:
             data = tar.extractfile(tar.getmember(parts[2])).read()
         f = fast5.H5File(data)
@@ -472,9 +473,9 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
     except (TypeError, ValueError):
         takes_alloc = False
 
-    def fetch(qname, alloc=None):
+    def fetch(qname, alloc=None, defer=False):
         try:
-            return get_raw(qname, alloc) if takes_alloc else get_raw(qname)
+            return get_raw(qname, alloc, defer) if takes_alloc else get_raw(qname)
         except NotImplementedError as e:          # a storage layout / filter the HDF5 subset reader does not cover
             log("Detector: cannot read %s: %s" % (qname, e), 'error'); stats["failed"] += 1
             return None
@@ -494,7 +495,23 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
         from .fast5 import SlabAllocator
         # STRQ_READ_SLABS=1: the reads of a task share huge-page slabs instead of one numpy array each (tools/reader_probe.py)
         alloc = SlabAllocator() if takes_alloc and os.environ.get("STRQ_READ_SLABS") else None
-        return [fetch(q, alloc) for q in qnames]
+        if not takes_alloc or os.environ.get("STRQ_READ_ONE_BY_ONE"):
+            return [fetch(q, alloc) for q in qnames]
+        # compressed datasets: located first (Python, under the interpreter lock), then inflated together in one native call
+        from .fast5 import InflatePlan, inflate_plans
+        got = [fetch(q, alloc, True) for q in qnames]
+        plans = [(i, g) for i, g in enumerate(got) if isinstance(g, InflatePlan)]
+        if plans:
+            try:
+                errors = inflate_plans([p for _, p in plans])
+            except Exception as e:
+                errors = [str(e)] * len(plans)
+            for (i, p), err in zip(plans, errors):
+                if err is None:
+                    got[i] = p.out
+                else:
+                    log("Detector: cannot read %s: %s" % (qnames[i], err), 'warning'); got[i] = None
+        return got
 
     def push_group():
         nonlocal group

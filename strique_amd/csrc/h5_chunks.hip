@@ -113,3 +113,25 @@ extern "C" int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, in
     }
     return 0;
 }
+
+// The datasets of one reader task in one call (the `count` command reads 32 reads per task): dataset i has the chunks
+// [chunk_first[i], chunk_first[i + 1]) of the concatenated addr / csize / elem_off arrays and its own mapped file.  One call
+// instead of 32 means the reader thread takes the interpreter lock once per task, not twice per read -- with 16 threads and
+// more the handovers, not the inflate, were what the readers waited for (tools/reader_probe.py).  status[i] = the return
+// value strq_inflate_chunks would give for dataset i; returns the number of datasets that failed.
+extern "C" int64_t strq_inflate_many(int64_t n_ds, const uint8_t* const* base, const int64_t* base_len, const int64_t* chunk_first,
+                                     const int64_t* addr, const int32_t* csize, const int64_t* elem_off, const int32_t* elem_size,
+                                     const int32_t* shuffle, const int64_t* chunk_elems, const int64_t* n_total, void* const* out,
+                                     int64_t* status)
+{
+    if (n_ds < 0 || (n_ds > 0 && (!base || !base_len || !chunk_first || !elem_size || !shuffle || !chunk_elems || !n_total || !out || !status))) return -1;
+    int64_t failed = 0;
+    for (int64_t i = 0; i < n_ds; ++i) {
+        const int64_t c0 = chunk_first[i], c1 = chunk_first[i + 1];
+        if (c0 < 0 || c1 < c0) { status[i] = -1; ++failed; continue; }
+        status[i] = strq_inflate_chunks(base[i], base_len[i], c1 - c0, addr ? addr + c0 : nullptr, csize ? csize + c0 : nullptr,
+                                        elem_off ? elem_off + c0 : nullptr, elem_size[i], shuffle[i], chunk_elems[i], n_total[i], out[i]);
+        if (status[i] != 0) ++failed;
+    }
+    return failed;
+}

@@ -312,8 +312,11 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         const int segs = -std::get<2>(g.first);
         const int tables = std::min(-std::get<3>(g.first), tables_for(lds_floats, segs));       // members that joined from a smaller-slice group
         if (tables < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
-        bool known = true;          // every flank of the launch ends in its lane's last register, or is STRique's own 870 rows at 14 per lane
-        for (int i : v) known = known && (in.m[i] % std::get<0>(g.first) == 0 || (std::get<0>(g.first) == 14 && in.m[i] == 870));
+        // every flank of the launch is STRique's own 870 rows at 14 per lane: round 3's kernel body.  (Flanks that fill their last lane,
+        // m % 14 == 0, would also find their instance there, but it measures 14 % slower than the same case of the switched loop:
+        // gpurun_out/r4d/flank_sweep.md against r4b.)
+        bool known = std::get<0>(g.first) == 14;
+        for (int i : v) known = known && in.m[i] == 870;
         launches.push_back({std::get<0>(g.first), NS, tables, (int)out.order.size(), (int)v.size(), (int)n_tasks, 0, lds_floats, pk, segs, known});
         out.order.insert(out.order.end(), v.begin(), v.end());
         n_tasks += (size_t)v.size() * segs;

@@ -221,9 +221,10 @@ class H5File(object):
             p += 16 + ((osize + 7) & ~7)
         return None
 
-    def dataset(self, path, alloc=None):
+    def dataset(self, path, alloc=None, defer=False):
         """The values of a dataset.  `alloc(n, dtype)` (optional) supplies the ZERO-FILLED output array of a chunked dataset
-        instead of numpy (the `count` command hands out slices of huge-page slabs: SlabAllocator)."""
+        instead of numpy (SlabAllocator).  `defer`: a deflate-compressed dataset comes back as an InflatePlan -- its output
+        array allocated, its chunks located, nothing inflated yet -- for inflate_plans() to fill together with others."""
         b = self.buf
         shape = None; dtype = None; layout = None; filters = []
         for mtype, _, pl in self._messages(self._resolve(path)):
@@ -279,6 +280,8 @@ class H5File(object):
         out = alloc(n, dtype) if alloc is not None else np.zeros(n, dtype)          # chunks that were never written read as the fill value
         if fids and set(fids) <= {1, 2} and fids.count(1) == 1 and (2 not in fids or fids.index(2) < fids.index(1)):
             # deflate (after an optional shuffle): all chunks of the dataset in one native call, outside the interpreter lock
+            if defer and _inflate_many_fn() is not None:
+                return InflatePlan(self, self._chunk_arrays(layout[1], len(shape)), out, csize, 2 in fids)
             if self._native_inflate(layout[1], len(shape), out, csize, 2 in fids):
                 return out
         for off, data in self._chunks(layout[1], len(shape)):
@@ -322,22 +325,32 @@ class H5File(object):
             for child in tab["child"]:
                 self._chunk_table(int(child), rank, rows)
 
+    def _chunk_arrays(self, addr, rank):
+        """(file addresses, stored sizes, first elements) of the chunks of a dataset, or None when it has none."""
+        rows = []
+        self._chunk_table(addr, rank, rows)
+        if not rows:
+            return None
+        tab = np.concatenate(rows) if len(rows) > 1 else rows[0]
+        return (np.ascontiguousarray(tab["child"], np.int64), np.ascontiguousarray(tab["csize"], np.int32), np.ascontiguousarray(tab["off0"], np.int64))
+
+    def _base(self):
+        base = self.__dict__.get("_base_u8")
+        if base is None:
+            base = self._base_u8 = np.frombuffer(self.buf, np.uint8)
+            self._base_ptr = base.ctypes.data
+        return base
+
     def _native_inflate(self, addr, rank, out, chunk_elems, shuffle):
         """strq_inflate_chunks (csrc/h5_chunks.hip).  False when the library is not built: the Python loop takes over."""
         fn = _inflate_fn()
         if fn is None:
             return False
-        rows = []
-        self._chunk_table(addr, rank, rows)
-        if not rows:
+        arrs = self._chunk_arrays(addr, rank)
+        if arrs is None:
             return True
-        tab = np.concatenate(rows) if len(rows) > 1 else rows[0]
-        caddr = np.ascontiguousarray(tab["child"], np.int64); csz = np.ascontiguousarray(tab["csize"], np.int32)
-        eoff = np.ascontiguousarray(tab["off0"], np.int64)
-        base = self.__dict__.get("_base_u8")
-        if base is None:
-            base = self._base_u8 = np.frombuffer(self.buf, np.uint8)
-            self._base_ptr = base.ctypes.data
+        caddr, csz, eoff = arrs
+        base = self._base()
         rc = fn(self._base_ptr, base.size, len(caddr), caddr.ctypes.data, csz.ctypes.data, eoff.ctypes.data,
                 out.dtype.itemsize, 1 if shuffle else 0, chunk_elems, out.size, out.ctypes.data)
         if rc != 0:
@@ -366,6 +379,41 @@ class H5File(object):
             else:
                 for x in self._chunks(child, rank):
                     yield x
+
+
+class InflatePlan(object):
+    """A deflate-compressed dataset whose chunks are located and whose output array exists, but which is not inflated yet."""
+    __slots__ = ("file", "chunks", "out", "chunk_elems", "shuffle")
+
+    def __init__(self, file, chunks, out, chunk_elems, shuffle):
+        self.file = file; self.chunks = chunks; self.out = out; self.chunk_elems = chunk_elems; self.shuffle = shuffle
+
+
+def inflate_plans(plans):
+    """Fill the output arrays of `plans` with ONE native call (strq_inflate_many): the interpreter lock is released once for
+    the whole list.  Returns a list with None for every plan that inflated and the error text for every one that did not."""
+    import ctypes
+    fn = _inflate_many_fn()
+    n = len(plans)
+    if n == 0:
+        return []
+    first = np.zeros(n + 1, np.int64)
+    for i, p in enumerate(plans):
+        first[i + 1] = first[i] + (len(p.chunks[0]) if p.chunks is not None else 0)
+    cat = lambda j, dt: (np.concatenate([p.chunks[j] for p in plans if p.chunks is not None]) if first[-1] else np.zeros(0, dt))
+    addr = cat(0, np.int64); csz = cat(1, np.int32); eoff = cat(2, np.int64)
+    bases = (ctypes.c_void_p * n)(); outs = (ctypes.c_void_p * n)()
+    blen = np.zeros(n, np.int64); esz = np.zeros(n, np.int32); shuf = np.zeros(n, np.int32); cel = np.zeros(n, np.int64); ntot = np.zeros(n, np.int64)
+    for i, p in enumerate(plans):
+        b = p.file._base()
+        bases[i] = p.file._base_ptr; blen[i] = b.size; outs[i] = p.out.ctypes.data
+        esz[i] = p.out.dtype.itemsize; shuf[i] = 1 if p.shuffle else 0; cel[i] = p.chunk_elems; ntot[i] = p.out.size
+    status = np.zeros(n, np.int64)
+    rc = fn(n, bases, blen.ctypes.data, first.ctypes.data, addr.ctypes.data, csz.ctypes.data, eoff.ctypes.data, esz.ctypes.data,
+            shuf.ctypes.data, cel.ctypes.data, ntot.ctypes.data, outs, status.ctypes.data)
+    if rc < 0:
+        raise ValueError("strq_inflate_many: bad argument")
+    return [None if s == 0 else ("chunk %d of a deflate-compressed dataset is damaged" % (-s - 2) if s < -1 else "bad chunk table") for s in status]
 
 
 class SlabAllocator(object):
@@ -421,6 +469,24 @@ def _inflate_fn():
         except (ImportError, OSError, AttributeError):
             _INFLATE.append(None)
     return _INFLATE[0]
+
+
+_INFLATE_MANY = []
+
+
+def _inflate_many_fn():
+    if not _INFLATE_MANY:
+        import ctypes
+        try:
+            from . import ffi
+            fn = ffi.load_library().strq_inflate_many
+            fn.restype = ctypes.c_int64
+            fn.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            _INFLATE_MANY.append(fn)
+        except (ImportError, OSError, AttributeError):
+            _INFLATE_MANY.append(None)
+    return _INFLATE_MANY[0]
 
 
 def read_raw(path):

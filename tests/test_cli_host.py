@@ -148,6 +148,56 @@ def test_device_fault_stops_the_engine_without_running_the_queued_batch(cfg):
     assert calls == [7, 7], calls                    # nothing ran on the device after the fault
 
 
+def test_reader_tasks_inflate_their_reads_in_one_call(tmp_path, cfg, monkeypatch):
+    """`count` locates the compressed datasets of a reader task in Python and inflates them with ONE native call
+    (strq_inflate_many): the same rows as read by read (STRQ_READ_ONE_BY_ONE=1) and as with the huge-page slabs, a damaged read
+    is reported and skipped without taking its task's other reads with it."""
+    import io
+    import zlib
+    import numpy as np
+    from strique_amd import cli, h5write
+    rng = np.random.default_rng(8)
+    data = tmp_path / "data"; data.mkdir()
+    reads = [("%08x-4444-4000-8000-%012d" % (i, i), rng.integers(300, 900, 9000 + 37 * i).astype(np.int16)) for i in range(70)]
+    blob = bytearray(h5write.multi_read_fast5(reads[:40], compression="gzip"))
+    pos = bytes(blob).find(zlib.compress(reads[11][1][:8192].tobytes(), 4)[:16])
+    assert pos > 0
+    blob[pos + 30] ^= 0xFF; blob[pos + 31] ^= 0xFF; blob[pos + 55] ^= 0xFF          # read 11: a damaged chunk
+    (data / "a.fast5").write_bytes(bytes(blob))
+    (data / "b.fast5").write_bytes(h5write.multi_read_fast5(reads[40:]))              # contiguous datasets in the same run
+    from contextlib import redirect_stdout
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        cli.main(["index", str(data)])
+    (data / "reads.fofn").write_text(buf.getvalue())
+    loci = {}
+    for name, (chrom, b, e, *_r) in cfg["repeat"].items():
+        loci.setdefault(chrom, []).append((name, b, e))
+    lines = ["\t".join([rid, "0", "chr9", "27570000", "60", "8000M", "*", "0", "0", "ACGT", "*"]) for rid, _ in reads]
+
+    class FakeCounter(object):
+        def detect_batch(self, items):
+            return [(int(raw[:50].sum()) % 997, 1.0, 2.0, -1.0, len(raw), int(raw[-1]), "-") for t, raw, s in items]
+
+    outs = {}
+    for mode, env in (("batched", {}), ("one_by_one", {"STRQ_READ_ONE_BY_ONE": "1"}), ("slabs", {"STRQ_READ_SLABS": "1"})):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            idx = cli.Fast5Index(str(data / "reads.fofn"))
+            out = io.StringIO(); err = []
+            log = lambda msg, level='info': err.append((level, msg))
+            cli.run_count(iter(lines), loci, idx.get_raw, FakeCounter(), log, 16, 0, 1, out, readers=3)
+            outs[mode] = out.getvalue()
+            assert any(reads[11][0] in m for _, m in err), (mode, err)
+    assert outs["batched"] == outs["one_by_one"] == outs["slabs"]
+    rows = outs["batched"].splitlines()[1:]
+    assert len(rows) == 69 and all(reads[11][0] not in r for r in rows)
+    by_id = {r.split("\t")[0]: r.split("\t") for r in rows}
+    for rid, sig in reads[:11] + reads[12:]:
+        assert int(by_id[rid][7]) == len(sig) and int(by_id[rid][8]) == int(sig[-1])          # offset / ticks columns carry the fake values
+
+
 def test_vlen_read_id_and_user_block(tmp_path):
     """read_id stored as a variable-length string (global heap), and a file with a user block in front of
     the superblock (non-zero base address): both forms real fast5 writers produce."""

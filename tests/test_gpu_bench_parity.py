@@ -135,7 +135,7 @@ def test_bench_line_single_gpu_small():
     lines, recs = _run_bench(["--reads", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check", "2", "--host-leg-batches", "2"])
     r = recs[0]
     roof = r["roofline"]
-    assert roof["bound"] == "valu" and re.match(r"align_forward_seg_kernel<1[45], 6, false, 4, [34], false>", roof["kernel"])
+    assert roof["bound"] == "valu" and re.match(r"align_forward_seg_kernel<14, 6, false, 4, [34], false, true>", roof["kernel"])
     assert 0 < roof["useful_frac"] < roof["frac"] < 1
     assert len(roof["overlap_columns_per_step"]) == 3 and roof["overlap_columns_per_step"][-1] < roof["overlap_worst_case"]
     assert r["config"]["distinct_batches_per_gpu"] == 3

@@ -4,8 +4,8 @@
     python tools/reader_probe.py [n_reads] [read_nt]
 
 Writes n_reads synthetic reads into bulk fast5 files with deflate-compressed chunks (what h5py / MinKNOW write), indexes
-them, and reads every signal back with 1 ... 48 threads in tasks of 32 reads (the `count` command's reader pattern), with
-numpy's allocator and with the huge-page slabs (fast5.SlabAllocator), with libdeflate and with zlib.  Tells whether the
+them, and reads every signal back with 1 ... 48 threads in tasks of 32 reads (the `count` command's reader pattern): one native
+inflate call per read, one per task (strq_inflate_many), the latter into huge-page slabs (fast5.SlabAllocator); with libdeflate and with zlib.  Tells whether the
 readers or something behind them bound `count` on compressed files."""
 import io
 import multiprocessing as mp
@@ -46,20 +46,24 @@ def measure(data):
     backend = "libdeflate" if ffi.load_library().strq_inflate_backend() else "zlib"
     tasks = [ids[i:i + 32] for i in range(0, len(ids), 32)]
 
-    def task(names, slab):
-        alloc = fast5.SlabAllocator() if slab else None
-        return sum(len(idx.get_raw(q, alloc)) for q in names)
+    def task(names, mode):
+        alloc = fast5.SlabAllocator() if mode == "slabs" else None
+        if mode == "one call per read":
+            return sum(len(idx.get_raw(q, alloc)) for q in names)
+        plans = [idx.get_raw(q, alloc, True) for q in names]          # located under the interpreter lock, inflated in one native call
+        assert all(e is None for e in fast5.inflate_plans(plans))
+        return sum(len(p.out) for p in plans)
 
     for q in ids[:64]:
         idx.get_raw(q)
-    for slab in (False, True):
+    for mode in ("one call per read", "one call per task", "slabs"):
         for threads in (1, 8, 16, 32, 48):
             sub = tasks if threads > 1 else tasks[:16]
             t0 = time.time()
             with ThreadPoolExecutor(threads) as ex:
-                total = sum(ex.map(lambda nm: task(nm, slab), sub))
+                total = sum(ex.map(lambda nm: task(nm, mode), sub))
             dt = time.time() - t0
-            print("%-10s %-6s %2d threads: %6.0f reads/s  (%.2f GB/s of samples)" % (backend, "slabs" if slab else "numpy", threads, sum(len(s) for s in sub) / dt, total * 2 / dt / 1e9), flush=True)
+            print("%-10s %-17s %2d threads: %6.0f reads/s  (%.2f GB/s of samples)" % (backend, mode, threads, sum(len(s) for s in sub) / dt, total * 2 / dt / 1e9), flush=True)
 
 
 def main():
