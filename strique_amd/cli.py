@@ -131,7 +131,9 @@ class Fast5Index(object):
             f = self._open.pop(path, None)
             if f is None:
                 f = fast5.H5File(path)
-                while len(self._open) >= 4:
+                # dozens of reader threads work on tasks from several bulk files at once: with only a few files kept, every
+                # task re-opened (mmap) and dropped (munmap: a TLB shoot-down on every CPU the process runs on) its file
+                while len(self._open) >= 32:
                     self._open.pop(next(iter(self._open)))
             self._open[path] = f         # most recently used last
             return f
