@@ -266,7 +266,7 @@ def count(argv):
         share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         if share == (os.cpu_count() or 1):          # not pinned: an equal share by count
             share //= local_world
-        readers = max(1, min(16, share // 2))
+        readers = max(1, min(24, share // 2))          # compressed files: 24 threads read fastest end to end (16: -12 %, 32: -12 %; gpurun_out/r4e, r4f)
     stats = {}
     fault = 0
     try:
