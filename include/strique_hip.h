@@ -226,6 +226,9 @@ int64_t strq_inflate_many(int64_t n_ds, const uint8_t* const* base, const int64_
                           const int64_t* addr, const int32_t* csize, const int64_t* elem_off, const int32_t* elem_size,
                           const int32_t* shuffle, const int64_t* chunk_elems, const int64_t* n_total, void* const* out,
                           int64_t* status);
+/* Diagnostics of the two calls above: out[0] = nanoseconds spent inside the inflate itself (all threads together), out[1] = zlib
+ * streams inflated, out[2] = bytes produced, since the last reset; reset != 0 clears the counters. */
+void strq_inflate_stats(int64_t out[3], int32_t reset);
 /* 1 when libdeflate (dlopen of libdeflate.so.0) decodes the zlib streams of strq_inflate_chunks in this process, 0 when
  * zlib does (library absent, or STRQ_NO_LIBDEFLATE=1).  Same bytes either way. */
 int strq_inflate_backend(void);

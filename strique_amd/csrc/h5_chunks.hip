@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <zlib.h>
@@ -72,7 +74,18 @@ int64_t inflate_one(const uint8_t* src, size_t n, uint8_t* dst, size_t cap)
     return (int64_t)got;
 }
 
+// time spent inside the inflate itself, all threads together (diagnostics: strq_inflate_stats)
+std::atomic<int64_t> g_inflate_ns{0}, g_inflate_streams{0}, g_inflate_bytes{0};
+
 }  // namespace
+
+// Diagnostics (tools/reader_probe.py): out[0] = nanoseconds spent inside the inflate calls since the last reset, summed over all
+// threads; out[1] = zlib streams inflated; out[2] = bytes produced.  reset != 0 clears the counters after reading them.
+extern "C" void strq_inflate_stats(int64_t out[3], int32_t reset)
+{
+    if (out) { out[0] = g_inflate_ns.load(); out[1] = g_inflate_streams.load(); out[2] = g_inflate_bytes.load(); }
+    if (reset) { g_inflate_ns = 0; g_inflate_streams = 0; g_inflate_bytes = 0; }
+}
 
 // 1 when libdeflate serves strq_inflate_chunks in this process, 0 when zlib does
 extern "C" int strq_inflate_backend(void) { return libdeflate().ok ? 1 : 0; }
@@ -90,7 +103,10 @@ extern "C" int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, in
         if (addr[k] < 0 || csize[k] < 0 || (int64_t)csize[k] > base_len || addr[k] > base_len - (int64_t)csize[k] || elem_off[k] < 0) return -(k + 2);
         const bool direct = !shuffle && elem_off[k] < n_total && n_total - elem_off[k] >= chunk_elems;      // a whole chunk inside the array: no staging copy
         uint8_t* dst = direct ? static_cast<uint8_t*>(out) + (size_t)elem_off[k] * elem_size : tmp.data();
+        const auto t0 = std::chrono::steady_clock::now();
         const int64_t got = inflate_one(base + addr[k], (size_t)csize[k], dst, raw);
+        g_inflate_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        ++g_inflate_streams; g_inflate_bytes += got > 0 ? got : 0;
         // libhdf5 stores every chunk whole, the last one of a dataset padded to the chunk size; other writers (the file the
         // reference bundles, data/c9orf72.fast5) end the last chunk with the data.  Either way a chunk must deliver every
         // element of the dataset that falls into it -- anything shorter is a damaged file, not zeros

@@ -59,11 +59,19 @@ def measure(data):
     for mode in ("one call per read", "one call per task", "slabs"):
         for threads in (1, 8, 16, 32, 48):
             sub = tasks if threads > 1 else tasks[:16]
+            import ctypes
+            st = (ctypes.c_int64 * 3)()
+            lib = ffi.load_library(); lib.strq_inflate_stats.restype = None
+            lib.strq_inflate_stats(st, 1)
             t0 = time.time()
             with ThreadPoolExecutor(threads) as ex:
                 total = sum(ex.map(lambda nm: task(nm, mode), sub))
             dt = time.time() - t0
-            print("%-10s %-17s %2d threads: %6.0f reads/s  (%.2f GB/s of samples)" % (backend, mode, threads, sum(len(s) for s in sub) / dt, total * 2 / dt / 1e9), flush=True)
+            lib.strq_inflate_stats(st, 1)
+            n_reads = sum(len(s) for s in sub)
+            # inflate ms per read = time inside libdeflate / zlib; busy = that time over (threads x wall): what share of the pool's time is the inflate itself
+            print("%-10s %-17s %2d threads: %6.0f reads/s  (%.2f GB/s of samples; inflate %.2f ms per read, %.0f %% of the threads' wall time)" % (
+                backend, mode, threads, n_reads / dt, total * 2 / dt / 1e9, st[0] / 1e6 / max(1, n_reads), 100.0 * st[0] / 1e9 / (threads * dt)), flush=True)
 
 
 def main():
