@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -219,6 +219,17 @@ int64_t strq_svb_decode(const uint8_t* stream, int64_t stream_len, int64_t n, in
 int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, int64_t n_chunks, const int64_t* addr,
                             const int32_t* csize, const int64_t* elem_off, int32_t elem_size, int32_t shuffle,
                             int64_t chunk_elems, int64_t n_total, void* out);
+/* Host-side helper of the fast5 reader: resolve the 1-D dataset `path` (components separated by '/') below the old-style group
+ * whose version-1 object header sits at `group_ohdr` of the mapped file, and list its chunks -- what h5py does when the reference
+ * opens /read_<id>/Raw/Signal (STRique_lib/fast5Index.py:76-84,220-233).  meta = {elements, element size, 0 unsigned | 1 signed |
+ * 2 float, layout 1 contiguous | 2 chunked, data address (contiguous) or chunk B-tree address, elements per chunk, filters
+ * (bit 0 deflate, bit 1 shuffle before it), 1 when the chunks tile the dataset -- every element is then written by the inflate}.  Returns the number of chunks written to chunk_addr / chunk_size / chunk_off (0 for
+ * a contiguous dataset), STRQ_H5_MORE_CHUNKS when max_chunks is too small, STRQ_H5_UNHANDLED for anything else -- a structure this
+ * helper does not cover or a malformed file: the caller then takes its general (Python) path, which also reports errors. */
+#define STRQ_H5_UNHANDLED (-100)
+#define STRQ_H5_MORE_CHUNKS (-101)
+int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t group_ohdr, const char* path, int64_t meta[8],
+                       int64_t* chunk_addr, int32_t* chunk_size, int64_t* chunk_off, int64_t max_chunks);
 /* The same for n_ds datasets in one call (one reader task of the `count` command): dataset i owns the chunks
  * [chunk_first[i], chunk_first[i + 1]) of addr / csize / elem_off and has its own mapped file base[i].  status[i] receives what
  * strq_inflate_chunks would return for it; the return value is the number of datasets that failed (-1: bad argument). */

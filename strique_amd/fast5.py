@@ -8,6 +8,8 @@ carry `read_id` (fixed-length and variable-length strings, the latter through th
 user block (non-zero base address).  HDF5 features outside that subset raise NotImplementedError.
 """
 import mmap
+import os
+import threading
 import struct
 import zlib
 
@@ -225,6 +227,9 @@ class H5File(object):
         """The values of a dataset.  `alloc(n, dtype)` (optional) supplies the ZERO-FILLED output array of a chunked dataset
         instead of numpy (SlabAllocator).  `defer`: a deflate-compressed dataset comes back as an InflatePlan -- its output
         array allocated, its chunks located, nothing inflated yet -- for inflate_plans() to fill together with others."""
+        fast = self._fast_dataset(path, alloc, defer)          # the common layout, resolved by the library in one call
+        if fast is not None:
+            return fast
         b = self.buf
         shape = None; dtype = None; layout = None; filters = []
         for mtype, _, pl in self._messages(self._resolve(path)):
@@ -324,6 +329,61 @@ class H5File(object):
         else:
             for child in tab["child"]:
                 self._chunk_table(int(child), rank, rows)
+
+    def _fast_dataset(self, path, alloc, defer):
+        """strq_h5_locate (csrc/h5_locate.hip): version-1 headers, old-style groups, a 1-D dataset that is contiguous or chunked
+        behind deflate -- what bulk fast5 files look like.  None for everything else (and without the library): the Python code
+        below then does the work, and reports what is wrong with a file."""
+        fn = _locate_fn()
+        if fn is None or os.environ.get("STRQ_H5_PYTHON"):
+            return None
+        comps = [x for x in path.split("/") if x]
+        if not comps:
+            return None
+        start = self.root["ohdr"]
+        if len(comps) > 1:
+            try:
+                start = self._group_entries(start).get(comps[0])          # memoised: a bulk file's root group holds thousands of reads
+            except (NotImplementedError, ValueError, struct.error):
+                return None
+            if start is None:
+                return None
+            comps = comps[1:]
+        self._base()
+        tl = _TLS
+        if getattr(tl, "cap", 0) == 0:
+            tl.cap = 256
+            tl.meta = np.zeros(8, np.int64); tl.ca = np.zeros(tl.cap, np.int64); tl.cs = np.zeros(tl.cap, np.int32); tl.co = np.zeros(tl.cap, np.int64)
+        rel = "/".join(comps).encode()
+        while True:
+            rows = fn(self._base_ptr, self._base_u8.size, start, rel, tl.meta.ctypes.data, tl.ca.ctypes.data, tl.cs.ctypes.data, tl.co.ctypes.data, tl.cap)
+            if rows != -101:
+                break
+            tl.cap *= 4
+            tl.ca = np.zeros(tl.cap, np.int64); tl.cs = np.zeros(tl.cap, np.int32); tl.co = np.zeros(tl.cap, np.int64)
+        if rows < 0:
+            return None
+        n, esize, kind, layout, addr, chunk_elems, filters = (int(v) for v in tl.meta[:7])
+        dtype = _DTYPES.get((kind, esize))
+        if dtype is None:
+            return None
+        if layout == 1:
+            return np.frombuffer(self.buf, dtype, n, addr)               # a read-only view of the mapped file
+        # chunks that were never written read as the fill value: zero-fill unless the chunks tile the dataset (then the inflate writes
+        # every element, and zeroing 750 KB per read is half of what is left of this call's time under the interpreter lock)
+        out = alloc(n, dtype) if alloc is not None else (np.empty(n, dtype) if tl.meta[7] else np.zeros(n, dtype))
+        chunks = (tl.ca[:rows].copy(), tl.cs[:rows].copy(), tl.co[:rows].copy()) if rows else None
+        if defer and _inflate_many_fn() is not None:
+            return InflatePlan(self, chunks, out, chunk_elems, bool(filters & 2))
+        inflate = _inflate_fn()
+        if inflate is None:
+            return None
+        if chunks is not None:
+            rc = inflate(self._base_ptr, self._base_u8.size, rows, chunks[0].ctypes.data, chunks[1].ctypes.data, chunks[2].ctypes.data,
+                         out.dtype.itemsize, 1 if filters & 2 else 0, chunk_elems, out.size, out.ctypes.data)
+            if rc != 0:
+                raise ValueError("chunk %d of a deflate-compressed dataset is damaged" % (-rc - 2) if rc < -1 else "bad chunk table")
+        return out
 
     def _chunk_arrays(self, addr, rank):
         """(file addresses, stored sizes, first elements) of the chunks of a dataset, or None when it has none."""
@@ -469,6 +529,27 @@ def _inflate_fn():
         except (ImportError, OSError, AttributeError):
             _INFLATE.append(None)
     return _INFLATE[0]
+
+
+_TLS = threading.local()          # per reader thread: the scratch arrays strq_h5_locate fills
+_DTYPES = {(0, 1): np.dtype("<u1"), (0, 2): np.dtype("<u2"), (0, 4): np.dtype("<u4"), (0, 8): np.dtype("<u8"),
+           (1, 1): np.dtype("<i1"), (1, 2): np.dtype("<i2"), (1, 4): np.dtype("<i4"), (1, 8): np.dtype("<i8"),
+           (2, 4): np.dtype("<f4"), (2, 8): np.dtype("<f8")}
+_LOCATE = []
+
+
+def _locate_fn():
+    if not _LOCATE:
+        import ctypes
+        try:
+            from . import ffi
+            fn = ffi.load_library().strq_h5_locate
+            fn.restype = ctypes.c_int64
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+            _LOCATE.append(fn)
+        except (ImportError, OSError, AttributeError):
+            _LOCATE.append(None)
+    return _LOCATE[0]
 
 
 _INFLATE_MANY = []

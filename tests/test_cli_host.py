@@ -198,6 +198,58 @@ def test_reader_tasks_inflate_their_reads_in_one_call(tmp_path, cfg, monkeypatch
         assert int(by_id[rid][7]) == len(sig) and int(by_id[rid][8]) == int(sig[-1])          # offset / ticks columns carry the fake values
 
 
+def test_native_locator_equals_the_python_reader_and_survives_damage(tmp_path, monkeypatch):
+    """strq_h5_locate resolves /read_<id>/Raw/Signal on the mapped file in one call (old-style groups, version-1 headers, contiguous
+    or deflate-chunked 1-D datasets); the Python reader stays the authority for everything else.  Same arrays from both on bulk
+    files of every kind the writer knows, a group of 3000 reads (several symbol-table nodes: the B-tree descent by key), and --
+    every address in a file being untrusted -- a few hundred randomly damaged copies: an exception or an array, never a crash,
+    and whenever both paths return something, the same thing."""
+    import numpy as np
+    from strique_amd import fast5, h5write
+    rng = np.random.default_rng(12)
+    reads = [("%08x-5555-4000-8000-%012d" % (i * 7919 % 100003, i), rng.integers(-500, 900, int(rng.integers(1, 20000))).astype(np.int16)) for i in range(3000)]
+    for compression in (None, "gzip"):
+        blob = h5write.multi_read_fast5(reads[:3000 if compression is None else 300], compression=compression)
+        f = fast5.H5File(blob)
+        assert fast5._locate_fn() is not None
+        for rid, sig in reads[:3000 if compression is None else 300:7]:
+            a = f.dataset("/read_%s/Raw/Signal" % rid)
+            assert f._fast_dataset("/read_%s/Raw/Signal" % rid, None, False) is not None          # the native path took it
+            monkeypatch.setenv("STRQ_H5_PYTHON", "1")
+            b = f.dataset("/read_%s/Raw/Signal" % rid)
+            monkeypatch.delenv("STRQ_H5_PYTHON")
+            assert a.dtype == b.dtype == np.int16 and np.array_equal(a, sig) and np.array_equal(b, sig)
+        with pytest.raises(KeyError):
+            f.dataset("/read_nope/Raw/Signal")
+    # VBZ-compressed and single-read files: not the locator's business, the Python path serves them as before
+    f = fast5.H5File(h5write.multi_read_fast5(reads[:5], compression="vbz"))
+    assert f._fast_dataset("/read_%s/Raw/Signal" % reads[2][0], None, False) is None
+    assert np.array_equal(f.dataset("/read_%s/Raw/Signal" % reads[2][0]), reads[2][1])
+    # damage
+    small = [(rid, sig[:3000]) for rid, sig in reads[:12]]
+    clean = bytearray(h5write.multi_read_fast5(small, compression="gzip"))
+    agree = 0
+    for trial in range(400):
+        blob = bytearray(clean)
+        for _ in range(int(rng.integers(1, 5))):
+            pos = int(rng.integers(8, len(blob)))
+            blob[pos] = int(rng.integers(0, 256))
+        rid = small[trial % len(small)][0]
+        got = {}
+        for mode in ("native", "python"):
+            if mode == "python":
+                monkeypatch.setenv("STRQ_H5_PYTHON", "1")
+            try:
+                got[mode] = np.array(fast5.H5File(bytes(blob)).dataset("/read_%s/Raw/Signal" % rid))
+            except Exception as e:          # whatever it is, it is an exception
+                got[mode] = type(e).__name__
+            if mode == "python":
+                monkeypatch.delenv("STRQ_H5_PYTHON")
+        if isinstance(got["native"], np.ndarray) and isinstance(got["python"], np.ndarray):
+            assert np.array_equal(got["native"], got["python"]); agree += 1
+    assert agree > 100          # most damage hits signal bytes or unused space: both readers return the same samples
+
+
 def test_vlen_read_id_and_user_block(tmp_path):
     """read_id stored as a variable-length string (global heap), and a file with a user block in front of
     the superblock (non-zero base address): both forms real fast5 writers produce."""
@@ -404,15 +456,18 @@ def test_deflate_chunks_native_and_python_paths(tmp_path, monkeypatch):
         path = tmp_path / ("bulk%d.fast5" % shuffle)
         path.write_bytes(bulk(signals, shuffle))
         f = fast5.H5File(str(path))
+        located = [f.dataset("/read_r%d/Raw/Signal" % i) for i in range(len(signals))]          # strq_h5_locate + strq_inflate_chunks
+        monkeypatch.setenv("STRQ_H5_PYTHON", "1")                                               # the Python parse, native inflate
         native = [f.dataset("/read_r%d/Raw/Signal" % i) for i in range(len(signals))]
         calls = []
         orig = fast5.H5File._native_inflate
         monkeypatch.setattr(fast5.H5File, "_native_inflate", lambda self, *a: calls.append(1) and False)
-        python = [f.dataset("/read_r%d/Raw/Signal" % i) for i in range(len(signals))]
+        python = [f.dataset("/read_r%d/Raw/Signal" % i) for i in range(len(signals))]           # the per-chunk Python loop
         monkeypatch.setattr(fast5.H5File, "_native_inflate", orig)
+        monkeypatch.delenv("STRQ_H5_PYTHON")
         assert len(calls) == len(signals)
-        for s, a, b in zip(signals, native, python):
-            assert np.array_equal(s, a) and np.array_equal(s, b)
+        for s, a, b, c in zip(signals, native, python, located):
+            assert np.array_equal(s, a) and np.array_equal(s, b) and np.array_equal(s, c) and c.dtype == np.int16
     # the reference's own data file goes through the same path
     rid, sig = fast5.read_raw(os.path.join(GOLDEN, "c9orf72.fast5"))[0]
     assert rid == "ce47b364-ed6e-4409-808a-1041c0b5aac2" and len(sig) == 284184 and int(sig.min()) == -4096 and int(sig.max()) == 3008
