@@ -22,6 +22,8 @@ compression = sys.argv[sys.argv.index("--compression") + 1] if "--compression" i
 pm, cfg = bench.load_inputs()
 table = synth.KmerTable(pm)
 tmp = tempfile.mkdtemp(prefix="strq_cli_")
+import atexit, shutil
+atexit.register(shutil.rmtree, tmp, True)          # 16 -- 50 GB of fast5 per run: never leave them behind
 t = np.load(os.path.join(R, "tests", "golden", "pore_tables.npz"))
 with open(os.path.join(tmp, "r9.model"), "w") as fp:
     for k, m, s in zip(t["base_kmer"], t["base_mean"], t["base_stdv"]):

@@ -80,6 +80,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     nt = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
     tmp = tempfile.mkdtemp(prefix="strq_rd_")
+    import atexit, shutil
+    atexit.register(shutil.rmtree, tmp, True)
     data = os.path.join(tmp, "data"); os.makedirs(data)
     t0 = time.time()
     with mp.get_context("fork").Pool(min(16, max(1, (n + PER_FILE - 1) // PER_FILE))) as pool:
