@@ -178,7 +178,11 @@ def cpu_baseline(sigs, strands, max_workers=0, sweep=(32, 64, 128)):
     # a worker holds the full (N + 1) x 871 float32 matrix and its byte trace: ~2.5 GB at 50 kb
     mem_cap = max(1, int(_mem_available_gb() * 0.8 / 2.6))
     cap = max(1, min(max_workers or len(cpus), len(cpus), len(sigs), mem_cap))
-    counts = sorted({min(w, cap) for w in sweep} | ({cap} if cap < min(sweep) else set()))
+    # a container may show 256 CPUs and be throttled to a quota (cgroup cpu.max: 16 CPUs' worth on the MI355X boxes): that many
+    # workers is a sweep point of its own -- more workers only share the same CPU time
+    from strique_amd import dist as _sd
+    quota = _sd.cpu_quota()
+    counts = sorted({min(w, cap) for w in sweep} | ({cap} if cap < min(sweep) else set()) | ({min(cap, max(1, int(quota)))} if quota else set()))
     ctx = mp.get_context("spawn")
     runs = []
     best = None
@@ -203,6 +207,8 @@ def cpu_baseline(sigs, strands, max_workers=0, sweep=(32, 64, 128)):
     cores = run["workers"]; wall = run["wall_s"]; per_core = run["seconds_per_read_per_core"]
     return {"value": run["reads_per_s"], "unit": "reads/s", "cores": cores, "kind": "port",
             "host_cpu_count": host_cores, "physical_cores": len(cpus), "cpu_model": _cpu_model(),
+            "cpu_quota_cores": quota,
+            "cpu_quota_note": None if not quota else "the job's control group is limited to %.0f CPUs' worth of time (cpu.max): worker counts above it share that time" % quota,
             "cores_note": "best of the sweep: %d pinned worker processes, one per physical core, spread evenly over the %d physical cores" % (cores, len(cpus)),
             "sweep": runs,
             "wall_s": wall, "per_core_reads_per_s": 1.0 / per_core, "seconds_per_read_per_core": per_core,
@@ -248,7 +254,8 @@ def main():
 
     # ---- synthetic reads (before anything touches the GPU): `batches` distinct batches per rank
     t_gen = time.time()
-    synth_workers = args.synth_workers or max(1, min(32, (os.cpu_count() or 1) // max(1, 2 * world)))
+    from strique_amd import dist as _sdq
+    synth_workers = args.synth_workers or max(1, min(32, _sdq.effective_cpus() // max(1, world)))          # CPUs the job can really use (affinity, cgroup quota) over the ranks
     first_read = rank * n_batches * args.reads
     sigs, strands, nreps = make_batches_parallel(n_batches * args.reads, args.read_nt, first_read, synth_workers)
     t_gen = time.time() - t_gen

@@ -266,7 +266,10 @@ def count(argv):
         share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         if share == (os.cpu_count() or 1):          # not pinned: an equal share by count
             share //= local_world
-        readers = max(1, min(24, share // 2))          # compressed files: 24 threads read fastest end to end (16: -12 %, 32: -12 %; gpurun_out/r4e, r4f)
+        quota = sdist.cpu_quota()                   # a container's CPU quota counts, not the CPUs it shows (16 of 256 on the MI355X boxes)
+        if quota:
+            share = min(share, max(1, int(quota) // local_world))
+        readers = max(1, min(24, share))            # inflating is what the readers do: one per core they can get, 16 ... 24 measure the same end to end
     stats = {}
     fault = 0
     try:

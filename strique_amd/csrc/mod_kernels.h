@@ -28,6 +28,8 @@ struct HubTask {
     const void* result;      // VitResult of the window (device): status, dbg[0] = time of the last e0 emission
     char* out;
 };
+struct GatherTask { int64_t src, dst, len; };      // bytes [src, src + len) of the sparse pattern buffer -> [dst, dst + len) of the dense pool
+int launch_mod_gather(hipStream_t s, const GatherTask* tasks, int n, const char* src, char* dst);
 int launch_mod_hub_pattern(hipStream_t s, const HubTask* tasks, int n, int64_t* out_len);
 int launch_mod_compact(hipStream_t s, const ModTask* tasks, int n, int64_t* out_len);
 int launch_mod_pattern(hipStream_t s, const PatTask* tasks, int n, int64_t* out_len);

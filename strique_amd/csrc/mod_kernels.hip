@@ -90,6 +90,23 @@ mod_hub_pattern_kernel(const HubTask* __restrict__ tasks, int n, int64_t* __rest
     out_len[i] = cnt;
 }
 
+// The pattern kernels write the characters of read k at an offset sized for the worst case (one per time step); the strings
+// themselves are ~1000 characters.  Gather them into a dense pool before the read-back: 4 MB instead of ~180 MB per 4096 reads.
+__global__ void mod_gather_kernel(const GatherTask* __restrict__ tasks, int n, const char* __restrict__ src, char* __restrict__ dst)
+{
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    const GatherTask t = tasks[k];
+    for (int64_t i = threadIdx.x; i < t.len; i += blockDim.x) dst[t.dst + i] = src[t.src + i];
+}
+
+int launch_mod_gather(hipStream_t s, const GatherTask* tasks, int n, const char* src, char* dst)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mod_gather_kernel, dim3(n), dim3(128), 0, s, tasks, n, src, dst);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 int launch_mod_hub_pattern(hipStream_t s, const HubTask* tasks, int n, int64_t* out_len)
 {
     if (n <= 0) return 0;

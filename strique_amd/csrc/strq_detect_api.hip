@@ -137,7 +137,7 @@ struct DetectState {
     bool have_ps = false;
     std::vector<Target> targets;
     Batch batch;
-    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange;
+    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange, modpool;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
     int levels_shift = 0;                // bytes the level stream of the current sub-batch starts behind the buffer's base (alignment phase)
@@ -157,7 +157,7 @@ void detect_state_free(strq_ctx* c)
     if (!c->detect) return;
     DetectState* d = static_cast<DetectState*>(c->detect);
     for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx, &d->order,
-                      &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern, &d->hrange}) b->release();
+                      &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern, &d->hrange, &d->modpool}) b->release();
     if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     for (int i = 0; i < DetectState::N_STAGE; ++i) { if (d->stage[i]) (void)hipHostFree(d->stage[i]); if (d->stage_ev[i]) (void)hipEventDestroy(d->stage_ev[i]); }
@@ -291,14 +291,24 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
         STRQ_HIP(c, hipMemcpyAsync(d_pt, pt.data(), (size_t)nm * sizeof(PatTask), hipMemcpyHostToDevice, st));
         if (launch_mod_pattern(st, d_pt, nm, d_plen)) { c->err = "pattern launch failed"; return STRQ_ERR_DEVICE; }
     }
-    std::vector<int64_t> plen(nm); std::vector<char> chars(p2);
+    // read-back: the lengths first, then the strings gathered into a dense pool (the sparse buffer has one byte per time step:
+    // ~180 MB per 4096 reads of 50 kb, 25 ms through pageable memory, for ~4 MB of strings)
+    std::vector<int64_t> plen(nm);
     STRQ_HIP(c, hipMemcpyAsync(plen.data(), d_plen, (size_t)nm * 8, hipMemcpyDeviceToHost, st));
-    STRQ_HIP(c, hipMemcpyAsync(chars.data(), d_chars, p2, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
+    std::vector<GatherTask> gt(nm); size_t dense = 0;
     for (int k = 0; k < nm; ++k) {
-        const int sl = slot2[k];
-        B.mod[r0 + who[k]] = std::string(chars.data() + p2_off[k], (size_t)plen[sl]);
+        const int64_t ln = std::max<int64_t>(0, std::min<int64_t>(plen[slot2[k]], len[k] + 1));
+        gt[k] = {(int64_t)p2_off[k], (int64_t)dense, ln}; dense += (size_t)ln;
     }
+    STRQ_HIP(c, d->modpool.reserve(dense + (size_t)nm * sizeof(GatherTask) + 64));
+    GatherTask* d_gt = d->modpool.as<GatherTask>(); char* d_dense = reinterpret_cast<char*>(d_gt + nm);
+    STRQ_HIP(c, hipMemcpyAsync(d_gt, gt.data(), (size_t)nm * sizeof(GatherTask), hipMemcpyHostToDevice, st));
+    if (launch_mod_gather(st, d_gt, nm, d_chars, d_dense)) { c->err = "gather launch failed"; return STRQ_ERR_DEVICE; }
+    std::vector<char> chars(dense + 1);
+    if (dense) STRQ_HIP(c, hipMemcpyAsync(chars.data(), d_dense, dense, hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipStreamSynchronize(st));
+    for (int k = 0; k < nm; ++k) B.mod[r0 + who[k]] = std::string(chars.data() + gt[k].dst, (size_t)gt[k].len);
     return STRQ_OK;
 }
 

@@ -21,6 +21,33 @@ def shard_indices(n_items, rank, world, cost=None):
     return np.sort(order[rank::world])
 
 
+def cpu_quota():
+    """CPUs' worth of time the control group of this process may use (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us`), or None
+    when there is no quota.  A container can show 256 CPUs and be throttled to 16: thread pools sized by the CPU count then only
+    add contention (measured on the MI355X boxes: `tools/cpu_scaling_probe.py`, 16 processes 15.9 x, 128 processes 11.1 x)."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1.0, float(quota) / float(period))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0:
+            return max(1.0, quota / period)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def effective_cpus():
+    """CPUs this process can really keep busy: its affinity mask, capped by the control group's quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = cpu_quota()
+    return max(1, int(min(n, q))) if q else n
+
+
 def _core_groups(allowed):
     """Logical CPUs of `allowed` grouped by physical core (hyper-thread siblings together), cores in ascending order of
     their first CPU.  /sys topology when readable, one CPU per core otherwise."""

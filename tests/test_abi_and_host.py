@@ -169,3 +169,31 @@ def test_rank_cpu_share_partitions_the_host():
         assert s == list(range(16 * r, 16 * r + 16)) + list(range(128 + 16 * r, 128 + 16 * r + 16))
     assert sdist.rank_cpu_share(0, 1, {3, 4}) == [3, 4]
     assert sdist.rank_cpu_share(5, 8, {0, 1}) in ([0], [1])          # fewer cores than ranks: shared round-robin
+
+
+def test_cpu_quota_of_the_control_group(monkeypatch):
+    """strique_amd.dist.cpu_quota: cgroup v2 `cpu.max` ("1600000 100000" = 16 CPUs' worth: what the MI355X boxes give a job that sees
+    256 CPUs), "max" = no quota, cgroup v1 files as the fallback; effective_cpus caps the affinity count with it."""
+    import builtins
+    import io
+    from strique_amd import dist as sdist
+    files = {}
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/sys/fs/cgroup/"):
+            if path in files:
+                return io.StringIO(files[path])
+            raise FileNotFoundError(path)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert sdist.cpu_quota() is None
+    files["/sys/fs/cgroup/cpu.max"] = "1600000 100000\n"
+    assert sdist.cpu_quota() == 16.0 and sdist.effective_cpus() == min(16, len(os.sched_getaffinity(0)))
+    files["/sys/fs/cgroup/cpu.max"] = "max 100000\n"
+    assert sdist.cpu_quota() is None
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "250000"; files["/sys/fs/cgroup/cpu/cpu.cfs_period_us"] = "100000"
+    assert sdist.cpu_quota() == 2.5
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "-1"
+    assert sdist.cpu_quota() is None
