@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -223,12 +223,13 @@ int64_t strq_inflate_chunks(const uint8_t* base, int64_t base_len, int64_t n_chu
  * whose version-1 object header sits at `group_ohdr` of the mapped file, and list its chunks -- what h5py does when the reference
  * opens /read_<id>/Raw/Signal (STRique_lib/fast5Index.py:76-84,220-233).  meta = {elements, element size, 0 unsigned | 1 signed |
  * 2 float, layout 1 contiguous | 2 chunked, data address (contiguous) or chunk B-tree address, elements per chunk, filters
- * (bit 0 deflate, bit 1 shuffle before it), 1 when the chunks tile the dataset -- every element is then written by the inflate}.  Returns the number of chunks written to chunk_addr / chunk_size / chunk_off (0 for
+ * (bit 0 deflate, bit 1 shuffle before it, bit 2 VBZ alone), 1 when the chunks tile the dataset -- every element is then written by
+ * the decoder, then the VBZ client data {version, integer size, zig-zag flag, zstd level}, four reserved zeros}.  Returns the number of chunks written to chunk_addr / chunk_size / chunk_off (0 for
  * a contiguous dataset), STRQ_H5_MORE_CHUNKS when max_chunks is too small, STRQ_H5_UNHANDLED for anything else -- a structure this
  * helper does not cover or a malformed file: the caller then takes its general (Python) path, which also reports errors. */
 #define STRQ_H5_UNHANDLED (-100)
 #define STRQ_H5_MORE_CHUNKS (-101)
-int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t group_ohdr, const char* path, int64_t meta[8],
+int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t group_ohdr, const char* path, int64_t meta[16],
                        int64_t* chunk_addr, int32_t* chunk_size, int64_t* chunk_off, int64_t max_chunks);
 /* The same for n_ds datasets in one call (one reader task of the `count` command): dataset i owns the chunks
  * [chunk_first[i], chunk_first[i + 1]) of addr / csize / elem_off and has its own mapped file base[i].  status[i] receives what
@@ -237,6 +238,13 @@ int64_t strq_inflate_many(int64_t n_ds, const uint8_t* const* base, const int64_
                           const int64_t* addr, const int32_t* csize, const int64_t* elem_off, const int32_t* elem_size,
                           const int32_t* shuffle, const int64_t* chunk_elems, const int64_t* n_total, void* const* out,
                           int64_t* status);
+/* The same contract for chunks behind the VBZ filter (HDF5 filter 32020: Oxford Nanopore's vbz_compression, what MinKNOW writes;
+ * strique_amd/vbz.py has the format -- unpinned: no VBZ file or plugin exists in the image or the reference tree) with client data
+ * {version, integer size, zig-zag flag, zstd level}: zstd through the system's libzstd (dlopen), then strq_svb_decode.  -1 also for
+ * a combination this helper does not decode: the caller's general path then does, or says why not. */
+int64_t strq_vbz_chunks(const uint8_t* base, int64_t base_len, int64_t n_chunks, const int64_t* addr, const int32_t* csize,
+                        const int64_t* elem_off, int32_t elem_size, int32_t version, int32_t isize, int32_t zigzag, int32_t level,
+                        int64_t chunk_elems, int64_t n_total, void* out);
 /* Diagnostics of the two calls above: out[0] = nanoseconds spent inside the inflate itself (all threads together), out[1] = zlib
  * streams inflated, out[2] = bytes produced, since the last reset; reset != 0 clears the counters. */
 void strq_inflate_stats(int64_t out[3], int32_t reset);

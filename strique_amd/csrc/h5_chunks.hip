@@ -151,3 +151,76 @@ extern "C" int64_t strq_inflate_many(int64_t n_ds, const uint8_t* const* base, c
     }
     return failed;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// VBZ chunks (HDF5 filter 32020, strique_amd/vbz.py for the format and its provenance -- UNPINNED like that module: this is the
+// same decode, moved out of a per-chunk Python loop): u32 size of the decoded chunk, then a zstd frame (zstd level != 0) around the
+// variable-byte stream that strq_svb_decode reads.  zstd comes from the system's libzstd.so.1 through dlopen (no headers in the
+// image: the three entry points are declared here).  Every layer is length-checked as in vbz.decode: the frame must decode, the
+// stream must be consumed exactly, the decoded size must be the size the chunk states.
+namespace {
+
+typedef size_t (*zstd_decompress_fn)(void* dst, size_t cap, const void* src, size_t n);
+typedef unsigned (*zstd_iserror_fn)(size_t code);
+typedef unsigned long long (*zstd_content_size_fn)(const void* src, size_t n);
+struct LibZstd { zstd_decompress_fn decompress = nullptr; zstd_iserror_fn is_error = nullptr; zstd_content_size_fn content_size = nullptr; bool ok = false; };
+
+const LibZstd& libzstd()
+{
+    static LibZstd L;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        L.decompress = reinterpret_cast<zstd_decompress_fn>(dlsym(h, "ZSTD_decompress"));
+        L.is_error = reinterpret_cast<zstd_iserror_fn>(dlsym(h, "ZSTD_isError"));
+        L.content_size = reinterpret_cast<zstd_content_size_fn>(dlsym(h, "ZSTD_getFrameContentSize"));
+        L.ok = L.decompress && L.is_error && L.content_size;
+    });
+    return L;
+}
+
+}  // namespace
+
+// Same contract as strq_inflate_chunks for chunks behind the VBZ filter with client data {version, integer size, zig-zag flag,
+// zstd level}; elem_size must equal the integer size (2 or 4).  Returns 0, -1 on a bad argument or a combination this helper does
+// not decode (the caller's Python path then does, or says why not), -(k + 2) when chunk k is out of bounds or damaged.
+extern "C" int64_t strq_vbz_chunks(const uint8_t* base, int64_t base_len, int64_t n_chunks, const int64_t* addr, const int32_t* csize,
+                                   const int64_t* elem_off, int32_t elem_size, int32_t version, int32_t isize, int32_t zigzag, int32_t level,
+                                   int64_t chunk_elems, int64_t n_total, void* out)
+{
+    if (!base || base_len < 0 || n_chunks < 0 || (n_chunks > 0 && (!addr || !csize || !elem_off)) || chunk_elems < 1 || n_total < 0 || !out) return -1;
+    if ((version != 0 && version != 1) || (isize != 2 && isize != 4) || isize != elem_size) return -1;
+    const LibZstd& Z = libzstd();
+    if (level && !Z.ok) return -1;
+    const int key_bits = (version == 1 && isize == 2) ? 1 : 2;
+    std::vector<uint8_t> stream, vals((size_t)chunk_elems * (size_t)isize);
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        if (addr[k] < 0 || csize[k] < 4 || (int64_t)csize[k] > base_len || addr[k] > base_len - (int64_t)csize[k] || elem_off[k] < 0) return -(k + 2);
+        const uint8_t* chunk = base + addr[k];
+        uint32_t size; memcpy(&size, chunk, 4);
+        if (size % (uint32_t)isize != 0 || (int64_t)(size / (uint32_t)isize) > chunk_elems) return -(k + 2);
+        const int64_t n = size / (uint32_t)isize;
+        const uint8_t* payload = chunk + 4; size_t plen = (size_t)csize[k] - 4;
+        if (level) {
+            const size_t bound = (size_t)((n + 3) / 4 + 4 * n) + size + 64;
+            const unsigned long long stated = Z.content_size(payload, plen);
+            const size_t cap = stated < (1ull << 40) ? (size_t)stated : bound;          // unknown / error codes are huge values
+            if (cap > bound) return -(k + 2);
+            stream.resize(cap > 0 ? cap : 1);
+            const size_t got = Z.decompress(stream.data(), cap, payload, plen);
+            if (Z.is_error(got)) return -(k + 2);
+            payload = stream.data(); plen = got;
+        }
+        const bool direct = elem_off[k] < n_total && n_total - elem_off[k] >= n;      // the whole chunk lies inside the array
+        uint8_t* dst = direct ? static_cast<uint8_t*>(out) + (size_t)elem_off[k] * (size_t)isize : vals.data();
+        const int64_t used = strq_svb_decode(payload, (int64_t)plen, n, key_bits, zigzag ? 1 : 0, isize, dst);
+        if (used != (int64_t)plen) return -(k + 2);                                    // the stream must be consumed exactly
+        int64_t need = elem_off[k] < n_total ? n_total - elem_off[k] : 0;
+        if (need > chunk_elems) need = chunk_elems;
+        if (n < need) return -(k + 2);                                                 // a chunk delivers every element that falls into it
+        if (!direct && elem_off[k] < n_total) memcpy(static_cast<uint8_t*>(out) + (size_t)elem_off[k] * (size_t)isize, vals.data(), (size_t)need * (size_t)isize);
+    }
+    return 0;
+}

@@ -136,7 +136,7 @@ int64_t chunk_rows(const View& b, uint64_t addr, int rank, int64_t* caddr, int32
 
 }  // namespace
 
-extern "C" int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t group_ohdr, const char* path, int64_t meta[8],
+extern "C" int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t group_ohdr, const char* path, int64_t meta[16],
                                   int64_t* chunk_addr, int32_t* chunk_size, int64_t* chunk_off, int64_t max_chunks)
 {
     if (!base || base_len < 0 || group_ohdr < 0 || !path || !meta) return STRQ_H5_UNHANDLED;
@@ -153,6 +153,7 @@ extern "C" int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t
     }
     // the dataset's own header: dataspace, datatype, layout, filter pipeline
     int64_t n = -1, esize = 0, tclass = -1, is_signed = 0, layout = 0, addr = -1, chunk_elems = 0, filters = 0; bool bad = false;
+    int64_t vbz_cd[4] = {0, 0, 0, 0};
     int rank = 0;
     if (!messages(b, ohdr, [&](int t, uint64_t p, uint64_t sz) {
             if (t == 0x01) {
@@ -184,11 +185,16 @@ extern "C" int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t
                     if (q + 8 > p + sz) { bad = true; return false; }
                     const int fid = b.u16(q), nlen = b.u16(q + 2), ncd = b.u16(q + 6); q += 8;
                     if (ver == 1 || fid >= 256) q += ver == 1 ? (uint64_t)((nlen + 7) & ~7) : (uint64_t)nlen;
+                    const uint64_t cd_at = q;
                     q += 4 * (uint64_t)ncd;
                     if (ver == 1 && (ncd % 2)) q += 4;
                     if (q > p + sz) { bad = true; return false; }
                     if (fid == 2 && !(filters & 1)) { filters |= 2; seen_shuffle = 1; }          // shuffle, before the deflate
                     else if (fid == 1 && !(filters & 1)) filters |= 1;
+                    else if (fid == 32020 && nf == 1) {                                          // VBZ, alone in the pipeline
+                        filters |= 4;
+                        for (int j = 0; j < 4 && j < ncd; ++j) vbz_cd[j] = b.u32(cd_at + 4 * (uint64_t)j);
+                    }
                     else { bad = true; return false; }
                     (void)seen_shuffle;
                 }
@@ -196,12 +202,13 @@ extern "C" int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t
             return true; }) || bad) return STRQ_H5_UNHANDLED;
     if (n < 0 || tclass < 0 || layout == 0 || !(esize == 1 || esize == 2 || esize == 4 || esize == 8) || (tclass == 1 && esize < 4)) return STRQ_H5_UNHANDLED;
     meta[0] = n; meta[1] = esize; meta[2] = tclass == 1 ? 2 : (is_signed ? 1 : 0); meta[3] = layout; meta[4] = addr; meta[5] = chunk_elems; meta[6] = filters; meta[7] = 0;
+    for (int j = 0; j < 4; ++j) { meta[8 + j] = vbz_cd[j]; meta[12 + j] = 0; }
     if (layout == 1) {
         if (filters) return STRQ_H5_UNHANDLED;
         if (n > 0 && (addr < 0 || (uint64_t)addr == UNDEF || !b.ok((uint64_t)addr, (uint64_t)n * (uint64_t)esize))) return STRQ_H5_UNHANDLED;
         return 0;
     }
-    if (!(filters & 1) || chunk_elems < 1 || !chunk_addr || !chunk_size || !chunk_off) return STRQ_H5_UNHANDLED;      // chunked without deflate: the Python loop
+    if (!(filters & 5) || chunk_elems < 1 || !chunk_addr || !chunk_size || !chunk_off) return STRQ_H5_UNHANDLED;      // chunked without deflate / VBZ: the Python loop
     const int64_t rows = chunk_rows(b, (uint64_t)addr, 1, chunk_addr, chunk_size, chunk_off, max_chunks, 0, 0);
     if (rows == -2) return STRQ_H5_MORE_CHUNKS;
     if (rows < 0) return STRQ_H5_UNHANDLED;

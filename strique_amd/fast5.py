@@ -353,7 +353,7 @@ class H5File(object):
         tl = _TLS
         if getattr(tl, "cap", 0) == 0:
             tl.cap = 256
-            tl.meta = np.zeros(8, np.int64); tl.ca = np.zeros(tl.cap, np.int64); tl.cs = np.zeros(tl.cap, np.int32); tl.co = np.zeros(tl.cap, np.int64)
+            tl.meta = np.zeros(16, np.int64); tl.ca = np.zeros(tl.cap, np.int64); tl.cs = np.zeros(tl.cap, np.int32); tl.co = np.zeros(tl.cap, np.int64)
         rel = "/".join(comps).encode()
         while True:
             rows = fn(self._base_ptr, self._base_u8.size, start, rel, tl.meta.ctypes.data, tl.ca.ctypes.data, tl.cs.ctypes.data, tl.co.ctypes.data, tl.cap)
@@ -373,6 +373,19 @@ class H5File(object):
         # every element, and zeroing 750 KB per read is half of what is left of this call's time under the interpreter lock)
         out = alloc(n, dtype) if alloc is not None else (np.empty(n, dtype) if tl.meta[7] else np.zeros(n, dtype))
         chunks = (tl.ca[:rows].copy(), tl.cs[:rows].copy(), tl.co[:rows].copy()) if rows else None
+        if filters & 4:
+            # VBZ (what MinKNOW writes): zstd + variable-byte decode of all chunks in one native call (strq_vbz_chunks); a layout it
+            # does not decode (-1) goes to the Python decoder below, which also says what is wrong with a chunk
+            vfn = _vbz_fn()
+            if vfn is None:
+                return None
+            if chunks is not None:
+                version, isize, zigzag, level = (int(v) for v in tl.meta[8:12])
+                rc = vfn(self._base_ptr, self._base_u8.size, rows, chunks[0].ctypes.data, chunks[1].ctypes.data, chunks[2].ctypes.data,
+                         out.dtype.itemsize, version, isize, zigzag, level, chunk_elems, out.size, out.ctypes.data)
+                if rc != 0:
+                    return None
+            return out
         if defer and _inflate_many_fn() is not None:
             return InflatePlan(self, chunks, out, chunk_elems, bool(filters & 2))
         inflate = _inflate_fn()
@@ -550,6 +563,24 @@ def _locate_fn():
         except (ImportError, OSError, AttributeError):
             _LOCATE.append(None)
     return _LOCATE[0]
+
+
+_VBZ = []
+
+
+def _vbz_fn():
+    if not _VBZ:
+        import ctypes
+        try:
+            from . import ffi
+            fn = ffi.load_library().strq_vbz_chunks
+            fn.restype = ctypes.c_int64
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+            _VBZ.append(fn)
+        except (ImportError, OSError, AttributeError):
+            _VBZ.append(None)
+    return _VBZ[0]
 
 
 _INFLATE_MANY = []

@@ -221,10 +221,35 @@ def test_native_locator_equals_the_python_reader_and_survives_damage(tmp_path, m
             assert a.dtype == b.dtype == np.int16 and np.array_equal(a, sig) and np.array_equal(b, sig)
         with pytest.raises(KeyError):
             f.dataset("/read_nope/Raw/Signal")
-    # VBZ-compressed and single-read files: not the locator's business, the Python path serves them as before
-    f = fast5.H5File(h5write.multi_read_fast5(reads[:5], compression="vbz"))
-    assert f._fast_dataset("/read_%s/Raw/Signal" % reads[2][0], None, False) is None
-    assert np.array_equal(f.dataset("/read_%s/Raw/Signal" % reads[2][0]), reads[2][1])
+    # VBZ-compressed files (what MinKNOW writes; both layouts of the variable-byte layer): chunks decoded by the library in one call
+    # (strq_vbz_chunks: zstd through dlopen + strq_svb_decode), the same samples as the per-chunk Python decoder
+    for version in (0, 1):
+        f = fast5.H5File(h5write.multi_read_fast5(reads[:40], compression="vbz", vbz_version=version))
+        for rid, sig in reads[:40:3]:
+            a = f._fast_dataset("/read_%s/Raw/Signal" % rid, None, False)
+            assert a is not None and a.dtype == np.int16 and np.array_equal(a, sig)
+            monkeypatch.setenv("STRQ_H5_PYTHON", "1")
+            assert np.array_equal(f.dataset("/read_%s/Raw/Signal" % rid), sig)
+            monkeypatch.delenv("STRQ_H5_PYTHON")
+    vclean = bytearray(h5write.multi_read_fast5([(rid, sig[:3000]) for rid, sig in reads[:12]], compression="vbz"))
+    for trial in range(200):
+        blob = bytearray(vclean)
+        for _ in range(int(rng.integers(1, 4))):
+            blob[int(rng.integers(8, len(blob)))] = int(rng.integers(0, 256))
+        got = {}
+        for mode in ("native", "python"):
+            if mode == "python":
+                monkeypatch.setenv("STRQ_H5_PYTHON", "1")
+            try:
+                got[mode] = np.array(fast5.H5File(bytes(blob)).dataset("/read_%s/Raw/Signal" % reads[trial % 12][0]))
+            except Exception as e:
+                got[mode] = type(e).__name__
+            if mode == "python":
+                monkeypatch.delenv("STRQ_H5_PYTHON")
+        if isinstance(got["native"], np.ndarray) and isinstance(got["python"], np.ndarray):
+            assert np.array_equal(got["native"], got["python"])
+        else:
+            assert not isinstance(got["native"], np.ndarray) or isinstance(got["python"], np.ndarray), got          # never samples where the Python decoder refuses
     # damage
     small = [(rid, sig[:3000]) for rid, sig in reads[:12]]
     clean = bytearray(h5write.multi_read_fast5(small, compression="gzip"))
