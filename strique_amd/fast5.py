@@ -368,6 +368,8 @@ class H5File(object):
         if dtype is None:
             return None
         if layout == 1:
+            if n == 0:
+                return np.zeros(0, dtype)                                # an empty dataset has no storage (undefined address)
             return np.frombuffer(self.buf, dtype, n, addr)               # a read-only view of the mapped file
         # chunks that were never written read as the fill value: zero-fill unless the chunks tile the dataset (then the inflate writes
         # every element, and zeroing 750 KB per read is half of what is left of this call's time under the interpreter lock)
