@@ -730,6 +730,39 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
 
         // chain sweeps: De (slot 0) takes from lane - 1's Do, Do (slot 1) from the lane's own De -- as in viterbi_kernel
         auto chain_sweeps = [&](double (&y)[2], Pay (&yc)[2]) {
+            // The first STRQ_G2_PRESWEEPS sweeps run without the convergence test: a sweep that changes nothing is harmless, a time step of
+            // the benchmark's windows needs ~3 productive ones anyway, and every test is a compare -> scalar branch round trip the wave
+            // waits for.  Measured (gpurun_out/r4o, A/B on one box): 66.4 ms per 4096 configs[2] windows with 0, 64.5 with 1, 63.7 with 2,
+            // 63.8 with 3 unconditional sweeps.
+#ifndef STRQ_G2_PRESWEEPS
+#define STRQ_G2_PRESWEEPS 2
+#endif
+#pragma unroll
+            for (int pre = 0; pre < STRQ_G2_PRESWEEPS; ++pre) {
+                double tin = dpp_shr1_f64(y[1]) + clp[0];
+                if constexpr (MARK) yc[0] = sel_shr1_u64(tin, y[0], yc[1], yc[0]); else yc[0] = sel_shr1_i32(tin, y[0], yc[1], yc[0]);
+                y[0] = max_f64_raw(y[0], tin);
+                tin = y[0] + clp[1];
+                const bool win = tin > y[1];
+                y[1] = max_f64_raw(y[1], tin);
+                yc[1] = win ? yc[0] : yc[1];
+            }
+#ifdef STRQ_G2_TESTFIRST
+            // experiment: test the cross-lane hop first (2 DPP moves + add + compare) and run the rest of a sweep only when some lane takes
+            // its left neighbour's value: the last, fruitless pass then costs 4 instead of 10 instructions.  Valid behind >= 1 full sweep
+            // (the in-lane hop has been applied to the current slot-0 values, so slot 1 can only change after slot 0 did).
+            static_assert(STRQ_G2_PRESWEEPS >= 1, "the test-first loop needs one full sweep in front of it");
+            for (;;) {
+                double tin = dpp_shr1_f64(y[1]) + clp[0];
+                if (!__any(tin > y[0])) break;
+                if constexpr (MARK) yc[0] = sel_shr1_u64(tin, y[0], yc[1], yc[0]); else yc[0] = sel_shr1_i32(tin, y[0], yc[1], yc[0]);
+                y[0] = max_f64_raw(y[0], tin);
+                tin = y[0] + clp[1];
+                const bool win = tin > y[1];
+                y[1] = max_f64_raw(y[1], tin);
+                yc[1] = win ? yc[0] : yc[1];
+            }
+#else
             for (;;) {
                 double tin = dpp_shr1_f64(y[1]) + clp[0];
                 if constexpr (MARK) yc[0] = sel_shr1_u64(tin, y[0], yc[1], yc[0]); else yc[0] = sel_shr1_i32(tin, y[0], yc[1], yc[0]);
@@ -740,6 +773,7 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 yc[1] = win ? yc[0] : yc[1];
                 if (!__any(win)) break;
             }
+#endif
         };
 
         double pv[4]; Pay pc[4]; double dv[2]; Pay dc[2];      // Me, Mo, Ie, Io of the previous time step; De, Do
