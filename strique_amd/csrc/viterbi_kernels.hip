@@ -737,6 +737,8 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
 #ifndef STRQ_G2_PRESWEEPS
 #define STRQ_G2_PRESWEEPS 2
 #endif
+            bool pre_win = true;
+            (void)pre_win;
 #pragma unroll
             for (int pre = 0; pre < STRQ_G2_PRESWEEPS; ++pre) {
                 double tin = dpp_shr1_f64(y[1]) + clp[0];
@@ -746,7 +748,12 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 const bool win = tin > y[1];
                 y[1] = max_f64_raw(y[1], tin);
                 yc[1] = win ? yc[0] : yc[1];
+                pre_win = win;
             }
+#ifdef STRQ_G2_WHILE
+            // experiment: the last unconditional sweep already says whether anything is left to do
+            if (STRQ_G2_PRESWEEPS > 0 && !__any(pre_win)) return;
+#endif
 #ifdef STRQ_G2_TESTFIRST
             // experiment: test the cross-lane hop first (2 DPP moves + add + compare) and run the rest of a sweep only when some lane takes
             // its left neighbour's value: the last, fruitless pass then costs 4 instead of 10 instructions.  Valid behind >= 1 full sweep
