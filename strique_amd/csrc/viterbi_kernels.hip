@@ -672,11 +672,26 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
         else { v3u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = (unsigned)c; *reinterpret_cast<v3u*>(xst + kind * (G2_LDS_CELLS * 16)) = q; }
     };
     auto xload = [&](int kind, double& v, Pay& c) {         // ds_read_b128
+#ifdef STRQ_G2_LOAD96
+        // experiment: ds_read_b96 where the payload is one word -- no dead fourth register for the allocator to reuse under the load
+        if constexpr (!MARK) {
+            const v3u q = *reinterpret_cast<const v3u*>(xld + kind * (G2_LDS_CELLS * 16));
+            v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x); c = (int)q.z;
+            return;
+        }
+#endif
         const v4u q = *reinterpret_cast<const v4u*>(xld + kind * (G2_LDS_CELLS * 16));
         v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
         if constexpr (MARK) c = ((uint64_t)q.w << 32) | q.z; else c = (int)q.z;
     };
     auto xload_at = [&](int kind, int src_lane, double& v, Pay& c) {      // the cell of one lane, read by all (same address: one LDS cycle)
+#ifdef STRQ_G2_LOAD96
+        if constexpr (!MARK) {
+            const v3u q = *reinterpret_cast<const v3u*>(xbase + kind * (G2_LDS_CELLS * 16) + 16 * (src_lane + 1));
+            v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x); c = (int)q.z;
+            return;
+        }
+#endif
         const v4u q = *reinterpret_cast<const v4u*>(xbase + kind * (G2_LDS_CELLS * 16) + 16 * (src_lane + 1));
         v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
         if constexpr (MARK) c = ((uint64_t)q.w << 32) | q.z; else c = (int)q.z;
@@ -799,8 +814,13 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             if (lane < 5) { const uint64_t u = __builtin_bit_cast(uint64_t, NEGINF); v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = 0; q.w = 0; *reinterpret_cast<v4u*>(xbase + lane * (G2_LDS_CELLS * 16)) = q; }
             VIT_FENCE();
             xstore(2, dv[1], dc[1]);
+#ifdef STRQ_G2_EARLY2
+            if constexpr (LX2) { xstore(0, NEGINF, 0); xstore(1, NEGINF, 0); xstore(3, NEGINF, 0); xstore(4, NEGINF, 0); }
+#endif
             VIT_FENCE();
+#ifndef STRQ_G2_LATE_DO
             xload(2, rDo, qDo);
+#endif
         }
 
         auto step = [&](auto fast_c, auto odd_c, double x, int64_t t) {
@@ -810,6 +830,17 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             constexpr bool ODD = decltype(odd_c)::value;
             constexpr int B0 = ODD ? 1 : 0, B1 = ODD ? 3 : 2;
             (void)t;
+#ifdef STRQ_G2_LATE_DO
+            // experiment: lane - 1's odd delete slot is fetched at the head of the step that uses it, not behind the store of the step before
+            if constexpr (LX) xload(2, rDo, qDo);
+#endif
+#ifdef STRQ_G2_EARLY2
+            // experiment: everything lane - 1 / the broadcast lane hands to the even match slot is fetched here and used last
+            if constexpr (LX2) { xload(3, rMe, qMe); xload_at(ODD ? 0 : 3, bc0_lane, rB0, qB0); }
+#ifdef STRQ_G2_EARLY2_BARRIER
+            if constexpr (LX2) __builtin_amdgcn_sched_barrier(0);          // the scheduler otherwise sinks the three loads to their first use
+#endif
+#endif
             // previous values of lane - 1 (lane 0 receives 0.0: every column that uses them is -inf there)
             double sMe; Pay cMe;
             if constexpr (LX2) { sMe = rMe; cMe = qMe; } else { sMe = dpp_shr1_f64(pv[0]); cMe = shr1_pay(pc[0]); }
@@ -883,6 +914,22 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             {
                 double nI, nM, nB; Pay cI, cM, cB;      // lane - 1's new Io, Mo; the new value of B1
                 if constexpr (LX) {
+#ifdef STRQ_G2_EARLY2
+                  if constexpr (LX2) {
+                    tour_mo(); tour_io(); tour_ie(); finish(K1{}); finish(K3{}); finish(K2{});
+                    xstore(0, nv[1], nc[1]); xstore(1, nv[3], nc[3]); if constexpr (!ODD) xstore(4, nv[2], nc[2]);
+                    VIT_FENCE();
+                    xload(0, nM, cM); xload(1, nI, cI); xload_at(ODD ? 1 : 4, bc1_lane, nB, cB);
+#ifdef STRQ_G2_EARLY2_BARRIER
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    tour_me(); finish(K0{});
+                    xstore(3, nv[0], nc[0]);
+                    VIT_FENCE();
+                    rMo = nM; rIo = nI; qMo = cM; qIo = cI;
+                  } else
+#endif
+                  {
 #ifdef STRQ_G2_EARLY
                     // experiment: the odd slots first -- their cells are on their way through LDS while the even slots (the larger tournaments) are evaluated
                     tour_mo(); tour_io(); finish(K1{}); finish(K3{});
@@ -902,8 +949,11 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                     rMo = nM; rIo = nI; qMo = cM; qIo = cI;          // ... which are next step's shifted previous values
                     if constexpr (LX2) {
                         xload_at(ODD ? 1 : 4, bc1_lane, nB, cB);
+#ifndef STRQ_G2_EARLY2
                         xload(3, rMe, qMe); xload_at(ODD ? 0 : 3, bc0_lane, rB0, qB0);      // for the next time step
+#endif
                     } else { nB = readlane_f64(nv[B1], bc1_lane); cB = readlane_pay(nc[B1], bc1_lane); }
+                  }
                 } else {
                     tour_me(); tour_mo(); tour_ie(); tour_io(); finish(K0{}); finish(K1{}); finish(K2{}); finish(K3{});
                     nI = dpp_shr1_f64(nv[3]); nM = dpp_shr1_f64(nv[1]); cI = shr1_pay(nc[3]); cM = shr1_pay(nc[1]);
@@ -928,7 +978,9 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 VIT_FENCE();
                 xstore(2, y[1], yc[1]);
                 VIT_FENCE();
+#ifndef STRQ_G2_LATE_DO
                 xload(2, rDo, qDo);
+#endif
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) { pv[k] = nv[k]; pc[k] = nc[k]; }
