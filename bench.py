@@ -322,6 +322,7 @@ def main():
     t0 = time.time()
     fwd_ms = 0.0; fwd_launches = 0; stage_ms = np.zeros(8); counters = np.zeros(8)
     last = {}; geoms = []; mine = []
+    screen = {"ms": 0.0, "wave_steps": 0.0, "screened": 0.0, "windowed": 0.0, "whole_read": 0.0, "window_columns": 0.0, "scale": 0.0}
     gathered_rows = None
     for _ in range(args.steps):
         bi, res = step(k_step); k_step += 1
@@ -331,6 +332,10 @@ def main():
         fwd_ms += float(tm[1]); fwd_launches += int(tm[7]); stage_ms += tm
         counters[:3] += cn[:3]; counters[3:7] = cn[3:7]; counters[7] += cn[7]
         geoms.append(ctx.last_geometry())
+        scr = ctx.last_screen()
+        for key in ("ms", "wave_steps", "screened", "windowed", "whole_read", "window_columns"):
+            screen[key] += scr[key]
+        screen["scale"] = scr["scale"]
     table = None
     if dist is not None and not args.gather_every_step:
         table = gather(mine)                    # ONE gather of all steps' records, inside the timed region
@@ -462,6 +467,39 @@ def main():
                     roof["frac_of_measured_ceiling"] = roof["achieved"] / rates["dp_cell_mix_independent"]
         else:
             roof["achieved"] = None; roof["frac"] = None
+        if screen["ms"] > 0.5 * fwd_ms:
+            # The upper-bound screen (csrc/screen_kernels.hip) ran and is the dominant kernel: an integer DP over the whole read
+            # (one add + one max3 per cell) that tells the float32 DP which column windows can hold the optimum.  The line's
+            # roofline is its VALU issue rate; the float32 kernel's figures over the windows move to `exact_pass`.
+            exact = dict(roof)
+            exact["ms_per_step"] = (fwd_ms - screen["ms"]) / args.steps
+            exact["note"] = "float32 DP over the screen's windows only (plus the host planning between the two passes, which the forward stage time includes)"
+            scr_ip = by_kernel.get("align_screen_kernel")
+            scr_note = None
+            if scr_ip is None:
+                scr_ip = 111.0; scr_note = "no committed SQ_INSTS_VALU profile of this kernel: instruction count of the steady-state loop (ISA)"
+            scr_launch_s = screen["ms"] / 1e3 / max(1, fwd_launches)
+            scr_steps_per_launch = screen["wave_steps"] / max(1, fwd_launches)
+            achieved = scr_ip * scr_steps_per_launch / scr_launch_s / 1e9 if scr_launch_s > 0 else None
+            roof = {"bound": "valu", "unit": "G wave-instructions/s", "peak": valu_peak, "kernel": "align_screen_kernel",
+                    "avg_launch_ms": scr_launch_s * 1e3, "launches_per_step": launches_per_step,
+                    "wave_steps_per_launch": scr_steps_per_launch, "valu_insts_per_wave_step": scr_ip,
+                    "valu_insts_source": prof.get("valu_source") if scr_note is None else scr_note,
+                    "achieved": achieved, "frac": achieved / valu_peak if achieved else None,
+                    "instr_per_cell": scr_ip / 28.0, "instr_per_cell_floor": 2.0,
+                    "lane_utilisation": FLANK_ROWS / float(64 * 14),
+                    "gcups": gcups, "traffic": None,
+                    "traffic_note": "reads the uint8 levels once per piece (1 B per column) and writes 4 B per 128 columns: ~0.4 GB per launch",
+                    "scale": screen["scale"],
+                    "alignments_screened_per_step": screen["screened"] / args.steps, "with_windows": screen["windowed"] / args.steps,
+                    "whole_read": screen["whole_read"] / args.steps,
+                    "window_columns_over_columns_of_the_reads": screen["window_columns"] / max(1.0, 2.0 * n_samples * args.steps),
+                    "hbm_algorithmic": exact.get("hbm_algorithmic"),
+                    "exact_pass": {k: exact.get(k) for k in ("kernel", "ms_per_step", "note", "waves_per_alignment", "score_tables_per_cu", "wave_steps_per_launch",
+                                                              "columns_computed_over_columns_of_the_reads", "valu_insts_per_wave_step", "overlap_worst_case")}}
+            if achieved:
+                roof["useful_achieved"] = achieved * (2.0 * 28.0 / scr_ip) * roof["lane_utilisation"]
+                roof["useful_frac"] = roof["useful_achieved"] / valu_peak
         out = {
             "metric": "reads/s for STRique 'count' on 50 kb r9.4 signals", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -470,7 +508,7 @@ def main():
                                 "contract); `host_inclusive_reads_per_s` is the same pipeline with the signals starting in pageable host "
                                 "RAM (SURVEY.md 8d's wording), uploads overlapped with the kernels",
             "vs_baseline_note": "BASELINE.md holds no published number for this metric; `vs_cpu_baseline` = value / cpu_baseline.value of this run",
-            "dtype_note": "float32 flank DP (dominant), float64 HMM Viterbi and conditioning statistics",
+            "dtype_note": "float32 flank DP over the windows an int32 upper-bound screen leaves (the screen is the dominant kernel when it runs), float64 HMM Viterbi and conditioning statistics",
             "data": "synthetic (SURVEY.md 8d recipe, seeded), int16 signals resident in HBM; %d distinct batches per GPU, a different one every step" % n_batches,
             "config": {"workload": "BASELINE configs[2]: %d reads/GPU/step, %d nt (N~%d samples), C9orf72 GGGGCC x {200,500,1000,1500,2000}"
                                    % (args.reads, args.read_nt, n_samples // max(1, args.reads)),

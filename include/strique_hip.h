@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 9 (9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 10 (10: strq_last_screen; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -291,6 +291,12 @@ int strq_last_viterbi_launches(const strq_ctx* ctx, int32_t out[4]);
  * overlap -- did not reach the score that certifies it, and which therefore ran the second round with the worst-case
  * overlap: [0] such alignments, [1] all alignments (two per read).  What a read that does not contain its flank costs. */
 int strq_last_second_round(const strq_ctx* ctx, int64_t out[2]);
+/* The upper-bound screen of the last batched call (csrc/screen_kernels.hip: an integer DP over the whole read whose last-row
+ * values bound the float32 ones of src/align_raw.h:106-158 from above, so that the exact DP only runs over the column windows
+ * that can hold the optimum): [0] ms in align_screen_kernel   [1] alignments screened   [2] of them with windows
+ * [3] without (their whole read ran)   [4] columns inside the windows   [5] screen wave-steps (one step = two columns of
+ * every flank row)   [6] scale (scores are rounded up to multiples of 1 / scale)   [7] candidate chunks of 128 columns. */
+int strq_last_screen(const strq_ctx* ctx, double out[8]);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,8 @@ int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const Align
                          const int* n_list = nullptr, const float* min_score = nullptr, int* redo = nullptr, int* redo_count = nullptr,
                          unsigned int* redo_total = nullptr);
 float align_segment_min_score(const AlignParams& p, int m, int overlap_used);
+// columns a path that scores at least `score` can span (the overlap a cold-started piece needs to hold every such path)
+int align_overlap_for_score(const AlignParams& p, int m, float score);
 // phase 0 = forward, 1 = trace.  `queue`: one zero-initialised int per launch.
 // trace: task of alignment ti is tasks[pick[ti]] (pick may be null: identity), result slot is results[ti].
 // mode (forward only): bit 0 = strip has an input boundary, bit 1 = strip has an output boundary.

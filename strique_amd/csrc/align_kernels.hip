@@ -1127,6 +1127,19 @@ int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const Align
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+int align_overlap_for_score(const AlignParams& p, int m, float score)
+{
+    // align_segment_overlap with the bound B = score instead of 0; never more than the worst case
+    const int worst = align_segment_overlap(p, m);
+    if (worst <= 0 || !(score > 0.0f)) return worst;
+    const double c_h = -(double)(p.open_h > p.ext_h ? p.open_h : p.ext_h);
+    const double gain = (double)(p.dist_min > p.dist_offset ? p.dist_min : p.dist_offset);
+    double h = ((double)m * gain - (double)score + 1.0) / c_h;
+    if (h < 0) h = 0;
+    const double L = (double)m + h * 1.01 + 66.0;
+    return L + 1 < (double)worst ? (int)L + 1 : worst;
+}
+
 float align_segment_min_score(const AlignParams& p, int m, int overlap_used)
 {
     // inverse of align_segment_overlap for paths that score at least B: span <= m + (m * dist_offset - B) / c_h (+ 1 % + 64)

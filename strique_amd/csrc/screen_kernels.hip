@@ -1,0 +1,352 @@
+// Upper-bound screen of the flank alignment on gfx950 (MI355X).
+//
+// The reference aligns each flank against the WHOLE read (scripts/STRique.py:538-548 -> src/align_raw.h:106-158): 870 rows x
+// ~375 k columns x 2 flanks per 50 kb read, of which the optimal path crosses ~1 k columns.  This kernel does not replace that
+// DP -- align_kernels.hip still computes it, in float32, bit for bit -- it tells it where to look: a cheaper DP over the same
+// matrix whose last-row values are PROVEN upper bounds of the float32 ones, reported as one maximum per 128 columns.  The
+// host then runs the exact DP over the few column windows whose bound reaches the best bound minus the (known) slack of the
+// bound, and every other column is excluded by inequality, not by heuristic:
+//
+//   * scores are rounded UP to multiples of 1/sc (sc = 1024 for STRique's parameters and reads below ~1.9 M samples) and the
+//     DP runs in 32-bit integers.  A max-plus DP is monotone in its scores, and integer arithmetic does not round: the
+//     result bounds the real-arithmetic DP of the float32 table from above by less than m / sc (one rounding per diagonal
+//     step), and that one is within a few units of the float32 DP (`slack`);
+//   * collapsed recurrence (open == extend, as STRique configures): S = max(diag + s, left + e_h, up + e_v).  Stored is
+//     T = S + i |e_v| + j |e_h|: both gap terms vanish from the recurrence, T = max3(diag + s'', left, up) with
+//     s'' = s + |e_v| + |e_h| baked into the (16-bit) table -- one v_add_u32 and one max3 per cell where the float32
+//     kernel needs three adds and a max3.  The transformation is exact in integers; in float32 it would change roundings,
+//     which is why the exact kernel cannot use it;
+//   * rows below the flank (the rest of lane (m-1)/R) score 0 <= s'': with T monotone along rows and columns they copy the
+//     last flank row, so its value is read from the lane's LAST register whatever m is;
+//   * pieces of a read start cold like the exact kernel's (align_kernels.h): their values are exact (as bounds) wherever they
+//     reach the score the overlap was sized for, and below it otherwise -- the windows kernel only prunes above that score.
+//
+// (A first version ran both flanks of a read in the halves of 16-bit pairs -- v_pk_add_u16 / v_pk_max_u16, 141 instructions per
+// step for two alignments.  gfx950 issues the packed 16-bit integer instructions at half rate, like v_pk_add_f32: 96 ms per
+// 2048 reads where the float32 pass takes 130; tools/ubench_pk16.hip)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <cmath>
+#include "screen_kernels.h"
+
+namespace strq {
+
+namespace {
+
+constexpr int R = STRQ_SCREEN_R, S = STRQ_SCREEN_S, SEG = STRQ_SCREEN_SEG;
+constexpr int G = 2, C = 3;              // gcd(R, S); k-mer classes a lane can touch
+static_assert(R == 14 && S == 6, "class expansion below is written for 14 rows per lane, 6 samples per class");
+
+__device__ __forceinline__ int dpp_shr1(int v, int fill)      // lane l receives lane l - 1; lane 0 keeps `fill`
+{
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int med3i(int a, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(lo), "v"(hi));
+    return r;
+}
+// Maximum of three stored values.  They are integers in [STRQ_SCREEN_BIAS, 2^31 - 2^24): as bit patterns, positive NORMAL
+// float32 numbers, whose order is the order of the integers -- so this is v_max3_f32, which gfx950 issues at the full rate
+// (v_max3_i32 / v_max_u32 and the packed 16-bit instructions take about twice as long: tools/ubench_pk16.hip).
+#define STRQ_SCREEN_BIAS 0x00800000
+#ifndef STRQ_SCREEN_WPE
+#define STRQ_SCREEN_WPE 6          // waves per SIMD the kernel is compiled for (caps its registers): six tables of four waves per CU
+#endif
+__device__ __forceinline__ int max3i(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int sel_mask(int if0, int if1, uint64_t mask)      // wave-uniform lane mask in an SGPR pair
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+    return r;
+}
+
+struct LaneConst { int lo2[C], hi2[C], off[C]; };
+
+struct Screen {
+    const char* lds;
+    const LaneConst& lc;
+    const uint64_t (&pm)[3];
+    const int lane, n, hh;
+    int T[R], SbotA, upS, potB, cmax;
+    int qq;                            // levels (x2) of the two columns of the step about to run
+    int scA[C], scB[C];                // their class scores, fetched one step ahead
+
+    __device__ __forceinline__ void fetch(int q2, int (&sc)[C])
+    {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            sc[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(q2, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
+    }
+    __device__ __forceinline__ void advance(int qsrc, int snext, int& qn, int (&nA)[C], int (&nB)[C])
+    {
+        qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
+        fetch(qn & 0xffff, nA);
+        fetch((int)((unsigned)qn >> 16), nB);
+    }
+    __device__ __forceinline__ void prime(int qcur)
+    {
+        qq = 0;
+        int qn, nA[C], nB[C];
+        advance(qcur, 0, qn, nA, nB);
+        qq = qn;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
+    }
+    // rows of the lane <- class scores (row r of a lane with phase p belongs to class slot (p + r) / S)
+    __device__ __forceinline__ void expand(const int (&sc)[C], int (&rs)[R])
+    {
+#pragma unroll
+        for (int r = 0; r < R; r += G) {
+            const int base = r / S, x = (r % S) / G;
+            int v;
+            if (x == 0 || base + 1 >= C) v = sc[base < C ? base : C - 1];
+            else v = sel_mask(sc[base], sc[base + 1], pm[x]);
+#pragma unroll
+            for (int g = 0; g < G && r + g < R; ++g) rs[r + g] = v;
+        }
+    }
+
+    template <bool PRED>
+    __device__ __forceinline__ void step(int t, int qsrc, int snext)
+    {
+        int qn, nA[C], nB[C];
+        advance(qsrc, snext, qn, nA, nB);
+        // potentials j |e_h| of this step's two columns: what the free top row holds there
+        const int potA = potB + hh, potBn = potA + hh;
+        // the row above the lane: lane - 1's bottom cells (lane 0: the top row)
+        const int upA = dpp_shr1(SbotA, potA);
+        const int upB = dpp_shr1(T[R - 1], potBn);
+        bool act = true, okB = true;
+        if constexpr (PRED) { const int jB = 2 * (t - lane), jA = jB - 1; act = (jA >= 1) && (jA <= n); okB = jB <= n; }
+        if (act) {
+            int rsA[R], rsB[R];
+            expand(scA, rsA);
+            expand(scB, rsB);
+            int TA[R], TB[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                {
+                    const int diag = r == 0 ? upS : T[r - 1];
+                    const int up = r == 0 ? upA : TA[r > 0 ? r - 1 : 0];
+                    TA[r] = max3i(diag + rsA[r], T[r], up);
+                }
+                {
+                    const int diag = r == 0 ? upA : TA[r > 0 ? r - 1 : 0];
+                    const int up = r == 0 ? upB : TB[r > 0 ? r - 1 : 0];
+                    TB[r] = max3i(diag + rsB[r], TA[r], up);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) T[r] = TB[r];
+            SbotA = TA[R - 1];
+            upS = upB;
+            // last row (this lane's last register, see the header) minus the column potential: S[m][j] * sc + m |e_v| (+ bias)
+            const int cA = TA[R - 1] - potA + STRQ_SCREEN_BIAS, cB = okB ? TB[R - 1] - potBn + STRQ_SCREEN_BIAS : cA;
+            cmax = max3i(cmax, cA, cB);
+        }
+        potB = potBn;
+        qq = qn;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
+    }
+};
+
+__device__ __forceinline__ int load_chunk(const ScreenTask& tk, int chunk, int lane)
+{
+    const int idx = (chunk * 64 + lane) * 2;
+    int a = 0, b = 0;
+    if (idx < tk.n) a = tk.levels[idx];
+    if (idx + 1 < tk.n) b = tk.levels[idx + 1];
+    return (a * 2) | ((b * 2) << 16);
+}
+
+}  // namespace
+
+size_t screen_lds_bytes(int tsize)
+{
+    // the table as 16-bit entries, padded to a dword, and one zero entry (the rows below the flank)
+    return (size_t)((tsize + 1) & ~1) * 2 + 4;
+}
+
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(STRQ_SCREEN_WPE, STRQ_SCREEN_WPE)))
+align_screen_kernel(const ScreenTask* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp)
+{
+    extern __shared__ uint32_t lds_all[];
+    __shared__ int next_group;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char* ldsb = reinterpret_cast<const char*>(lds_all);
+    for (;;) {
+        __syncthreads();                       // every wave is done with the previous table
+        if (threadIdx.x == 0) next_group = atomicAdd(queue, 1);
+        __syncthreads();
+        const int gi = __builtin_amdgcn_readfirstlane(next_group);
+        if (gi >= n_groups) break;
+        const ScreenTask& t0 = tasks[(size_t)gi * SEG];
+        const int ts = t0.tsize, zero_idx = (ts + 1) & ~1;      // in 16-bit entries
+        {
+            // ceil(s * sc) + cadd, as 16-bit entries (s * sc is exact: sc is a power of two; the table holds 0 <= s <= dist_offset)
+            uint16_t* dst = reinterpret_cast<uint16_t*>(lds_all);
+            const float scf = (float)sp.sc;
+            for (int i = threadIdx.x; i < ts; i += 64 * SEG) dst[i] = (uint16_t)((int)ceilf(t0.table[i] * scf) + sp.cadd);
+            if (threadIdx.x == 0) { dst[zero_idx] = 0; dst[zero_idx + 1] = 0; }
+        }
+        __syncthreads();
+        const ScreenTask& tk = tasks[(size_t)gi * SEG + wave];
+        if (tk.n <= 0) continue;               // unused piece of a short read (wave-uniform)
+
+        LaneConst lc; uint64_t pm[3];
+        {
+            const int row0 = lane * R, kbase = row0 / S, phase = row0 % S;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int k = kbase + c;
+                if (k < tk.k) {
+                    const uint32_t d = (uint32_t)tk.band_lo[k];
+                    const int lo = (int)(d & 255u), w1 = (int)((d >> 8) & 255u), off = (int)(d >> 16);
+                    lc.lo2[c] = lo * 2; lc.hi2[c] = (lo + w1) * 2;
+                    lc.off[c] = (off - lo) * 2;
+                } else {      // below the flank: the zero entry
+                    lc.lo2[c] = 0; lc.hi2[c] = 0; lc.off[c] = zero_idx * 2;
+                }
+            }
+            pm[0] = 0;
+#pragma unroll
+            for (int x = 1; x < 3; ++x) {
+                const uint64_t b = __ballot(phase >= S - x * G);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+                pm[x] = ((uint64_t)hi << 32) | lo;
+            }
+        }
+        const int lM = (tk.m - 1) / R;
+        Screen f{ldsb, lc, pm, lane, tk.n, sp.hh};
+        {
+            // column 0 (cold start): S[i][0] = i * e_v, i.e. T = 0 (+ bias) in every row; the top row holds the column potential
+#pragma unroll
+            for (int r = 0; r < R; ++r) f.T[r] = STRQ_SCREEN_BIAS;
+            f.SbotA = STRQ_SCREEN_BIAS; f.upS = STRQ_SCREEN_BIAS;
+            f.potB = STRQ_SCREEN_BIAS - 2 * lane * sp.hh;       // the lane's column jB = 2 (t - lane) at t = 0 (used once j >= 1)
+            f.cmax = STRQ_SCREEN_BIAS;
+        }
+        const int nsteps = (tk.n + 1) / 2 + 63;
+        int qcur = load_chunk(tk, 0, lane);
+        f.prime(qcur);
+        for (int t0s = 0; t0s < nsteps; t0s += 64) {
+            const int qnext = load_chunk(tk, t0s / 64 + 1, lane);
+            const bool full = (t0s >= 63) && (2 * (t0s + 64) <= tk.n);
+            const int send = nsteps - t0s < 64 ? nsteps - t0s : 64;
+            if (full) {
+                for (int s = 0; s < 63; ++s) f.template step<false>(t0s + s + 1, qcur, s + 1);
+                f.template step<false>(t0s + 64, qnext, 0);
+            } else {
+                for (int s = 0; s < send; ++s) {
+                    const int qsrc = s == 63 ? qnext : qcur, snext = (s + 1) & 63;
+                    f.template step<true>(t0s + s + 1, qsrc, snext);
+                }
+            }
+            // the chunk's maximum of the last row (lane lM)
+            const int cm = __builtin_amdgcn_readlane(f.cmax, lM) - STRQ_SCREEN_BIAS;
+            if (lane == 0) tk.out[t0s / 64] = cm;
+            f.cmax = STRQ_SCREEN_BIAS;
+            qcur = qnext;
+        }
+    }
+}
+
+// Candidate windows of every alignment.
+// A chunk's value v bounds the float32 last-row values S of its columns: S * sc <= max(v', bound) + slack, v' = v - m * v_gap
+// (bound: the cold-start score of the pieces).  The best chunk value vmax is reached by a real path whose float32 score is at
+// least (vmax' - m) / sc - slack / sc.  Columns of chunks with max(v', bound) + slack < vmax' - m - slack cannot hold the optimum.
+__global__ void screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, ScreenParams sp,
+                                      const int32_t* __restrict__ bound_scaled, ScreenWindows* __restrict__ out)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const ScreenTask* tg = tasks + (size_t)g * SEG;
+    const int m = tg[0].m, lM = (m - 1) / R;
+    const int shift = -m * sp.v;            // v' = v + shift
+    int vmax = 0;
+    for (int w = 0; w < SEG; ++w) {
+        if (tg[w].n <= 0) continue;
+        for (int c = 0; c < tg[w].n_chunks; ++c) { const int v = tg[w].out[c]; vmax = v > vmax ? v : vmax; }
+    }
+    ScreenWindows r;
+    r.n_win = 0; r.n_cand = 0;
+    for (int k = 0; k < STRQ_SCREEN_MAX_WINDOWS; ++k) { r.lo[k] = 0; r.hi[k] = 0; }
+    const int theta = vmax - m - 2 * sp.slack;             // in chunk units (before the shift)
+    r.lower_bound = (float)(vmax + shift - m - sp.slack) / (float)sp.sc;
+    r.upper_bound = (float)(vmax + shift + sp.slack) / (float)sp.sc;
+    // prune only above the cold-start bound of the pieces, and only when the lower bound is a score worth the name
+    bool ok = theta + shift > 0 && theta + shift > bound_scaled[g];
+    if (ok) {
+        int nw = 0;
+        for (int w = 0; w < SEG && ok; ++w) {
+            if (tg[w].n <= 0) continue;
+            for (int c = 0; c < tg[w].n_chunks; ++c) {
+                if (tg[w].out[c] < theta) continue;
+                ++r.n_cand;
+                // columns of the chunk (lane lM, steps 64 c + 1 .. 64 c + 64), in read coordinates
+                int lo = 128 * c - 2 * lM + 1, hi = 128 * c - 2 * lM + 128;
+                if (lo < 1) lo = 1;
+                if (hi > tg[w].n) hi = tg[w].n;
+                if (hi < lo) continue;
+                lo += tg[w].col_off; hi += tg[w].col_off;
+                // pieces and chunks come in ascending column order, the overlap zones of a piece repeat columns of the one before
+                if (nw > 0 && lo <= r.hi[nw - 1] + sp.merge_gap) {
+                    if (hi > r.hi[nw - 1]) r.hi[nw - 1] = hi;
+                    if (lo < r.lo[nw - 1]) r.lo[nw - 1] = lo;
+                } else if (nw < STRQ_SCREEN_MAX_WINDOWS) {
+                    r.lo[nw] = lo; r.hi[nw] = hi; ++nw;
+                } else { ok = false; break; }
+            }
+        }
+        r.n_win = ok ? nw : 0;
+    }
+    out[g] = r;
+}
+
+int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
+{
+    if (getenv("STRQ_NO_SCREEN")) return 0;
+    if (samples != S) return 0;
+    if (!(p.open_h == p.ext_h && p.open_v == p.ext_v)) return 0;
+    if (!(p.dist_min >= 0.0f) || !(p.ext_h < 0.0f) || !(p.ext_v < 0.0f) || !(p.dist_offset > 0.0f) || !(p.dist_min <= p.dist_offset)) return 0;
+    // largest power-of-two scale at which T = S + i |e_v| + j |e_h| stays below 2^31 and a table entry below 2^16
+    for (int sc = 1024; sc >= 16; sc >>= 1) {
+        const double hh = -(double)p.ext_h * sc, v = -(double)p.ext_v * sc, smax = std::ceil((double)p.dist_offset * sc);
+        if (hh != (double)(long)hh || v != (double)(long)v) continue;
+        if (hh < 1 || smax + v + hh > 65000.0) continue;
+        const double top = 64.0 * R * (smax + v) + ((double)max_n + 256.0) * hh + smax + v + hh + (double)STRQ_SCREEN_BIAS;
+        if (top > 2.0e9) continue;          // below 0x7f800000: every stored value is the bit pattern of a finite float32
+        sp->sc = sc; sp->hh = (int)hh; sp->v = (int)v; sp->cadd = (int)(hh + v);
+        sp->slack = 32 * sc; sp->merge_gap = 3072;
+        return 1;
+    }
+    return 0;
+}
+
+int launch_screen(hipStream_t stream, const ScreenTask* tasks, int n_groups, int* queue, const ScreenParams& sp,
+                  size_t lds_bytes, int tables_per_cu, int n_cu)
+{
+    if (n_groups <= 0) return 0;
+    (void)hipFuncSetAttribute((const void*)align_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(align_screen_kernel, dim3(tables_per_cu * n_cu), dim3(64 * SEG), lds_bytes, stream, tasks, n_groups, queue, sp);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_screen_windows(hipStream_t stream, const ScreenTask* tasks, int n_groups, const ScreenParams& sp,
+                          const int32_t* bound_scaled, ScreenWindows* out)
+{
+    if (n_groups <= 0) return 0;
+    hipLaunchKernelGGL(screen_windows_kernel, dim3((n_groups + 127) / 128), dim3(128), 0, stream, tasks, n_groups, sp, bound_scaled, out);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+}  // namespace strq

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <climits>
 #include <cstring>
 #include <cstdlib>
 #include <time.h>
@@ -240,6 +241,129 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         return t;
     };
     auto packed_dwords = [](int entries) { return (((2 * entries + 3) & ~3) + entries + 3) / 4; };
+    struct Piece { int col_off, n; size_t ck; };
+    auto cut = [](int n, int segs, int ov, Piece* out) {     // returns the number of pieces used
+        int use = segs;
+        while (use > 1 && (ov <= 0 || (long)n < (long)(use + 1) * ov)) --use;      // every piece owns >= `overlap` columns
+        const long len = use > 1 ? ((long)n + (long)(use - 1) * ov + use - 1) / use : n;      // columns each piece computes
+        long o = 0;                                                                        // columns owned so far
+        for (int k = 0; k < segs; ++k) {
+            if (k >= use) { out[k].col_off = 0; out[k].n = 0; continue; }
+            const long start = k == 0 ? 0 : o - ov;
+            long end = k == use - 1 ? n : start + len; if (end > n) end = n;
+            out[k].col_off = (int)start; out[k].n = (int)(end - start);
+            o = end;
+        }
+        return use;
+    };
+
+    // ---- upper-bound screen (screen_kernels.hip): where in the read the exact DP has to look.
+    // Result per alignment: up to four column windows and a lower bound of its best score -- or nothing, then the whole read runs.
+    std::vector<ScreenWindows> wins(nb);
+    for (auto& w : wins) { w.n_win = 0; w.lower_bound = 0; }
+    c->screen_ran = false;
+    STRQ_HIP(c, hipEventRecord(c->ev[2], st));          // the forward time of the sub-batch includes the screen
+    ScreenParams sp;
+    int scr_max_n = 0;
+    for (int i = 0; i < nb; ++i) scr_max_n = std::max(scr_max_n, in.n[i]);
+    const bool scr_forced = getenv("STRQ_SCREEN_ALWAYS") != nullptr;      // tests: no pause
+    if (collapsed && c->screen_pause > 0 && !scr_forced) {
+        --c->screen_pause; c->screen_stats[3] += nb;      // counted as whole-read alignments
+    } else if (collapsed && screen_plan(c->ap, S, scr_max_n, &sp)) {
+        // reads below ~64 k samples: the pieces' overlaps eat what the cheaper pass saves (STRQ_SCREEN_MIN_N: tests)
+        int min_n = 65536, scr_tables = 6;
+        if (const char* e = getenv("STRQ_SCREEN_MIN_N")) min_n = atoi(e);
+        if (const char* e = getenv("STRQ_SCREEN_TABLES")) { const int v = atoi(e); if (v >= 1 && v <= 8) scr_tables = v; }
+        std::vector<int> sel;
+        for (int i = 0; i < nb; ++i)
+            if (in.NS[i] == 1 && NJ[i] == 1 && in.n[i] >= min_n && screen_flank_ok(in.m[i]) && in.k[i] * S == in.m[i]) sel.push_back(i);
+        std::stable_sort(sel.begin(), sel.end(), [&](int x, int y) { return in.n[x] > in.n[y]; });
+        const int ng = (int)sel.size();
+        if (ng > 0) {
+            constexpr int SSEG = STRQ_SCREEN_SEG;
+            std::vector<ScreenTask> stasks((size_t)ng * SSEG);
+            std::vector<int32_t> bound((size_t)ng);
+            size_t out_words = 0, lds_bytes = 0; double steps = 0;
+            for (int g = 0; g < ng; ++g) {
+                const int a = sel[g], n = in.n[a], m = in.m[a];
+                const int ov_worst = align_segment_overlap(c->ap, m), ov_s = overlap_for(m, ov_worst);
+                Piece pc[SSEG];
+                const int used = cut(n, SSEG, ov_s, pc);
+                // what the cold start of the pieces costs: below this score a piece's values are not bounds of the whole matrix
+                bound[g] = used <= 1 ? INT32_MIN / 2 : (ov_s >= ov_worst ? 0 : (int32_t)std::ceil((double)align_segment_min_score(c->ap, m, ov_s) * sp.sc));
+                lds_bytes = std::max(lds_bytes, screen_lds_bytes(info[J0[a]].total));
+                for (int w = 0; w < SSEG; ++w) {
+                    ScreenTask t; std::memset(&t, 0, sizeof(t));
+                    t.levels = in.d_levels + in.read_off[in.read[a]] + pc[w].col_off;
+                    t.table = jobs[J0[a]].table; t.band_lo = jobs[J0[a]].band_lo; t.tsize = info[J0[a]].total;
+                    t.n = pc[w].n; t.m = m; t.k = in.k[a]; t.col_off = pc[w].col_off;
+                    t.n_chunks = pc[w].n > 0 ? (align_num_steps(pc[w].n) + 63) / 64 : 0;
+                    t.out = reinterpret_cast<int32_t*>(out_words);      // offset for now
+                    out_words += (size_t)t.n_chunks;
+                    if (pc[w].n > 0) steps += align_num_steps(pc[w].n);
+                    stasks[(size_t)g * SSEG + w] = t;
+                }
+            }
+            if (lds_bytes > 160 * 1024 - 64) { c->err = "score table does not fit LDS (screen)"; return STRQ_ERR_UNSUPPORTED; }
+            scr_tables = std::max(1, std::min(scr_tables, (int)((160 * 1024 - 64) / lds_bytes)));
+            const size_t task_bytes = (stasks.size() * sizeof(ScreenTask) + 255) & ~(size_t)255;
+            const size_t bound_bytes = ((size_t)ng * 4 + 255) & ~(size_t)255, win_bytes = ((size_t)ng * sizeof(ScreenWindows) + 255) & ~(size_t)255;
+            STRQ_HIP(c, c->screen.reserve(task_bytes + bound_bytes + win_bytes + out_words * 4 + 256));
+            char* base = c->screen.as<char>();
+            ScreenTask* d_st = reinterpret_cast<ScreenTask*>(base);
+            int32_t* d_bound = reinterpret_cast<int32_t*>(base + task_bytes);
+            ScreenWindows* d_win = reinterpret_cast<ScreenWindows*>(base + task_bytes + bound_bytes);
+            int32_t* d_out = reinterpret_cast<int32_t*>(base + task_bytes + bound_bytes + win_bytes);
+            for (auto& t : stasks) t.out = d_out + reinterpret_cast<size_t>(t.out);
+            STRQ_HIP(c, hipMemcpyAsync(d_st, stasks.data(), stasks.size() * sizeof(ScreenTask), hipMemcpyHostToDevice, st));
+            STRQ_HIP(c, hipMemcpyAsync(d_bound, bound.data(), (size_t)ng * 4, hipMemcpyHostToDevice, st));
+            STRQ_HIP(c, hipEventRecord(c->ev[5], st));
+            if (launch_screen(st, d_st, ng, c->queue.as<int>() + STRQ_QUEUE_FIRST - 1, sp, lds_bytes, scr_tables, c->n_cu)) { c->err = "screen launch failed"; return STRQ_ERR_DEVICE; }
+            STRQ_HIP(c, hipEventRecord(c->ev[6], st));
+            if (launch_screen_windows(st, d_st, ng, sp, d_bound, d_win)) { c->err = "screen windows launch failed"; return STRQ_ERR_DEVICE; }
+            std::vector<ScreenWindows> hw((size_t)ng);
+            STRQ_HIP(c, hipMemcpyAsync(hw.data(), d_win, hw.size() * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
+            STRQ_HIP(c, hipStreamSynchronize(st));
+            c->screen_ran = true;
+            if (const char* path = getenv("STRQ_SCREEN_DUMP")) {
+                // tests: the chunk maxima as the kernel wrote them (tests/test_gpu_screen.py checks them against the exact last row)
+                std::vector<int32_t> ho(out_words);
+                STRQ_HIP(c, hipMemcpy(ho.data(), d_out, out_words * 4, hipMemcpyDeviceToHost));
+                if (FILE* fp = fopen(path, "wb")) {
+                    const int32_t hdr[8] = {ng, sp.sc, sp.hh, sp.v, 0, SSEG, sp.slack, 0};
+                    fwrite(hdr, 4, 8, fp);
+                    for (int g = 0; g < ng; ++g) {
+                        const int32_t gh[4] = {sel[g], sel[g], bound[g], 0};
+                        fwrite(gh, 4, 4, fp);
+                        for (int w = 0; w < SSEG; ++w) {
+                            const ScreenTask& t = stasks[(size_t)g * SSEG + w];
+                            const int32_t th[4] = {t.col_off, t.n, t.m, t.n_chunks};
+                            fwrite(th, 4, 4, fp);
+                            fwrite(ho.data() + (t.out - d_out), 4, (size_t)t.n_chunks, fp);
+                        }
+                        fwrite(&hw[(size_t)g], sizeof(ScreenWindows), 1, fp);
+                    }
+                    fclose(fp);
+                }
+            }
+            const bool no_prune = getenv("STRQ_SCREEN_NO_PRUNE") != nullptr;      // tests: run the screen, then the whole reads
+            for (int g = 0; g < ng; ++g) {
+                const ScreenWindows& w = hw[(size_t)g];
+                c->screen_stats[1] += 1; c->screen_stats[7] += w.n_cand;
+                if (w.n_win > 0 && !no_prune) {
+                    wins[sel[g]] = w; c->screen_stats[2] += 1;
+                    for (int k = 0; k < w.n_win; ++k) c->screen_stats[4] += w.hi[k] - w.lo[k] + 1;
+                } else c->screen_stats[3] += 1;
+            }
+            c->screen_stats[5] += steps; c->screen_stats[6] = sp.sc;
+            {
+                int windowed = 0;
+                for (int g = 0; g < ng; ++g) windowed += wins[sel[g]].n_win > 0;
+                if (ng >= 64 && windowed < 0.9 * ng && !no_prune) c->screen_pause = 8;
+            }
+            STRQ_DBG("screen: %d alignments, scale %d, %d tables per CU, LDS %zu bytes; windows for %.0f of %.0f alignments so far", ng, sp.sc, scr_tables, lds_bytes, c->screen_stats[2], c->screen_stats[1]);
+        }
+    }
     std::vector<char> packed(nb, 0), segmentable(nb, 0);
     std::vector<int> overlap(nb, 0), segs_of(nb, 1);
     const bool force_pack = getenv("STRQ_PACK") != nullptr;
@@ -262,6 +386,11 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 }
             }
         }
+        if (wins[i].n_win > 0) {
+            // one piece per window (compiled piece counts: 1, 2, 4; 3 with STRQ_SEG=3), float32 tables
+            const int w = wins[i].n_win;
+            best_s = seg_want >= w ? seg_want : (w <= 2 ? w : 4); best_p = 0;
+        }
         segs_of[i] = best_s; packed[i] = (char)best_p;
         ++class_count[best_s];
     }
@@ -269,8 +398,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         // a length class too small to fill the chip once joins the class with fewer waves per alignment
         int few = 2 * c->n_cu;
         if (const char* e = getenv("STRQ_CLASS_MIN")) few = atoi(e);      // tests: keep small length classes apart
-        if (class_count[4] && class_count[4] < few) { for (int i = 0; i < nb; ++i) if (segs_of[i] == 4) segs_of[i] = 2; class_count[2] += class_count[4]; class_count[4] = 0; }
-        if (class_count[2] && class_count[2] < few && class_count[1]) { for (int i = 0; i < nb; ++i) if (segs_of[i] == 2) segs_of[i] = 1; class_count[1] += class_count[2]; class_count[2] = 0; }
+        // (an alignment with more windows than its new launch has pieces runs its whole read instead)
+        if (class_count[4] && class_count[4] < few) { for (int i = 0; i < nb; ++i) if (segs_of[i] == 4) { segs_of[i] = 2; if (wins[i].n_win > 2) wins[i].n_win = 0; } class_count[2] += class_count[4]; class_count[4] = 0; }
+        if (class_count[2] && class_count[2] < few && class_count[1]) { for (int i = 0; i < nb; ++i) if (segs_of[i] == 2) { segs_of[i] = 1; if (wins[i].n_win > 1) wins[i].n_win = 0; } class_count[1] += class_count[2]; class_count[2] = 0; }
     }
     // key: rows per lane, strips, waves per alignment (descending), -tables per CU, 0 = packed / 1 = float32 (packed first among equals)
     std::map<std::tuple<int, int, int, int, int>, std::vector<int>> groups;
@@ -304,7 +434,13 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     int n_up = 0; size_t n_tasks = 0;
     for (auto& g : groups) {
         auto& v = g.second;
-        std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return in.n[x] > in.n[y]; });
+        auto work = [&](int x) {      // columns the forward pass of the alignment computes, roughly
+            if (wins[x].n_win <= 0) return (long)in.n[x];
+            long w = 0;
+            for (int k = 0; k < wins[x].n_win; ++k) w += wins[x].hi[k] - wins[x].lo[k] + 1 + 4096;
+            return w;
+        };
+        std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return work(x) > work(y); });
         const int NS = std::get<1>(g.first);
         const int pk = std::get<4>(g.first) == 0;
         int lds_floats = 0;      // LDS slice of a table in dwords
@@ -328,27 +464,12 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // reaches align_segment_min_score -- true for every read that contains the flank; the combine kernel
     // lists the alignments that do not, and those run a second time with the worst-case overlap (`safe`
     // pieces, same checkpoint areas).  Task array: [fast pieces | upper strips | heads | safe pieces].
-    struct Piece { int col_off, n; size_t ck; };
     const size_t safe0 = n_tasks + n_up + (size_t)nb;
     std::vector<Piece> pieces(n_tasks), safe(n_tasks);
     std::vector<float> min_score(nb, -INFINITY);            // by alignment position
     std::vector<char> two_round(launches.size(), 0);
     std::vector<size_t> ck_up(nb, 0);
     size_t ck_floats = 0;
-    auto cut = [](int n, int segs, int ov, Piece* out) {     // returns the number of pieces used
-        int use = segs;
-        while (use > 1 && (ov <= 0 || (long)n < (long)(use + 1) * ov)) --use;      // every piece owns >= `overlap` columns
-        const long len = use > 1 ? ((long)n + (long)(use - 1) * ov + use - 1) / use : n;      // columns each piece computes
-        long o = 0;                                                                        // columns owned so far
-        for (int k = 0; k < segs; ++k) {
-            if (k >= use) { out[k].col_off = 0; out[k].n = 0; continue; }
-            const long start = k == 0 ? 0 : o - ov;
-            long end = k == use - 1 ? n : start + len; if (end > n) end = n;
-            out[k].col_off = (int)start; out[k].n = (int)(end - start);
-            o = end;
-        }
-        return use;
-    };
     for (size_t li = 0; li < launches.size(); ++li) {
         auto& L = launches[li];
         for (int x = 0; x < L.count; ++x) {
@@ -359,7 +480,20 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             Piece* ps = &safe[(size_t)L.first_task + (size_t)x * L.segs];
             cut(n, L.segs, ov, ps);
             const int ov_fast = overlap_for(in.m[i], ov);
-            if (L.segs > 1 && ov_fast < ov && cut(n, L.segs, ov_fast, pf) > 1) {
+            if (wins[i].n_win > 0) {
+                // the screen's windows, each started cold as far to the left as a path with the screen's lower bound can reach.
+                // Certified like the short overlaps: the best score found must reach that lower bound -- then every column
+                // outside the windows is excluded by its upper bound and every path that matters lies inside a piece;
+                // an alignment that does not reach it runs its whole read in the second round.
+                const ScreenWindows& w = wins[i];
+                const int ov_w = std::min(ov > 0 ? ov : (1 << 30), align_overlap_for_score(c->ap, in.m[i], w.lower_bound));
+                for (int k = 0; k < L.segs; ++k) {
+                    if (k < w.n_win) { const int start = std::max(0, w.lo[k] - 1 - ov_w); pf[k].col_off = start; pf[k].n = w.hi[k] - start; }
+                    else { pf[k].col_off = 0; pf[k].n = 0; }
+                }
+                min_score[pos] = std::max(w.lower_bound, align_segment_min_score(c->ap, in.m[i], ov_w));
+                two_round[li] = 1;
+            } else if (L.segs > 1 && ov_fast < ov && cut(n, L.segs, ov_fast, pf) > 1) {
                 min_score[pos] = align_segment_min_score(c->ap, in.m[i], ov_fast);
                 two_round[li] = 1;
             } else {
@@ -451,7 +585,6 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     const int trace_wpb = 8;
     STRQ_HIP(c, c->scratch.reserve(scratch_words * 8 * (size_t)c->n_cu * trace_wpb));
     int qi = STRQ_QUEUE_FIRST;
-    STRQ_HIP(c, hipEventRecord(c->ev[2], st));
     out.n_launches = 0; out.wave_steps = 0; out.columns = 0;
     for (size_t t = 0; t < n_tasks + n_up; ++t) if (tasks[t].n > 0) { out.wave_steps += align_num_steps(tasks[t].n); out.columns += tasks[t].n; }
     if (!launches.empty()) {
@@ -521,6 +654,7 @@ int align_core_times(strq_ctx* c, float* t_lut, float* t_fwd, float* t_tr)
     STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); *t_lut += ms;
     STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); *t_fwd += ms;
     STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); *t_tr += ms;
+    if (c->screen_ran) { STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[5], c->ev[6])); c->screen_stats[0] += ms; }
     return STRQ_OK;
 }
 
@@ -551,6 +685,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
     const int S = align_effective_samples(in.samples);
     const int64_t NA = in.n_align;
     std::fill(c->timing, c->timing + 8, 0.0f);
+    for (double& v : c->screen_stats) v = 0;
     if (NA == 0) return STRQ_OK;
     std::vector<int> m(NA), k(NA), R(NA), n(NA), NS(NA);
     for (int64_t a = 0; a < NA; ++a) {
@@ -615,7 +750,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 
 extern "C" {
 
-int strq_abi_version(void) { return 9; }
+int strq_abi_version(void) { return 10; }
 
 int strq_ctx_create(int device_id, strq_ctx** out)
 {
@@ -643,7 +778,7 @@ void strq_ctx_destroy(strq_ctx* c)
     detect_state_free(c);
     for (DevBuf* b : {&c->levels, &c->level_val, &c->flank_cls, &c->tables, &c->tables3, &c->band_lo, &c->col0, &c->ckpt,
                       &c->rec, &c->tasks, &c->results, &c->queue, &c->scratch, &c->lutinfo, &c->hard, &c->misc,
-                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd, &c->gen_codes, &c->gen_table, &c->gen_bnd, &c->gen_trace, &c->gen_hard, &c->redo_total})
+                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd, &c->gen_codes, &c->gen_table, &c->gen_bnd, &c->gen_trace, &c->gen_hard, &c->redo_total, &c->screen})
         b->release();
     for (HostModel* m : c->models) if (m) { m->blob.release(); delete m; }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -686,6 +821,13 @@ int strq_last_counters(const strq_ctx* c, double out[8])
 {
     if (!c || !out) return STRQ_ERR_ARG;
     std::memcpy(out, c->counters, sizeof(c->counters));
+    return STRQ_OK;
+}
+
+int strq_last_screen(const strq_ctx* c, double out[8])
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    for (int i = 0; i < 8; ++i) out[i] = c->screen_stats[i];
     return STRQ_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include "align_kernels.h"
 #include "viterbi_kernels.h"
+#include "screen_kernels.h"
 
 namespace strq {
 
@@ -82,10 +83,16 @@ struct strq_ctx {
     int32_t vit_launches[4] = {};             // strq_last_viterbi_launches
     int64_t second_round[2] = {};             // strq_last_second_round: alignments that ran the second forward round / alignments, last batched call
     strq::DevBuf redo_total;                  // device counter behind second_round[0]
+    double screen_stats[8] = {};              // strq_last_screen
+    bool screen_ran = false;                  // the last align_core call ran the screen (events 5, 6 bracket it)
+    // The screen pays when nearly every alignment gets windows (a read that holds its flank clearly) and costs a pass when not:
+    // a sub-batch in which fewer than 90 % did pauses it for the next eight sub-batches of this context, then it is tried again.
+    int screen_pause = 0;
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd,
-        gen_codes, gen_table, gen_bnd, gen_trace, gen_hard;      // generic align_overlap path
+        gen_codes, gen_table, gen_bnd, gen_trace, gen_hard,      // generic align_overlap path
+        screen;                                                   // upper-bound screen: tasks, chunk maxima, windows
     std::vector<strq::HostModel*> models;
     void* detect = nullptr;                   // DetectState (strq_detect_api.hip)
     size_t max_ws_bytes = (size_t)96 << 30;   // cap for checkpoint workspace per sub-batch

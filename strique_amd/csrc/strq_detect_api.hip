@@ -726,6 +726,7 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
     std::fill(c->counters, c->counters + 8, 0.0);
     c->second_round[0] = c->second_round[1] = 0;
+    for (double& v : c->screen_stats) v = 0;
     STRQ_HIP(c, c->redo_total.reserve(64));
     STRQ_HIP(c, hipMemsetAsync(c->redo_total.p, 0, 64, c->stream));
     // partition into sub-batches first, so that the upload of piece k + 1 can overlap the kernels of piece k

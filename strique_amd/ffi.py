@@ -195,6 +195,13 @@ class Context(object):
         self._check(self._lib.strq_last_second_round(self._h, _ptr(g)))
         return int(g[0]), int(g[1])
 
+    def last_screen(self):
+        """strq_last_screen as a dict: what the upper-bound screen of the last batched call did."""
+        g = np.zeros(8, np.float64)
+        self._check(self._lib.strq_last_screen(self._h, _ptr(g)))
+        keys = ("ms", "screened", "windowed", "whole_read", "window_columns", "wave_steps", "scale", "candidate_chunks")
+        return dict(zip(keys, (float(v) for v in g)))
+
     def last_geometry(self):
         """strq_last_geometry as a dict: which forward-DP kernel instance the last batched call ran."""
         g = np.zeros(8, np.int32)

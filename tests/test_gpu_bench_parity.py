@@ -29,8 +29,27 @@ def _bench_batch(pm, cfg, n, first):
     return bench.make_batch(pm, cfg, n, 50000, first)
 
 
+def test_benchmarked_reads_through_the_screen_all_fields(pm, cfg, targets):
+    """bench.py's own reads on the path its default line runs: the upper-bound screen over the whole reads, the float32 DP over
+    the windows it leaves (one wave per window).  Every field of every row equals the oracle's."""
+    sigs, strands, nreps = _bench_batch(pm, cfg, 40, 0)
+    rc = _fresh_counter(pm, cfg, targets)
+    got = rc.detect_batch([("c9orf72", s, st) for s, st in zip(sigs, strands)])
+    scr = rc.ctx.last_screen(); geo = rc.ctx.last_geometry(); redo = rc.ctx.last_second_round()
+    rc.ctx.close()
+    assert scr["screened"] == 80 and scr["windowed"] == 80 and scr["scale"] == 1024, scr
+    assert scr["window_columns"] < 0.02 * sum(2 * len(s) for s in sigs), scr
+    assert geo["waves_per_alignment"] == 1 and redo[0] == 0, (geo, redo)
+    target = targets["c9orf72"]
+    want = oracle_pool.detect_many([(s, st, target) for s, st in zip(sigs, strands)])
+    for i, (w, a) in enumerate(zip(want, got)):
+        assert tuple(a[:6]) == tuple(w[:6]), (i, a, w)
+        assert abs(a[0] - nreps[i]) <= 2
+
+
 def test_benchmarked_kernel_instance_all_fields(pm, cfg, targets, monkeypatch):
     monkeypatch.setenv("STRQ_CLASS_MIN", "1")          # 64 alignments do not fill the chip: keep them on four waves per alignment anyway
+    monkeypatch.setenv("STRQ_NO_SCREEN", "1")          # the float32 pass over whole reads (what runs when the screen is paused or cannot prune)
     sigs1, strands1, nreps1 = _bench_batch(pm, cfg, 32, 0)          # bench.py's rank-0 batch, reads 0..31
     sigs2, strands2, nreps2 = _bench_batch(pm, cfg, 16, 4096)       # reads of another step's batch
     assert set(strands1) == {"+", "-"} and set(nreps1) == {200, 500, 1000, 1500, 2000}
@@ -128,16 +147,26 @@ def test_bench_four_and_eight_ranks_on_one_gpu(world, tmp_path, pm, cfg):
                 assert (g[0], g[1], g[2], g[3], g[4], g[5]) == (int(t["count"]), float(t["score_prefix"]), float(t["score_suffix"]), float(t["log_p"]), int(t["offset"]), int(t["ticks"]))
 
 
-def test_bench_line_single_gpu_small():
+@pytest.mark.parametrize("screen", [True, False])
+def test_bench_line_single_gpu_small(screen, monkeypatch):
     """The default single-GPU line at a reduced batch (512 reads so that four waves per alignment is what runs):
     roofline + host leg present, three distinct batches rotated, rows of the host-buffer leg equal the resident
-    run's, the spot check covers all six fields on reads of different batches."""
+    run's, the spot check covers all six fields on reads of different batches.  With the upper-bound screen (the default) the
+    line's roofline is the screen kernel's and the float32 kernel's figures sit under `exact_pass`; without, as in round 3."""
+    if not screen:
+        monkeypatch.setenv("STRQ_NO_SCREEN", "1")
     lines, recs = _run_bench(["--reads", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check", "2", "--host-leg-batches", "2"])
     r = recs[0]
     roof = r["roofline"]
-    assert roof["bound"] == "valu" and re.match(r"align_forward_seg_kernel<14, 6, false, 4, [34], false, true>", roof["kernel"])
+    assert roof["bound"] == "valu"
+    if screen:
+        assert roof["kernel"] == "align_screen_kernel" and roof["with_windows"] == roof["alignments_screened_per_step"] == 1024
+        assert re.match(r"align_forward_seg_kernel<14, 6, false, 1, 2, false, true>", roof["exact_pass"]["kernel"])
+        assert roof["window_columns_over_columns_of_the_reads"] < 0.02
+    else:
+        assert re.match(r"align_forward_seg_kernel<14, 6, false, 4, [34], false, true>", roof["kernel"])
+        assert len(roof["overlap_columns_per_step"]) == 3 and roof["overlap_columns_per_step"][-1] < roof["overlap_worst_case"]
     assert 0 < roof["useful_frac"] < roof["frac"] < 1
-    assert len(roof["overlap_columns_per_step"]) == 3 and roof["overlap_columns_per_step"][-1] < roof["overlap_worst_case"]
     assert r["config"]["distinct_batches_per_gpu"] == 3
     assert r["check_ok"] and len(r["check"]) == 2 and {c["batch"] for c in r["check"]} == {0, 1}
     assert r["host_buffers"]["same_rows_as_resident_run"] and r["host_inclusive_reads_per_s"] > 0

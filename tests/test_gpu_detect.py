@@ -275,6 +275,11 @@ def test_mixed_read_lengths_run_as_length_classes(gpu_counter, want, pm, targets
     plan = [("c9orf72", "+", 3000, 12), ("fmr1", "-", 3500, 20), ("c9orf72", "-", 5000, 25), ("htt", "+", 6000, 40),
             ("c9orf72", "+", 12000, 60), ("fmr1", "+", 30000, 300), ("c9orf72", "-", 60000, 500)]
     items = [(name, _read(pm, targets, name, st, nt, nrep, 900 + i), st) for i, (name, st, nt, nrep) in enumerate(plan)]
+    # with the upper-bound screen the long reads run over their windows only (one wave per window); the length classes are
+    # what the whole-read passes are cut into
+    got = _check(gpu_counter, want, items)
+    assert gpu_counter.ctx.last_screen()["windowed"] >= 4
+    monkeypatch.setenv("STRQ_NO_SCREEN", "1")
     got = _check(gpu_counter, want, items)
     assert [abs(g[0] - p[3]) <= 2 for g, p in zip(got, plan)] == [True] * len(plan)
     assert gpu_counter.ctx.last_timing()[7] >= 3            # at least three forward-DP launches
