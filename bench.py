@@ -484,12 +484,14 @@ def main():
             roof = {"bound": "valu", "unit": "G wave-instructions/s", "peak": valu_peak, "kernel": "align_screen_kernel",
                     "avg_launch_ms": scr_launch_s * 1e3, "launches_per_step": launches_per_step,
                     "wave_steps_per_launch": scr_steps_per_launch, "valu_insts_per_wave_step": scr_ip,
-                    "valu_insts_source": prof.get("valu_source") if scr_note is None else scr_note,
+                    "valu_insts_source": prof.get("screen_valu_source") if scr_note is None else scr_note,
                     "achieved": achieved, "frac": achieved / valu_peak if achieved else None,
                     "instr_per_cell": scr_ip / 28.0, "instr_per_cell_floor": 2.0,
                     "lane_utilisation": FLANK_ROWS / float(64 * 14),
-                    "gcups": gcups, "traffic": None,
-                    "traffic_note": "reads the uint8 levels once per piece (1 B per column) and writes 4 B per 128 columns: ~0.4 GB per launch",
+                    "gcups": gcups,
+                    "traffic": (prof.get("screen_hbm_bytes_per_read_column", 0.0) * 2.0 * n_samples / launches_per_step) or None,
+                    "traffic_source": prof.get("screen_traffic_source"),
+                    "traffic_note": "the uint8 levels once per piece (1 B per column, overlaps included), the float32 score table of every alignment, 4 B written per 128 columns",
                     "scale": screen["scale"],
                     "alignments_screened_per_step": screen["screened"] / args.steps, "with_windows": screen["windowed"] / args.steps,
                     "whole_read": screen["whole_read"] / args.steps,

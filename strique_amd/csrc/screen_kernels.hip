@@ -10,7 +10,7 @@
 //   * scores are rounded UP to multiples of 1/sc (sc = 1024 for STRique's parameters and reads below ~1.9 M samples) and the
 //     DP runs in 32-bit integers.  A max-plus DP is monotone in its scores, and integer arithmetic does not round: the
 //     result bounds the real-arithmetic DP of the float32 table from above by less than m / sc (one rounding per diagonal
-//     step), and that one is within a few units of the float32 DP (`slack`);
+//     step), and that one is within `slack` (16 score units for STRique's parameters) of the float32 DP;
 //   * collapsed recurrence (open == extend, as STRique configures): S = max(diag + s, left + e_h, up + e_v).  Stored is
 //     T = S + i |e_v| + j |e_h|: both gap terms vanish from the recurrence, T = max3(diag + s'', left, up) with
 //     s'' = s + |e_v| + |e_h| baked into the (16-bit) table -- one v_add_u32 and one max3 per cell where the float32
@@ -326,7 +326,18 @@ int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
         const double top = 64.0 * R * (smax + v) + ((double)max_n + 256.0) * hh + smax + v + hh + (double)STRQ_SCREEN_BIAS;
         if (top > 2.0e9) continue;          // below 0x7f800000: every stored value is the bit pattern of a finite float32
         sp->sc = sc; sp->hh = (int)hh; sp->v = (int)v; sp->cadd = (int)(hh + v);
-        sp->slack = 32 * sc; sp->merge_gap = 3072;
+        // float32 rounding of the exact DP against real arithmetic: one addition per step of a path, each off by at most 2^-24 of a
+        // value below the next power of two above 64 R dist_offset; a path that matters has at most 64 R rows and
+        // 64 R dist_offset / |e_h| horizontal steps (14.9 score units for STRique's parameters)
+        {
+            const double rows = 64.0 * R, maxval = rows * (double)p.dist_offset;
+            double p2 = 1.0; while (p2 < maxval) p2 *= 2.0;
+            const double adds = rows * (1.0 + (double)p.dist_offset / -(double)p.ext_h);
+            const double e = adds * p2 / 16777216.0;
+            if (!(e < 1.0e4)) continue;
+            sp->slack = ((int)std::ceil(e) + 1) * sc;
+        }
+        sp->merge_gap = 3072;
         return 1;
     }
     return 0;

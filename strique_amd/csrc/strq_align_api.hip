@@ -209,10 +209,13 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // Without the variable: 8192 columns for the first sub-batch, afterwards the overlap that would have been cheapest
     // for the previous sub-batch -- extra columns per piece against the share of alignments whose best score would
     // not certify that overlap and which therefore run twice (any choice is exact; this one only sets the cost).
-    std::map<int, int> ov_of_m;
-    auto overlap_for = [&](int m, int ov_worst) -> int {
+    // redo_weight: what an alignment that misses the certificate costs, in whole-read passes (1 for the exact pass's own second
+    // round; the screen's pieces are cut more carefully -- an alignment whose score lies below their cold-start bound gets no
+    // windows and runs its whole read in a launch of its own, a ~20 ms tail behind thousands of windows: gpurun_out/r4z)
+    std::map<std::pair<int, int>, int> ov_of_m;
+    auto overlap_for = [&](int m, int ov_worst, int redo_weight = 1) -> int {
         if (ov_fixed || c->score_fracs.size() < 64 || c->mean_n <= 0) return std::min(ov_worst, ov_cap);
-        auto it = ov_of_m.find(m);
+        auto it = ov_of_m.find(std::make_pair(m, redo_weight));
         if (it != ov_of_m.end()) return it->second;
         const std::vector<float>& f = c->score_fracs;
         double best_cost = 0; int best_ov = std::min(ov_worst, ov_cap);
@@ -220,11 +223,11 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             if (ov > ov_worst) ov = ov_worst;
             const float need = align_segment_min_score(c->ap, m, ov) / ((float)m * c->ap.dist_offset) + 0.01f;      // 1 % margin on last batch's scores
             const double redo = (double)(std::lower_bound(f.begin(), f.end(), need) - f.begin()) / (double)f.size();
-            const double cost = 3.0 * ov / c->mean_n + redo * (1.0 + 3.0 * ov_worst / c->mean_n);
+            const double cost = 3.0 * ov / c->mean_n + redo_weight * redo * (1.0 + 3.0 * ov_worst / c->mean_n);
             if (best_cost == 0 || cost < best_cost) { best_cost = cost; best_ov = ov; }
             if (ov >= ov_worst) break;
         }
-        ov_of_m[m] = best_ov;
+        ov_of_m[std::make_pair(m, redo_weight)] = best_ov;
         STRQ_DBG("overlap for %d-row flanks: %d columns (worst case %d; previous sub-batch: median score fraction %.3f, mean read %.0f samples)", m, best_ov, ov_worst, f[f.size() / 2], c->mean_n);
         return best_ov;
     };
@@ -286,7 +289,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             size_t out_words = 0, lds_bytes = 0; double steps = 0;
             for (int g = 0; g < ng; ++g) {
                 const int a = sel[g], n = in.n[a], m = in.m[a];
-                const int ov_worst = align_segment_overlap(c->ap, m), ov_s = overlap_for(m, ov_worst);
+                const int ov_worst = align_segment_overlap(c->ap, m), ov_s = overlap_for(m, ov_worst, 16);
                 Piece pc[SSEG];
                 const int used = cut(n, SSEG, ov_s, pc);
                 // what the cold start of the pieces costs: below this score a piece's values are not bounds of the whole matrix
@@ -394,7 +397,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         segs_of[i] = best_s; packed[i] = (char)best_p;
         ++class_count[best_s];
     }
-    if (!seg_want) {
+    if (!seg_want && !c->screen_ran) {
+        // (Not behind the screen: there the small classes are the few alignments that run their whole read next to thousands
+        // of windows -- one wave over 375 k columns would be a 60 ms tail, gpurun_out/r4y.)
         // a length class too small to fill the chip once joins the class with fewer waves per alignment
         int few = 2 * c->n_cu;
         if (const char* e = getenv("STRQ_CLASS_MIN")) few = atoi(e);      // tests: keep small length classes apart

@@ -193,8 +193,9 @@ def test_other_parameters_and_short_reads_skip_the_screen(ctx, orc, monkeypatch)
 
 
 def test_screen_pauses_after_a_batch_it_cannot_prune(orc, monkeypatch):
-    """A sub-batch of reads without the flank gets no windows (no chunk stands out: the whole reads run, results as ever);
-    the context then skips the screen for its next sub-batches instead of paying for it again."""
+    """A sub-batch of reads that hold the flank six times, identically and far apart, gets no windows (six equal maxima are more
+    windows than the exact launch has pieces: the whole reads run, results as ever -- the leftmost occurrence wins); the context
+    then skips the screen for its next sub-batches instead of paying for it again."""
     from strique_amd import ffi
     c = ffi.Context(0)
     params = orc.align_params(None)
@@ -205,6 +206,11 @@ def test_screen_pauses_after_a_batch_it_cannot_prune(orc, monkeypatch):
     m = 6 * k
     reads = [_planted(rng, n, k, [])[0] for _ in range(na)]
     _, lval, flank = _planted(np.random.default_rng(3), n, k, [])
+    emb_rng = np.random.default_rng(4)
+    for lv in reads:
+        emb = np.repeat(np.clip(np.round((flank[::6] - 40) / 0.45), 0, 255).astype(np.uint8), emb_rng.integers(6, 10, k))
+        for p in (1000, 5500, 10000, 14500, 19000, 23500):
+            lv[p:p + len(emb)] = emb
     args = (np.concatenate(reads), np.arange(na + 1, dtype=np.int64) * n, np.tile(lval, (na, 1)), np.arange(na, dtype=np.int32),
             np.tile(flank, na), np.arange(na + 1, dtype=np.int64) * m)
     got = c.align_batch(*args)

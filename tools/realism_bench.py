@@ -51,8 +51,8 @@ def main():
     from strique_amd.counter import repeatCounter
     pm, cfg = bench.load_inputs()
     chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
-    print("| realism | median flank score / maximum | reads/s | ms per pass | forward DP ms | Viterbi ms | overlap columns (first round; worst case) | second-round alignments | counts within 2 |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print("| realism | median flank score / maximum | reads/s | ms per pass | forward DP ms | Viterbi ms | overlap columns (first round; worst case) | second-round alignments | counts within 2 | screen: alignments with windows / screened / whole read (last pass) |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     for r in a.levels:
         counter = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
         counter.add_target("c9orf72", repeat, prefix, suffix)
@@ -73,9 +73,10 @@ def main():
         m_rows = 6 * (len(prefix) - 5)
         fr = np.concatenate([res["score_prefix"], res["score_suffix"]])          # normalised scores; the raw fraction is what the library planned with
         ok = int(sum(abs(int(x["count"]) - w) <= 2 for x, w in zip(res, nreps)))
-        print("| %.2f | %s | %.0f | %.1f | %.1f | %.1f | %d; %d | %d of %d (%.2f %%) | %d / %d |" % (
+        scr = ctx.last_screen()
+        print("| %.2f | %s | %.0f | %.1f | %.1f | %.1f | %d; %d | %d of %d (%.2f %%) | %d / %d | %d / %d / %d |" % (
             r, os.environ.get("STRQ_FRACTION_NOTE", "see tools/realism_probe.py"), len(sigs) / dt, dt * 1e3, tm[1], tm[6], geo["overlap_first"], geo["overlap_worst"],
-            redo, total, 100.0 * redo / max(1, total), ok, len(sigs)), flush=True)
+            redo, total, 100.0 * redo / max(1, total), ok, len(sigs), scr["windowed"], scr["screened"], scr["whole_read"]), flush=True)
         ctx.close()
 
 
