@@ -304,7 +304,10 @@ __global__ void screen_windows_kernel(const ScreenTask* __restrict__ tasks, int 
                     if (lo < r.lo[nw - 1]) r.lo[nw - 1] = lo;
                 } else if (nw < STRQ_SCREEN_MAX_WINDOWS) {
                     r.lo[nw] = lo; r.hi[nw] = hi; ++nw;
-                } else { ok = false; break; }
+                } else {
+                    // more separate candidates than the exact launch has pieces: the last window takes everything from here on
+                    if (hi > r.hi[nw - 1]) r.hi[nw - 1] = hi;
+                }
             }
         }
         r.n_win = ok ? nw : 0;

@@ -360,9 +360,17 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             }
             c->screen_stats[5] += steps; c->screen_stats[6] = sp.sc;
             {
-                int windowed = 0;
-                for (int g = 0; g < ng; ++g) windowed += wins[sel[g]].n_win > 0;
-                if (ng >= 64 && windowed < 0.9 * ng && !no_prune) c->screen_pause = 8;
+                // does it pay?  The screen costs ~0.9 of the float32 pass over whole reads, the windows run at a lower rate than whole
+                // reads do: it wins when nearly every alignment gets windows and they hold a few per cent of the columns at most
+                int windowed = 0; double cols = 0, all = 0;
+                for (int g = 0; g < ng; ++g) {
+                    const ScreenWindows& w = wins[sel[g]];
+                    windowed += w.n_win > 0;
+                    all += in.n[sel[g]];
+                    if (w.n_win > 0) for (int k = 0; k < w.n_win; ++k) cols += w.hi[k] - w.lo[k] + 1 + 4096;
+                    else cols += in.n[sel[g]];
+                }
+                if (ng >= 64 && (windowed < 0.9 * ng || cols > 0.06 * all) && !no_prune) c->screen_pause = 8;
             }
             STRQ_DBG("screen: %d alignments, scale %d, %d tables per CU, LDS %zu bytes; windows for %.0f of %.0f alignments so far", ng, sp.sc, scr_tables, lds_bytes, c->screen_stats[2], c->screen_stats[1]);
         }
@@ -606,13 +614,28 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     if ((size_t)STRQ_QUEUE_FIRST + launches.size() * ((size_t)max_ns + 2) > (size_t)STRQ_QUEUE_SLOTS) {
         c->err = "too many distinct (flank shape, table size) groups in one batch"; return STRQ_ERR_UNSUPPORTED;
     }
+    // Behind the screen a sub-batch is thousands of windows (one launch, one wave per alignment) and a handful of alignments that
+    // run large parts of their reads (launches of two / four waves per alignment): a ~20 ms tail if the launches follow each other.
+    // The launch with the most alignments runs on a second stream, next to the others (gpurun_out/r4aa: degraded reads).
+    int side = -1;
+    if (c->screen_ran && launches.size() > 1 && max_ns == 1 && collapsed && !getenv("STRQ_ONE_STREAM")) {
+        side = 0;
+        for (size_t li = 1; li < launches.size(); ++li) if (launches[li].count > launches[side].count) side = (int)li;
+        if (!c->stream2) STRQ_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (!c->ev_fork) STRQ_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        if (!c->ev_join) STRQ_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        STRQ_HIP(c, hipEventRecord(c->ev_fork, st));
+        STRQ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
     for (int level = 0; level < max_ns; ++level) {          // top strips first, then the strips below them
-        for (auto& L : launches) {
+        for (size_t lidx = 0; lidx < launches.size(); ++lidx) {
+            auto& L = launches[lidx];
+            hipStream_t lst = (int)lidx == side ? c->stream2 : st;
             if (level >= L.NS) continue;
             STRQ_DBG("forward launch R=%d strips=%d slice dwords=%d packed=%d level=%d count=%d tables/CU=%d segments=%d", L.R, L.NS, L.lds_floats, L.packed, level, L.count, L.tables, L.segs);
             int rc;
             if (L.NS == 1 && collapsed) {
-                rc = launch_align_segments(st, L.R, S, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, c->queue.as<int>() + qi,
+                rc = launch_align_segments(lst, L.R, S, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, c->queue.as<int>() + qi,
                                            c->ap, L.lds_floats, L.tables, c->n_cu, L.packed, nullptr, nullptr, L.known_last_row);
             } else {
                 const bool last = level == L.NS - 1;
@@ -624,6 +647,10 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             if (rc) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
             ++qi; ++out.n_launches;
         }
+    }
+    if (side >= 0) {
+        STRQ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+        STRQ_HIP(c, hipStreamWaitEvent(st, c->ev_join, 0));
     }
     for (size_t li = 0; li < launches.size(); ++li) {
         auto& L = launches[li];
@@ -787,6 +814,9 @@ void strq_ctx_destroy(strq_ctx* c)
         b->release();
     for (HostModel* m : c->models) if (m) { m->blob.release(); delete m; }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

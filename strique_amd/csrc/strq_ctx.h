@@ -74,6 +74,8 @@ struct strq_ctx {
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // second forward launch of a screened sub-batch (align_core), created on first use
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev[8] = {};
     strq::AlignParams ap{-2.0f, -8.0f, -2.0f, -8.0f, 8.0f, -16.0f};   // src/align_raw.h:51-60
     std::string err;
@@ -86,7 +88,8 @@ struct strq_ctx {
     double screen_stats[8] = {};              // strq_last_screen
     bool screen_ran = false;                  // the last align_core call ran the screen (events 5, 6 bracket it)
     // The screen pays when nearly every alignment gets windows (a read that holds its flank clearly) and costs a pass when not:
-    // a sub-batch in which fewer than 90 % did pauses it for the next eight sub-batches of this context, then it is tried again.
+    // a sub-batch in which fewer than 90 % did, or whose windows hold more than 6 % of the columns, pauses it for the next eight
+    // sub-batches of this context, then it is tried again.
     int screen_pause = 0;
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,

@@ -3,8 +3,8 @@
 Two things are checked.  (1) What the screen claims: every chunk value it writes is an upper bound of the exact last-row
 values of the chunk's columns (computed here in float64 from the same scores), and a tight one (within m / 1024).  (2) What it is used for:
 alignments that ran only over the screen's windows return the oracle's score bits, end / start column and whole path --
-for planted flanks at piece seams, twice in one read, five times (more windows than the exact launch has pieces: whole
-read), and for reads without the flank (no window certifies: whole read)."""
+for planted flanks at piece seams, twice in one read, five and six times (more separate candidates than the exact launch has
+pieces: the last window takes the rest), and for reads the screen cannot prune (whole read, then the screen pauses)."""
 import os
 import struct
 
@@ -193,24 +193,20 @@ def test_other_parameters_and_short_reads_skip_the_screen(ctx, orc, monkeypatch)
 
 
 def test_screen_pauses_after_a_batch_it_cannot_prune(orc, monkeypatch):
-    """A sub-batch of reads that hold the flank six times, identically and far apart, gets no windows (six equal maxima are more
-    windows than the exact launch has pieces: the whole reads run, results as ever -- the leftmost occurrence wins); the context
-    then skips the screen for its next sub-batches instead of paying for it again."""
+    """A sub-batch of reads without the flank, screened in pieces whose cold start is sized for a score none of them reaches
+    (STRQ_OVERLAP pins a short overlap), gets no windows: the whole reads run, results as ever, and the context skips the screen
+    for its next sub-batches instead of paying for it again."""
     from strique_amd import ffi
     c = ffi.Context(0)
     params = orc.align_params(None)
     c.set_align_params(*[float(v) for v in params])
     monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
+    monkeypatch.setenv("STRQ_OVERLAP", "1500")
     rng = np.random.default_rng(31)
     n, k, na = 30000, 60, 70
     m = 6 * k
     reads = [_planted(rng, n, k, [])[0] for _ in range(na)]
     _, lval, flank = _planted(np.random.default_rng(3), n, k, [])
-    emb_rng = np.random.default_rng(4)
-    for lv in reads:
-        emb = np.repeat(np.clip(np.round((flank[::6] - 40) / 0.45), 0, 255).astype(np.uint8), emb_rng.integers(6, 10, k))
-        for p in (1000, 5500, 10000, 14500, 19000, 23500):
-            lv[p:p + len(emb)] = emb
     args = (np.concatenate(reads), np.arange(na + 1, dtype=np.int64) * n, np.tile(lval, (na, 1)), np.arange(na, dtype=np.int32),
             np.tile(flank, na), np.arange(na + 1, dtype=np.int64) * m)
     got = c.align_batch(*args)
@@ -228,3 +224,24 @@ def test_screen_pauses_after_a_batch_it_cannot_prune(orc, monkeypatch):
     c.align_batch(*args)
     assert c.last_screen()["screened"] == na
     c.close()
+
+
+def test_more_occurrences_than_windows(ctx, orc, monkeypatch):
+    """Six identical occurrences of the flank, far apart: more separate candidates than the exact launch has pieces -- the last
+    window takes the rest of the read, and the leftmost occurrence wins as in the oracle."""
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
+    rng = np.random.default_rng(41)
+    n, k = 60000, 145
+    m = 6 * k
+    lv, lval, flank = _planted(rng, n, k, [])
+    emb = np.repeat(np.clip(np.round((flank[::6] - 40) / 0.45), 0, 255).astype(np.uint8), rng.integers(6, 10, k))
+    for p in (2000, 11000, 20000, 29000, 38000, 47000):
+        lv[p:p + len(emb)] = emb
+    got = ctx.align_batch(lv, [0, n], lval[None, :], [0], flank, [0, m])
+    s = ctx.last_screen()
+    assert s["windowed"] == 1 and s["window_columns"] > 15000, s
+    o = orc.align_overlap(lval[lv], flank, params, want_idx=False)
+    assert np.float32(o[0]).tobytes() == np.float32(got[0][0]).tobytes() and (o[4], o[5]) == (int(got[1][0]), int(got[2][0]))
+    assert np.array_equal(o[3], got[3]) and 1900 < int(got[2][0]) < 2000 + len(emb)
