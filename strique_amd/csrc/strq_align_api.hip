@@ -362,15 +362,21 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             {
                 // does it pay?  The screen costs ~0.9 of the float32 pass over whole reads, the windows run at a lower rate than whole
                 // reads do: it wins when nearly every alignment gets windows and they hold a few per cent of the columns at most
-                int windowed = 0; double cols = 0, all = 0;
+                // -- and when hardly any alignment is left with a large share of its read to run: a few such alignments behind
+                // thousands of windows are a tail of their own (one piece of 100 k columns takes a lone wave ~17 ms; reads at
+                // `realism` 1: forward stage 94.6 ms per 1024 reads against 74.2 without the screen, gpurun_out/r4ad)
+                int windowed = 0, heavy = 0; double cols = 0, all = 0;
                 for (int g = 0; g < ng; ++g) {
                     const ScreenWindows& w = wins[sel[g]];
                     windowed += w.n_win > 0;
                     all += in.n[sel[g]];
-                    if (w.n_win > 0) for (int k = 0; k < w.n_win; ++k) cols += w.hi[k] - w.lo[k] + 1 + 4096;
-                    else cols += in.n[sel[g]];
+                    double mine = 0;
+                    if (w.n_win > 0) for (int k = 0; k < w.n_win; ++k) mine += w.hi[k] - w.lo[k] + 1 + 4096;
+                    else mine = in.n[sel[g]];
+                    cols += mine; heavy += mine > 32768.0;
                 }
-                if (ng >= 64 && (windowed < 0.9 * ng || cols > 0.06 * all) && !no_prune) c->screen_pause = 8;
+                if (ng >= 64 && (windowed < 0.9 * ng || cols > 0.06 * all || heavy > ng / 4096) && !no_prune) c->screen_pause = 8;
+                STRQ_DBG("screen verdict: %d of %d with windows, %.2f %% of the columns inside them, %d heavy alignments -> pause %d", windowed, ng, 100.0 * cols / std::max(1.0, all), heavy, c->screen_pause);
             }
             STRQ_DBG("screen: %d alignments, scale %d, %d tables per CU, LDS %zu bytes; windows for %.0f of %.0f alignments so far", ng, sp.sc, scr_tables, lds_bytes, c->screen_stats[2], c->screen_stats[1]);
         }

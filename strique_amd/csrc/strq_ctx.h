@@ -88,7 +88,8 @@ struct strq_ctx {
     double screen_stats[8] = {};              // strq_last_screen
     bool screen_ran = false;                  // the last align_core call ran the screen (events 5, 6 bracket it)
     // The screen pays when nearly every alignment gets windows (a read that holds its flank clearly) and costs a pass when not:
-    // a sub-batch in which fewer than 90 % did, or whose windows hold more than 6 % of the columns, pauses it for the next eight
+    // a sub-batch in which fewer than 90 % did, whose windows hold more than 6 % of the columns, or in which more than one alignment
+    // in 4096 is left with over 32 k columns to run (a tail behind thousands of small windows) pauses it for the next eight
     // sub-batches of this context, then it is tried again.
     int screen_pause = 0;
     // workspace
