@@ -1,0 +1,68 @@
+"""The arithmetic behind the upper-bound screen (csrc/screen_kernels.hip), restated in numpy -- no GPU.
+
+The kernel stores T = S * sc + i |e_v| sc + j |e_h| sc with scores rounded up to multiples of 1 / sc and runs
+T[i][j] = max3(T[i-1][j-1] + s'', T[i][j-1], T[i-1][j]).  Claims checked here against the float64 DP of the same scores
+(S = max(diag + s, left + e_h, up + e_v), free top row, column 0 = i e_v, as src/align_raw.h:106-158 with open == extend):
+the decoded last row is never below the exact one and less than m / sc above it, rows of score 0 <= s'' under the flank copy the
+last flank row, and every stored value stays below 2^31 for a 2 M-sample read."""
+import numpy as np
+import pytest
+
+
+def _exact(vals, flank, off=16.0, dmin=0.0, eh=-1.0, ev=-16.0):
+    n = len(vals)
+    j = np.arange(n + 1, dtype=np.float64)
+    prev = np.zeros(n + 1)
+    rows = []
+    for i, f in enumerate(flank, 1):
+        s = np.maximum(off - np.abs(vals - f) ** 1.2, dmin)
+        cur = np.empty(n + 1)
+        cur[0] = i * ev
+        cur[1:] = np.maximum(prev[:-1] + s, prev[1:] + ev)
+        cur = np.maximum.accumulate(cur - eh * j) + eh * j
+        prev = cur
+        rows.append(s)
+    return prev, rows
+
+
+def _screen(rows, n, sc, eh=-1.0, ev=-16.0, pad_rows=0):
+    hh, v = int(-eh * sc), int(-ev * sc)
+    T = np.arange(n + 1, dtype=np.int64) * hh            # top row: S = 0
+    m = len(rows)
+    for i in range(1, m + pad_rows + 1):
+        if i <= m:
+            s2 = np.ceil(rows[i - 1] * sc).astype(np.int64) + hh + v
+        else:
+            s2 = np.zeros(n, np.int64)                    # rows under the flank
+        cur = np.empty(n + 1, np.int64)
+        cur[0] = 0                                        # S[i][0] = i e_v
+        cur[1:] = np.maximum(T[:-1] + s2, T[1:])
+        T = np.maximum.accumulate(cur)                    # the horizontal move is free in T
+    return T
+
+
+@pytest.mark.parametrize("sc", [1024, 8])
+def test_integer_potential_dp_bounds_the_exact_last_row(sc):
+    rng = np.random.default_rng(5)
+    k, n = 20, 4000
+    flank = np.repeat(rng.uniform(60, 120, k), 6)
+    m = len(flank)
+    vals = np.repeat(rng.uniform(50, 130, n // 5 + 1), rng.integers(3, 10, n // 5 + 1))[:n]
+    vals[1500:1500 + m] = flank + rng.normal(0, 1.5, m)
+    exact, rows = _exact(vals, flank)
+    T = _screen(rows, n, sc)
+    j = np.arange(n + 1)
+    ub = (T - j * sc - m * 16 * sc) / sc                  # decode: S = (T - j |e_h| sc - m |e_v| sc) / sc
+    assert np.all(ub >= exact - 1e-9)
+    assert np.all(ub < exact + m / sc + 1e-9)
+    assert exact.argmax() == ub.argmax() or abs(exact.max() - exact[ub.argmax()]) < m / sc
+    # rows below the flank copy its last row
+    Tp = _screen(rows, n, sc, pad_rows=9)
+    assert np.array_equal(Tp, T)
+
+
+def test_stored_values_fit_31_bits_for_the_longest_reads():
+    sc, rows_max, n_max = 1024, 896, 1_900_000
+    top = rows_max * (16 * sc + 16 * sc) + (n_max + 256) * sc + 0x00800000
+    assert top < 2 ** 31 - 2 ** 24            # below 0x7f800000: every bit pattern is a finite positive float32 (v_max3_f32 orders them)
+    assert 16 * sc + 16 * sc + sc < 65536     # a table entry fits 16 bits
