@@ -286,6 +286,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             constexpr int SSEG = STRQ_SCREEN_SEG;
             std::vector<ScreenTask> stasks((size_t)ng * SSEG);
             std::vector<int32_t> bound((size_t)ng);
+            std::vector<size_t> out_off((size_t)ng * SSEG, 0);
             size_t out_words = 0, lds_bytes = 0; double steps = 0;
             for (int g = 0; g < ng; ++g) {
                 const int a = sel[g], n = in.n[a], m = in.m[a];
@@ -301,7 +302,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                     t.table = jobs[J0[a]].table; t.band_lo = jobs[J0[a]].band_lo; t.tsize = info[J0[a]].total;
                     t.n = pc[w].n; t.m = m; t.k = in.k[a]; t.col_off = pc[w].col_off;
                     t.n_chunks = pc[w].n > 0 ? (align_num_steps(pc[w].n) + 63) / 64 : 0;
-                    t.out = reinterpret_cast<int32_t*>(out_words);      // offset for now
+                    out_off[(size_t)g * SSEG + w] = out_words;
                     out_words += (size_t)t.n_chunks;
                     if (pc[w].n > 0) steps += align_num_steps(pc[w].n);
                     stasks[(size_t)g * SSEG + w] = t;
@@ -317,7 +318,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             int32_t* d_bound = reinterpret_cast<int32_t*>(base + task_bytes);
             ScreenWindows* d_win = reinterpret_cast<ScreenWindows*>(base + task_bytes + bound_bytes);
             int32_t* d_out = reinterpret_cast<int32_t*>(base + task_bytes + bound_bytes + win_bytes);
-            for (auto& t : stasks) t.out = d_out + reinterpret_cast<size_t>(t.out);
+            for (size_t x = 0; x < stasks.size(); ++x) stasks[x].out = d_out + out_off[x];
             STRQ_HIP(c, hipMemcpyAsync(d_st, stasks.data(), stasks.size() * sizeof(ScreenTask), hipMemcpyHostToDevice, st));
             STRQ_HIP(c, hipMemcpyAsync(d_bound, bound.data(), (size_t)ng * 4, hipMemcpyHostToDevice, st));
             STRQ_HIP(c, hipEventRecord(c->ev[5], st));
@@ -350,6 +351,11 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 }
             }
             const bool no_prune = getenv("STRQ_SCREEN_NO_PRUNE") != nullptr;      // tests: run the screen, then the whole reads
+            if (const char* e = getenv("STRQ_SCREEN_TEST_RAISE")) {
+                // tests: claim a lower bound no alignment reaches -- the certificate must fail and the second round (whole reads) must deliver
+                const float up = (float)atof(e);
+                for (auto& w : hw) w.lower_bound += up;
+            }
             for (int g = 0; g < ng; ++g) {
                 const ScreenWindows& w = hw[(size_t)g];
                 c->screen_stats[1] += 1; c->screen_stats[7] += w.n_cand;
@@ -737,6 +743,9 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
         m[a] = (int)mm; n[a] = (int)nn;
     }
     hipStream_t st = c->stream;
+    c->second_round[0] = 0; c->second_round[1] = NA;          // strq_last_second_round of this call
+    STRQ_HIP(c, c->redo_total.reserve(64));
+    STRQ_HIP(c, hipMemsetAsync(c->redo_total.p, 0, 64, st));
     const int64_t tot_levels = in.read_off[in.n_reads];
     STRQ_HIP(c, c->levels.reserve((size_t)tot_levels + 64));
     STRQ_HIP(c, c->level_val.reserve((size_t)in.n_reads * 256 * 4));
@@ -781,6 +790,11 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
         a0 = a1;
     }
     c->timing[0] = t_lut; c->timing[1] = t_fwd; c->timing[2] = t_tr; c->timing[3] = t_lut + t_fwd + t_tr; c->timing[4] = n_hard; c->timing[7] = n_launch;
+    {
+        unsigned int redo = 0;
+        STRQ_HIP(c, hipMemcpy(&redo, c->redo_total.p, 4, hipMemcpyDeviceToHost));
+        c->second_round[0] = redo;
+    }
     return STRQ_OK;
 }
 

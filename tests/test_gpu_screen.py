@@ -245,3 +245,34 @@ def test_more_occurrences_than_windows(ctx, orc, monkeypatch):
     o = orc.align_overlap(lval[lv], flank, params, want_idx=False)
     assert np.float32(o[0]).tobytes() == np.float32(got[0][0]).tobytes() and (o[4], o[5]) == (int(got[1][0]), int(got[2][0]))
     assert np.array_equal(o[3], got[3]) and 1900 < int(got[2][0]) < 2000 + len(emb)
+
+
+def test_a_lower_bound_nobody_reaches_sends_everything_through_the_second_round(orc, monkeypatch):
+    """The safety net under the windows: the exact pass must find a score that reaches the screen's lower bound, or the alignment
+    runs its whole read in the second round.  With the bound raised artificially (STRQ_SCREEN_TEST_RAISE) every alignment takes
+    that route -- and returns the oracle's result."""
+    from strique_amd import ffi
+    c = ffi.Context(0)
+    params = orc.align_params(None)
+    c.set_align_params(*[float(v) for v in params])
+    monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
+    monkeypatch.setenv("STRQ_SCREEN_TEST_RAISE", "500")
+    rng = np.random.default_rng(51)
+    n, k = 50000, 145
+    m = 6 * k
+    reads = []
+    _, lval, flank = _planted(np.random.default_rng(6), n, k, [])
+    for p in (3000, 20000, 44000):
+        lv = _planted(rng, n, k, [])[0]
+        emb = np.repeat(np.clip(np.round((flank[::6] - 40) / 0.45), 0, 255).astype(np.uint8), rng.integers(6, 10, k))
+        lv[p:p + len(emb)] = emb
+        reads.append(lv)
+    na = len(reads)
+    got = c.align_batch(np.concatenate(reads), np.arange(na + 1, dtype=np.int64) * n, np.tile(lval, (na, 1)), np.arange(na, dtype=np.int32),
+                        np.tile(flank, na), np.arange(na + 1, dtype=np.int64) * m)
+    assert c.last_screen()["windowed"] == na and c.last_second_round()[0] == na, (c.last_screen(), c.last_second_round())
+    for i, lv in enumerate(reads):
+        o = orc.align_overlap(lval[lv], flank, params, want_idx=False)
+        assert np.float32(o[0]).tobytes() == np.float32(got[0][i]).tobytes() and (o[4], o[5]) == (int(got[1][i]), int(got[2][i]))
+        assert np.array_equal(o[3], got[3][i * m:(i + 1) * m])
+    c.close()
