@@ -264,10 +264,13 @@ align_screen_kernel(const ScreenTask* __restrict__ tasks, int n_groups, int* __r
 // A chunk's value v bounds the float32 last-row values S of its columns: S * sc <= max(v', bound) + slack, v' = v - m * v_gap
 // (bound: the cold-start score of the pieces).  The best chunk value vmax is reached by a real path whose float32 score is at
 // least (vmax' - m) / sc - slack / sc.  Columns of chunks with max(v', bound) + slack < vmax' - m - slack cannot hold the optimum.
-__global__ void screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, ScreenParams sp,
-                                      const int32_t* __restrict__ bound_scaled, ScreenWindows* __restrict__ out)
+__global__ void __launch_bounds__(256)
+screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, ScreenParams sp,
+                      const int32_t* __restrict__ bound_scaled, ScreenWindows* __restrict__ out)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per alignment: coalesced reads of the chunk values, lane 0 merges the (few) candidates in column order
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_groups) return;
     const ScreenTask* tg = tasks + (size_t)g * SEG;
     const int m = tg[0].m, lM = (m - 1) / R;
@@ -275,8 +278,10 @@ __global__ void screen_windows_kernel(const ScreenTask* __restrict__ tasks, int 
     int vmax = 0;
     for (int w = 0; w < SEG; ++w) {
         if (tg[w].n <= 0) continue;
-        for (int c = 0; c < tg[w].n_chunks; ++c) { const int v = tg[w].out[c]; vmax = v > vmax ? v : vmax; }
+        for (int c = lane; c < tg[w].n_chunks; c += 64) { const int v = tg[w].out[c]; vmax = v > vmax ? v : vmax; }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(vmax, d, 64); vmax = o > vmax ? o : vmax; }
     ScreenWindows r;
     r.n_win = 0; r.n_cand = 0;
     for (int k = 0; k < STRQ_SCREEN_MAX_WINDOWS; ++k) { r.lo[k] = 0; r.hi[k] = 0; }
@@ -284,35 +289,41 @@ __global__ void screen_windows_kernel(const ScreenTask* __restrict__ tasks, int 
     r.lower_bound = (float)(vmax + shift - m - sp.slack) / (float)sp.sc;
     r.upper_bound = (float)(vmax + shift + sp.slack) / (float)sp.sc;
     // prune only above the cold-start bound of the pieces, and only when the lower bound is a score worth the name
-    bool ok = theta + shift > 0 && theta + shift > bound_scaled[g];
+    const bool ok = theta + shift > 0 && theta + shift > bound_scaled[g];
     if (ok) {
         int nw = 0;
-        for (int w = 0; w < SEG && ok; ++w) {
+        for (int w = 0; w < SEG; ++w) {
             if (tg[w].n <= 0) continue;
-            for (int c = 0; c < tg[w].n_chunks; ++c) {
-                if (tg[w].out[c] < theta) continue;
-                ++r.n_cand;
-                // columns of the chunk (lane lM, steps 64 c + 1 .. 64 c + 64), in read coordinates
-                int lo = 128 * c - 2 * lM + 1, hi = 128 * c - 2 * lM + 128;
-                if (lo < 1) lo = 1;
-                if (hi > tg[w].n) hi = tg[w].n;
-                if (hi < lo) continue;
-                lo += tg[w].col_off; hi += tg[w].col_off;
-                // pieces and chunks come in ascending column order, the overlap zones of a piece repeat columns of the one before
-                if (nw > 0 && lo <= r.hi[nw - 1] + sp.merge_gap) {
-                    if (hi > r.hi[nw - 1]) r.hi[nw - 1] = hi;
-                    if (lo < r.lo[nw - 1]) r.lo[nw - 1] = lo;
-                } else if (nw < STRQ_SCREEN_MAX_WINDOWS) {
-                    r.lo[nw] = lo; r.hi[nw] = hi; ++nw;
-                } else {
-                    // more separate candidates than the exact launch has pieces: the last window takes everything from here on
-                    if (hi > r.hi[nw - 1]) r.hi[nw - 1] = hi;
+            for (int c0 = 0; c0 < tg[w].n_chunks; c0 += 64) {
+                const int c1 = c0 + lane;
+                const bool cand = c1 < tg[w].n_chunks && tg[w].out[c1] >= theta;
+                uint64_t mask = __ballot(cand);
+                while (mask) {              // wave-uniform: every lane walks the same candidates, lane 0's copy is stored
+                    const int bit = __builtin_ctzll(mask); mask &= mask - 1;
+                    const int c = c0 + bit;
+                    ++r.n_cand;
+                    // columns of the chunk (lane lM, steps 64 c + 1 .. 64 c + 64), in read coordinates
+                    int lo = 128 * c - 2 * lM + 1, hi = 128 * c - 2 * lM + 128;
+                    if (lo < 1) lo = 1;
+                    if (hi > tg[w].n) hi = tg[w].n;
+                    if (hi < lo) continue;
+                    lo += tg[w].col_off; hi += tg[w].col_off;
+                    // pieces and chunks come in ascending column order, the overlap zones of a piece repeat columns of the one before
+                    if (nw > 0 && lo <= r.hi[nw - 1] + sp.merge_gap) {
+                        if (hi > r.hi[nw - 1]) r.hi[nw - 1] = hi;
+                        if (lo < r.lo[nw - 1]) r.lo[nw - 1] = lo;
+                    } else if (nw < STRQ_SCREEN_MAX_WINDOWS) {
+                        r.lo[nw] = lo; r.hi[nw] = hi; ++nw;
+                    } else {
+                        // more separate candidates than the exact launch has pieces: the last window takes everything from here on
+                        if (hi > r.hi[nw - 1]) r.hi[nw - 1] = hi;
+                    }
                 }
             }
         }
-        r.n_win = ok ? nw : 0;
+        r.n_win = nw;
     }
-    out[g] = r;
+    if (lane == 0) out[g] = r;
 }
 
 int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
@@ -359,7 +370,7 @@ int launch_screen_windows(hipStream_t stream, const ScreenTask* tasks, int n_gro
                           const int32_t* bound_scaled, ScreenWindows* out)
 {
     if (n_groups <= 0) return 0;
-    hipLaunchKernelGGL(screen_windows_kernel, dim3((n_groups + 127) / 128), dim3(128), 0, stream, tasks, n_groups, sp, bound_scaled, out);
+    hipLaunchKernelGGL(screen_windows_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, stream, tasks, n_groups, sp, bound_scaled, out);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
