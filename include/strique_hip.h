@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 10 (10: strq_last_screen; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 10 (10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -265,6 +265,12 @@ int strq_debug_g2_layout(int32_t n_states, int32_t silent_start, int32_t start, 
                          const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,
                          const int32_t* emis_kind, const int32_t* count_inc, const int32_t* kind, const int32_t* pos,
                          double* out_lp, int32_t* out_own, int32_t* out_meta, char* why, int32_t why_len);
+
+/* Test hook, host only (no context, no device): the integer frame the upper-bound screen would run in for these alignment
+ * parameters (open_h, ext_h, open_v, ext_v, dist_offset, dist_min; src/align_raw.h:84-103) and reads of up to `max_n` samples.
+ * Returns 1 and out[6] = {scale, -ext_h * scale, -ext_v * scale, what is added to every table entry, float32 slack * scale,
+ * columns below which candidate chunks merge}, or 0 when the parameters allow no screen (then the float32 DP runs over whole reads). */
+int strq_debug_screen_plan(const float params[6], int32_t samples, int32_t max_n, int32_t out[6]);
 
 /* Kernel timing of the last batched call, milliseconds (HIP events on the library's stream):
  * [0] table build  [1] forward DP  [2] trace pass  [3] total  [4] table entries re-evaluated on

@@ -879,6 +879,16 @@ int strq_last_counters(const strq_ctx* c, double out[8])
     return STRQ_OK;
 }
 
+int strq_debug_screen_plan(const float params[6], int32_t samples, int32_t max_n, int32_t out[6])
+{
+    if (!params || !out) return 0;
+    const AlignParams p{params[0], params[1], params[2], params[3], params[4], params[5]};
+    ScreenParams sp;
+    if (!screen_plan(p, samples, max_n, &sp)) return 0;
+    out[0] = sp.sc; out[1] = sp.hh; out[2] = sp.v; out[3] = sp.cadd; out[4] = sp.slack; out[5] = sp.merge_gap;
+    return 1;
+}
+
 int strq_last_screen(const strq_ctx* c, double out[8])
 {
     if (!c || !out) return STRQ_ERR_ARG;

@@ -66,3 +66,30 @@ def test_stored_values_fit_31_bits_for_the_longest_reads():
     top = rows_max * (16 * sc + 16 * sc) + (n_max + 256) * sc + 0x00800000
     assert top < 2 ** 31 - 2 ** 24            # below 0x7f800000: every bit pattern is a finite positive float32 (v_max3_f32 orders them)
     assert 16 * sc + 16 * sc + sc < 65536     # a table entry fits 16 bits
+
+
+def test_screen_plan_of_the_library(monkeypatch):
+    """The frame the library plans for (host code, no GPU): STRique's parameters run at a scale of 1024 with 16 score units of float32
+    slack; reads beyond ~1.9 M samples at 512; general affine gaps, a negative dist_min or other samples-per-k-mer get no screen."""
+    import ctypes
+    from strique_amd import build
+    lib = ctypes.CDLL(build.build_lib())
+    lib.strq_debug_screen_plan.restype = ctypes.c_int
+    out = (ctypes.c_int32 * 6)()
+
+    def plan(params, samples=6, max_n=400000):
+        arr = (ctypes.c_float * 6)(*params)
+        return lib.strq_debug_screen_plan(arr, ctypes.c_int32(samples), ctypes.c_int32(max_n), out), list(out)
+
+    ok, o = plan([-1, -1, -16, -16, 16, 0])
+    assert ok == 1 and o[:4] == [1024, 1024, 16384, 17408] and o[4] == 16 * 1024
+    assert o[2] + o[1] + 16 * o[0] < 65536                      # the largest table entry fits 16 bits
+    ok, o = plan([-1, -1, -16, -16, 16, 0], max_n=3_000_000)
+    assert ok == 1 and o[0] == 512
+    assert plan([-3, -1, -20, -4, 16, 0])[0] == 0                 # open != extend
+    assert plan([-1, -1, -16, -16, 16, -4])[0] == 0               # dist_min < 0
+    assert plan([-1, -1, -16, -16, 16, 0], samples=5)[0] == 0
+    ok, o = plan([-0.5, -0.5, -8, -8, 8, 0])
+    assert ok == 1 and o[1] * 2 == o[0] and o[2] == 8 * o[0]
+    monkeypatch.setenv("STRQ_NO_SCREEN", "1")
+    assert plan([-1, -1, -16, -16, 16, 0])[0] == 0
