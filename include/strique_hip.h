@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 10 (10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 11 (11: strq_set_option, strq_get_option, strq_batch_upload_part; 10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -44,6 +44,15 @@ void strq_ctx_destroy(strq_ctx* ctx);
 const char* strq_last_error(const strq_ctx* ctx);
 /* hipDeviceSynchronize on the context's device (benchmark brackets). */
 int strq_device_synchronize(strq_ctx* ctx);
+
+/* Switches of the library (the experiment / A-B switches that used to be environment variables only, e.g. STRQ_NO_SCREEN,
+ * STRQ_OVERLAP, STRQ_SEG; README "Switches"): per context when ctx != NULL, process-wide when ctx == NULL.  Every switch is read
+ * in this order: context, process, environment variable of the same name.  value NULL removes the entry (back to the next level),
+ * "" means "not set" whatever the lower levels say.  Keys start with "STRQ_".  No switch changes a result -- they choose between
+ * kernels / plans that are all exact (the reference has no counterpart: scripts/STRique.py:904-914 exposes --t and --config only).
+ * strq_get_option writes the effective value ("" when unset) to out[cap]. */
+int strq_set_option(strq_ctx* ctx, const char* key, const char* value);
+int strq_get_option(const strq_ctx* ctx, const char* key, char* out, int32_t cap);
 
 /* Alignment parameters, order: open_h, ext_h, open_v, ext_v, dist_offset, dist_min.
  * Defaults after create are align_raw's own (src/align_raw.h:51-60): -2,-8,-2,-8, 8,-16;
@@ -197,6 +206,13 @@ int strq_detect_batch_reads(strq_ctx* ctx, int64_t n_reads, const void* const* r
  * repeat) the device work alone: upload = host -> HBM copy, run = all kernels, fetch = results. */
 int strq_batch_upload(strq_ctx* ctx, int64_t n_reads, const void* signals, int32_t dtype,
                       const int64_t* offsets, const int32_t* target_id, const double* host_stats);
+/* strq_batch_upload in parts, so that a caller never holds more than one part in host memory: the first call (first_read = 0)
+ * sizes the resident batch for total_reads reads / total_samples int16 samples (a hint: the buffer grows when the parts hold
+ * more), every call uploads n_reads reads (signals +
+ * offsets[0 .. n_reads], offsets relative to `signals`) behind the ones before it (first_read = reads uploaded so far).  Reads not
+ * yet uploaded are empty.  int16 only (dtype 0).  bench.py stages its resident batches with it (synthesise -> upload -> free). */
+int strq_batch_upload_part(strq_ctx* ctx, int64_t total_reads, int64_t total_samples, int64_t first_read, int64_t n_reads,
+                           const void* signals, int32_t dtype, const int64_t* offsets, const int32_t* target_id);
 int strq_batch_run(strq_ctx* ctx);
 /* Only reads [first, last) of the uploaded batch (several batches kept resident side by side: a benchmark that
  * times a different one every step); strq_batch_fetch still returns the rows of the whole upload. */
@@ -258,8 +274,9 @@ int strq_debug_conditioning(strq_ctx* ctx, int64_t read, uint8_t* levels, int64_
                             double* scalars10);
 /* Test hook, host only (no context, no device): the tables strq_model_set_positions would upload for this model --
  * out_lp[31 * 64] (log-probability of every column of the layout per lane, -inf where a lane has no such edge),
- * out_own[6 * 64] (state of every slot and lane, -1 if none), out_meta[8] = {slot, lane of the two broadcast sources,
- * of start and of end}.  STRQ_ERR_UNSUPPORTED and the reason in `why` when the model is no profile chain.
+ * out_own[6 * 64] (state of every slot and lane, -1 if none, -2 for a virtual relay state), out_meta[10] = {slot, lane of
+ * the two broadcast sources, of start and of end, then the low and high word of the lane mask of relayed hub states} -- the
+ * caller provides TEN int32.  STRQ_ERR_UNSUPPORTED and the reason in `why` when the model is no profile chain.
  * tests/test_g2_layout.py drives a plain restatement of the kernel's time step with them. */
 int strq_debug_g2_layout(int32_t n_states, int32_t silent_start, int32_t start, int32_t end,
                          const int32_t* in_ptr, const int32_t* in_src, const double* in_logp,

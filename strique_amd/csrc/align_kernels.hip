@@ -28,6 +28,7 @@
 //
 // All arithmetic is float32 add / max exactly in the order of the CPU oracle
 // (oracle/align_oracle.c); compile with -ffp-contract=off.
+#include "strq_opt.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "align_kernels.h"
@@ -988,11 +989,11 @@ int align_plan(int m, int samples, int* rows_per_lane, int* n_strips)
     // Measured on MI355X (50 kb reads, 870-row flanks): two strips at two waves per SIMD take as long
     // as one strip at one wave per SIMD -- the per-step overhead is amortised over half the rows --
     // so one strip is preferred whenever a single-strip shape fits.  STRQ_STRIPS=2 forces two.
-    const char* e = getenv("STRQ_STRIPS");
+    const char* e = strq::opt("STRQ_STRIPS");
     const bool force_two = e && e[0] == '2';
     // 14 rows per lane: STRique's 870-row flanks keep 63 of 64 lanes busy (15 rows: 58).  STRQ_NO_R14 leaves the shape
     // out (A/B runs).
-    const bool no14 = getenv("STRQ_NO_R14") != nullptr;          // read on every call, like STRQ_STRIPS
+    const bool no14 = strq::opt("STRQ_NO_R14") != nullptr;          // read on every call, like STRQ_STRIPS
     const int single[] = {6, 7, 8, 12, 14, 15};
     const int two[] = {6, 7, 8, 12};
     // Flanks of 129 ... 149 classes fit 14 and 15 rows per lane; 14 keeps more lanes busy, and since round 4 the register the
@@ -1102,7 +1103,7 @@ int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tas
                           int tables_per_cu, int n_cu, int packed, const int* group_list, const int* n_list, bool known_last_row)
 {
     if (!(p.open_h == p.ext_h && p.open_v == p.ext_v)) return 2;
-    if (getenv("STRQ_DP_SWITCHED")) known_last_row = false;          // A/B: the switched loop for STRique's own flanks too
+    if (strq::opt("STRQ_DP_SWITCHED")) known_last_row = false;          // A/B: the switched loop for STRique's own flanks too
     AlignParams ps = p;
     if (packed) { ps.open_h *= STRQ_PK_SCALE; ps.ext_h *= STRQ_PK_SCALE; ps.open_v *= STRQ_PK_SCALE; ps.ext_v *= STRQ_PK_SCALE; }
     const int wpe = align_segments_wpe(segs, tables_per_cu);

@@ -13,6 +13,7 @@
 //
 // These kernels are byte/short streaming: coalesced 2-byte loads, LDS tiles for the four sliding
 // min/max passes, histograms accumulated in an LDS window per tile and flushed bin by bin.
+#include "strq_opt.h"
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -558,7 +559,7 @@ int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, con
     const dim3 hgrid((max_n + HIST_TILE - 1) / HIST_TILE, n_reads);
     // 16 bytes per lane when the raw and the filtered buffer have the same alignment phase (the caller arranges that);
     // its tiles start up to seven samples in front of a read: one more tile covers the longest read
-    const bool same_phase = ((reinterpret_cast<uintptr_t>(raw) ^ reinterpret_cast<uintptr_t>(flt)) & 15) == 0 && !getenv("STRQ_COND_SCALAR");
+    const bool same_phase = ((reinterpret_cast<uintptr_t>(raw) ^ reinterpret_cast<uintptr_t>(flt)) & 15) == 0 && !strq::opt("STRQ_COND_SCALAR");
     const dim3 vgrid((max_n + 7 + HIST_TILE - 1) / HIST_TILE, n_reads);
     if (hist_flt && same_phase) hipLaunchKernelGGL(medfilt_hist16_vec_kernel, vgrid, dim3(256), 0, s, raw, flt, rc, hist_flt, range4, 4);
     else if (hist_flt) hipLaunchKernelGGL(medfilt_hist16_kernel, hgrid, dim3(256), 0, s, raw, flt, rc, hist_flt, range4, 4);

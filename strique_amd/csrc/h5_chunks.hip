@@ -9,6 +9,7 @@
 // its three entry points are declared here and resolved with dlopen -- decodes the same zlib streams about three times as
 // fast; zlib stays as the fallback when the library is absent (or STRQ_NO_LIBDEFLATE=1: A/B runs).  Same bytes either way
 // (tests/test_cli_host.py::test_deflate_chunks_native_and_python_paths).
+#include "strq_opt.h"
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -38,7 +39,7 @@ const LibDeflate& libdeflate()
     static LibDeflate L;
     static std::once_flag once;
     std::call_once(once, [] {
-        if (getenv("STRQ_NO_LIBDEFLATE")) return;
+        if (strq::opt("STRQ_NO_LIBDEFLATE")) return;
         void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;

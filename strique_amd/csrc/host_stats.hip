@@ -148,7 +148,7 @@ void host_stats_batch(const double* signals, const int64_t* offsets, int64_t n_r
     // one process per GPU under torchrun and not pinned: every rank still takes only its share of the host's cores
     if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int w = atoi(e); if (w > 1 && threads == machine) threads = threads / w > 0 ? threads / w : 1; }
     if (threads > 64) threads = 64;          // 9 ms per 375 k-sample read and core: 64 threads ~ 7 k reads/s of float64 input
-    if (const char* e = getenv("STRQ_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }
+    if (const char* e = strq::opt("STRQ_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) threads = v; }
     if ((int64_t)threads > n_reads) threads = (int)n_reads;
     std::atomic<int64_t> next{0};
     auto work = [&]() {

@@ -24,6 +24,7 @@
 // (A first version ran both flanks of a read in the halves of 16-bit pairs -- v_pk_add_u16 / v_pk_max_u16, 141 instructions per
 // step for two alignments.  gfx950 issues the packed 16-bit integer instructions at half rate, like v_pk_add_f32: 96 ms per
 // 2048 reads where the float32 pass takes 130; tools/ubench_pk16.hip)
+#include "strq_opt.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -328,7 +329,7 @@ screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, Screen
 
 int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
 {
-    if (getenv("STRQ_NO_SCREEN")) return 0;
+    if (strq::opt("STRQ_NO_SCREEN")) return 0;
     if (samples != S) return 0;
     if (!(p.open_h == p.ext_h && p.open_v == p.ext_v)) return 0;
     if (!(p.dist_min >= 0.0f) || !(p.ext_h < 0.0f) || !(p.ext_v < 0.0f) || !(p.dist_offset > 0.0f) || !(p.dist_min <= p.dist_offset)) return 0;

@@ -9,6 +9,8 @@
 #include <time.h>
 #include <unistd.h>
 #include <map>
+#include <mutex>
+#include <string>
 #include <tuple>
 #include <numeric>
 #include <vector>
@@ -20,9 +22,29 @@
 
 using namespace strq;
 
-#define STRQ_DBG(...) do { if (getenv("STRQ_DEBUG")) { fprintf(stderr, "[strq] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+#define STRQ_DBG(...) do { if (strq::opt("STRQ_DEBUG")) { fprintf(stderr, "[strq] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
 
 namespace strq {
+
+// ---- switches (strq_opt.h)
+static thread_local const strq_ctx* t_cur_ctx = nullptr;
+static std::mutex g_opt_mu;
+static std::map<std::string, std::string> g_opts;
+CtxScope::CtxScope(const strq_ctx* c) : prev(t_cur_ctx) { t_cur_ctx = c; }
+CtxScope::~CtxScope() { t_cur_ctx = prev; }
+const char* opt(const char* key)
+{
+    if (t_cur_ctx) {
+        auto it = t_cur_ctx->options.find(key);
+        if (it != t_cur_ctx->options.end()) return it->second.empty() ? nullptr : it->second.c_str();
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        auto it = g_opts.find(key);
+        if (it != g_opts.end()) return it->second.empty() ? nullptr : it->second.c_str();
+    }
+    return getenv(key);
+}
 
 // Score<float,Distance>::score, evaluated with the host libm exactly like the reference
 // (src/score_distance.h:117-122)
@@ -147,8 +169,8 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipMemcpyAsync(&hard_count, d_hard_count, 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
     STRQ_DBG("lut done nb=%d hard=%d floats0=%d", nb, hard_count, info[0].total);
-    if (getenv("STRQ_DEBUG")) { int hist[9] = {0}; for (int i = 0; i < nj; ++i) hist[std::min(8, info[i].need / 8)]++; STRQ_DBG("band need histogram (x8 levels): %d %d %d %d %d %d %d %d %d", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]); }
-    if (getenv("STRQ_DEBUG")) { long tot = 0; int mx = 0; for (int i = 0; i < nj; ++i) { tot += info[i].total; mx = std::max(mx, info[i].total); } STRQ_DBG("table floats: mean %.0f max %d (k=%d)", (double)tot / nj, mx, in.k[0]); }
+    if (strq::opt("STRQ_DEBUG")) { int hist[9] = {0}; for (int i = 0; i < nj; ++i) hist[std::min(8, info[i].need / 8)]++; STRQ_DBG("band need histogram (x8 levels): %d %d %d %d %d %d %d %d %d", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]); }
+    if (strq::opt("STRQ_DEBUG")) { long tot = 0; int mx = 0; for (int i = 0; i < nj; ++i) { tot += info[i].total; mx = std::max(mx, info[i].total); } STRQ_DBG("table floats: mean %.0f max %d (k=%d)", (double)tot / nj, mx, in.k[0]); }
     if (hard_count > hard_cap) { c->err = "too many borderline table entries"; return STRQ_ERR_DEVICE; }
     bool any_rebuild = false;
     for (int j = 0; j < nj; ++j) any_rebuild |= info[j].n_hard < 0;
@@ -198,14 +220,14 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // tasks; results / pick / heads are indexed by alignment position.
     const bool collapsed = S == 6 && c->ap.open_h == c->ap.ext_h && c->ap.open_v == c->ap.ext_v;      // the collapsed / segmented / packed kernels exist for samples = 6
     int seg_want = 0, max_tables = 8, max_waves = 16;      // seg_want 0: chosen below from the read lengths
-    if (const char* e = getenv("STRQ_SEG")) { const int v = atoi(e); if (v >= 1 && v <= 4) seg_want = v; }
-    if (const char* e = getenv("STRQ_TABLES")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_tables = v; }
-    if (const char* e = getenv("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_tables = v; }      // older name
-    if (const char* e = getenv("STRQ_MAX_WAVES")) { const int v = atoi(e); if (v >= 4 && v <= 16) max_waves = v; }
-    bool allow_pack = collapsed && !getenv("STRQ_NO_PACK");
+    if (const char* e = strq::opt("STRQ_SEG")) { const int v = atoi(e); if (v >= 1 && v <= 4) seg_want = v; }
+    if (const char* e = strq::opt("STRQ_TABLES")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_tables = v; }
+    if (const char* e = strq::opt("STRQ_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 8) max_tables = v; }      // older name
+    if (const char* e = strq::opt("STRQ_MAX_WAVES")) { const int v = atoi(e); if (v >= 4 && v <= 16) max_waves = v; }
+    bool allow_pack = collapsed && !strq::opt("STRQ_NO_PACK");
     // overlap the pieces are cut with first (the worst case is ~15 k columns for an 870-row flank); see the piece planning below
     int ov_cap = 8192; bool ov_fixed = false;
-    if (const char* e = getenv("STRQ_OVERLAP")) { const int v = atoi(e); ov_cap = v > 0 ? v : (1 << 30); ov_fixed = true; }      // 0: always the worst-case overlap
+    if (const char* e = strq::opt("STRQ_OVERLAP")) { const int v = atoi(e); ov_cap = v > 0 ? v : (1 << 30); ov_fixed = true; }      // 0: always the worst-case overlap
     // Without the variable: 8192 columns for the first sub-batch, afterwards the overlap that would have been cheapest
     // for the previous sub-batch -- extra columns per piece against the share of alignments whose best score would
     // not certify that overlap and which therefore run twice (any choice is exact; this one only sets the cost).
@@ -269,14 +291,14 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     ScreenParams sp;
     int scr_max_n = 0;
     for (int i = 0; i < nb; ++i) scr_max_n = std::max(scr_max_n, in.n[i]);
-    const bool scr_forced = getenv("STRQ_SCREEN_ALWAYS") != nullptr;      // tests: no pause
+    const bool scr_forced = strq::opt("STRQ_SCREEN_ALWAYS") != nullptr;      // tests: no pause
     if (collapsed && c->screen_pause > 0 && !scr_forced) {
         --c->screen_pause; c->screen_stats[3] += nb;      // counted as whole-read alignments
     } else if (collapsed && screen_plan(c->ap, S, scr_max_n, &sp)) {
         // reads below ~64 k samples: the pieces' overlaps eat what the cheaper pass saves (STRQ_SCREEN_MIN_N: tests)
         int min_n = 65536, scr_tables = 6;
-        if (const char* e = getenv("STRQ_SCREEN_MIN_N")) min_n = atoi(e);
-        if (const char* e = getenv("STRQ_SCREEN_TABLES")) { const int v = atoi(e); if (v >= 1 && v <= 8) scr_tables = v; }
+        if (const char* e = strq::opt("STRQ_SCREEN_MIN_N")) min_n = atoi(e);
+        if (const char* e = strq::opt("STRQ_SCREEN_TABLES")) { const int v = atoi(e); if (v >= 1 && v <= 8) scr_tables = v; }
         std::vector<int> sel;
         for (int i = 0; i < nb; ++i)
             if (in.NS[i] == 1 && NJ[i] == 1 && in.n[i] >= min_n && screen_flank_ok(in.m[i]) && in.k[i] * S == in.m[i]) sel.push_back(i);
@@ -329,7 +351,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             STRQ_HIP(c, hipMemcpyAsync(hw.data(), d_win, hw.size() * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
             STRQ_HIP(c, hipStreamSynchronize(st));
             c->screen_ran = true;
-            if (const char* path = getenv("STRQ_SCREEN_DUMP")) {
+            if (const char* path = strq::opt("STRQ_SCREEN_DUMP")) {
                 // tests: the chunk maxima as the kernel wrote them (tests/test_gpu_screen.py checks them against the exact last row)
                 std::vector<int32_t> ho(out_words);
                 STRQ_HIP(c, hipMemcpy(ho.data(), d_out, out_words * 4, hipMemcpyDeviceToHost));
@@ -350,8 +372,8 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                     fclose(fp);
                 }
             }
-            const bool no_prune = getenv("STRQ_SCREEN_NO_PRUNE") != nullptr;      // tests: run the screen, then the whole reads
-            if (const char* e = getenv("STRQ_SCREEN_TEST_RAISE")) {
+            const bool no_prune = strq::opt("STRQ_SCREEN_NO_PRUNE") != nullptr;      // tests: run the screen, then the whole reads
+            if (const char* e = strq::opt("STRQ_SCREEN_TEST_RAISE")) {
                 // tests: claim a lower bound no alignment reaches -- the certificate must fail and the second round (whole reads) must deliver
                 const float up = (float)atof(e);
                 for (auto& w : hw) w.lower_bound += up;
@@ -389,7 +411,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     }
     std::vector<char> packed(nb, 0), segmentable(nb, 0);
     std::vector<int> overlap(nb, 0), segs_of(nb, 1);
-    const bool force_pack = getenv("STRQ_PACK") != nullptr;
+    const bool force_pack = strq::opt("STRQ_PACK") != nullptr;
     int class_count[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < nb; ++i) {
         segmentable[i] = collapsed && in.NS[i] == 1;
@@ -422,7 +444,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         // of windows -- one wave over 375 k columns would be a 60 ms tail, gpurun_out/r4y.)
         // a length class too small to fill the chip once joins the class with fewer waves per alignment
         int few = 2 * c->n_cu;
-        if (const char* e = getenv("STRQ_CLASS_MIN")) few = atoi(e);      // tests: keep small length classes apart
+        if (const char* e = strq::opt("STRQ_CLASS_MIN")) few = atoi(e);      // tests: keep small length classes apart
         // (an alignment with more windows than its new launch has pieces runs its whole read instead)
         if (class_count[4] && class_count[4] < few) { for (int i = 0; i < nb; ++i) if (segs_of[i] == 4) { segs_of[i] = 2; if (wins[i].n_win > 2) wins[i].n_win = 0; } class_count[2] += class_count[4]; class_count[4] = 0; }
         if (class_count[2] && class_count[2] < few && class_count[1]) { for (int i = 0; i < nb; ++i) if (segs_of[i] == 2) { segs_of[i] = 1; if (wins[i].n_win > 1) wins[i].n_win = 0; } class_count[1] += class_count[2]; class_count[2] = 0; }
@@ -439,7 +461,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // slices); groups are ordered by descending tables per CU within (R, strips, waves per alignment).
     {
         int min_rounds = 4;
-        if (const char* e = getenv("STRQ_MIN_ROUNDS")) min_rounds = atoi(e);
+        if (const char* e = strq::opt("STRQ_MIN_ROUNDS")) min_rounds = atoi(e);
         for (auto it = groups.begin(); it != groups.end();) {
             auto nx = std::next(it);
             const int w = -std::get<3>(it->first);
@@ -630,7 +652,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // run large parts of their reads (launches of two / four waves per alignment): a ~20 ms tail if the launches follow each other.
     // The launch with the most alignments runs on a second stream, next to the others (gpurun_out/r4aa: degraded reads).
     int side = -1;
-    if (c->screen_ran && launches.size() > 1 && max_ns == 1 && collapsed && !getenv("STRQ_ONE_STREAM")) {
+    if (c->screen_ran && launches.size() > 1 && max_ns == 1 && collapsed && !strq::opt("STRQ_ONE_STREAM")) {
         side = 0;
         for (size_t li = 1; li < launches.size(); ++li) if (launches[li].count > launches[side].count) side = (int)li;
         if (!c->stream2) STRQ_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -802,7 +824,27 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 
 extern "C" {
 
-int strq_abi_version(void) { return 10; }
+int strq_abi_version(void) { return 11; }
+
+int strq_set_option(strq_ctx* c, const char* key, const char* value)
+{
+    if (!key || std::strncmp(key, "STRQ_", 5) != 0) { if (c) c->err = "option keys start with STRQ_"; return STRQ_ERR_ARG; }
+    if (c) { if (value) c->options[key] = value; else c->options.erase(key); return STRQ_OK; }
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (value) g_opts[key] = value; else g_opts.erase(key);
+    return STRQ_OK;
+}
+
+int strq_get_option(const strq_ctx* c, const char* key, char* out, int32_t cap)
+{
+    if (!key || !out || cap < 1) return STRQ_ERR_ARG;
+    CtxScope scope(c);
+    const char* v = opt(key);
+    out[0] = 0;
+    if (!v) return STRQ_OK;
+    std::strncpy(out, v, (size_t)cap - 1); out[cap - 1] = 0;
+    return STRQ_OK;
+}
 
 int strq_ctx_create(int device_id, strq_ctx** out)
 {
@@ -922,6 +964,7 @@ int strq_align_batch(strq_ctx* c, int64_t n_align, int64_t n_reads, const uint8_
                      const float* flank, const int64_t* flank_off, int32_t samples,
                      float* score, int64_t* j_end, int64_t* j0, int32_t* rec)
 {
+    strq::CtxScope scope_(c);
     if (!c) return STRQ_ERR_ARG;
     if (n_align < 0 || n_reads < 0 || (n_align > 0 && (!levels || !read_off || !level_val || !align_read || !flank || !flank_off)) || samples < 1) {
         c->err = "bad argument"; return STRQ_ERR_ARG;
@@ -1030,6 +1073,7 @@ static int align_overlap_generic(strq_ctx* c, const float* a, int64_t n, const f
 int strq_align_overlap(strq_ctx* c, const float* a, int64_t n, const float* b, int64_t m, float* score,
                        uint64_t* a_idx, uint64_t* b_idx, int32_t* rec_out, int64_t* j_end_out, int64_t* j0_out)
 {
+    strq::CtxScope scope_(c);
     if (!c) return STRQ_ERR_ARG;
     if ((!a && n > 0) || !b || n < 0 || m < 1 || !score) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
@@ -1046,7 +1090,7 @@ int strq_align_overlap(strq_ctx* c, const float* a, int64_t n, const float* b, i
     { int64_t start = 0;
       for (int64_t i = 1; i <= m; ++i)
           if (i == m || std::memcmp(&b[i], &b[start], 4) != 0) { int len = (int)std::min<int64_t>(i - start, 1 << 20); run = run ? std::__gcd(run, len) : len; start = i; } }
-    bool fast = vals.size() <= 256 && run >= 1 && !getenv("STRQ_GENERIC_ALIGN");
+    bool fast = vals.size() <= 256 && run >= 1 && !strq::opt("STRQ_GENERIC_ALIGN");
     for (float v : vals) if (v != v) fast = false;
     if (fast) {
         std::sort(vals.begin(), vals.end());

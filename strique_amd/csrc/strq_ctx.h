@@ -4,10 +4,12 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <map>
 #include <cstdio>
 #include "align_kernels.h"
 #include "viterbi_kernels.h"
 #include "screen_kernels.h"
+#include "strq_opt.h"
 
 namespace strq {
 
@@ -71,6 +73,10 @@ struct HostModel {
 }  // namespace strq
 
 struct strq_ctx {
+    // strq_set_option: per-context switches (key -> value; an empty value = "unset", whatever the environment says).  Every switch
+    // of the library is read through strq::opt(key): this map first, then the process-wide table (strq_set_option(NULL, ...)),
+    // then the environment variable of the same name -- so that one process can run A/B legs on the same resident batches.
+    std::map<std::string, std::string> options;
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -106,6 +112,8 @@ struct strq_ctx {
 };
 
 namespace strq {
+// marks `c` as that context for the lifetime of the object (every C-ABI entry that takes a context opens one)
+struct CtxScope { const strq_ctx* prev; explicit CtxScope(const strq_ctx* c); ~CtxScope(); };
 int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out);
 int align_core_times(strq_ctx* c, float* t_lut, float* t_fwd, float* t_tr);
 int align_validate_flank(strq_ctx* c, const float* f, int64_t m, int samples, int* k_out, int* R_out, int* NS_out);

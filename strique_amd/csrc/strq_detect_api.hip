@@ -21,7 +21,7 @@
 
 using namespace strq;
 
-#define STRQ_DBG(...) do { if (getenv("STRQ_DEBUG")) { fprintf(stderr, "[strq] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+#define STRQ_DBG(...) do { if (strq::opt("STRQ_DEBUG")) { fprintf(stderr, "[strq] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
 static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 namespace strq {
@@ -140,6 +140,7 @@ struct DetectState {
     DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange, modpool;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
+    int64_t part_reads = 0, part_samples = 0;      // strq_batch_upload_part: reads uploaded so far / samples announced
     int levels_shift = 0;                // bytes the level stream of the current sub-batch starts behind the buffer's base (alignment phase)
     hipStream_t copy_stream = nullptr;   // host -> HBM uploads that overlap the kernels of the previous sub-batch
     static constexpr int N_STAGE = 4;    // pinned staging ring of upload_reads
@@ -223,7 +224,7 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
     // 3. Viterbi on the modification model.  Hub records (one 8-byte record per time step, read back with one
     //    hop per repeat unit) when the model has the hub structure; back-pointers + traceback otherwise.
     std::map<int, std::vector<int>> by_shape;
-    bool use_hub = !getenv("STRQ_MOD_BACKPOINTERS");
+    bool use_hub = !strq::opt("STRQ_MOD_BACKPOINTERS");
     for (int k = 0; k < nm; ++k) {
         HostModel* hm = c->models[d->targets[B.target[r0 + who[k]]].mod_model_id];
         const int shape = vit_shape_of(hm->h);
@@ -340,7 +341,7 @@ static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
     const size_t b0 = (size_t)B.off[B.uploaded] * esz, b1 = (size_t)B.off[upto] * esz;
     const size_t SLOT = (size_t)32 << 20;
     int n_threads = 6;
-    if (const char* e = getenv("STRQ_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 0 && v <= 32) n_threads = v; }
+    if (const char* e = strq::opt("STRQ_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 0 && v <= 32) n_threads = v; }
     if (b1 > b0 && n_threads == 0) {          // the runtime's pageable path
         if (B.host_reads.empty()) STRQ_HIP(c, hipMemcpyAsync(B.raw.as<char>() + b0, B.host_src + b0, b1 - b0, hipMemcpyHostToDevice, d->copy_stream));
         else for (int64_t r = B.uploaded; r < upto; ++r) {
@@ -469,7 +470,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     // kernels running under the upload of the next (only the first piece's upload is exposed); a resident
     // or prefetched sub-batch is one piece.  The Viterbi launches below always cover the whole sub-batch.
     int parts = 1;
-    if (B.on_host && B.uploaded < r1 && nr >= 1024) { parts = 2; if (const char* e = getenv("STRQ_UPLOAD_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= 16) parts = v; } }
+    if (B.on_host && B.uploaded < r1 && nr >= 1024) { parts = 2; if (const char* e = strq::opt("STRQ_UPLOAD_PARTS")) { const int v = atoi(e); if (v >= 1 && v <= 16) parts = v; } }
     for (int part = 0; part < parts; ++part) {
         const int i0 = (int)((int64_t)nr * part / parts), i1 = (int)((int64_t)nr * (part + 1) / parts), np_ = i1 - i0;
         if (np_ <= 0) continue;
@@ -624,6 +625,7 @@ int strq_target_add(strq_ctx* c, const float* prefix_ext, int64_t m_prefix, cons
                     int32_t trim_prefix, int32_t trim_suffix, int32_t samples, int32_t hmm_model_id, int32_t count_bias,
                     int32_t* target_id)
 {
+    strq::CtxScope scope_(c);
     if (!c) return STRQ_ERR_ARG;
     if (!prefix_ext || !suffix_ext || !target_id || hmm_model_id < 0 || hmm_model_id >= (int32_t)c->models.size() ||
         trim_prefix < 0 || trim_suffix < 0 || trim_prefix >= m_prefix || trim_suffix >= m_suffix) { c->err = "bad argument"; return STRQ_ERR_ARG; }
@@ -707,7 +709,62 @@ static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int3
 int strq_batch_upload(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
                       const int32_t* target_id, const double* host_stats)
 {
+    strq::CtxScope scope_(c);
     return batch_prepare(c, n_reads, signals, dtype, offsets, target_id, host_stats, false);
+}
+
+int strq_batch_upload_part(strq_ctx* c, int64_t total_reads, int64_t total_samples, int64_t first_read, int64_t n_reads,
+                           const void* signals, int32_t dtype, const int64_t* offsets, const int32_t* target_id)
+{
+    if (!c) return STRQ_ERR_ARG;
+    strq::CtxScope scope_(c);
+    DetectState* d = dstate(c);
+    if (total_reads < 0 || total_samples < 0 || first_read < 0 || n_reads < 0 || first_read + n_reads > total_reads || dtype != 0 ||
+        (n_reads > 0 && (!signals || !offsets || !target_id))) { c->err = "bad argument (strq_batch_upload_part takes int16 reads)"; return STRQ_ERR_ARG; }
+    if (!d->have_ps) { c->err = "strq_set_pore_stats has not been called"; return STRQ_ERR_ARG; }
+    STRQ_HIP(c, hipSetDevice(c->device));
+    Batch& B = d->batch;
+    if (first_read == 0) {
+        // a new resident batch: device memory for all of it now, the parts follow in order
+        B.forget_host();
+        B.n_reads = total_reads; B.dtype = dtype;
+        B.off.assign((size_t)total_reads + 1, 0); B.target.assign((size_t)total_reads, 0);
+        B.host_stats.clear();
+        STRQ_HIP(c, B.raw.reserve((size_t)total_samples * 2 + 64));      // total_samples is a hint: the buffer grows (below) when the parts hold more
+        B.results.assign((size_t)total_reads, strq_result());
+        B.mod.assign((size_t)total_reads, std::string("-"));
+        B.uploaded = 0; B.on_host = false;
+        d->part_reads = 0; d->part_samples = total_samples;
+        if (!d->ev_ok) { for (auto& e : d->ev) STRQ_HIP(c, hipEventCreate(&e)); d->ev_ok = true; }
+    }
+    if (B.n_reads != total_reads || d->part_reads != first_read) { c->err = "parts of a resident batch must follow each other, first_read = reads uploaded so far"; return STRQ_ERR_ARG; }
+    const int64_t base = B.off[(size_t)first_read];
+    for (int64_t i = 0; i < n_reads; ++i) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        if (target_id[i] < 0 || target_id[i] >= (int32_t)d->targets.size()) { c->err = "unknown target id"; return STRQ_ERR_ARG; }
+        if (len < 0 || len > ((int64_t)1 << 30)) { c->err = "bad offsets"; return STRQ_ERR_ARG; }
+        B.off[(size_t)(first_read + i + 1)] = base + (offsets[i + 1] - offsets[0]);
+        B.target[(size_t)(first_read + i)] = target_id[i];
+    }
+    {
+        const size_t need = (size_t)B.off[(size_t)(first_read + n_reads)] * 2 + 64;
+        if (need > B.raw.cap) {          // more samples than announced: a larger buffer, the parts uploaded so far move over
+            DevBuf bigger;
+            STRQ_HIP(c, bigger.reserve(need + need / 2));
+            if (base > 0) STRQ_HIP(c, hipMemcpy(bigger.p, B.raw.p, (size_t)base * 2, hipMemcpyDeviceToDevice));
+            B.raw.release();
+            B.raw = bigger;
+        }
+    }
+    for (int64_t i = first_read + n_reads; i < total_reads; ++i) B.off[(size_t)i + 1] = B.off[(size_t)(first_read + n_reads)];      // reads not yet uploaded: empty
+    // the staging ring of upload_reads addresses the caller's buffer by the batch's own byte positions
+    B.host_src = static_cast<const char*>(signals) + (size_t)offsets[0] * 2 - (size_t)base * 2;
+    B.host_reads.clear(); B.uploaded = first_read; B.on_host = true;
+    const int rc = upload_reads(c, d, first_read + n_reads);
+    B.forget_host();
+    if (rc) return rc;
+    d->part_reads = first_read + n_reads;
+    return STRQ_OK;
 }
 
 int strq_batch_run(strq_ctx* c)
@@ -718,6 +775,7 @@ int strq_batch_run(strq_ctx* c)
 
 int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
 {
+    strq::CtxScope scope_(c);
     if (!c) return STRQ_ERR_ARG;
     DetectState* d = dstate(c);
     Batch& B = d->batch;
@@ -743,7 +801,7 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
         // 4608 reads measured 437 ms against 365 ms for 4096).
         const int64_t full = std::min<int64_t>(16 * (int64_t)c->n_cu, 8192);      // 8192: task limit of vit_sort_kernel
         int64_t full_env = 0;
-        if (const char* e = getenv("STRQ_SUBBATCH_READS")) full_env = atoll(e);      // testing: force small sub-batches
+        if (const char* e = strq::opt("STRQ_SUBBATCH_READS")) full_env = atoll(e);      // testing: force small sub-batches
         for (int64_t r = r0; r < n_end && r < r0 + full; ++r) mod_batch |= d->targets[B.target[r]].mod_model_id >= 0;
         const int64_t cap = full_env > 0 ? std::min<int64_t>(full_env, 8192) : full;      // (the modification pass keeps back-pointers of the small dual model only: ~3 MB per 50 kb read)
         (void)mod_batch;
@@ -782,6 +840,7 @@ int strq_batch_fetch(strq_ctx* c, strq_result* out)
 int strq_detect_batch(strq_ctx* c, int64_t n_reads, const void* signals, int32_t dtype, const int64_t* offsets,
                       const int32_t* target_id, const double* host_stats, strq_result* out)
 {
+    strq::CtxScope scope_(c);
     // signals stay in the caller's buffer and are uploaded one sub-batch ahead of the kernels
     int rc = batch_prepare(c, n_reads, signals, dtype, offsets, target_id, host_stats, true);
     if (rc) return rc;
@@ -794,6 +853,7 @@ int strq_detect_batch(strq_ctx* c, int64_t n_reads, const void* signals, int32_t
 int strq_detect_batch_reads(strq_ctx* c, int64_t n_reads, const void* const* reads, const int64_t* lengths, int32_t dtype,
                             const int32_t* target_id, const double* host_stats, strq_result* out)
 {
+    strq::CtxScope scope_(c);
     // one buffer per read (what a caller holding a list of arrays has): no concatenated copy on the host, the staging
     // threads gather straight from the reads
     if (!c) return STRQ_ERR_ARG;

@@ -525,6 +525,7 @@ int strq_model_create(strq_ctx* c, int32_t n_states, int32_t silent_start, int32
                       const int32_t* count_inc, const int32_t* state_tag,
                       const int32_t* hint_slot, const int32_t* hint_lane, int32_t* model_id)
 {
+    strq::CtxScope scope_(c);
     if (!c) return STRQ_ERR_ARG;
     if (!in_ptr || !in_src || !in_logp || !emis_kind || !emis_a || !emis_b || !emis_c || !model_id) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
@@ -570,6 +571,7 @@ int strq_debug_g2_layout(int32_t n_states, int32_t silent_start, int32_t start, 
 
 int strq_model_set_positions(strq_ctx* c, int32_t model_id, const int32_t* kind, const int32_t* pos)
 {
+    strq::CtxScope scope_(c);
     if (!c) return STRQ_ERR_ARG;
     if (model_id < 0 || model_id >= (int32_t)c->models.size() || !c->models[model_id] || !kind || !pos) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
@@ -579,6 +581,7 @@ int strq_model_set_positions(strq_ctx* c, int32_t model_id, const int32_t* kind,
 int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const double* x, const int64_t* x_off,
                        double* logp, int64_t* counted, int32_t* status, int32_t* paths)
 {
+    strq::CtxScope scope_(c);
     if (!c) return STRQ_ERR_ARG;
     if (model_id < 0 || model_id >= (int32_t)c->models.size() || !c->models[model_id] || n_seq < 0 || (n_seq > 0 && (!x || !x_off))) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     if (n_seq == 0) return STRQ_OK;
@@ -643,6 +646,7 @@ int strq_viterbi_batch(strq_ctx* c, int32_t model_id, int64_t n_seq, const doubl
 int strq_viterbi(strq_ctx* c, int32_t model_id, const double* x, int64_t T, double* logp, int64_t* counted,
                  int32_t* status, int32_t* path)
 {
+    strq::CtxScope scope_(c);
     const int64_t off[2] = {0, T};
     return strq_viterbi_batch(c, model_id, 1, x, off, logp, counted, status, path);
 }

@@ -28,6 +28,7 @@
 // Repeat counting does not need a traceback: the number of visits of the counted states
 // (the two `dummy` states of repeatHMM, STRique.py:374-378) is carried along the best path.
 // Back-pointers are written only when the caller wants the state path (modification pass).
+#include "strq_opt.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -1040,8 +1041,8 @@ static int launch_viterbi_g2(hipStream_t stream, const VitTask* tasks, VitResult
 {
     if (want_bp != 0 && want_bp != 2) return 2;
     int nw = 8, lx = 2;
-    if (const char* e = getenv("STRQ_VIT_G2_WAVES")) { const int v = atoi(e); if (v == 12 || v == 8 || v == 4) nw = v; }      // experiments
-    if (const char* e = getenv("STRQ_VIT_G2_LDS")) { const int v = atoi(e); if (v >= 0 && v <= 2) lx = v; }
+    if (const char* e = strq::opt("STRQ_VIT_G2_WAVES")) { const int v = atoi(e); if (v == 12 || v == 8 || v == 4) nw = v; }      // experiments
+    if (const char* e = strq::opt("STRQ_VIT_G2_LDS")) { const int v = atoi(e); if (v >= 0 && v <= 2) lx = v; }
     const dim3 grid(n_cu), block(64 * nw);
     const size_t lds = lx ? (size_t)nw * G2_LDS_WAVE_BYTES : 0;
 #define G2_GO2(MK_, W_, LX_) hipLaunchKernelGGL((viterbi_g2_kernel<MK_, W_, LX_>), grid, block, lds, stream, tasks, results, n_tasks, queue, order)
@@ -1308,7 +1309,7 @@ int vit_shape_silent_slots(int shape)
 
 int vit_shape_for(const VitModel& mh, int want_bp)
 {
-    const bool no_g2 = getenv("STRQ_VIT_NO_G2") != nullptr;      // A/B: the lane layout for every mode
+    const bool no_g2 = strq::opt("STRQ_VIT_NO_G2") != nullptr;      // A/B: the lane layout for every mode
     if (mh.g2 && !no_g2 && (want_bp == 0 || (want_bp == 2 && mh.g2_mark))) return VIT_SHAPE_G2;          // either parity of the chain: decided per window inside the kernel
     return vit_shape_of(mh);
 }
@@ -1327,7 +1328,7 @@ static int vit_launch_shape(hipStream_t stream, int max_cells, const VitTask* ta
     if (max_cells > VitLds<E_, S_>::TRASH) return 3;
     // per wave: two buffers of 16-byte {value, count} cells; waves of a block are independent
     int nw = VitLds<E_, S_>::WAVES;
-    if (const char* e = getenv("STRQ_VIT_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= nw) nw = v; }      // experiments: fewer waves per CU
+    if (const char* e = strq::opt("STRQ_VIT_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= nw) nw = v; }      // experiments: fewer waves per CU
     const size_t lds = (size_t)nw * 2 * VitLds<E_, S_>::BUF;
     const dim3 grid(n_cu), block(64 * nw);
 #define VIT_GO(BP_, SS_, MK_, HB_)                                                                                        \

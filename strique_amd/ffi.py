@@ -84,6 +84,8 @@ def load_library(path=None):
         lib.strq_last_error.argtypes = [ctypes.c_void_p]
         lib.strq_ctx_destroy.restype = None
         lib.strq_ctx_destroy.argtypes = [ctypes.c_void_p]
+        lib.strq_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+        lib.strq_get_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32]
         _lib = lib
     return _lib
 
@@ -137,6 +139,18 @@ class Context(object):
 
     def device_synchronize(self):
         self._check(self._lib.strq_device_synchronize(self._h))
+
+    def set_option(self, key, value):
+        """strq_set_option on this context: `value` None removes the entry (the process-wide table / the environment variable
+        of the same name decide again), "" means "not set" whatever they say; anything else is stored as its str()."""
+        v = None if value is None else str(value).encode()
+        self._check(self._lib.strq_set_option(self._h, key.encode(), v))
+
+    def get_option(self, key):
+        """Effective value of a switch for this context ("" when unset)."""
+        buf = ctypes.create_string_buffer(256)
+        self._check(self._lib.strq_get_option(self._h, key.encode(), buf, ctypes.c_int32(256)))
+        return buf.value.decode()
 
     # ---- alignment ------------------------------------------------------------------------
     def set_align_params(self, open_h, ext_h, open_v, ext_v, dist_offset, dist_min):
@@ -287,6 +301,17 @@ class Context(object):
         self._n_batch = len(target_ids)
         self._check(self._lib.strq_batch_upload(self._h, ctypes.c_int64(len(target_ids)), _ptr(signals), ctypes.c_int32(dtype),
                                                 _ptr(offsets), _ptr(target_ids), _ptr(hs)))
+
+    def batch_upload_part(self, total_reads, total_samples, first_read, signals, offsets, target_ids):
+        """strq_batch_upload_part: reads [first_read, first_read + len(target_ids)) of a resident batch of `total_reads` int16 reads
+        (`total_samples` samples in all); parts follow each other, the first one (first_read = 0) sizes the device buffers."""
+        signals = np.ascontiguousarray(signals)
+        if signals.dtype != np.int16:
+            raise ValueError("signals must be int16")
+        offsets = _c(offsets, np.int64); target_ids = _c(target_ids, np.int32)
+        self._n_batch = int(total_reads)
+        self._check(self._lib.strq_batch_upload_part(self._h, ctypes.c_int64(total_reads), ctypes.c_int64(total_samples), ctypes.c_int64(first_read),
+                                                     ctypes.c_int64(len(target_ids)), _ptr(signals), ctypes.c_int32(0), _ptr(offsets), _ptr(target_ids)))
 
     def batch_run(self):
         self._check(self._lib.strq_batch_run(self._h))

@@ -53,8 +53,41 @@ def make_sequence(rng, total_nt, prefix, repeat, n_repeat, suffix, strand="+"):
     return seq
 
 
-def make_signal(rng, table, seq_bytes, as_int16=True, realism=0.0):
-    """realism = 0: the reference's generate_signal(noise=True) distribution (dwell U{6..9}, N(mean, stdv) per sample) -- the
+class EmpiricalNoise(object):
+    """Dwell times, per-occurrence level offsets and per-sample residuals of the one real read the reference bundles
+    (tests/golden/empirical_noise.npz, made by tests/golden/make_empirical_noise.py from the oracle's decode of
+    data/c9orf72.fast5), resampled independently (bootstrap): a k-mer occurrence gets a dwell from the pool (0 = the k-mer
+    is skipped), its level is the table mean plus an offset from the pool, every sample adds a residual from the pool scaled
+    by the k-mer's table stdv.
+    Calibration (tools/empirical_probe.py, CPU oracle on 28 reads of 50 kb, 200 ... 2000 repeats): with the pools as measured
+    (`offset_scale` 1) the median flank score is 0.685 of the maximum (the real read: 0.670 / 0.704) and the oracle recovers the
+    planted count within max(2, 1 %) on 76 % of the reads -- a flank at that score level sits at the background's own maximum and
+    ~1 search in 8 ends at a wrong place; the default `offset_scale` 0.8 is the value at which the median is 0.70, the top of the
+    real read's range, and the count is recovered on 96 % (within +-2 on 68 %: over 1000+ repeat units a decode at this noise
+    level loses a few).  `resid_scale` stays 1."""
+
+    def __init__(self, path=None, offset_scale=0.8, resid_scale=1.0):
+        import os
+        if path is None:
+            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "empirical_noise.npz")
+        z = np.load(path)
+        self.dwell = z["dwell"].astype(np.int64)
+        self.level_offset = z["level_offset"].astype(np.float64) * offset_scale
+        self.resid_z = z["resid_z"].astype(np.float64) * resid_scale
+        self.source = str(z["source"])
+
+    def signal(self, rng, table, idx):
+        n_k = len(idx)
+        dwell = self.dwell[rng.integers(0, len(self.dwell), n_k)]
+        level = table.mean[idx] + self.level_offset[rng.integers(0, len(self.level_offset), n_k)]
+        n = int(dwell.sum())
+        return np.repeat(level, dwell) + np.repeat(table.stdv[idx], dwell) * self.resid_z[rng.integers(0, len(self.resid_z), n)]
+
+
+def make_signal(rng, table, seq_bytes, as_int16=True, realism=0.0, noise=None):
+    """noise = an EmpiricalNoise: dwell, level offsets and sample residuals resampled from the bundled real read (the
+    "degraded" workload of bench.py); `realism` is ignored then.
+    realism = 0: the reference's generate_signal(noise=True) distribution (dwell U{6..9}, N(mean, stdv) per sample) -- the
     easiest input the flank alignment will ever see.  realism in (0, 2] degrades the read the way real r9.4 signal differs
     from the k-mer table, all of it scaled by `realism`:
       * levels: sample noise wider by (1 + 2.5 x realism); every k-mer occurrence off its table mean by N(0, 1.5 pA x realism)
@@ -69,6 +102,11 @@ def make_signal(rng, table, seq_bytes, as_int16=True, realism=0.0):
     than it does on the real read -- the knob is a stress test of the pipeline's heuristics, not a simulator."""
     idx = table.indices(seq_bytes)
     n_k = len(idx)
+    if noise is not None:
+        pa = noise.signal(rng, table, idx)
+        if as_int16:
+            return np.clip(np.round(pa * (8192 / 1400.0) - 10), -32768, 32767).astype(np.int16)
+        return pa
     dwell = rng.integers(6, 10, n_k)
     if realism > 0.0:
         r = float(min(realism, 2.0))
@@ -95,11 +133,11 @@ def make_signal(rng, table, seq_bytes, as_int16=True, realism=0.0):
     return pa
 
 
-def make_read(table, config_id, read_idx, total_nt, target, n_repeat, strand=None, as_int16=True, realism=0.0):
-    """target = (repeat, prefix, suffix).  Returns (signal, strand).  `realism`: see make_signal (0 = the SURVEY.md 8d recipe)."""
+def make_read(table, config_id, read_idx, total_nt, target, n_repeat, strand=None, as_int16=True, realism=0.0, noise=None):
+    """target = (repeat, prefix, suffix).  Returns (signal, strand).  `realism` / `noise`: see make_signal (0 / None = the SURVEY.md 8d recipe)."""
     rng = np.random.Generator(np.random.PCG64(read_seed(config_id, read_idx)))
     if strand is None:
         strand = "+" if rng.random() < 0.5 else "-"
     repeat, prefix, suffix = target
     seq = make_sequence(rng, total_nt, prefix, repeat, n_repeat, suffix, strand)
-    return make_signal(rng, table, seq, as_int16, realism), strand
+    return make_signal(rng, table, seq, as_int16, realism, noise), strand

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.strq_abi_version() == 10
+    assert lib.strq_abi_version() == 11
 
 
 def test_no_cpu_fallback_without_gpu():
