@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 11 (11: strq_set_option, strq_get_option, strq_batch_upload_part; 10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 11 (11: strq_set_option, strq_get_option, strq_batch_upload_part, strq_last_screen_mode; 10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -320,6 +320,11 @@ int strq_last_second_round(const strq_ctx* ctx, int64_t out[2]);
  * [3] without (their whole read ran)   [4] columns inside the windows   [5] screen wave-steps (one step = two columns of
  * every flank row)   [6] scale (scores are rounded up to multiples of 1 / scale)   [7] candidate chunks of 128 columns. */
 int strq_last_screen(const strq_ctx* ctx, double out[8]);
+/* Which screen the last sub-batch of the last batched call ran: [0] 0 none, 1 the fine screen (align_screen_kernel: one DP row per flank
+ * row, bound within m / scale of the exact last row), 2 the coarse one (align_screen2_kernel: two flank rows per DP row, both flanks
+ * of a read per wave, candidates taken with a margin)   [1] / [2] sub-batches for which the coarse / the fine screen stays paused
+ * (it did not pay on the last one it ran on)   [3] the coarse screen's candidate margin in score units. */
+int strq_last_screen_mode(const strq_ctx* ctx, int32_t out[4]);
 
 #ifdef __cplusplus
 }

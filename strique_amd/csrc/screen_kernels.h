@@ -9,6 +9,11 @@
 #define STRQ_SCREEN_SEG 4                // pieces (waves) per read
 #define STRQ_SCREEN_CHUNK_COLS 128       // columns per reported chunk (64 steps x 2 columns)
 #define STRQ_SCREEN_MAX_WINDOWS 4
+// the coarse screen (align_screen2_kernel): two flank rows per DP row, both flanks of a read in the two halves of one wave
+#define STRQ_SCREEN2_R 15                // coarse rows per lane = 30 flank rows = 5 k-mer classes, no class straddles a lane
+#define STRQ_SCREEN2_CPL 5               // classes per lane
+#define STRQ_SCREEN2_LPF 29              // lanes per flank: 29 x 5 = 145 classes = 870 rows (STRique's flanks)
+#define STRQ_SCREEN2_LANE_B 32           // first lane of the second flank
 
 namespace strq {
 
@@ -19,6 +24,7 @@ struct ScreenParams {
     int32_t cadd;        // hh + v: added to every table entry (the two potentials absorb the gap scores)
     int32_t slack;       // float32 rounding slack of the exact DP, scaled (32 * sc)
     int32_t merge_gap;   // candidate chunks closer than this many columns share a window
+    int32_t margin;      // coarse screen: how far below the best chunk value a chunk is still a candidate (scaled); 0: the fine rule (m + 2 slack)
 };
 
 // one piece (wave) of one alignment
@@ -30,6 +36,17 @@ struct ScreenTask {
     int32_t tsize;
     int32_t n, m, k, col_off;    // columns of the piece; flank rows / classes; read column of the piece's column 0
     int32_t n_chunks;
+    int32_t lane_last;           // lane whose last register holds the flank's last row ((m - 1) / R for the fine screen)
+};
+
+// one piece (wave) of one READ for the coarse screen: both flank alignments of the read
+struct Screen2Task {
+    const uint8_t* levels;
+    const float* table[2];       // float32 score tables of the prefix / suffix alignment
+    const int32_t* band_lo[2];
+    int32_t* out[2];             // chunk maxima of this piece, per flank
+    int32_t tsize[2], k[2];
+    int32_t n, col_off, n_chunks;
 };
 
 // per alignment: the columns the exact DP has to look at
@@ -50,6 +67,13 @@ int launch_screen(hipStream_t stream, const ScreenTask* tasks, int n_groups, int
                   size_t lds_bytes, int tables_per_cu, int n_cu);
 // windows of alignment g from the chunk maxima of its pieces; bound_scaled[g]: the score (scaled) above which
 // the cold-started pieces of the alignment are exact
+// coarse screen: scores of two flank rows at once, both flanks of a read per wave.  screen2_plan like screen_plan (entries are twice
+// as large, so the scale is half); screen2_flank_ok: the flank fits 29 lanes of 5 classes
+int screen2_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp);
+static inline bool screen2_flank_ok(int m, int k) { return k >= 1 && k <= STRQ_SCREEN2_LPF * STRQ_SCREEN2_CPL && m == k * STRQ_SCREEN_S; }
+size_t screen2_lds_bytes(int tsize_a, int tsize_b);
+int launch_screen2(hipStream_t stream, const Screen2Task* tasks, int n_groups, int* queue, const ScreenParams& sp,
+                   size_t lds_bytes, int groups_per_cu, int n_cu);
 int launch_screen_windows(hipStream_t stream, const ScreenTask* tasks, int n_groups, const ScreenParams& sp,
                           const int32_t* bound_scaled, ScreenWindows* out);
 

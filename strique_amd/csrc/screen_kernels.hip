@@ -261,6 +261,211 @@ align_screen_kernel(const ScreenTask* __restrict__ tasks, int n_groups, int* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The COARSE screen: half the rows, both flanks of a read in one wave.
+//
+// The six rows of a k-mer class are identical (generate_signal repeats every level `samples` = 6 times, scripts/STRique.py:
+// 186-194).  Two identical neighbouring rows i, i + 1 are merged into one DP row whose diagonal step gains BOTH rows' scores at one
+// column: a path of the fine matrix that takes its two diagonals of that row pair at columns j1 < j2 gains s(j1) + s(j2)
+// <= 2 max(s(j1), s(j2)), and the merged row may take the better of the two columns (rows and columns of the remaining path stay
+// ordered, horizontal moves are free in the T potential), so the merged DP's last row bounds the fine one's from above -- by more
+// than the fine screen's m / sc (the merged row pays for one column where the pair needs two), which is why its candidates are
+// taken with a margin (ScreenParams::margin) and certified by the exact pass like any other window.
+// 870 rows -> 435 merged rows = 29 lanes x 15: every lane owns exactly five whole classes (no class selects), and the two flanks of a
+// read (prefix / suffix alignment, the same columns) sit in lanes 0 .. 28 and 32 .. 60 of one wave: lane 32 takes the free top row
+// instead of lane 31's bottom cells, the packed levels travel through all 64 lanes.  One wave-step = 2 columns x 870 rows x 2 flanks.
+namespace {
+
+constexpr int R2 = STRQ_SCREEN2_R, CPL = STRQ_SCREEN2_CPL, LPF = STRQ_SCREEN2_LPF, LB = STRQ_SCREEN2_LANE_B;
+static_assert(R2 == 3 * CPL && S == 6, "three merged rows per class of six");
+
+struct Lane2Const { int lo2[CPL], hi2[CPL], off[CPL]; };
+
+struct Screen2 {
+    const char* lds;
+    const Lane2Const& lc;
+    const uint64_t top_mask;           // lane LB: its row above is the free top row
+    const int lane, n, hh;
+    int T[R2], SbotA, upS, potB, cmax;
+    int qq;
+    int scA[CPL], scB[CPL];
+
+    __device__ __forceinline__ void fetch(int q2, int (&sc)[CPL])
+    {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            sc[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(q2, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
+    }
+    __device__ __forceinline__ void advance(int qsrc, int snext, int& qn, int (&nA)[CPL], int (&nB)[CPL])
+    {
+        qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
+        fetch(qn & 0xffff, nA);
+        fetch((int)((unsigned)qn >> 16), nB);
+    }
+    __device__ __forceinline__ void prime(int qcur)
+    {
+        qq = 0;
+        int qn, nA[CPL], nB[CPL];
+        advance(qcur, 0, qn, nA, nB);
+        qq = qn;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
+    }
+
+    // One step = the lane's two columns.  Written so that nothing is copied from one step to the next: column B of row r - 1 is
+    // computed right after column A of row r and takes the register of the old T[r - 1] (dead from there on), and the scores of a
+    // class are fetched for the NEXT step as soon as its three rows are done, into the registers they just left (the LDS latency
+    // hides behind the rest of the step).
+    template <bool PRED>
+    __device__ __forceinline__ void step(int t, int qsrc, int snext)
+    {
+        const int qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
+        const int qa = qn & 0xffff, qb = (int)((unsigned)qn >> 16);
+        const int potA = potB + hh, potBn = potA + hh;
+        // the row above the lane: lane - 1's bottom cells; lanes 0 and LB: the top row (the column potential)
+        const int upA = sel_mask(dpp_shr1(SbotA, potA), potA, top_mask);
+        const int upB = sel_mask(dpp_shr1(T[R2 - 1], potBn), potBn, top_mask);
+        bool act = true, okB = true;
+        if constexpr (PRED) { const int jB = 2 * (t - lane), jA = jB - 1; act = (jA >= 1) && (jA <= n); okB = jB <= n; }
+        int ta_prev = upA, ta_prev2 = upS;          // column A of rows r - 1, r - 2 (row -1: the row above the lane)
+        int tb_prev2 = upB;                         // column B of row r - 2
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            if (act) {
+#pragma unroll
+                for (int r = 3 * c; r < 3 * c + 3; ++r) {
+                    const int diagA = r == 0 ? upS : T[r - 1];
+                    const int ta = max3i(diagA + scA[c], T[r], ta_prev);
+                    if (r > 0) {
+                        // column B of row r - 1: diag = column A of row r - 2, left = column A of row r - 1, up = column B of row r - 2
+                        const int tb = max3i(ta_prev2 + scB[(r - 1) / 3], ta_prev, tb_prev2);
+                        T[r - 1] = tb; tb_prev2 = tb;
+                    }
+                    ta_prev2 = ta_prev; ta_prev = ta;
+                }
+                if (c == CPL - 1) {
+                    const int tb = max3i(ta_prev2 + scB[c], ta_prev, tb_prev2);
+                    T[R2 - 1] = tb;
+                    SbotA = ta_prev;
+                    upS = upB;
+                    const int cA = ta_prev - potA + STRQ_SCREEN_BIAS, cB = okB ? tb - potBn + STRQ_SCREEN_BIAS : cA;
+                    cmax = max3i(cmax, cA, cB);
+                }
+            }
+            // the class's scores for the next step (scB[c] of the last row of class c is used one row later: fetch B one class behind)
+            scA[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(qa, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
+            if (c > 0) scB[c - 1] = *reinterpret_cast<const uint16_t*>(lds + med3i(qb, lc.lo2[c - 1], lc.hi2[c - 1]) + lc.off[c - 1]);
+            if (c == CPL - 1) scB[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(qb, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
+        }
+        potB = potBn;
+        qq = qn;
+    }
+};
+
+__device__ __forceinline__ int load_chunk2(const Screen2Task& tk, int chunk, int lane)
+{
+    const int idx = (chunk * 64 + lane) * 2;
+    int a = 0, b = 0;
+    if (idx < tk.n) a = tk.levels[idx];
+    if (idx + 1 < tk.n) b = tk.levels[idx + 1];
+    return (a * 2) | ((b * 2) << 16);
+}
+
+}  // namespace
+
+#ifndef STRQ_SCREEN2_WPE
+#define STRQ_SCREEN2_WPE 5
+#endif
+
+size_t screen2_lds_bytes(int tsize_a, int tsize_b)
+{
+    // both tables as 16-bit entries, each padded to a dword and followed by a zero pair (the rows below a flank)
+    return (size_t)(((tsize_a + 1) & ~1) + 2 + ((tsize_b + 1) & ~1) + 2) * 2;
+}
+
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(STRQ_SCREEN2_WPE, STRQ_SCREEN2_WPE)))
+align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp)
+{
+    extern __shared__ uint32_t lds_all[];
+    __shared__ int next_group;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char* ldsb = reinterpret_cast<const char*>(lds_all);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_group = atomicAdd(queue, 1);
+        __syncthreads();
+        const int gi = __builtin_amdgcn_readfirstlane(next_group);
+        if (gi >= n_groups) break;
+        const Screen2Task& t0 = tasks[(size_t)gi * SEG];
+        int base[2], zero_idx[2];          // in 16-bit entries
+        base[0] = 0; zero_idx[0] = (t0.tsize[0] + 1) & ~1;
+        base[1] = zero_idx[0] + 2; zero_idx[1] = base[1] + ((t0.tsize[1] + 1) & ~1);
+        {
+            // 2 (ceil(s * sc) + hh + v): what the merged row gains on a diagonal step (both rows' scores, both rows' potentials)
+            uint16_t* dst = reinterpret_cast<uint16_t*>(lds_all);
+            const float scf = (float)sp.sc;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                for (int i = threadIdx.x; i < t0.tsize[f]; i += 64 * SEG) dst[base[f] + i] = (uint16_t)(2 * ((int)ceilf(t0.table[f][i] * scf) + sp.cadd));
+                if (threadIdx.x == 0) { dst[zero_idx[f]] = 0; dst[zero_idx[f] + 1] = 0; }
+            }
+        }
+        __syncthreads();
+        const Screen2Task& tk = tasks[(size_t)gi * SEG + wave];
+        if (tk.n <= 0) continue;
+
+        Lane2Const lc;
+        const int f = lane >= LB ? 1 : 0, lf = lane - f * LB;
+        {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int k = lf * CPL + c;
+                if (lf < LPF && k < tk.k[f]) {
+                    const uint32_t d = (uint32_t)tk.band_lo[f][k];
+                    const int lo = (int)(d & 255u), w1 = (int)((d >> 8) & 255u), off = (int)(d >> 16);
+                    lc.lo2[c] = lo * 2; lc.hi2[c] = (lo + w1) * 2;
+                    lc.off[c] = (base[f] + off - lo) * 2;
+                } else {
+                    lc.lo2[c] = 0; lc.hi2[c] = 0; lc.off[c] = zero_idx[f] * 2;
+                }
+            }
+        }
+        const uint64_t top_mask = 1ull | (1ull << LB);
+        // lanes whose last register holds a flank's last row (rows below a flank score 0 and copy it)
+        const int lMa = (3 * tk.k[0] - 1) / R2, lMb = LB + (3 * tk.k[1] - 1) / R2;
+        Screen2 s2{ldsb, lc, top_mask, lane, tk.n, sp.hh};
+        {
+#pragma unroll
+            for (int r = 0; r < R2; ++r) s2.T[r] = STRQ_SCREEN_BIAS;
+            s2.SbotA = STRQ_SCREEN_BIAS; s2.upS = STRQ_SCREEN_BIAS;
+            s2.potB = STRQ_SCREEN_BIAS - 2 * lane * sp.hh;
+            s2.cmax = STRQ_SCREEN_BIAS;
+        }
+        const int nsteps = (tk.n + 1) / 2 + 63;
+        int qcur = load_chunk2(tk, 0, lane);
+        s2.prime(qcur);
+        for (int t0s = 0; t0s < nsteps; t0s += 64) {
+            const int qnext = load_chunk2(tk, t0s / 64 + 1, lane);
+            const bool full = (t0s >= 63) && (2 * (t0s + 64) <= tk.n);
+            const int send = nsteps - t0s < 64 ? nsteps - t0s : 64;
+            if (full) {
+                for (int s = 0; s < 63; ++s) s2.template step<false>(t0s + s + 1, qcur, s + 1);
+                s2.template step<false>(t0s + 64, qnext, 0);
+            } else {
+                for (int s = 0; s < send; ++s) {
+                    const int qsrc = s == 63 ? qnext : qcur, snext = (s + 1) & 63;
+                    s2.template step<true>(t0s + s + 1, qsrc, snext);
+                }
+            }
+            const int cma = __builtin_amdgcn_readlane(s2.cmax, lMa) - STRQ_SCREEN_BIAS;
+            const int cmb = __builtin_amdgcn_readlane(s2.cmax, lMb) - STRQ_SCREEN_BIAS;
+            if (lane == 0) { tk.out[0][t0s / 64] = cma; tk.out[1][t0s / 64] = cmb; }
+            s2.cmax = STRQ_SCREEN_BIAS;
+            qcur = qnext;
+        }
+    }
+}
+
 // Candidate windows of every alignment.
 // A chunk's value v bounds the float32 last-row values S of its columns: S * sc <= max(v', bound) + slack, v' = v - m * v_gap
 // (bound: the cold-start score of the pieces).  The best chunk value vmax is reached by a real path whose float32 score is at
@@ -274,7 +479,7 @@ screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, Screen
     const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_groups) return;
     const ScreenTask* tg = tasks + (size_t)g * SEG;
-    const int m = tg[0].m, lM = (m - 1) / R;
+    const int m = tg[0].m, lM = tg[0].lane_last;
     const int shift = -m * sp.v;            // v' = v + shift
     int vmax = 0;
     for (int w = 0; w < SEG; ++w) {
@@ -286,8 +491,22 @@ screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, Screen
     ScreenWindows r;
     r.n_win = 0; r.n_cand = 0;
     for (int k = 0; k < STRQ_SCREEN_MAX_WINDOWS; ++k) { r.lo[k] = 0; r.hi[k] = 0; }
-    const int theta = vmax - m - 2 * sp.slack;             // in chunk units (before the shift)
-    r.lower_bound = (float)(vmax + shift - m - sp.slack) / (float)sp.sc;
+    // fine screen: a chunk value is less than m above the exact one (one rounding per diagonal step); coarse screen: sp.margin
+    const int drop = (sp.margin > 0 ? sp.margin : m) + 2 * sp.slack;
+    const int theta = vmax - drop;                          // in chunk units (before the shift)
+    {
+        // every column of a chunk below theta has a float32 score below (theta + shift + slack) / sc =: lower_bound; the exact pass
+        // certifies its windows by reaching it.  Rounded UP to float32: a bound a hair too high costs a spurious second round, one a
+        // hair too low would let an excluded column tie with the certificate
+        const double lb = (double)(theta + shift + sp.slack) / (double)sp.sc;
+        float lbf = (float)lb;
+        if ((double)lbf < lb) {          // the next float32 up
+            int32_t bits = __float_as_int(lbf);
+            bits = lbf > 0.0f ? bits + 1 : (lbf < 0.0f ? bits - 1 : 1);
+            lbf = __int_as_float(bits);
+        }
+        r.lower_bound = lbf;
+    }
     r.upper_bound = (float)(vmax + shift + sp.slack) / (float)sp.sc;
     // prune only above the cold-start bound of the pieces, and only when the lower bound is a score worth the name
     const bool ok = theta + shift > 0 && theta + shift > bound_scaled[g];
@@ -322,7 +541,19 @@ screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, Screen
                 }
             }
         }
-        r.n_win = nw;
+        // ascending and disjoint (a candidate in a piece's overlap zone may have pulled the last window's start to the left of the
+        // window before it): the combine kernel breaks score ties by piece order
+        for (int a = 1; a < nw; ++a)
+            for (int b = a; b > 0 && r.lo[b] < r.lo[b - 1]; --b) {
+                const int tl = r.lo[b], th = r.hi[b]; r.lo[b] = r.lo[b - 1]; r.hi[b] = r.hi[b - 1]; r.lo[b - 1] = tl; r.hi[b - 1] = th;
+            }
+        int kept = nw > 0 ? 1 : 0;
+        for (int a = 1; a < nw; ++a) {
+            if (r.lo[a] <= r.hi[kept - 1] + 1) { if (r.hi[a] > r.hi[kept - 1]) r.hi[kept - 1] = r.hi[a]; }
+            else { r.lo[kept] = r.lo[a]; r.hi[kept] = r.hi[a]; ++kept; }
+        }
+        for (int a = kept; a < STRQ_SCREEN_MAX_WINDOWS; ++a) { r.lo[a] = 0; r.hi[a] = 0; }
+        r.n_win = kept;
     }
     if (lane == 0) out[g] = r;
 }
@@ -352,10 +583,33 @@ int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
             if (!(e < 1.0e4)) continue;
             sp->slack = ((int)std::ceil(e) + 1) * sc;
         }
-        sp->merge_gap = 3072;
+        sp->merge_gap = 3072; sp->margin = 0;
         return 1;
     }
     return 0;
+}
+
+int screen2_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
+{
+    // the fine frame at half the scale: a table entry is 2 (ceil(s sc) + hh + v) and has to fit 16 bits
+    if (!screen_plan(p, samples, max_n, sp)) return 0;
+    while (sp->sc >= 16) {
+        const double smax = std::ceil((double)p.dist_offset * sp->sc);
+        if (2.0 * (smax + sp->cadd) <= 65000.0) return 1;
+        if ((sp->hh & 1) || (sp->v & 1)) return 0;
+        sp->slack = (sp->slack / sp->sc) * (sp->sc / 2);
+        sp->sc /= 2; sp->hh /= 2; sp->v /= 2; sp->cadd = sp->hh + sp->v;
+    }
+    return 0;
+}
+
+int launch_screen2(hipStream_t stream, const Screen2Task* tasks, int n_groups, int* queue, const ScreenParams& sp,
+                   size_t lds_bytes, int groups_per_cu, int n_cu)
+{
+    if (n_groups <= 0) return 0;
+    (void)hipFuncSetAttribute((const void*)align_screen2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(align_screen2_kernel, dim3(groups_per_cu * n_cu), dim3(64 * SEG), lds_bytes, stream, tasks, n_groups, queue, sp);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int launch_screen(hipStream_t stream, const ScreenTask* tasks, int n_groups, int* queue, const ScreenParams& sp,

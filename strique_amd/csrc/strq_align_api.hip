@@ -292,7 +292,134 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     int scr_max_n = 0;
     for (int i = 0; i < nb; ++i) scr_max_n = std::max(scr_max_n, in.n[i]);
     const bool scr_forced = strq::opt("STRQ_SCREEN_ALWAYS") != nullptr;      // tests: no pause
-    if (collapsed && c->screen_pause > 0 && !scr_forced) {
+    // STRQ_SCREEN_MODE: "fine" = the row-exact screen only, "coarse" = the merged-row screen whenever the sub-batch allows it,
+    // default: coarse until it stops paying (then fine, then none), each retried after eight sub-batches
+    const char* mode_opt = strq::opt("STRQ_SCREEN_MODE");
+    const bool mode_fine = mode_opt && std::strcmp(mode_opt, "fine") == 0, mode_coarse = mode_opt && std::strcmp(mode_opt, "coarse") == 0;
+    c->screen_mode_last = 0;
+    bool did_coarse = false;
+    if (collapsed && !mode_fine && !strq::opt("STRQ_NO_SCREEN") && c->coarse_pause > 0 && !mode_coarse && !scr_forced) --c->coarse_pause;
+    else if (collapsed && !mode_fine && screen2_plan(c->ap, S, scr_max_n, &sp)) {
+        // ---- coarse screen (align_screen2_kernel): reads whose two flank alignments are both in this sub-batch
+        int min_n = 65536, scr_groups = 5;
+        if (const char* e = strq::opt("STRQ_SCREEN_MIN_N")) min_n = atoi(e);
+        if (const char* e = strq::opt("STRQ_SCREEN2_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 8) scr_groups = v; }
+        std::map<int, std::vector<int>> by_read;
+        for (int i = 0; i < nb; ++i)
+            if (in.NS[i] == 1 && NJ[i] == 1 && in.n[i] >= min_n && screen2_flank_ok(in.m[i], in.k[i])) by_read[in.read[i]].push_back(i);
+        std::vector<std::pair<int, int>> pairs;
+        for (auto& kv : by_read) if (kv.second.size() == 2) pairs.emplace_back(kv.second[0], kv.second[1]);
+        std::stable_sort(pairs.begin(), pairs.end(), [&](const std::pair<int, int>& x, const std::pair<int, int>& y) { return in.n[x.first] > in.n[y.first]; });
+        const int ngr = (int)pairs.size();
+        if (ngr > 0 && 2 * ngr >= (nb * 9) / 10) {
+            constexpr int SSEG = STRQ_SCREEN_SEG;
+            sp.margin = (int32_t)std::lround((double)c->coarse_margin * sp.sc);
+            if (const char* e = strq::opt("STRQ_SCREEN2_MARGIN")) sp.margin = (int32_t)std::lround(atof(e) * sp.sc);
+            std::vector<Screen2Task> t2((size_t)ngr * SSEG);
+            std::vector<ScreenTask> stasks((size_t)2 * ngr * SSEG);
+            std::vector<int32_t> bound((size_t)2 * ngr);
+            std::vector<size_t> out_off((size_t)2 * ngr * SSEG, 0);
+            size_t out_words = 0, lds_bytes = 0; double steps = 0;
+            for (int g = 0; g < ngr; ++g) {
+                const int a[2] = {pairs[g].first, pairs[g].second};
+                const int n = in.n[a[0]];
+                const int m_big = std::max(in.m[a[0]], in.m[a[1]]);
+                const int ov_worst = align_segment_overlap(c->ap, m_big), ov_s = overlap_for(m_big, ov_worst, 16);
+                Piece pc[SSEG];
+                const int used = cut(n, SSEG, ov_s, pc);
+                lds_bytes = std::max(lds_bytes, screen2_lds_bytes(info[J0[a[0]]].total, info[J0[a[1]]].total));
+                for (int f = 0; f < 2; ++f)
+                    bound[(size_t)2 * g + f] = used <= 1 ? INT32_MIN / 2 : (ov_s >= ov_worst ? 0 : (int32_t)std::ceil((double)align_segment_min_score(c->ap, in.m[a[f]], ov_s) * sp.sc));
+                for (int w = 0; w < SSEG; ++w) {
+                    Screen2Task t; std::memset(&t, 0, sizeof(t));
+                    t.levels = in.d_levels + in.read_off[in.read[a[0]]] + pc[w].col_off;
+                    t.n = pc[w].n; t.col_off = pc[w].col_off;
+                    t.n_chunks = pc[w].n > 0 ? (align_num_steps(pc[w].n) + 63) / 64 : 0;
+                    for (int f = 0; f < 2; ++f) {
+                        t.table[f] = jobs[J0[a[f]]].table; t.band_lo[f] = jobs[J0[a[f]]].band_lo; t.tsize[f] = info[J0[a[f]]].total; t.k[f] = in.k[a[f]];
+                        ScreenTask v; std::memset(&v, 0, sizeof(v));
+                        v.n = pc[w].n; v.m = in.m[a[f]]; v.k = in.k[a[f]]; v.col_off = pc[w].col_off; v.n_chunks = t.n_chunks;
+                        v.lane_last = f * STRQ_SCREEN2_LANE_B + (3 * in.k[a[f]] - 1) / STRQ_SCREEN2_R;
+                        out_off[((size_t)2 * g + f) * SSEG + w] = out_words; out_words += (size_t)t.n_chunks;
+                        stasks[((size_t)2 * g + f) * SSEG + w] = v;
+                    }
+                    if (pc[w].n > 0) steps += align_num_steps(pc[w].n);
+                    t2[(size_t)g * SSEG + w] = t;
+                }
+            }
+            if (lds_bytes > 160 * 1024 - 64) { c->err = "score tables do not fit LDS (coarse screen)"; return STRQ_ERR_UNSUPPORTED; }
+            scr_groups = std::max(1, std::min(scr_groups, (int)((160 * 1024 - 64) / lds_bytes)));
+            const size_t t2_bytes = (t2.size() * sizeof(Screen2Task) + 255) & ~(size_t)255, task_bytes = (stasks.size() * sizeof(ScreenTask) + 255) & ~(size_t)255;
+            const size_t bound_bytes = ((size_t)2 * ngr * 4 + 255) & ~(size_t)255, win_bytes = ((size_t)2 * ngr * sizeof(ScreenWindows) + 255) & ~(size_t)255;
+            STRQ_HIP(c, c->screen.reserve(t2_bytes + task_bytes + bound_bytes + win_bytes + out_words * 4 + 256));
+            char* base = c->screen.as<char>();
+            Screen2Task* d_t2 = reinterpret_cast<Screen2Task*>(base);
+            ScreenTask* d_st = reinterpret_cast<ScreenTask*>(base + t2_bytes);
+            int32_t* d_bound = reinterpret_cast<int32_t*>(base + t2_bytes + task_bytes);
+            ScreenWindows* d_win = reinterpret_cast<ScreenWindows*>(base + t2_bytes + task_bytes + bound_bytes);
+            int32_t* d_out = reinterpret_cast<int32_t*>(base + t2_bytes + task_bytes + bound_bytes + win_bytes);
+            for (int g = 0; g < ngr; ++g) for (int f = 0; f < 2; ++f) for (int w = 0; w < SSEG; ++w) {
+                int32_t* o = d_out + out_off[((size_t)2 * g + f) * SSEG + w];
+                stasks[((size_t)2 * g + f) * SSEG + w].out = o; t2[(size_t)g * SSEG + w].out[f] = o;
+            }
+            STRQ_HIP(c, hipMemcpyAsync(d_t2, t2.data(), t2.size() * sizeof(Screen2Task), hipMemcpyHostToDevice, st));
+            STRQ_HIP(c, hipMemcpyAsync(d_st, stasks.data(), stasks.size() * sizeof(ScreenTask), hipMemcpyHostToDevice, st));
+            STRQ_HIP(c, hipMemcpyAsync(d_bound, bound.data(), bound.size() * 4, hipMemcpyHostToDevice, st));
+            STRQ_HIP(c, hipEventRecord(c->ev[5], st));
+            if (launch_screen2(st, d_t2, ngr, c->queue.as<int>() + STRQ_QUEUE_FIRST - 1, sp, lds_bytes, scr_groups, c->n_cu)) { c->err = "coarse screen launch failed"; return STRQ_ERR_DEVICE; }
+            STRQ_HIP(c, hipEventRecord(c->ev[6], st));
+            if (launch_screen_windows(st, d_st, 2 * ngr, sp, d_bound, d_win)) { c->err = "screen windows launch failed"; return STRQ_ERR_DEVICE; }
+            std::vector<ScreenWindows> hw((size_t)2 * ngr);
+            STRQ_HIP(c, hipMemcpyAsync(hw.data(), d_win, hw.size() * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
+            STRQ_HIP(c, hipStreamSynchronize(st));
+            c->screen_ran = true; did_coarse = true; c->screen_mode_last = 2;
+            if (const char* path = strq::opt("STRQ_SCREEN_DUMP")) {
+                std::vector<int32_t> ho(out_words);
+                STRQ_HIP(c, hipMemcpy(ho.data(), d_out, out_words * 4, hipMemcpyDeviceToHost));
+                if (FILE* fp = fopen(path, "wb")) {
+                    const int32_t hdr[8] = {2 * ngr, sp.sc, sp.hh, sp.v, 2, SSEG, sp.slack, sp.margin};
+                    fwrite(hdr, 4, 8, fp);
+                    for (int g2 = 0; g2 < 2 * ngr; ++g2) {
+                        const int al = g2 & 1 ? pairs[(size_t)g2 / 2].second : pairs[(size_t)g2 / 2].first;
+                        const int32_t gh[4] = {al, al, bound[(size_t)g2], stasks[(size_t)g2 * SSEG].lane_last};
+                        fwrite(gh, 4, 4, fp);
+                        for (int w = 0; w < SSEG; ++w) {
+                            const ScreenTask& t = stasks[(size_t)g2 * SSEG + w];
+                            const int32_t th[4] = {t.col_off, t.n, t.m, t.n_chunks};
+                            fwrite(th, 4, 4, fp);
+                            fwrite(ho.data() + (t.out - d_out), 4, (size_t)t.n_chunks, fp);
+                        }
+                        fwrite(&hw[(size_t)g2], sizeof(ScreenWindows), 1, fp);
+                    }
+                    fclose(fp);
+                }
+            }
+            const bool no_prune = strq::opt("STRQ_SCREEN_NO_PRUNE") != nullptr;
+            if (const char* e = strq::opt("STRQ_SCREEN_TEST_RAISE")) { const float up = (float)atof(e); for (auto& w : hw) w.lower_bound += up; }
+            int windowed = 0, heavy = 0; double cols = 0, all = 0;
+            for (int g2 = 0; g2 < 2 * ngr; ++g2) {
+                const int al = g2 & 1 ? pairs[(size_t)g2 / 2].second : pairs[(size_t)g2 / 2].first;
+                const ScreenWindows& w = hw[(size_t)g2];
+                c->screen_stats[1] += 1; c->screen_stats[7] += w.n_cand;
+                double mine = in.n[al];
+                if (w.n_win > 0 && !no_prune) {
+                    wins[al] = w; c->screen_stats[2] += 1; ++windowed; mine = 0;
+                    for (int k = 0; k < w.n_win; ++k) { c->screen_stats[4] += w.hi[k] - w.lo[k] + 1; mine += w.hi[k] - w.lo[k] + 1 + 4096; }
+                } else c->screen_stats[3] += 1;
+                all += in.n[al]; cols += mine; heavy += mine > 32768.0;
+            }
+            c->screen_stats[3] += nb - 2 * ngr;          // alignments of the sub-batch the coarse screen does not take: their whole reads run
+            c->screen_stats[5] += steps; c->screen_stats[6] = sp.sc;
+            // does it pay?  The coarse pass costs about half the float32 pass; its windows are wider than the fine screen's.  Reads on
+            // which it leaves large parts of the columns -- real reads often do: its bound is ~5 - 10 % above the exact scores where
+            // events are short, and the background of such reads is that close to the flank -- go to the fine screen for a while
+            if (2 * ngr >= 64 && (windowed < 0.9 * 2 * ngr || cols > 0.10 * all || (long)heavy * 2048 > 2L * ngr) && !no_prune && !mode_coarse && !scr_forced) c->coarse_pause = 8;
+            STRQ_DBG("coarse screen: %d reads, scale %d, margin %.0f, %d groups per CU, LDS %zu bytes: %d of %d alignments with windows, %.2f %% of the columns, %d heavy -> pause %d",
+                     ngr, sp.sc, (double)sp.margin / sp.sc, scr_groups, lds_bytes, windowed, 2 * ngr, 100.0 * cols / std::max(1.0, all), heavy, c->coarse_pause);
+        }
+    }
+    if (did_coarse) {
+    } else if (collapsed && c->screen_pause > 0 && !scr_forced) {
         --c->screen_pause; c->screen_stats[3] += nb;      // counted as whole-read alignments
     } else if (collapsed && screen_plan(c->ap, S, scr_max_n, &sp)) {
         // reads below ~64 k samples: the pieces' overlaps eat what the cheaper pass saves (STRQ_SCREEN_MIN_N: tests)
@@ -322,7 +449,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                     ScreenTask t; std::memset(&t, 0, sizeof(t));
                     t.levels = in.d_levels + in.read_off[in.read[a]] + pc[w].col_off;
                     t.table = jobs[J0[a]].table; t.band_lo = jobs[J0[a]].band_lo; t.tsize = info[J0[a]].total;
-                    t.n = pc[w].n; t.m = m; t.k = in.k[a]; t.col_off = pc[w].col_off;
+                    t.n = pc[w].n; t.m = m; t.k = in.k[a]; t.col_off = pc[w].col_off; t.lane_last = (m - 1) / STRQ_SCREEN_R;
                     t.n_chunks = pc[w].n > 0 ? (align_num_steps(pc[w].n) + 63) / 64 : 0;
                     out_off[(size_t)g * SSEG + w] = out_words;
                     out_words += (size_t)t.n_chunks;
@@ -350,16 +477,16 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             std::vector<ScreenWindows> hw((size_t)ng);
             STRQ_HIP(c, hipMemcpyAsync(hw.data(), d_win, hw.size() * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
             STRQ_HIP(c, hipStreamSynchronize(st));
-            c->screen_ran = true;
+            c->screen_ran = true; c->screen_mode_last = 1;
             if (const char* path = strq::opt("STRQ_SCREEN_DUMP")) {
                 // tests: the chunk maxima as the kernel wrote them (tests/test_gpu_screen.py checks them against the exact last row)
                 std::vector<int32_t> ho(out_words);
                 STRQ_HIP(c, hipMemcpy(ho.data(), d_out, out_words * 4, hipMemcpyDeviceToHost));
                 if (FILE* fp = fopen(path, "wb")) {
-                    const int32_t hdr[8] = {ng, sp.sc, sp.hh, sp.v, 0, SSEG, sp.slack, 0};
+                    const int32_t hdr[8] = {ng, sp.sc, sp.hh, sp.v, 1, SSEG, sp.slack, 0};
                     fwrite(hdr, 4, 8, fp);
                     for (int g = 0; g < ng; ++g) {
-                        const int32_t gh[4] = {sel[g], sel[g], bound[g], 0};
+                        const int32_t gh[4] = {sel[g], sel[g], bound[g], (in.m[sel[g]] - 1) / STRQ_SCREEN_R};
                         fwrite(gh, 4, 4, fp);
                         for (int w = 0; w < SSEG; ++w) {
                             const ScreenTask& t = stasks[(size_t)g * SSEG + w];
@@ -403,7 +530,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                     else mine = in.n[sel[g]];
                     cols += mine; heavy += mine > 32768.0;
                 }
-                if (ng >= 64 && (windowed < 0.9 * ng || cols > 0.06 * all || heavy > ng / 4096) && !no_prune) c->screen_pause = 8;
+                if (ng >= 64 && (windowed < 0.9 * ng || cols > 0.06 * all || (long)heavy * 4096 > (long)ng) && !no_prune) c->screen_pause = 8;
                 STRQ_DBG("screen verdict: %d of %d with windows, %.2f %% of the columns inside them, %d heavy alignments -> pause %d", windowed, ng, 100.0 * cols / std::max(1.0, all), heavy, c->screen_pause);
             }
             STRQ_DBG("screen: %d alignments, scale %d, %d tables per CU, LDS %zu bytes; windows for %.0f of %.0f alignments so far", ng, sp.sc, scr_tables, lds_bytes, c->screen_stats[2], c->screen_stats[1]);
@@ -935,6 +1062,13 @@ int strq_last_screen(const strq_ctx* c, double out[8])
 {
     if (!c || !out) return STRQ_ERR_ARG;
     for (int i = 0; i < 8; ++i) out[i] = c->screen_stats[i];
+    return STRQ_OK;
+}
+
+int strq_last_screen_mode(const strq_ctx* c, int32_t out[4])
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    out[0] = c->screen_mode_last; out[1] = c->coarse_pause; out[2] = c->screen_pause; out[3] = (int32_t)c->coarse_margin;
     return STRQ_OK;
 }
 

@@ -98,6 +98,12 @@ struct strq_ctx {
     // in 4096 is left with over 32 k columns to run (a tail behind thousands of small windows) pauses it for the next eight
     // sub-batches of this context, then it is tried again.
     int screen_pause = 0;
+    // the coarse screen in front of it (align_screen2_kernel): paused the same way when it leaves too many columns; its candidate
+    // margin (score units below the best chunk bound) grows when alignments miss the certificate (strq_detect_api.hip)
+    int coarse_pause = 0;
+    float coarse_margin = 384.0f;
+    int screen_mode_last = 0;                 // screen of the last align_core call: 0 none, 1 fine, 2 coarse
+    int64_t redo_prev = 0;                    // second-round alignments of the batched call up to the previous sub-batch
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd,

@@ -569,6 +569,9 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     if (c->redo_total.p) STRQ_HIP(c, hipMemcpyAsync(&redo_so_far, c->redo_total.p, 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
     c->second_round[0] = redo_so_far; c->second_round[1] += 2 * (int64_t)nr;
+    if (c->screen_mode_last == 2 && ((int64_t)redo_so_far - c->redo_prev) * 200 > 2 * (int64_t)nr)
+        c->coarse_margin = std::min(c->coarse_margin * 1.5f, 2048.0f);      // more than 0.5 % missed the coarse screen's certificate: a wider candidate margin from here on
+    c->redo_prev = redo_so_far;
     for (int i = 0; i < nr; ++i) {
         strq_result& o = B.results[r0 + i];
         std::memset(&o, 0, sizeof(o));
@@ -783,7 +786,7 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
     STRQ_HIP(c, hipSetDevice(c->device));
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
     std::fill(c->counters, c->counters + 8, 0.0);
-    c->second_round[0] = c->second_round[1] = 0;
+    c->second_round[0] = c->second_round[1] = 0; c->redo_prev = 0;
     for (double& v : c->screen_stats) v = 0;
     STRQ_HIP(c, c->redo_total.reserve(64));
     STRQ_HIP(c, hipMemsetAsync(c->redo_total.p, 0, 64, c->stream));

@@ -138,12 +138,14 @@ def any_rank(flag, device=None):
     return bool(int(t.item()))
 
 
-def gather_results(records, index, n_total, mods=None, device=None):
+def gather_results(records, index, n_total, mods=None, device=None, group=None):
     """The one collective of a run, used by `bench.py` and by `count` alike: every rank contributes the
     fixed-size result records of the items it processed (structured numpy array), their global
     positions `index` and, optionally, one byte string per record (`mods`: the modification patterns,
     variable length) in a byte pool.  Three all_gathers of padded tensors (sizes, records + positions,
     pool); with the "nccl" backend that is RCCL over xGMI, ~100 B per read.
+    `group`: the process group the three all_gathers run on (default: the default group) -- bench.py keeps gloo as its control
+    plane and gathers over a second, RCCL group.
     Returns (records, mods) for all n_total items on rank 0, (None, None) elsewhere."""
     import torch
     import torch.distributed as dist
@@ -155,7 +157,7 @@ def gather_results(records, index, n_total, mods=None, device=None):
         pool = np.frombuffer(b"".join(blobs), np.uint8)
     else:
         lens = np.zeros(len(records), np.int64); pool = np.zeros(0, np.uint8)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
         out = np.zeros(n_total, dtype=records.dtype)
         out[index] = records
         out_m = None
@@ -164,12 +166,12 @@ def gather_results(records, index, n_total, mods=None, device=None):
             for i, m in zip(index, mods):
                 out_m[int(i)] = m if isinstance(m, str) else bytes(m).decode()
         return out, out_m
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     itemsize = records.dtype.itemsize
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
     sizes = torch.tensor([len(records), len(pool)], dtype=torch.int64, device=dev)
     all_sizes = [torch.empty_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
+    dist.all_gather(all_sizes, sizes, group=group)
     all_sizes = [t.cpu().numpy() for t in all_sizes]
     cap = max(1, max(int(t[0]) for t in all_sizes)); pool_cap = max(1, max(int(t[1]) for t in all_sizes))
     # one row per record: [payload bytes | position (8) | pattern length (8)]
@@ -182,8 +184,8 @@ def gather_results(records, index, n_total, mods=None, device=None):
     pool_pad = np.zeros(pool_cap, np.uint8); pool_pad[:len(pool)] = pool
     t_pay = torch.from_numpy(payload).to(dev); t_pool = torch.from_numpy(pool_pad).to(dev)
     pays = [torch.empty_like(t_pay) for _ in range(world)]; pools = [torch.empty_like(t_pool) for _ in range(world)]
-    dist.all_gather(pays, t_pay)
-    dist.all_gather(pools, t_pool)
+    dist.all_gather(pays, t_pay, group=group)
+    dist.all_gather(pools, t_pool, group=group)
     if dist.get_rank() != 0:
         return None, None
     out = np.zeros(n_total, dtype=records.dtype)
@@ -204,6 +206,6 @@ def gather_results(records, index, n_total, mods=None, device=None):
     return out, out_m
 
 
-def gather_records(records, index, n_total, device=None):
+def gather_records(records, index, n_total, device=None, group=None):
     """Records only (no byte strings): see gather_results."""
-    return gather_results(records, index, n_total, None, device)[0]
+    return gather_results(records, index, n_total, None, device, group)[0]

@@ -214,7 +214,12 @@ class Context(object):
         g = np.zeros(8, np.float64)
         self._check(self._lib.strq_last_screen(self._h, _ptr(g)))
         keys = ("ms", "screened", "windowed", "whole_read", "window_columns", "wave_steps", "scale", "candidate_chunks")
-        return dict(zip(keys, (float(v) for v in g)))
+        out = dict(zip(keys, (float(v) for v in g)))
+        m = np.zeros(4, np.int32)
+        self._check(self._lib.strq_last_screen_mode(self._h, _ptr(m)))
+        out["mode"] = {0: None, 1: "fine", 2: "coarse"}.get(int(m[0]))
+        out["coarse_pause"], out["fine_pause"], out["coarse_margin"] = int(m[1]), int(m[2]), int(m[3])
+        return out
 
     def last_geometry(self):
         """strq_last_geometry as a dict: which forward-DP kernel instance the last batched call ran."""

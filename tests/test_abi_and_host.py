@@ -197,3 +197,61 @@ def test_cpu_quota_of_the_control_group(monkeypatch):
     assert sdist.cpu_quota() == 2.5
     files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "-1"
     assert sdist.cpu_quota() is None
+
+
+def test_switches_process_wide_table_and_environment(monkeypatch):
+    """strq_set_option(NULL, key, value): the process-wide table sits between a context's own options and the environment variable
+    of the same name; "" means "not set" whatever the environment says, NULL hands the decision back.  Read through a switch the
+    host-only planning hook consults (STRQ_NO_SCREEN -> no screen frame)."""
+    lib = _lib()
+    lib.strq_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+    lib.strq_get_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32]
+    buf = ctypes.create_string_buffer(64)
+    out = (ctypes.c_int32 * 6)()
+    arr = (ctypes.c_float * 6)(-1, -1, -16, -16, 16, 0)
+    plan = lambda: lib.strq_debug_screen_plan(arr, ctypes.c_int32(6), ctypes.c_int32(400000), out)
+    monkeypatch.delenv("STRQ_NO_SCREEN", raising=False)
+    assert plan() == 1
+    assert lib.strq_set_option(None, b"STRQ_NO_SCREEN", b"1") == 0
+    lib.strq_get_option(None, b"STRQ_NO_SCREEN", buf, 64)
+    assert buf.value == b"1" and plan() == 0
+    monkeypatch.setenv("STRQ_NO_SCREEN", "1")
+    assert lib.strq_set_option(None, b"STRQ_NO_SCREEN", b"") == 0          # unset for the process although the environment sets it
+    assert plan() == 1
+    assert lib.strq_set_option(None, b"STRQ_NO_SCREEN", None) == 0         # back to the environment
+    assert plan() == 0
+    assert lib.strq_set_option(None, b"NOT_A_SWITCH", b"1") != 0
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` started plainly launches its own rank processes -- and exits non-zero, without a JSON line, when fewer
+    than N HIP devices are visible: a request for 8 GPUs must never end as an `n_gpus: 1` measurement (scripts/STRique.py:912 `--t`)."""
+    import subprocess
+    import sys
+    import torch
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 8), "--reads", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 2 and b"HIP device" in p.stderr and b'"n_gpus"' not in p.stdout
+    # and an external launcher whose world size disagrees with --gpus is refused as well
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--reads", "8", "--no-cpu-baseline"],
+                       env=dict(env, RANK="0", WORLD_SIZE="1"), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr and b'"n_gpus"' not in p.stdout
+
+
+def test_empirical_noise_fixture_and_generator(pm, cfg):
+    """The degraded-read workload: dwell / level-offset / residual pools taken from the bundled real read (tests/golden/
+    make_empirical_noise.py), resampled by strique_amd.synth.EmpiricalNoise -- seeded, and with the real read's statistics."""
+    from strique_amd import synth
+    z = np.load(os.path.join(ROOT, "tests", "golden", "empirical_noise.npz"))
+    dw = z["dwell"]
+    assert 4000 < len(dw) < 5000 and 8.5 < dw.mean() < 10.0 and np.median(dw) == 7 and (dw == 0).sum() > 10
+    assert 1.0 < z["level_offset"].std() < 2.0 and 1.8 < z["resid_z"].std() < 2.3
+    chrom, b, e, repeat, prefix, suffix = cfg["repeat"]["c9orf72"]
+    t = synth.KmerTable(pm)
+    noise = synth.EmpiricalNoise()
+    a, sa = synth.make_read(t, 7, 3, 8000, (repeat, prefix, suffix), 40, noise=noise)
+    b2, sb = synth.make_read(t, 7, 3, 8000, (repeat, prefix, suffix), 40, noise=noise)
+    assert sa == sb and np.array_equal(a, b2) and a.dtype == np.int16
+    assert 7.5 * 8000 < len(a) < 11.0 * 8000

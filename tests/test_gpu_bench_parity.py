@@ -29,15 +29,19 @@ def _bench_batch(pm, cfg, n, first):
     return bench.make_batch(pm, cfg, n, 50000, first)
 
 
-def test_benchmarked_reads_through_the_screen_all_fields(pm, cfg, targets):
-    """bench.py's own reads on the path its default line runs: the upper-bound screen over the whole reads, the float32 DP over
-    the windows it leaves (one wave per window).  Every field of every row equals the oracle's."""
+@pytest.mark.parametrize("mode", ["coarse", "fine"])
+def test_benchmarked_reads_through_the_screen_all_fields(pm, cfg, targets, mode):
+    """bench.py's own reads on the path its default line runs: an upper-bound screen over the whole reads -- the coarse one (two
+    flank rows per DP row, both flanks of a read per wave: the default) or the fine one -- and the float32 DP over the windows it
+    leaves (one wave per window).  Every field of every row equals the oracle's."""
     sigs, strands, nreps = _bench_batch(pm, cfg, 40, 0)
     rc = _fresh_counter(pm, cfg, targets)
+    if mode == "fine":
+        rc.ctx.set_option("STRQ_SCREEN_MODE", "fine")
     got = rc.detect_batch([("c9orf72", s, st) for s, st in zip(sigs, strands)])
     scr = rc.ctx.last_screen(); geo = rc.ctx.last_geometry(); redo = rc.ctx.last_second_round()
     rc.ctx.close()
-    assert scr["screened"] == 80 and scr["windowed"] == 80 and scr["scale"] == 1024, scr
+    assert scr["mode"] == mode and scr["screened"] == 80 and scr["windowed"] == 80 and scr["scale"] == (512 if mode == "coarse" else 1024), scr
     assert scr["window_columns"] < 0.02 * sum(2 * len(s) for s in sigs), scr
     assert geo["waves_per_alignment"] == 1 and redo[0] == 0, (geo, redo)
     target = targets["c9orf72"]
@@ -155,12 +159,23 @@ def test_bench_line_single_gpu_small(screen, monkeypatch):
     line's roofline is the screen kernel's and the float32 kernel's figures sit under `exact_pass`; without, as in round 3."""
     if not screen:
         monkeypatch.setenv("STRQ_NO_SCREEN", "1")
-    lines, recs = _run_bench(["--reads", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check", "2", "--host-leg-batches", "2"])
+    lines, recs = _run_bench(["--reads", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--check", "2", "--host-leg-batches", "2", "--leg-steps", "2"]
+                             + ([] if screen else ["--no-legs"]))
     r = recs[0]
     roof = r["roofline"]
     assert roof["bound"] == "valu"
     if screen:
-        assert roof["kernel"] == "align_screen_kernel" and roof["with_windows"] == roof["alignments_screened_per_step"] == 1024
+        # the A/B legs of the same run, on the same resident batches: no screen, the fine screen, degraded reads -- each with its roofline
+        legs = r["legs"]
+        assert set(legs) == {"no_screen", "fine_screen", "degraded"}
+        assert legs["no_screen"]["screen"]["alignments_screened_per_step"] == 0 and re.match(r"align_forward_seg_kernel<14, 6, false, 4", legs["no_screen"]["roofline"]["kernel"])
+        assert legs["fine_screen"]["roofline"]["kernel"] == "align_screen_kernel" and legs["fine_screen"]["screen"]["mode"] == "fine"
+        assert r["value_no_screen"] == legs["no_screen"]["value"] > 0 and r["value_degraded"] == legs["degraded"]["value"] > 0
+        assert legs["degraded"]["check"]["all_fields_equal"] and legs["degraded"]["planted_count_recovered"]["of"] == 512
+        assert r["roofline_viterbi"]["kernel"].startswith("viterbi_g2_kernel") and 0 < r["roofline_viterbi"]["frac"] < 1
+        assert r["host"]["peak_host_rss_gb_per_rank"] > 0
+    if screen:
+        assert roof["kernel"] == "align_screen2_kernel" and roof["screen_mode"] == "coarse" and roof["with_windows"] == roof["alignments_screened_per_step"] == 1024
         assert re.match(r"align_forward_seg_kernel<14, 6, false, 1, 2, false, true>", roof["exact_pass"]["kernel"])
         assert roof["window_columns_over_columns_of_the_reads"] < 0.02
     else:
@@ -170,3 +185,32 @@ def test_bench_line_single_gpu_small(screen, monkeypatch):
     assert r["config"]["distinct_batches_per_gpu"] == 3
     assert r["check_ok"] and len(r["check"]) == 2 and {c["batch"] for c in r["check"]} == {0, 1}
     assert r["host_buffers"]["same_rows_as_resident_run"] and r["host_inclusive_reads_per_s"] > 0
+
+
+def test_bench_launches_its_own_ranks_from_a_clean_environment(tmp_path):
+    """`python bench.py --gpus 4 ...` with NO launcher and no RANK / WORLD_SIZE in the environment (how the driver calls the 1-GPU
+    line, and so probably the N-GPU one): bench.py starts four fresh rank processes itself, relays rank 0's one JSON line, and the
+    collective saw four ranks.  Asking for more GPUs than the box has (without --share-device) exits non-zero and prints no line --
+    never an `n_gpus: 1` line for an 8-GPU request."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--share-device", "--backend", "gloo", "--reads", "64", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--check", "1", "--synth-workers", "1"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 4 == r["world_size_seen_by_the_collective"] and r["check_ok"]
+    coll = r["collective"]
+    assert coll["backend"] == "gloo" and "bench.py itself" in coll["launched_by"] and coll["rows_on_rank_0"] == 2 * 4 * 64
+    assert coll["ranks"]["rows_equal_every_ranks_digest"] is True and max(coll["ranks"]["peak_host_rss_gb_per_rank"]) < 6.0
+    # more GPUs than the box has
+    import torch
+    have = torch.cuda.device_count()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 7), "--reads", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert "HIP device" in p.stderr.decode()

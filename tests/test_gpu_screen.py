@@ -48,7 +48,7 @@ def _read_dump(path):
     pos = 32
     groups = []
     for _g in range(ng):
-        a, b, bound, _ = struct.unpack_from("4i", raw, pos); pos += 16
+        a, b, bound, lane_last = struct.unpack_from("4i", raw, pos); pos += 16
         pieces = []
         for _w in range(seg):
             col_off, n, m, nch = struct.unpack_from("4i", raw, pos); pos += 16
@@ -56,8 +56,8 @@ def _read_dump(path):
             pieces.append(dict(col_off=col_off, n=n, m=m, vals=vals))
         f = struct.unpack_from("9i2fi", raw, pos); pos += 48
         win = dict(n_win=f[0], lo=f[1:5], hi=f[5:9], lower=f[9], upper=f[10], n_cand=f[11])
-        groups.append(dict(a=a, bound=bound, pieces=pieces, win=win))
-    return dict(sc=sc, hh=hh, v=v, delta=delta, slack=slack, groups=groups)
+        groups.append(dict(a=a, bound=bound, pieces=pieces, win=win, lane_last=lane_last))
+    return dict(sc=sc, hh=hh, v=v, mode=delta, slack=slack, groups=groups)
 
 
 def _planted(rng, n, k, plants, scale=0.45):
@@ -87,12 +87,13 @@ def test_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp_path):
     got = ctx.align_batch(levels, np.arange(len(reads) + 1, dtype=np.int64) * n, np.stack([r[1] for r in reads]),
                           np.arange(len(reads), dtype=np.int32), flanks, foff)
     d = _read_dump(dump)
-    assert d["sc"] == 1024 and len(d["groups"]) == len(reads)
+    assert d["sc"] == 1024 and d["mode"] == 1 and len(d["groups"]) == len(reads)
     checked = 0
     for g in d["groups"]:
         lv, lval, flank = reads[g["a"]]
         m = len(flank)
         lM = (m - 1) // R
+        assert g["lane_last"] == lM
         shift = -m * d["v"]
         exact = _exact_last_row(lval[lv], flank, params)
         o = orc.align_overlap(lval[lv], flank, params, want_idx=False)
@@ -275,4 +276,157 @@ def test_a_lower_bound_nobody_reaches_sends_everything_through_the_second_round(
         o = orc.align_overlap(lval[lv], flank, params, want_idx=False)
         assert np.float32(o[0]).tobytes() == np.float32(got[0][i]).tobytes() and (o[4], o[5]) == (int(got[1][i]), int(got[2][i]))
         assert np.array_equal(o[3], got[3][i * m:(i + 1) * m])
+    c.close()
+
+
+# ---- the coarse screen (align_screen2_kernel): two flank rows per DP row, both flank alignments of a read in one wave
+
+def _pair_reads(rng, n, ka, kb, plants_a, plants_b):
+    """Reads with two flanks each (the prefix / suffix alignment of detect): level streams, one level-value table, flank A and B."""
+    cls_a = rng.uniform(60, 120, ka).astype(np.float32); cls_b = rng.uniform(60, 120, kb).astype(np.float32)
+    lval = (40 + 0.45 * np.arange(256)).astype(np.float32)
+    reads = []
+    for pa, pb in zip(plants_a, plants_b):
+        lv = np.repeat(rng.integers(30, 200, n // 5 + 1), rng.integers(3, 10, n // 5 + 1))[:n].astype(np.uint8)
+        for cls, pl in ((cls_a, pa), (cls_b, pb)):
+            emb = np.repeat(np.clip(np.round((cls - 40) / 0.45), 0, 255).astype(np.uint8), rng.integers(6, 10, len(cls)))
+            for p in pl:
+                p = max(0, min(n - len(emb), p))
+                lv[p:p + len(emb)] = emb
+        reads.append(lv)
+    return reads, lval, np.repeat(cls_a, 6), np.repeat(cls_b, 6)
+
+
+def _align_pairs(ctx, reads, lval, fa, fb):
+    nr, n = len(reads), len(reads[0])
+    flanks = np.concatenate([np.concatenate([fa, fb])] * nr)
+    foff = np.zeros(2 * nr + 1, np.int64)
+    foff[1:] = np.cumsum([len(fa), len(fb)] * nr)
+    got = ctx.align_batch(np.concatenate(reads), np.arange(nr + 1, dtype=np.int64) * n, np.tile(lval, (nr, 1)),
+                          np.repeat(np.arange(nr, dtype=np.int32), 2), flanks, foff)
+    return got, foff
+
+
+def _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff):
+    for i, lv in enumerate(reads):
+        for f, flank in enumerate((fa, fb)):
+            a = 2 * i + f
+            o = orc.align_overlap(lval[lv], flank, params, want_idx=False)
+            assert np.float32(o[0]).tobytes() == np.float32(got[0][a]).tobytes(), (i, f)
+            assert (o[4], o[5]) == (int(got[1][a]), int(got[2][a])), (i, f)
+            assert np.array_equal(o[3], got[3][foff[a]:foff[a + 1]]), (i, f)
+
+
+@pytest.mark.parametrize("ka,kb", [(145, 145), (100, 140)])
+def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp_path, ka, kb):
+    """What the coarse screen claims: every chunk value is an upper bound of the exact last row of its columns, for both flanks of a
+    read (lanes 0 .. 28 / 32 .. 60 of the wave), flanks shorter than 145 classes included; and what it is used for: the alignments
+    return the oracle's bits through its windows."""
+    rng = np.random.default_rng(1000 + ka)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
+    monkeypatch.setenv("STRQ_SCREEN_MODE", "coarse")
+    dump = str(tmp_path / "screen2.bin")
+    monkeypatch.setenv("STRQ_SCREEN_DUMP", dump)
+    n = 60000
+    reads, lval, fa, fb = _pair_reads(rng, n, ka, kb, [[20000], [41000, 5000], []], [[30000], [12000], [50000]])
+    got, foff = _align_pairs(ctx, reads, lval, fa, fb)
+    s = ctx.last_screen()
+    assert s["mode"] == "coarse" and s["scale"] == 512 and s["screened"] == 6, s
+    d = _read_dump(dump)
+    assert d["sc"] == 512 and d["mode"] == 2 and len(d["groups"]) == 6
+    checked = 0
+    for g in d["groups"]:
+        lv = reads[g["a"] // 2]; flank = (fa, fb)[g["a"] % 2]
+        m = len(flank)
+        lM = g["lane_last"]
+        assert lM == (g["a"] % 2) * 32 + (m // 2 - 1) // 15
+        shift = -m * d["v"]
+        exact = _exact_last_row(lval[lv], flank, params)
+        for pc in g["pieces"]:
+            if pc["n"] <= 0:
+                continue
+            for c, x in enumerate(pc["vals"]):
+                lo, hi = 128 * c - 2 * lM + 1, 128 * c - 2 * lM + 128
+                lo, hi = max(lo, 1), min(hi, pc["n"])
+                if hi < lo:
+                    continue
+                ub = (int(x) + shift) / d["sc"]
+                ex = exact[pc["col_off"] + lo:pc["col_off"] + hi + 1].max()
+                if ex * d["sc"] >= g["bound"] and (pc["col_off"] == 0 or lo > 8192):
+                    assert ub >= ex - 1e-3, (g["a"], pc["col_off"], c, ub, ex)
+                    checked += 1
+        assert exact.max() <= g["win"]["upper"]
+    assert checked > 1000
+    _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
+
+
+def test_coarse_windowed_alignments_equal_the_oracle(ctx, orc, monkeypatch):
+    """Planted flanks at the seams of the coarse screen's pieces, in their overlap zones, at the ends of the read, twice, five times
+    (more candidates than pieces) and not at all: score bits, end / start column and whole path equal the oracle's for both
+    alignments of every read; without the screen the same bytes."""
+    rng = np.random.default_rng(2024)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
+    monkeypatch.setenv("STRQ_SCREEN_MODE", "coarse")
+    n, k = 90000, 145
+    seams = [n // 4, n // 2, 3 * n // 4, 8192, n - 8192]
+    pa = [[p + d] for p in seams for d in (-700, -1, 0, 1, 130)] + [[3000, n - 4000], [100, 9000, 20000, 30000, n - 2000], [], [0], [n]]
+    pb = [[(p[0] + 37000) % n] if p else [n // 2] for p in pa]
+    pb[-3] = []
+    reads, lval, fa, fb = _pair_reads(rng, n, k, k, pa, pb)
+    got, foff = _align_pairs(ctx, reads, lval, fa, fb)
+    s = ctx.last_screen()
+    na = 2 * len(reads)
+    assert s["mode"] == "coarse" and s["screened"] == na and s["windowed"] >= na - 8, s
+    assert s["window_columns"] < 0.25 * na * n, s
+    _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
+    monkeypatch.setenv("STRQ_NO_SCREEN", "1")
+    ref, _ = _align_pairs(ctx, reads, lval, fa, fb)
+    assert ctx.last_screen()["screened"] == 0
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+
+
+def test_coarse_margin_too_small_ends_in_the_second_round(orc, monkeypatch):
+    """The coarse bound is loose: with a candidate margin of one score unit the lower bound it hands on lies above what the exact
+    pass can find, the certificate fails, and the alignments run their whole reads in the second round -- the oracle's results."""
+    from strique_amd import ffi
+    c = ffi.Context(0)
+    params = orc.align_params(None)
+    c.set_align_params(*[float(v) for v in params])
+    c.set_option("STRQ_SCREEN_MIN_N", "0"); c.set_option("STRQ_SCREEN_MODE", "coarse"); c.set_option("STRQ_SCREEN2_MARGIN", "1")
+    assert c.get_option("STRQ_SCREEN_MODE") == "coarse"
+    rng = np.random.default_rng(77)
+    n, k = 50000, 145
+    # short dwells inside the planted flanks: the merged rows gain there what the exact DP cannot
+    reads, lval, fa, fb = _pair_reads(rng, n, k, k, [[3000], [20000], [44000]], [[30000], [5000], [10000]])
+    for lv in reads:
+        lv[::2] = lv[1::2][:len(lv[::2])]          # halve every event: two-sample steps
+    got, foff = _align_pairs(c, reads, lval, fa, fb)
+    assert c.last_screen()["mode"] == "coarse" and c.last_second_round()[0] >= 1, (c.last_screen(), c.last_second_round())
+    _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
+    c.close()
+
+
+def test_options_per_context_override_the_environment(orc, monkeypatch):
+    """strq_set_option: a switch set on a context wins over the environment, "" unsets it for that context, None hands it back."""
+    from strique_amd import ffi
+    c = ffi.Context(0)
+    monkeypatch.setenv("STRQ_NO_SCREEN", "1")
+    assert c.get_option("STRQ_NO_SCREEN") == "1"
+    c.set_option("STRQ_NO_SCREEN", "")
+    assert c.get_option("STRQ_NO_SCREEN") == ""
+    params = orc.align_params(None)
+    c.set_align_params(*[float(v) for v in params])
+    c.set_option("STRQ_SCREEN_MIN_N", "0")
+    rng = np.random.default_rng(3)
+    lv, lval, flank = _planted(rng, 40000, 145, [12000])
+    c.align_batch(lv, [0, len(lv)], lval[None, :], [0], flank, [0, len(flank)])
+    assert c.last_screen()["screened"] == 1          # the context's "" beat the environment's STRQ_NO_SCREEN
+    c.set_option("STRQ_NO_SCREEN", None)
+    c.align_batch(lv, [0, len(lv)], lval[None, :], [0], flank, [0, len(flank)])
+    assert c.last_screen()["screened"] == 0
     c.close()

@@ -61,6 +61,48 @@ def test_integer_potential_dp_bounds_the_exact_last_row(sc):
     assert np.array_equal(Tp, T)
 
 
+def _screen_merged(rows, n, sc, eh=-1.0, ev=-16.0):
+    """The coarse screen's recurrence (align_screen2_kernel): rows 2 i - 1, 2 i of a class are one DP row whose diagonal step gains
+    both rows' entries at one column."""
+    hh, v = int(-eh * sc), int(-ev * sc)
+    T = np.arange(n + 1, dtype=np.int64) * hh
+    m = len(rows)
+    assert m % 2 == 0
+    for i in range(0, m, 2):
+        assert np.array_equal(rows[i], rows[i + 1])       # the two rows of a pair are the same k-mer class
+        s2 = 2 * (np.ceil(rows[i] * sc).astype(np.int64) + hh + v)
+        cur = np.empty(n + 1, np.int64)
+        cur[0] = 0
+        cur[1:] = np.maximum(T[:-1] + s2, T[1:])
+        T = np.maximum.accumulate(cur)
+    return T
+
+
+@pytest.mark.parametrize("sc", [512, 16])
+def test_merged_row_dp_bounds_the_exact_last_row(sc):
+    """Every last-row value of the merged-row DP is an upper bound of the exact one (the coarse screen prunes by it), on signals with
+    long events, short events (where a merged row gets away with one column for two rows: the bound is loose there) and noise."""
+    rng = np.random.default_rng(11)
+    k, n = 24, 5000
+    flank = np.repeat(rng.uniform(60, 120, k), 6)
+    m = len(flank)
+    for dwell in ((6, 10), (1, 4), (2, 12)):
+        vals = np.repeat(rng.uniform(50, 130, n), rng.integers(dwell[0], dwell[1], n))[:n]
+        emb = np.repeat(flank[::6] + rng.normal(0, 1.0, k), rng.integers(dwell[0], dwell[1], k))
+        vals[2000:2000 + len(emb)] = emb
+        exact, rows = _exact(vals, flank)
+        T = _screen_merged(rows, n, sc)
+        j = np.arange(n + 1)
+        ub = (T - j * sc - m * 16 * sc) / sc
+        assert np.all(ub >= exact - 1e-9), dwell
+        fine = (_screen(rows, n, sc) - j * sc - m * 16 * sc) / sc
+        assert np.all(ub >= fine - 1e-9)                    # and never below the fine screen's bound
+        if dwell[0] >= 6:
+            assert ub.max() - exact.max() < 0.05 * exact.max()   # events at least as long as a class: nearly tight
+    # the largest table entry of the coarse screen fits 16 bits at STRique's parameters
+    assert 2 * (16 * 512 + 512 + 16 * 512) < 65536
+
+
 def test_stored_values_fit_31_bits_for_the_longest_reads():
     sc, rows_max, n_max = 1024, 896, 1_900_000
     top = rows_max * (16 * sc + 16 * sc) + (n_max + 256) * sc + 0x00800000
