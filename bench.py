@@ -836,7 +836,7 @@ def main():
             kept_clean = kept; kept = None
             dargs = argparse.Namespace(**vars(args)); dargs.reads = args.degraded_reads or args.reads
             dl, dstr, dn, dkept, dgen, dup = stage_resident(ctx, counter, dargs, 0, 1, synth_workers, "empirical", keep_first=1, keep_all=False)
-            dleg = run_leg(ctx, dargs.reads, 1, args.leg_steps, 2, 0)          # two untimed steps: the screen's own adaptation (pause / margin) settles
+            dleg = run_leg(ctx, dargs.reads, 1, 2 * args.leg_steps, 3, 0)      # three untimed steps: the screens' own adaptation (overlap plan, pauses, margin) settles
             legs["degraded"] = leg_summary(dleg, dargs.reads, dl, prof, dn, 1)
             legs["degraded"]["workload"] = "%d reads, %d nt, noise resampled from the bundled real read (strique_amd.synth.EmpiricalNoise: N~%d samples)" % (dargs.reads, args.read_nt, int(dl.mean()))
             ctx.set_option("STRQ_NO_SCREEN", "1")

@@ -69,6 +69,10 @@ int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const Align
                          int segs, AlignResult* results, int32_t* pick, int pick_base = 0, const int* list = nullptr,
                          const int* n_list = nullptr, const float* min_score = nullptr, int* redo = nullptr, int* redo_count = nullptr,
                          unsigned int* redo_total = nullptr);
+// results / picks of a side launch (the coarse screen's second look: groups [first[a], first[a + 1]) of four pieces per alignment a) into the
+// slots of their alignments: dst[pos[a]] = the best group's result, the leftmost on ties
+int launch_align_scatter(hipStream_t stream, const AlignResult* src, const int32_t* pick_src, const int32_t* first, const int32_t* pos, int n,
+                         AlignResult* dst, int32_t* pick_dst);
 float align_segment_min_score(const AlignParams& p, int m, int overlap_used);
 // columns a path that scores at least `score` can span (the overlap a cold-started piece needs to hold every such path)
 int align_overlap_for_score(const AlignParams& p, int m, float score);

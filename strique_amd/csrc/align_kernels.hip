@@ -1128,6 +1128,26 @@ int launch_align_combine(hipStream_t stream, const AlignTask* tasks, const Align
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// The coarse screen's second look cuts an alignment's windows into groups of four pieces (one workgroup each): the best of an
+// alignment's groups [first[a], first[a + 1]) -- the leftmost on ties, groups are in column order -- goes to the alignment's slot.
+__global__ void align_scatter_kernel(const AlignResult* __restrict__ src, const int32_t* __restrict__ pick_src, const int32_t* __restrict__ first,
+                                     const int32_t* __restrict__ pos, int n, AlignResult* __restrict__ dst, int32_t* __restrict__ pick_dst)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    int best = first[a];
+    for (int g = first[a] + 1; g < first[a + 1]; ++g) if (src[g].best > src[best].best) best = g;
+    dst[pos[a]] = src[best]; pick_dst[pos[a]] = pick_src[best];
+}
+
+int launch_align_scatter(hipStream_t stream, const AlignResult* src, const int32_t* pick_src, const int32_t* first, const int32_t* pos, int n,
+                         AlignResult* dst, int32_t* pick_dst)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(align_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, pick_src, first, pos, n, dst, pick_dst);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 int align_overlap_for_score(const AlignParams& p, int m, float score)
 {
     // align_segment_overlap with the bound B = score instead of 0; never more than the worst case

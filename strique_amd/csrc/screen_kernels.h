@@ -24,6 +24,7 @@ struct ScreenParams {
     int32_t cadd;        // hh + v: added to every table entry (the two potentials absorb the gap scores)
     int32_t slack;       // float32 rounding slack of the exact DP, scaled (32 * sc)
     int32_t merge_gap;   // candidate chunks closer than this many columns share a window
+    int32_t max_cand;    // coarse screen: at most this many candidate chunks per alignment in the first look (0: no limit)
     int32_t margin;      // coarse screen: how far below the best chunk value a chunk is still a candidate (scaled); 0: the fine rule (m + 2 slack)
 };
 
@@ -74,7 +75,9 @@ static inline bool screen2_flank_ok(int m, int k) { return k >= 1 && k <= STRQ_S
 size_t screen2_lds_bytes(int tsize_a, int tsize_b);
 int launch_screen2(hipStream_t stream, const Screen2Task* tasks, int n_groups, int* queue, const ScreenParams& sp,
                    size_t lds_bytes, int groups_per_cu, int n_cu);
+// list / theta_list (nullable, device): only the alignments list[0 .. n_groups), each with the candidate threshold theta_list[idx]
+// in chunk units (the coarse screen's second look: every chunk whose bound reaches the score the first look found); out[idx]
 int launch_screen_windows(hipStream_t stream, const ScreenTask* tasks, int n_groups, const ScreenParams& sp,
-                          const int32_t* bound_scaled, ScreenWindows* out);
+                          const int32_t* bound_scaled, ScreenWindows* out, const int32_t* list = nullptr, const int32_t* theta_list = nullptr);
 
 }  // namespace strq

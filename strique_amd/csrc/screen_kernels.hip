@@ -472,12 +472,16 @@ align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* _
 // least (vmax' - m) / sc - slack / sc.  Columns of chunks with max(v', bound) + slack < vmax' - m - slack cannot hold the optimum.
 __global__ void __launch_bounds__(256)
 screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, ScreenParams sp,
-                      const int32_t* __restrict__ bound_scaled, ScreenWindows* __restrict__ out)
+                      const int32_t* __restrict__ bound_scaled, ScreenWindows* __restrict__ out,
+                      const int32_t* __restrict__ list, const int32_t* __restrict__ theta_list)
 {
-    // one wave per alignment: coalesced reads of the chunk values, lane 0 merges the (few) candidates in column order
+    // one wave per alignment: coalesced reads of the chunk values, lane 0 merges the (few) candidates in column order.
+    // list / theta_list (second look of the coarse screen): alignment list[idx] with the candidate threshold theta_list[idx]
+    // (chunk units) instead of the best chunk value minus the margin; the result goes to out[idx].
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (g >= n_groups) return;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= n_groups) return;
+    const int g = list ? list[idx] : idx;
     const ScreenTask* tg = tasks + (size_t)g * SEG;
     const int m = tg[0].m, lM = tg[0].lane_last;
     const int shift = -m * sp.v;            // v' = v + shift
@@ -493,7 +497,82 @@ screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, Screen
     for (int k = 0; k < STRQ_SCREEN_MAX_WINDOWS; ++k) { r.lo[k] = 0; r.hi[k] = 0; }
     // fine screen: a chunk value is less than m above the exact one (one rounding per diagonal step); coarse screen: sp.margin
     const int drop = (sp.margin > 0 ? sp.margin : m) + 2 * sp.slack;
-    const int theta = vmax - drop;                          // in chunk units (before the shift)
+    int theta = theta_list ? theta_list[idx] : vmax - drop;          // in chunk units (before the shift)
+    if (!theta_list && sp.max_cand > 0) {
+        // at most max_cand candidate chunks in the first look: the smallest threshold >= theta with no more chunks above it
+        // (bisection on the value; an alignment whose bound profile is flat -- a read that holds its flank no better than its
+        // background -- would otherwise hand hundreds of chunks to the exact pass; what the raised threshold leaves out is the
+        // second look's business: coarse screen, strq_align_api.hip)
+        auto count_at = [&](int t) {
+            int n = 0;
+            for (int w = 0; w < SEG; ++w) {
+                if (tg[w].n <= 0) continue;
+                for (int c = lane; c < tg[w].n_chunks; c += 64) n += tg[w].out[c] >= t;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+            return n;
+        };
+        if (count_at(theta) > sp.max_cand) {
+            int lo = theta, hi = vmax;              // count(lo) > max_cand >= count(hi + 1)
+            while (hi - lo > 1) {
+                const int mid = lo + (hi - lo) / 2;
+                if (count_at(mid) > sp.max_cand) lo = mid; else hi = mid;
+            }
+            theta = hi;
+        }
+    }
+    r.upper_bound = (float)(vmax + shift + sp.slack) / (float)sp.sc;
+    // candidates of a threshold, in column order, merged into windows: returns how many separate windows they need; with `store`
+    // fills r (at most STRQ_SCREEN_MAX_WINDOWS: the last one takes everything from there on)
+    auto scan = [&](int th, bool store) -> int {
+        int nw = 0, last_hi = -(1 << 30), ncand = 0;
+        for (int w = 0; w < SEG; ++w) {
+            if (tg[w].n <= 0) continue;
+            for (int c0 = 0; c0 < tg[w].n_chunks; c0 += 64) {
+                const int c1 = c0 + lane;
+                const bool cand = c1 < tg[w].n_chunks && tg[w].out[c1] >= th;
+                uint64_t mask = __ballot(cand);
+                while (mask) {              // wave-uniform: every lane walks the same candidates, lane 0's copy is stored
+                    const int bit = __builtin_ctzll(mask); mask &= mask - 1;
+                    const int c = c0 + bit;
+                    ++ncand;
+                    // columns of the chunk (lane lM, steps 64 c + 1 .. 64 c + 64), in read coordinates
+                    int lo = 128 * c - 2 * lM + 1, hi = 128 * c - 2 * lM + 128;
+                    if (lo < 1) lo = 1;
+                    if (hi > tg[w].n) hi = tg[w].n;
+                    if (hi < lo) continue;
+                    lo += tg[w].col_off; hi += tg[w].col_off;
+                    // pieces and chunks come in ascending column order, the overlap zones of a piece repeat columns of the one before
+                    if (nw > 0 && lo <= last_hi + sp.merge_gap) {
+                        if (hi > last_hi) last_hi = hi;
+                        if (store) {
+                            const int k = nw <= STRQ_SCREEN_MAX_WINDOWS ? nw - 1 : STRQ_SCREEN_MAX_WINDOWS - 1;
+                            if (hi > r.hi[k]) r.hi[k] = hi;
+                            if (lo < r.lo[k]) r.lo[k] = lo;
+                        }
+                    } else {
+                        ++nw; last_hi = hi;
+                        if (store) {
+                            if (nw <= STRQ_SCREEN_MAX_WINDOWS) { r.lo[nw - 1] = lo; r.hi[nw - 1] = hi; }
+                            else if (hi > r.hi[STRQ_SCREEN_MAX_WINDOWS - 1]) r.hi[STRQ_SCREEN_MAX_WINDOWS - 1] = hi;      // more separate candidates than windows: the last one takes the rest
+                        }
+                    }
+                }
+            }
+        }
+        if (store) r.n_cand = ncand;
+        return nw;
+    };
+    if (!theta_list && sp.max_cand > 0 && scan(theta, false) > STRQ_SCREEN_MAX_WINDOWS) {
+        // first look of the coarse screen: the best four windows only (what a raised threshold leaves out is the second look's business)
+        int lo = theta, hi = vmax;
+        while (hi - lo > 1) {
+            const int mid = lo + (hi - lo) / 2;
+            if (scan(mid, false) > STRQ_SCREEN_MAX_WINDOWS) lo = mid; else hi = mid;
+        }
+        theta = hi;
+    }
     {
         // every column of a chunk below theta has a float32 score below (theta + shift + slack) / sc =: lower_bound; the exact pass
         // certifies its windows by reaching it.  Rounded UP to float32: a bound a hair too high costs a spurious second round, one a
@@ -507,41 +586,12 @@ screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, Screen
         }
         r.lower_bound = lbf;
     }
-    r.upper_bound = (float)(vmax + shift + sp.slack) / (float)sp.sc;
     // prune only above the cold-start bound of the pieces, and only when the lower bound is a score worth the name
     const bool ok = theta + shift > 0 && theta + shift > bound_scaled[g];
     if (ok) {
-        int nw = 0;
-        for (int w = 0; w < SEG; ++w) {
-            if (tg[w].n <= 0) continue;
-            for (int c0 = 0; c0 < tg[w].n_chunks; c0 += 64) {
-                const int c1 = c0 + lane;
-                const bool cand = c1 < tg[w].n_chunks && tg[w].out[c1] >= theta;
-                uint64_t mask = __ballot(cand);
-                while (mask) {              // wave-uniform: every lane walks the same candidates, lane 0's copy is stored
-                    const int bit = __builtin_ctzll(mask); mask &= mask - 1;
-                    const int c = c0 + bit;
-                    ++r.n_cand;
-                    // columns of the chunk (lane lM, steps 64 c + 1 .. 64 c + 64), in read coordinates
-                    int lo = 128 * c - 2 * lM + 1, hi = 128 * c - 2 * lM + 128;
-                    if (lo < 1) lo = 1;
-                    if (hi > tg[w].n) hi = tg[w].n;
-                    if (hi < lo) continue;
-                    lo += tg[w].col_off; hi += tg[w].col_off;
-                    // pieces and chunks come in ascending column order, the overlap zones of a piece repeat columns of the one before
-                    if (nw > 0 && lo <= r.hi[nw - 1] + sp.merge_gap) {
-                        if (hi > r.hi[nw - 1]) r.hi[nw - 1] = hi;
-                        if (lo < r.lo[nw - 1]) r.lo[nw - 1] = lo;
-                    } else if (nw < STRQ_SCREEN_MAX_WINDOWS) {
-                        r.lo[nw] = lo; r.hi[nw] = hi; ++nw;
-                    } else {
-                        // more separate candidates than the exact launch has pieces: the last window takes everything from here on
-                        if (hi > r.hi[nw - 1]) r.hi[nw - 1] = hi;
-                    }
-                }
-            }
-        }
-        // ascending and disjoint (a candidate in a piece's overlap zone may have pulled the last window's start to the left of the
+        int nw = scan(theta, true);
+        if (nw > STRQ_SCREEN_MAX_WINDOWS) nw = STRQ_SCREEN_MAX_WINDOWS;
+        // ascending and disjoint (a candidate in a piece's overlap zone may have pulled a window's start to the left of the
         // window before it): the combine kernel breaks score ties by piece order
         for (int a = 1; a < nw; ++a)
             for (int b = a; b > 0 && r.lo[b] < r.lo[b - 1]; --b) {
@@ -555,7 +605,7 @@ screen_windows_kernel(const ScreenTask* __restrict__ tasks, int n_groups, Screen
         for (int a = kept; a < STRQ_SCREEN_MAX_WINDOWS; ++a) { r.lo[a] = 0; r.hi[a] = 0; }
         r.n_win = kept;
     }
-    if (lane == 0) out[g] = r;
+    if (lane == 0) out[idx] = r;
 }
 
 int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
@@ -583,7 +633,7 @@ int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
             if (!(e < 1.0e4)) continue;
             sp->slack = ((int)std::ceil(e) + 1) * sc;
         }
-        sp->merge_gap = 3072; sp->margin = 0;
+        sp->merge_gap = 3072; sp->margin = 0; sp->max_cand = 0;
         return 1;
     }
     return 0;
@@ -622,10 +672,10 @@ int launch_screen(hipStream_t stream, const ScreenTask* tasks, int n_groups, int
 }
 
 int launch_screen_windows(hipStream_t stream, const ScreenTask* tasks, int n_groups, const ScreenParams& sp,
-                          const int32_t* bound_scaled, ScreenWindows* out)
+                          const int32_t* bound_scaled, ScreenWindows* out, const int32_t* list, const int32_t* theta_list)
 {
     if (n_groups <= 0) return 0;
-    hipLaunchKernelGGL(screen_windows_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, stream, tasks, n_groups, sp, bound_scaled, out);
+    hipLaunchKernelGGL(screen_windows_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, stream, tasks, n_groups, sp, bound_scaled, out, list, theta_list);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -298,6 +298,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     const bool mode_fine = mode_opt && std::strcmp(mode_opt, "fine") == 0, mode_coarse = mode_opt && std::strcmp(mode_opt, "coarse") == 0;
     c->screen_mode_last = 0;
     bool did_coarse = false;
+    std::vector<int> g2_of(nb, -1);                 // alignment -> its index in the coarse screen's task views
+    ScreenTask* d_st2 = nullptr; int32_t* d_bound2 = nullptr; ScreenParams sp2; std::memset(&sp2, 0, sizeof(sp2));
+    double coarse_cols = 0, coarse_all = 0;
     if (collapsed && !mode_fine && !strq::opt("STRQ_NO_SCREEN") && c->coarse_pause > 0 && !mode_coarse && !scr_forced) --c->coarse_pause;
     else if (collapsed && !mode_fine && screen2_plan(c->ap, S, scr_max_n, &sp)) {
         // ---- coarse screen (align_screen2_kernel): reads whose two flank alignments are both in this sub-batch
@@ -315,6 +318,8 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             constexpr int SSEG = STRQ_SCREEN_SEG;
             sp.margin = (int32_t)std::lround((double)c->coarse_margin * sp.sc);
             if (const char* e = strq::opt("STRQ_SCREEN2_MARGIN")) sp.margin = (int32_t)std::lround(atof(e) * sp.sc);
+            sp.max_cand = 16;
+            if (const char* e = strq::opt("STRQ_SCREEN2_MAX_CAND")) sp.max_cand = atoi(e);
             std::vector<Screen2Task> t2((size_t)ngr * SSEG);
             std::vector<ScreenTask> stasks((size_t)2 * ngr * SSEG);
             std::vector<int32_t> bound((size_t)2 * ngr);
@@ -373,6 +378,8 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             STRQ_HIP(c, hipMemcpyAsync(hw.data(), d_win, hw.size() * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
             STRQ_HIP(c, hipStreamSynchronize(st));
             c->screen_ran = true; did_coarse = true; c->screen_mode_last = 2;
+            d_st2 = d_st; d_bound2 = d_bound; sp2 = sp;
+            for (int g2 = 0; g2 < 2 * ngr; ++g2) g2_of[g2 & 1 ? pairs[(size_t)g2 / 2].second : pairs[(size_t)g2 / 2].first] = g2;
             if (const char* path = strq::opt("STRQ_SCREEN_DUMP")) {
                 std::vector<int32_t> ho(out_words);
                 STRQ_HIP(c, hipMemcpy(ho.data(), d_out, out_words * 4, hipMemcpyDeviceToHost));
@@ -396,7 +403,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             }
             const bool no_prune = strq::opt("STRQ_SCREEN_NO_PRUNE") != nullptr;
             if (const char* e = strq::opt("STRQ_SCREEN_TEST_RAISE")) { const float up = (float)atof(e); for (auto& w : hw) w.lower_bound += up; }
-            int windowed = 0, heavy = 0; double cols = 0, all = 0;
+            int windowed = 0, heavy = 0, below_bound = 0; double cols = 0, all = 0;
             for (int g2 = 0; g2 < 2 * ngr; ++g2) {
                 const int al = g2 & 1 ? pairs[(size_t)g2 / 2].second : pairs[(size_t)g2 / 2].first;
                 const ScreenWindows& w = hw[(size_t)g2];
@@ -405,17 +412,26 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 if (w.n_win > 0 && !no_prune) {
                     wins[al] = w; c->screen_stats[2] += 1; ++windowed; mine = 0;
                     for (int k = 0; k < w.n_win; ++k) { c->screen_stats[4] += w.hi[k] - w.lo[k] + 1; mine += w.hi[k] - w.lo[k] + 1 + 4096; }
-                } else c->screen_stats[3] += 1;
-                all += in.n[al]; cols += mine; heavy += mine > 32768.0;
+                } else { c->screen_stats[3] += 1; below_bound += w.n_cand == 0; }
+                all += in.n[al]; cols += mine; heavy += mine > 4 * 32768.0;          // more than four pieces of 32 k columns (the cut below)
             }
+            coarse_cols = cols; coarse_all = all;
             c->screen_stats[3] += nb - 2 * ngr;          // alignments of the sub-batch the coarse screen does not take: their whole reads run
             c->screen_stats[5] += steps; c->screen_stats[6] = sp.sc;
             // does it pay?  The coarse pass costs about half the float32 pass; its windows are wider than the fine screen's.  Reads on
             // which it leaves large parts of the columns -- real reads often do: its bound is ~5 - 10 % above the exact scores where
             // events are short, and the background of such reads is that close to the flank -- go to the fine screen for a while
-            if (2 * ngr >= 64 && (windowed < 0.9 * 2 * ngr || cols > 0.10 * all || (long)heavy * 2048 > 2L * ngr) && !no_prune && !mode_coarse && !scr_forced) c->coarse_pause = 8;
-            STRQ_DBG("coarse screen: %d reads, scale %d, margin %.0f, %d groups per CU, LDS %zu bytes: %d of %d alignments with windows, %.2f %% of the columns, %d heavy -> pause %d",
-                     ngr, sp.sc, (double)sp.margin / sp.sc, scr_groups, lds_bytes, windowed, 2 * ngr, 100.0 * cols / std::max(1.0, all), heavy, c->coarse_pause);
+            // (heavy alignments are cut into four pieces below and run next to the small windows on the second stream: a few per
+            // cent of them cost their own work, not a tail)
+            if (2 * ngr >= 64 && !no_prune && !mode_coarse && !scr_forced) {
+                // (alignments whose best bound lies below the score the pieces' cold start was sized for get no windows: the overlap
+                // was planned on the previous sub-batch's scores and this one scores lower -- no reason to pause, the plan follows)
+                if (below_bound * 10 > 2 * ngr && !ov_fixed) c->score_fracs.clear();
+                else if (windowed < 0.9 * (2 * ngr - (ov_fixed ? 0 : below_bound)) || cols > 0.10 * all || (long)heavy * 100 > 2L * 2 * ngr) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
+                else c->coarse_fail = 0;
+            }
+            STRQ_DBG("coarse screen: %d reads, scale %d, margin %.0f, %d groups per CU, LDS %zu bytes: %d of %d alignments with windows (%d below the cold-start bound), %.2f %% of the columns, %d heavy -> pause %d",
+                     ngr, sp.sc, (double)sp.margin / sp.sc, scr_groups, lds_bytes, windowed, 2 * ngr, below_bound, 100.0 * cols / std::max(1.0, all), heavy, c->coarse_pause);
         }
     }
     if (did_coarse) {
@@ -520,18 +536,25 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 // -- and when hardly any alignment is left with a large share of its read to run: a few such alignments behind
                 // thousands of windows are a tail of their own (one piece of 100 k columns takes a lone wave ~17 ms; reads at
                 // `realism` 1: forward stage 94.6 ms per 1024 reads against 74.2 without the screen, gpurun_out/r4ad)
-                int windowed = 0, heavy = 0; double cols = 0, all = 0;
+                int windowed = 0, heavy = 0, below_bound = 0; double cols = 0, all = 0;
                 for (int g = 0; g < ng; ++g) {
                     const ScreenWindows& w = wins[sel[g]];
                     windowed += w.n_win > 0;
+                    below_bound += hw[(size_t)g].n_win == 0 && hw[(size_t)g].n_cand == 0;
                     all += in.n[sel[g]];
                     double mine = 0;
                     if (w.n_win > 0) for (int k = 0; k < w.n_win; ++k) mine += w.hi[k] - w.lo[k] + 1 + 4096;
                     else mine = in.n[sel[g]];
-                    cols += mine; heavy += mine > 32768.0;
+                    cols += mine; heavy += mine > 4 * 32768.0;          // more than four pieces of 32 k columns (the cut below)
                 }
-                if (ng >= 64 && (windowed < 0.9 * ng || cols > 0.06 * all || (long)heavy * 4096 > (long)ng) && !no_prune) c->screen_pause = 8;
-                STRQ_DBG("screen verdict: %d of %d with windows, %.2f %% of the columns inside them, %d heavy alignments -> pause %d", windowed, ng, 100.0 * cols / std::max(1.0, all), heavy, c->screen_pause);
+                if (ng >= 64 && !no_prune) {
+                    // (no windows because the best bound lies below the score the pieces' cold start was sized for: the overlap was
+                    // planned on the previous sub-batch's scores and this one scores lower -- the plan follows, no pause)
+                    if (below_bound * 10 > ng && !ov_fixed) c->score_fracs.clear();
+                    else if (windowed < 0.9 * (ng - (ov_fixed ? 0 : below_bound)) || cols > 0.06 * all || (long)heavy * 100 > 2L * ng) { c->screen_pause = std::min(256, 8 << std::min(c->screen_fail, 5)); ++c->screen_fail; }
+                    else c->screen_fail = 0;
+                }
+                STRQ_DBG("screen verdict: %d of %d with windows (%d below the cold-start bound), %.2f %% of the columns inside them, %d heavy alignments -> pause %d", windowed, ng, below_bound, 100.0 * cols / std::max(1.0, all), heavy, c->screen_pause);
             }
             STRQ_DBG("screen: %d alignments, scale %d, %d tables per CU, LDS %zu bytes; windows for %.0f of %.0f alignments so far", ng, sp.sc, scr_tables, lds_bytes, c->screen_stats[2], c->screen_stats[1]);
         }
@@ -559,9 +582,23 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             }
         }
         if (wins[i].n_win > 0) {
+            // An alignment left with a lot of columns (a read that does not hold its flank clearly: candidates all over it) is cut
+            // further, its widest window in two, until it has four pieces or none is wider than 16 k columns -- pieces start cold
+            // anyway (align_overlap_for_score), so a cut costs one more overlap, and a lone wave over 300 k columns would be a
+            // 25 ms tail behind thousands of small windows.
+            ScreenWindows& w = wins[i];
+            while (w.n_win < STRQ_SCREEN_MAX_WINDOWS) {
+                int widest = 0;
+                for (int k2 = 1; k2 < w.n_win; ++k2) if (w.hi[k2] - w.lo[k2] > w.hi[widest] - w.lo[widest]) widest = k2;
+                if (w.hi[widest] - w.lo[widest] < 16384) break;
+                const int mid = w.lo[widest] + (w.hi[widest] - w.lo[widest]) / 2;
+                for (int k2 = w.n_win; k2 > widest + 1; --k2) { w.lo[k2] = w.lo[k2 - 1]; w.hi[k2] = w.hi[k2 - 1]; }
+                w.lo[widest + 1] = mid + 1; w.hi[widest + 1] = w.hi[widest]; w.hi[widest] = mid;
+                ++w.n_win;
+            }
             // one piece per window (compiled piece counts: 1, 2, 4; 3 with STRQ_SEG=3), float32 tables
-            const int w = wins[i].n_win;
-            best_s = seg_want >= w ? seg_want : (w <= 2 ? w : 4); best_p = 0;
+            const int nw = w.n_win;
+            best_s = seg_want >= nw ? seg_want : (nw <= 2 ? nw : 4); best_p = 0;
         }
         segs_of[i] = best_s; packed[i] = (char)best_p;
         ++class_count[best_s];
@@ -684,7 +721,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     for (char t : two_round) any_two_round |= t != 0;
     const size_t n_all_tasks = safe0 + (any_two_round ? n_tasks : 0);
     STRQ_HIP(c, c->ckpt.reserve(ck_floats * 4 + 256));
-    STRQ_HIP(c, c->tasks.reserve(n_all_tasks * sizeof(AlignTask)));
+    const int r2_cap = did_coarse ? std::max(1024, std::min(nb, 8192)) : 0;      // alignments the coarse screen's second look can take: room for four pieces each
+    const size_t r2_0 = n_all_tasks;                                  // its tasks, behind everything else
+    STRQ_HIP(c, c->tasks.reserve((n_all_tasks + (size_t)r2_cap * 4) * sizeof(AlignTask)));
     // results: [fast pieces | per alignment | safe pieces], then pick, min_score, redo lists and counters
     STRQ_HIP(c, c->results.reserve((2 * n_tasks + nb) * sizeof(AlignResult) + (size_t)nb * 12 + launches.size() * 4 + 256));
     std::vector<AlignTask> tasks(n_all_tasks);      // pieces, upper strips, one head per alignment, safe pieces
@@ -772,7 +811,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     int max_ns = 1;
     for (auto& L : launches) max_ns = std::max(max_ns, L.NS);
     // one queue head per launch: forward (per strip level), second round, trace
-    if ((size_t)STRQ_QUEUE_FIRST + launches.size() * ((size_t)max_ns + 2) > (size_t)STRQ_QUEUE_SLOTS) {
+    if ((size_t)STRQ_QUEUE_FIRST + launches.size() * ((size_t)max_ns + 2) + 16 > (size_t)STRQ_QUEUE_SLOTS) {
         c->err = "too many distinct (flank shape, table size) groups in one batch"; return STRQ_ERR_UNSUPPORTED;
     }
     // Behind the screen a sub-batch is thousands of windows (one launch, one wave per alignment) and a handful of alignments that
@@ -819,6 +858,159 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         if (launch_align_combine(st, d_tasks + L.first_task, d_seg + L.first_task, L.count, L.segs, d_res + L.first, d_pick + L.first, L.first_task,
                                  nullptr, nullptr, two_round[li] ? d_min_score + L.first : nullptr, redo, cnt,
                                  c->redo_total.p ? c->redo_total.as<unsigned int>() : nullptr)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
+    }
+    // ---- the coarse screen's second look.  Its first look hands the exact pass at most sp.max_cand chunks per alignment, taken
+    // with a margin; an alignment whose best score found (B1, a real path's score) does not reach the certificate of that
+    // selection gets every chunk whose bound reaches B1 -- nothing else can beat B1 -- as new windows, four cold-started pieces,
+    // and the result of that pass is final (it contains the first look's optimum).  One host round trip, only for those
+    // alignments; what does not fit here (no windows above the cold-start bound, more than r2_cap alignments) keeps the
+    // whole-read second round below.
+    std::vector<std::vector<int>> redo_keep(launches.size());
+    std::vector<int> redo_keep_n(launches.size(), 0);
+    if (did_coarse && any_two_round && r2_cap > 0 && !strq::opt("STRQ_SCREEN2_NO_SECOND_LOOK")) {
+        std::vector<int> cnt(launches.size()), hredo((size_t)nb);
+        std::vector<AlignResult> hres((size_t)nb);
+        STRQ_HIP(c, hipMemcpyAsync(cnt.data(), d_redo_count, launches.size() * 4, hipMemcpyDeviceToHost, st));
+        STRQ_HIP(c, hipMemcpyAsync(hredo.data(), d_redo, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+        STRQ_HIP(c, hipMemcpyAsync(hres.data(), d_res, (size_t)nb * sizeof(AlignResult), hipMemcpyDeviceToHost, st));
+        STRQ_HIP(c, hipStreamSynchronize(st));
+        struct Look2 { int pos, i, g2; float b1; };
+        std::vector<Look2> l2;
+        bool any_redo = false;
+        for (size_t li = 0; li < launches.size(); ++li) {
+            if (!two_round[li]) continue;
+            const Launch& L = launches[li];
+            for (int x = 0; x < cnt[li]; ++x) {
+                const int a = hredo[(size_t)L.first + x], pos = L.first + a, i = out.order[pos];
+                any_redo = true;
+                if (g2_of[i] >= 0 && wins[i].n_win > 0 && (int)l2.size() < r2_cap && L.NS == 1) l2.push_back({pos, i, g2_of[i], hres[(size_t)pos].best});
+                else redo_keep[li].push_back(a);
+            }
+        }
+        if (!l2.empty()) {
+            const int n2 = (int)l2.size();
+            // device scratch: list, thresholds, windows, positions, piece results, alignment results, picks
+            const size_t o_list = 0, o_theta = o_list + (size_t)n2 * 4, o_win = (o_theta + (size_t)n2 * 4 + 15) & ~(size_t)15,
+                         o_pos = o_win + (size_t)n2 * sizeof(ScreenWindows), o_seg = (o_pos + (size_t)n2 * 4 + 15) & ~(size_t)15,
+                         o_res = o_seg + (size_t)n2 * 4 * sizeof(AlignResult), o_pick = o_res + (size_t)n2 * sizeof(AlignResult), o_end = o_pick + (size_t)n2 * 4;
+            STRQ_HIP(c, c->misc.reserve(o_end + 256));
+            char* mb = c->misc.as<char>();
+            std::vector<int32_t> h_list((size_t)n2), h_theta((size_t)n2), h_pos((size_t)n2);
+            for (int k2 = 0; k2 < n2; ++k2) {
+                const Look2& e = l2[(size_t)k2];
+                h_list[(size_t)k2] = e.g2; h_pos[(size_t)k2] = e.pos;
+                // chunk value v <-> S sc = v - m |e_v| sc: every chunk below theta2 holds float32 scores below (theta2 + shift + slack) / sc <= B1
+                const double b1s = std::floor((double)e.b1 * sp2.sc);
+                h_theta[(size_t)k2] = (int32_t)std::max(-2.0e9, std::min(2.0e9, b1s + (double)in.m[e.i] * sp2.v - (double)sp2.slack));
+            }
+            STRQ_HIP(c, hipMemcpyAsync(mb + o_list, h_list.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+            STRQ_HIP(c, hipMemcpyAsync(mb + o_theta, h_theta.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+            STRQ_HIP(c, hipMemcpyAsync(mb + o_pos, h_pos.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+            if (launch_screen_windows(st, d_st2, n2, sp2, d_bound2, reinterpret_cast<ScreenWindows*>(mb + o_win),
+                                      reinterpret_cast<const int32_t*>(mb + o_list), reinterpret_cast<const int32_t*>(mb + o_theta))) { c->err = "screen windows launch failed"; return STRQ_ERR_DEVICE; }
+            std::vector<ScreenWindows> w2((size_t)n2);
+            STRQ_HIP(c, hipMemcpyAsync(w2.data(), mb + o_win, (size_t)n2 * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
+            STRQ_HIP(c, hipStreamSynchronize(st));
+            // tasks: alignments with the same rows per lane share a launch (STRique's flanks: one launch).  An alignment's windows are
+            // cut into pieces of at most 8192 own columns (each started cold like any piece), four pieces per workgroup, as many
+            // workgroups ("groups") as that takes: an alignment whose candidates lie all over its read runs on dozens of waves
+            // instead of being a 20 ms tail on four
+            std::map<int, std::vector<int>> by_R;
+            for (int k2 = 0; k2 < n2; ++k2) {
+                if (w2[(size_t)k2].n_win > 0) by_R[in.R[l2[(size_t)k2].i]].push_back(k2);
+                else {          // no windows above the pieces' cold-start bound: the whole read, as before
+                    for (size_t li = 0; li < launches.size(); ++li) { const Launch& L = launches[li]; if (l2[(size_t)k2].pos >= L.first && l2[(size_t)k2].pos < L.first + L.count) redo_keep[li].push_back(l2[(size_t)k2].pos - L.first); }
+                }
+            }
+            const int piece_cols = 8192;
+            std::vector<AlignTask> t2; t2.reserve((size_t)n2 * 4);
+            std::vector<int32_t> pos_sorted, grp_first;          // per alignment: its slot, its first group
+            size_t ck2 = 0; int slot = 0, n_grp = 0; double cols2 = 0;
+            struct G2 { int R, first_grp, n_grp, lds, tables; bool known; };
+            std::vector<G2> groups2;
+            const size_t r2_task_cap = (size_t)r2_cap * 4;
+            for (auto& kv : by_R) {
+                G2 g{kv.first, n_grp, 0, 0, 0, kv.first == 14};
+                for (int k2 : kv.second) {
+                    const Look2& e = l2[(size_t)k2];
+                    const ScreenWindows& w = w2[(size_t)k2];
+                    const int ov = overlap[e.i];
+                    const int ov_w = std::min(ov > 0 ? ov : (1 << 30), align_overlap_for_score(c->ap, in.m[e.i], w.lower_bound));
+                    int need = 0;
+                    for (int q = 0; q < w.n_win; ++q) need += (w.hi[q] - w.lo[q] + piece_cols) / piece_cols;
+                    need = (need + 3) & ~3;
+                    if (t2.size() + (size_t)need > r2_task_cap) {          // out of room: the whole read, as before
+                        for (size_t li = 0; li < launches.size(); ++li) { const Launch& L = launches[li]; if (e.pos >= L.first && e.pos < L.first + L.count) redo_keep[li].push_back(e.pos - L.first); }
+                        continue;
+                    }
+                    const AlignTask& head = tasks[n_tasks + n_up + (size_t)e.pos];
+                    const size_t per_ckpt = (size_t)STRQ_CKPT_FIELDS(in.R[e.i]) * 64;
+                    int made = 0;
+                    for (int q = 0; q < w.n_win; ++q) {
+                        const int len = w.hi[q] - w.lo[q] + 1, np = (len + piece_cols - 1) / piece_cols;
+                        for (int j = 0; j < np; ++j) {
+                            const int own_lo = w.lo[q] + (int)((long)len * j / np), own_hi = w.lo[q] + (int)((long)len * (j + 1) / np) - 1;
+                            AlignTask t = head;
+                            const int start = std::max(0, own_lo - 1 - ov_w);
+                            t.levels = head.levels + start; t.n = own_hi - start; t.col_off = start;
+                            t.ckpt = reinterpret_cast<float*>((uintptr_t)ck2 * 4);          // offset for now: the buffer is sized below
+                            ck2 += (size_t)align_num_ckpts(t.n) * per_ckpt;
+                            cols2 += t.n; out.wave_steps += align_num_steps(t.n); out.columns += t.n;
+                            t2.push_back(t); ++made;
+                        }
+                        c->screen_stats[4] += len;
+                    }
+                    for (; made < need; ++made) { AlignTask t = head; t.n = 0; t.col_off = 0; t2.push_back(t); }
+                    g.lds = std::max(g.lds, tab_total[e.i]); g.known = g.known && in.m[e.i] == 870;
+                    pos_sorted.push_back(e.pos); grp_first.push_back(n_grp); n_grp += need / 4; ++slot;
+                }
+                g.n_grp = n_grp - g.first_grp;
+                if (g.n_grp <= 0) continue;
+                g.tables = tables_for(g.lds, 4);
+                if (g.tables < 1) { c->err = "score table does not fit LDS"; return STRQ_ERR_UNSUPPORTED; }
+                groups2.push_back(g);
+            }
+            grp_first.push_back(n_grp);
+            if (slot > 0) {
+                // device scratch of the launch: piece results, group results, picks, group ranges, slots
+                const size_t p_seg = 0, p_res = p_seg + (size_t)n_grp * 4 * sizeof(AlignResult), p_pick = p_res + (size_t)n_grp * sizeof(AlignResult),
+                             p_first = p_pick + (size_t)n_grp * 4, p_pos = p_first + ((size_t)slot + 1) * 4, p_end = p_pos + (size_t)slot * 4;
+                STRQ_HIP(c, c->ckpt2.reserve(ck2 * 4 + 256 + p_end + 256));
+                char* rb = c->ckpt2.as<char>() + ((ck2 * 4 + 255) & ~(size_t)255);
+                for (size_t x = 0; x < t2.size(); ++x) if (t2[x].n > 0) t2[x].ckpt = c->ckpt2.as<float>() + ((uintptr_t)t2[x].ckpt / 4);
+                AlignResult* d_seg2 = reinterpret_cast<AlignResult*>(rb + p_seg); AlignResult* d_res2 = reinterpret_cast<AlignResult*>(rb + p_res);
+                int32_t* d_pick2 = reinterpret_cast<int32_t*>(rb + p_pick);
+                STRQ_HIP(c, hipMemcpyAsync(d_tasks + r2_0, t2.data(), t2.size() * sizeof(AlignTask), hipMemcpyHostToDevice, st));
+                STRQ_HIP(c, hipMemcpyAsync(rb + p_first, grp_first.data(), grp_first.size() * 4, hipMemcpyHostToDevice, st));
+                STRQ_HIP(c, hipMemcpyAsync(rb + p_pos, pos_sorted.data(), (size_t)slot * 4, hipMemcpyHostToDevice, st));
+                STRQ_HIP(c, hipMemsetAsync(d_seg2, 0, (size_t)n_grp * 4 * sizeof(AlignResult), st));
+                for (const G2& g : groups2) {
+                    if (launch_align_segments(st, g.R, S, d_tasks + r2_0 + (size_t)g.first_grp * 4, d_seg2 + (size_t)g.first_grp * 4, g.n_grp, 4, c->queue.as<int>() + qi,
+                                              c->ap, g.lds, g.tables, c->n_cu, 0, nullptr, nullptr, g.known)) { c->err = "align launch failed"; return STRQ_ERR_DEVICE; }
+                    ++qi; ++out.n_launches;
+                    if (launch_align_combine(st, d_tasks + r2_0 + (size_t)g.first_grp * 4, d_seg2 + (size_t)g.first_grp * 4, g.n_grp, 4, d_res2 + g.first_grp, d_pick2 + g.first_grp,
+                                             (int)r2_0 + g.first_grp * 4)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
+                }
+                if (launch_align_scatter(st, d_res2, d_pick2, reinterpret_cast<const int32_t*>(rb + p_first), reinterpret_cast<const int32_t*>(rb + p_pos), slot, d_res, d_pick)) { c->err = "scatter launch failed"; return STRQ_ERR_DEVICE; }
+            }
+            // does the coarse screen still pay with what the second look had to run?
+            const bool forced = scr_forced || mode_coarse;
+            if (coarse_all > 0 && coarse_cols + cols2 > 0.10 * coarse_all && nb >= 64 && !forced && c->coarse_pause == 0) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
+            STRQ_DBG("coarse screen, second look: %d alignments, %.2f %% of the columns (first look %.2f %%) -> pause %d", slot, 100.0 * cols2 / std::max(1.0, coarse_all), 100.0 * coarse_cols / std::max(1.0, coarse_all), c->coarse_pause);
+        }
+        if (any_redo) {
+            // what is left for the whole-read second round
+            for (size_t li = 0; li < launches.size(); ++li) {
+                if (!two_round[li]) continue;
+                redo_keep_n[li] = (int)redo_keep[li].size();
+                if (!redo_keep[li].empty()) STRQ_HIP(c, hipMemcpyAsync(d_redo + launches[li].first, redo_keep[li].data(), redo_keep[li].size() * 4, hipMemcpyHostToDevice, st));
+            }
+            STRQ_HIP(c, hipMemcpyAsync(d_redo_count, redo_keep_n.data(), launches.size() * 4, hipMemcpyHostToDevice, st));
+        }
+    }
+    for (size_t li = 0; li < launches.size(); ++li) {
+        auto& L = launches[li];
+        int* redo = d_redo + L.first; int* cnt = d_redo_count + li;
         if (!two_round[li]) continue;
         // second round (normally empty): the listed alignments again, cut with the worst-case overlap
         if (launch_align_segments(st, L.R, S, d_tasks + safe0 + L.first_task, d_seg_safe + L.first_task, L.count, L.segs, c->queue.as<int>() + qi,
@@ -999,7 +1191,7 @@ void strq_ctx_destroy(strq_ctx* c)
     detect_state_free(c);
     for (DevBuf* b : {&c->levels, &c->level_val, &c->flank_cls, &c->tables, &c->tables3, &c->band_lo, &c->col0, &c->ckpt,
                       &c->rec, &c->tasks, &c->results, &c->queue, &c->scratch, &c->lutinfo, &c->hard, &c->misc,
-                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd, &c->gen_codes, &c->gen_table, &c->gen_bnd, &c->gen_trace, &c->gen_hard, &c->redo_total, &c->screen})
+                      &c->vit_x, &c->vit_tasks, &c->vit_bp, &c->vit_path, &c->bnd, &c->gen_codes, &c->gen_table, &c->gen_bnd, &c->gen_trace, &c->gen_hard, &c->redo_total, &c->screen, &c->ckpt2})
         b->release();
     for (HostModel* m : c->models) if (m) { m->blob.release(); delete m; }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);

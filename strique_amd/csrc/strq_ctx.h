@@ -101,6 +101,7 @@ struct strq_ctx {
     // the coarse screen in front of it (align_screen2_kernel): paused the same way when it leaves too many columns; its candidate
     // margin (score units below the best chunk bound) grows when alignments miss the certificate (strq_detect_api.hip)
     int coarse_pause = 0;
+    int coarse_fail = 0, screen_fail = 0;     // consecutive sub-batches on which the coarse / the fine screen did not pay: the pause doubles (8, 16, ... 256)
     float coarse_margin = 384.0f;
     int screen_mode_last = 0;                 // screen of the last align_core call: 0 none, 1 fine, 2 coarse
     int64_t redo_prev = 0;                    // second-round alignments of the batched call up to the previous sub-batch
@@ -108,7 +109,8 @@ struct strq_ctx {
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd,
         gen_codes, gen_table, gen_bnd, gen_trace, gen_hard,      // generic align_overlap path
-        screen;                                                   // upper-bound screen: tasks, chunk maxima, windows
+        screen,                                                   // upper-bound screen: tasks, chunk maxima, windows
+        ckpt2;                                                    // checkpoints of the coarse screen's second look
     std::vector<strq::HostModel*> models;
     void* detect = nullptr;                   // DetectState (strq_detect_api.hip)
     size_t max_ws_bytes = (size_t)96 << 30;   // cap for checkpoint workspace per sub-batch

@@ -569,8 +569,6 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     if (c->redo_total.p) STRQ_HIP(c, hipMemcpyAsync(&redo_so_far, c->redo_total.p, 4, hipMemcpyDeviceToHost, st));
     STRQ_HIP(c, hipStreamSynchronize(st));
     c->second_round[0] = redo_so_far; c->second_round[1] += 2 * (int64_t)nr;
-    if (c->screen_mode_last == 2 && ((int64_t)redo_so_far - c->redo_prev) * 200 > 2 * (int64_t)nr)
-        c->coarse_margin = std::min(c->coarse_margin * 1.5f, 2048.0f);      // more than 0.5 % missed the coarse screen's certificate: a wider candidate margin from here on
     c->redo_prev = redo_so_far;
     for (int i = 0; i < nr; ++i) {
         strq_result& o = B.results[r0 + i];

@@ -401,10 +401,13 @@ def test_coarse_margin_too_small_ends_in_the_second_round(orc, monkeypatch):
     assert c.get_option("STRQ_SCREEN_MODE") == "coarse"
     rng = np.random.default_rng(77)
     n, k = 50000, 145
-    # short dwells inside the planted flanks: the merged rows gain there what the exact DP cannot
-    reads, lval, fa, fb = _pair_reads(rng, n, k, k, [[3000], [20000], [44000]], [[30000], [5000], [10000]])
-    for lv in reads:
-        lv[::2] = lv[1::2][:len(lv[::2])]          # halve every event: two-sample steps
+    reads, lval, fa, fb = _pair_reads(rng, n, k, k, [[], [], []], [[], [], []])
+    # the flanks planted with three samples per k-mer: a merged row needs one column for its two flank rows and matches them all,
+    # the exact DP has to skip every other flank row -- the coarse bound lies far above the exact score there
+    for lv, pa, pb in zip(reads, (3000, 20000, 44000), (30000, 5000, 10000)):
+        for flank, p in ((fa, pa), (fb, pb)):
+            emb = np.repeat(np.clip(np.round((flank[::6] - 40) / 0.45), 0, 255).astype(np.uint8), 3)
+            lv[p:p + len(emb)] = emb
     got, foff = _align_pairs(c, reads, lval, fa, fb)
     assert c.last_screen()["mode"] == "coarse" and c.last_second_round()[0] >= 1, (c.last_screen(), c.last_second_round())
     _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
