@@ -215,7 +215,7 @@ def count(argv):
     parser.add_argument("--mod_model", default=None, help="Base modification pore model")
     parser.add_argument("--config", help="Config file with HMM transition probabilities")
     parser.add_argument("--t", type=int, default=0, help="Reader threads that fetch and inflate raw signals ahead of the GPU batches (the reference's worker-process count); "
-                                                          "0 (default): a share of the host's cores, at most 16 per rank")
+                                                          "0 (default): this rank's share of the CPUs the job may use (affinity mask, cgroup quota), at most 24")
     parser.add_argument("--log_level", default='warning', choices=LEVELS, help="Log level")
     parser.add_argument("--batch", type=int, default=2048, help="Reads per GPU batch")
     parser.add_argument("--device", type=int, default=0, help="HIP device")
@@ -238,8 +238,10 @@ def count(argv):
         # modification strings once at the end (strique_amd.dist.gather_results) and writes the rows in input order
         if not args.algn:
             log("Main: --algn FILE is required when running on several GPUs (stdin cannot be shared).", 'error'); raise SystemExit(1)
+        # this rank's share of the host's CPUs FIRST: sched_setaffinity pins the calling thread and what it creates afterwards, so the
+        # threads torch.distributed / RCCL / gloo start in init_process_group -- and the reader, upload and statistics threads -- follow
+        sdist.pin_rank_cpus()
         sdist.init_process_group(backend=args.backend)
-        sdist.pin_rank_cpus()                 # this rank's share of the host's CPUs: reader, upload and statistics threads follow
     _tune_allocator()
     from .counter import repeatCounter
     device = args.device if (world == 1 or args.share_device) else local
@@ -260,8 +262,8 @@ def count(argv):
     out = (open(args.out, 'w') if args.out else sys.stdout) if rank == 0 else None
     readers = args.t
     if readers <= 0:
-        # one process per GPU: every rank takes its share of the cores (LOCAL_WORLD_SIZE is set by torchrun), half of it for the
-        # readers -- the staging threads of the library and the engine thread want the rest
+        # one process per GPU: every rank takes its share of the cores (LOCAL_WORLD_SIZE is set by torchrun) for its reader threads, at most
+        # 24; the staging threads of the library and the engine thread run beside them
         local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         if share == (os.cpu_count() or 1):          # not pinned: an equal share by count

@@ -182,9 +182,17 @@ extern "C" int64_t strq_h5_locate(const uint8_t* base, int64_t base_len, int64_t
                 if ((ver != 1 && ver != 2) || nf > 2) { bad = true; return false; }
                 int seen_shuffle = 0;
                 for (int i = 0; i < nf; ++i) {
-                    if (q + 8 > p + sz) { bad = true; return false; }
-                    const int fid = b.u16(q), nlen = b.u16(q + 2), ncd = b.u16(q + 6); q += 8;
-                    if (ver == 1 || fid >= 256) q += ver == 1 ? (uint64_t)((nlen + 7) & ~7) : (uint64_t)nlen;
+                    // filter description: id, [name length], flags, number of client values.  A version-2 message leaves the name
+                    // length field (and the name) out for the library's own filters (id < 256: deflate, shuffle): a 6-byte header
+                    if (q + 6 > p + sz) { bad = true; return false; }
+                    const int fid = b.u16(q);
+                    int nlen = 0, ncd = 0;
+                    if (ver == 2 && fid < 256) { ncd = b.u16(q + 4); q += 6; }
+                    else {
+                        if (q + 8 > p + sz) { bad = true; return false; }
+                        nlen = b.u16(q + 2); ncd = b.u16(q + 6); q += 8;
+                        q += ver == 1 ? (uint64_t)((nlen + 7) & ~7) : (uint64_t)nlen;
+                    }
                     const uint64_t cd_at = q;
                     q += 4 * (uint64_t)ncd;
                     if (ver == 1 && (ncd % 2)) q += 4;

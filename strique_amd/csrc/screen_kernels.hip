@@ -316,9 +316,10 @@ struct Screen2 {
     // computed right after column A of row r and takes the register of the old T[r - 1] (dead from there on), and the scores of a
     // class are fetched for the NEXT step as soon as its three rows are done, into the registers they just left (the LDS latency
     // hides behind the rest of the step).
-    template <bool PRED>
+    template <bool PRED, bool HOIST = false>
     __device__ __forceinline__ void step(int t, int qsrc, int snext)
     {
+        if constexpr (HOIST && !PRED) { step_hoisted(qsrc, snext); return; }
         const int qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
         const int qa = qn & 0xffff, qb = (int)((unsigned)qn >> 16);
         const int potA = potB + hh, potBn = potA + hh;
@@ -360,6 +361,43 @@ struct Screen2 {
         potB = potBn;
         qq = qn;
     }
+
+    // The same step with the additions of column A taken out of the chain: `diag + score` of a cell of column A depends on the
+    // PREVIOUS step's values only, so all fifteen are issued first (independent, full rate) and the max3 chain of the step never
+    // waits for an addition it has just issued (A/B on the device: tools/runs_r05).  Fifteen more live registers.
+    __device__ __forceinline__ void step_hoisted(int qsrc, int snext)
+    {
+        const int qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
+        const int qa = qn & 0xffff, qb = (int)((unsigned)qn >> 16);
+        const int potA = potB + hh, potBn = potA + hh;
+        const int upA = sel_mask(dpp_shr1(SbotA, potA), potA, top_mask);
+        const int upB = sel_mask(dpp_shr1(T[R2 - 1], potBn), potBn, top_mask);
+        int dA[R2];
+#pragma unroll
+        for (int r = 0; r < R2; ++r) dA[r] = (r == 0 ? upS : T[r - 1]) + scA[r / 3];
+        // the class scores of column A are dead: next step's
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) scA[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(qa, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
+        int ta_prev = upA, ta_prev2 = upS, tb_prev2 = upB;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const int ta = max3i(dA[r], T[r], ta_prev);
+            if (r > 0) {
+                const int tb = max3i(ta_prev2 + scB[(r - 1) / 3], ta_prev, tb_prev2);
+                T[r - 1] = tb; tb_prev2 = tb;
+            }
+            ta_prev2 = ta_prev; ta_prev = ta;
+        }
+        const int tb = max3i(ta_prev2 + scB[CPL - 1], ta_prev, tb_prev2);
+        T[R2 - 1] = tb;
+        SbotA = ta_prev;
+        upS = upB;
+        cmax = max3i(cmax, ta_prev - potA + STRQ_SCREEN_BIAS, tb - potBn + STRQ_SCREEN_BIAS);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) scB[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(qb, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
+        potB = potBn;
+        qq = qn;
+    }
 };
 
 __device__ __forceinline__ int load_chunk2(const Screen2Task& tk, int chunk, int lane)
@@ -383,8 +421,8 @@ size_t screen2_lds_bytes(int tsize_a, int tsize_b)
     return (size_t)(((tsize_a + 1) & ~1) + 2 + ((tsize_b + 1) & ~1) + 2) * 2;
 }
 
-__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(STRQ_SCREEN2_WPE, STRQ_SCREEN2_WPE)))
-align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp)
+template <bool HOIST>
+__device__ __forceinline__ void screen2_body(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, const ScreenParams& sp)
 {
     extern __shared__ uint32_t lds_all[];
     __shared__ int next_group;
@@ -449,8 +487,8 @@ align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* _
             const bool full = (t0s >= 63) && (2 * (t0s + 64) <= tk.n);
             const int send = nsteps - t0s < 64 ? nsteps - t0s : 64;
             if (full) {
-                for (int s = 0; s < 63; ++s) s2.template step<false>(t0s + s + 1, qcur, s + 1);
-                s2.template step<false>(t0s + 64, qnext, 0);
+                for (int s = 0; s < 63; ++s) s2.template step<false, HOIST>(t0s + s + 1, qcur, s + 1);
+                s2.template step<false, HOIST>(t0s + 64, qnext, 0);
             } else {
                 for (int s = 0; s < send; ++s) {
                     const int qsrc = s == 63 ? qnext : qcur, snext = (s + 1) & 63;
@@ -465,6 +503,17 @@ align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* _
         }
     }
 }
+
+// the committed instance and its A/B variants (STRQ_SCREEN2_VARIANT: 1 = additions hoisted, 4 waves per SIMD; 2 = the default body compiled for
+// 4 waves per SIMD; 3 = additions hoisted, 5 waves per SIMD)
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(STRQ_SCREEN2_WPE, STRQ_SCREEN2_WPE)))
+align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<false>(tasks, n_groups, queue, sp); }
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(4, 4)))
+align_screen2_kernel_v1(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<true>(tasks, n_groups, queue, sp); }
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(4, 4)))
+align_screen2_kernel_v2(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<false>(tasks, n_groups, queue, sp); }
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(5, 5)))
+align_screen2_kernel_v3(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<true>(tasks, n_groups, queue, sp); }
 
 // Candidate windows of every alignment.
 // A chunk's value v bounds the float32 last-row values S of its columns: S * sc <= max(v', bound) + slack, v' = v - m * v_gap
@@ -657,8 +706,12 @@ int launch_screen2(hipStream_t stream, const Screen2Task* tasks, int n_groups, i
                    size_t lds_bytes, int groups_per_cu, int n_cu)
 {
     if (n_groups <= 0) return 0;
-    (void)hipFuncSetAttribute((const void*)align_screen2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(align_screen2_kernel, dim3(groups_per_cu * n_cu), dim3(64 * SEG), lds_bytes, stream, tasks, n_groups, queue, sp);
+    int variant = 0;
+    if (const char* e = strq::opt("STRQ_SCREEN2_VARIANT")) variant = atoi(e);
+    auto kern = variant == 1 ? align_screen2_kernel_v1 : variant == 2 ? align_screen2_kernel_v2 : variant == 3 ? align_screen2_kernel_v3 : align_screen2_kernel;
+    if (variant == 1 || variant == 2) groups_per_cu = groups_per_cu < 4 ? groups_per_cu : 4;          // compiled for four waves per SIMD
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(groups_per_cu * n_cu), dim3(64 * SEG), lds_bytes, stream, tasks, n_groups, queue, sp);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -87,7 +87,9 @@ def rank_cpu_share(local, local_world, allowed=None):
 def pin_rank_cpus(local=None, local_world=None):
     """Pin this rank process -- and with it the library's upload, order-statistic and reader threads -- to its share of
     the host's CPUs (256 CPUs / 8 ranks on the MI355X box: without it eight ranks size their pools for the whole
-    machine and migrate across sockets).  STRQ_NO_PIN=1 leaves the affinity alone.  Returns the CPUs, or None."""
+    machine and migrate across sockets).  sched_setaffinity acts on one thread (threads created later inherit it), so every
+    thread the process already has (/proc/self/task) gets the mask as well; callers still pin BEFORE they start
+    torch.distributed.  STRQ_NO_PIN=1 leaves the affinity alone.  Returns the CPUs, or None."""
     if os.environ.get("STRQ_NO_PIN") or not hasattr(os, "sched_setaffinity"):
         return None
     if local is None:
@@ -101,6 +103,14 @@ def pin_rank_cpus(local=None, local_world=None):
         os.sched_setaffinity(0, cpus)
     except OSError:
         return None
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
     return cpus
 
 

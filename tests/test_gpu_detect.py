@@ -382,6 +382,41 @@ def test_degraded_reads_equal_the_oracle(gpu_counter, pm, targets, monkeypatch):
         assert tuple(a[:6]) == tuple(w[:6]) and tuple(b[:6]) == tuple(w[:6]) and tuple(c[:6]) == tuple(w[:6]), (name, strand, w, a, b, c)
 
 
+def test_empirical_noise_reads_equal_the_oracle(pm, cfg, targets):
+    """Sixteen 50 kb reads whose dwell times, level offsets and sample residuals are resampled from the one real read the reference
+    bundles (strique_amd.synth.EmpiricalNoise; docs/installation/test.md:15-16 is that read's row) -- flank scores at the real
+    read's 0.67 ... 0.70 of the maximum, next to the background's own.  Through the default path (the coarse screen runs its first
+    and second look on them and decides for itself whether to go on), with the coarse screen forced, with the fine screen only and
+    without any screen: all six fields equal the oracle's every time."""
+    import oracle_pool
+    from strique_amd import synth
+    from strique_amd.counter import repeatCounter
+    table = synth.KmerTable(pm)
+    noise = synth.EmpiricalNoise()
+    items = []
+    for i in range(16):
+        strand = "+-"[i % 2]
+        sig = synth.make_read(table, 7, 500 + i, 50000, targets["c9orf72"], (200, 500, 1000, 1500)[i % 4], strand=strand, noise=noise)[0]
+        items.append(("c9orf72", sig, strand))
+    want = oracle_pool.detect_many([(sig, strand, targets[name]) for name, sig, strand in items])
+    rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    rc.add_target("c9orf72", *targets["c9orf72"])
+    runs = {}
+    runs["default"] = rc.detect_batch(items); modes = [rc.ctx.last_screen()["mode"]]
+    rc.ctx.set_option("STRQ_SCREEN_MODE", "coarse")
+    runs["coarse"] = rc.detect_batch(items); modes.append(rc.ctx.last_screen()["mode"]); redo = rc.ctx.last_second_round()
+    rc.ctx.set_option("STRQ_SCREEN_MODE", "fine")
+    runs["fine"] = rc.detect_batch(items); modes.append(rc.ctx.last_screen()["mode"])
+    rc.ctx.set_option("STRQ_NO_SCREEN", "1")
+    runs["none"] = rc.detect_batch(items); modes.append(rc.ctx.last_screen()["mode"])
+    rc.ctx.close()
+    assert modes == ["coarse", "coarse", "fine", None], modes
+    assert redo[0] >= 4, redo          # on such reads the coarse bound is loose: a good part of the alignments needs the second look
+    for key, got in runs.items():
+        for (name, sig, strand), w, a in zip(items, want, got):
+            assert tuple(a[:6]) == tuple(w[:6]), (key, strand, w, a)
+
+
 def test_every_flank_length_of_the_fourteen_row_shape(pm, cfg, orc, opm, monkeypatch):
     """Flanks of 134 ... 154 nt (129 ... 149 k-mer classes, 774 ... 894 flank rows) all run at 14 rows per lane, and the last
     flank row sits in register (m - 1) % 14 of its lane -- 1, 3, ..., 13 over this range.  Round 3 knew that register at
