@@ -9,9 +9,8 @@
 #define STRQ_SCREEN_SEG 4                // pieces (waves) per read
 #define STRQ_SCREEN_CHUNK_COLS 128       // columns per reported chunk (64 steps x 2 columns)
 #define STRQ_SCREEN_MAX_WINDOWS 4
-// the coarse screen (align_screen2_kernel): two flank rows per DP row, both flanks of a read in the two halves of one wave
-#define STRQ_SCREEN2_R 15                // coarse rows per lane = 30 flank rows = 5 k-mer classes, no class straddles a lane
-#define STRQ_SCREEN2_CPL 5               // classes per lane
+// the coarse screen (align_screen2 / 3 / 6_kernel): 2, 3 or 6 flank rows per DP row, both flanks of a read in the two halves of one wave
+#define STRQ_SCREEN2_CPL 5               // classes per lane: 30 flank rows, no class straddles a lane
 #define STRQ_SCREEN2_LPF 29              // lanes per flank: 29 x 5 = 145 classes = 870 rows (STRique's flanks)
 #define STRQ_SCREEN2_LANE_B 32           // first lane of the second flank
 
@@ -68,13 +67,13 @@ int launch_screen(hipStream_t stream, const ScreenTask* tasks, int n_groups, int
                   size_t lds_bytes, int tables_per_cu, int n_cu);
 // windows of alignment g from the chunk maxima of its pieces; bound_scaled[g]: the score (scaled) above which
 // the cold-started pieces of the alignment are exact
-// coarse screen: scores of two flank rows at once, both flanks of a read per wave.  screen2_plan like screen_plan (entries are twice
-// as large, so the scale is half); screen2_flank_ok: the flank fits 29 lanes of 5 classes
-int screen2_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp);
+// coarse screen: scores of `merge` (2, 3 or 6) flank rows at once, both flanks of a read per wave.  screen2_plan like screen_plan (entries are
+// merge times as large, so the scale is smaller); screen2_flank_ok: the flank fits 29 lanes of 5 classes
+int screen2_plan(const AlignParams& p, int samples, int max_n, int merge, ScreenParams* sp);
 static inline bool screen2_flank_ok(int m, int k) { return k >= 1 && k <= STRQ_SCREEN2_LPF * STRQ_SCREEN2_CPL && m == k * STRQ_SCREEN_S; }
 size_t screen2_lds_bytes(int tsize_a, int tsize_b);
 int launch_screen2(hipStream_t stream, const Screen2Task* tasks, int n_groups, int* queue, const ScreenParams& sp,
-                   size_t lds_bytes, int groups_per_cu, int n_cu);
+                   size_t lds_bytes, int groups_per_cu, int n_cu, int merge);
 // list / theta_list (nullable, device): only the alignments list[0 .. n_groups), each with the candidate threshold theta_list[idx]
 // in chunk units (the coarse screen's second look: every chunk whose bound reaches the score the first look found); out[idx]
 int launch_screen_windows(hipStream_t stream, const ScreenTask* tasks, int n_groups, const ScreenParams& sp,

@@ -262,64 +262,57 @@ align_screen_kernel(const ScreenTask* __restrict__ tasks, int n_groups, int* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The COARSE screen: half the rows, both flanks of a read in one wave.
+// The COARSE screen: merged rows, both flanks of a read in one wave.
 //
 // The six rows of a k-mer class are identical (generate_signal repeats every level `samples` = 6 times, scripts/STRique.py:
-// 186-194).  Two identical neighbouring rows i, i + 1 are merged into one DP row whose diagonal step gains BOTH rows' scores at one
-// column: a path of the fine matrix that takes its two diagonals of that row pair at columns j1 < j2 gains s(j1) + s(j2)
-// <= 2 max(s(j1), s(j2)), and the merged row may take the better of the two columns (rows and columns of the remaining path stay
-// ordered, horizontal moves are free in the T potential), so the merged DP's last row bounds the fine one's from above -- by more
-// than the fine screen's m / sc (the merged row pays for one column where the pair needs two), which is why its candidates are
-// taken with a margin (ScreenParams::margin) and certified by the exact pass like any other window.
-// 870 rows -> 435 merged rows = 29 lanes x 15: every lane owns exactly five whole classes (no class selects), and the two flanks of a
-// read (prefix / suffix alignment, the same columns) sit in lanes 0 .. 28 and 32 .. 60 of one wave: lane 32 takes the free top row
-// instead of lane 31's bottom cells, the packed levels travel through all 64 lanes.  One wave-step = 2 columns x 870 rows x 2 flanks.
+// 186-194).  MERGE = 2, 3 or 6 identical neighbouring rows become ONE DP row whose diagonal step gains all their scores at one
+// column: a path of the fine matrix that takes the diagonals of those rows at columns j1 < j2 < ... gains s(j1) + s(j2) + ...
+// <= MERGE max s(j), and the merged row may take the best of those columns (rows and columns of the remaining path stay ordered,
+// horizontal moves are free in the T potential), so the merged DP's last row bounds the fine one's from above -- by more than the
+// fine screen's m / sc (the merged row pays for one column where the rows need MERGE), which is why its candidates are taken with a
+// margin (ScreenParams::margin), limited in number, and certified by the exact pass -- with a second look for what the first one
+// cannot certify (strq_align_api.hip).
+// A lane owns five whole classes = 5 x RPC merged rows (RPC = 6 / MERGE rows per class: no class selects); 145 classes = 29 lanes,
+// and the two flanks of a read (prefix / suffix alignment, the same columns) sit in lanes 0 .. 28 and 32 .. 60 of one wave: lane 32
+// takes the free top row instead of lane 31's bottom cells, the packed levels travel through all 64 lanes.
+// One wave-step = 2 columns x both flanks.
 namespace {
 
-constexpr int R2 = STRQ_SCREEN2_R, CPL = STRQ_SCREEN2_CPL, LPF = STRQ_SCREEN2_LPF, LB = STRQ_SCREEN2_LANE_B;
-static_assert(R2 == 3 * CPL && S == 6, "three merged rows per class of six");
+constexpr int CPL = STRQ_SCREEN2_CPL, LPF = STRQ_SCREEN2_LPF, LB = STRQ_SCREEN2_LANE_B;
 
 struct Lane2Const { int lo2[CPL], hi2[CPL], off[CPL]; };
 
+template <int RPC>
 struct Screen2 {
+    static constexpr int R2 = RPC * CPL;
     const char* lds;
     const Lane2Const& lc;
-    const uint64_t top_mask;           // lane LB: its row above is the free top row
+    const uint64_t top_mask;           // lanes 0 and LB: their row above is the free top row
     const int lane, n, hh;
     int T[R2], SbotA, upS, potB, cmax;
     int qq;
     int scA[CPL], scB[CPL];
 
-    __device__ __forceinline__ void fetch(int q2, int (&sc)[CPL])
+    __device__ __forceinline__ int score(int q2, int c) const
     {
-#pragma unroll
-        for (int c = 0; c < CPL; ++c)
-            sc[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(q2, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
-    }
-    __device__ __forceinline__ void advance(int qsrc, int snext, int& qn, int (&nA)[CPL], int (&nB)[CPL])
-    {
-        qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
-        fetch(qn & 0xffff, nA);
-        fetch((int)((unsigned)qn >> 16), nB);
+        return *reinterpret_cast<const uint16_t*>(lds + med3i(q2, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
     }
     __device__ __forceinline__ void prime(int qcur)
     {
-        qq = 0;
-        int qn, nA[CPL], nB[CPL];
-        advance(qcur, 0, qn, nA, nB);
-        qq = qn;
+        qq = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qcur, 0), 0, 0x138, 0xF, 0xF, false);
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
+        for (int c = 0; c < CPL; ++c) { scA[c] = score(qq & 0xffff, c); scB[c] = score((int)((unsigned)qq >> 16), c); }
     }
 
     // One step = the lane's two columns.  Written so that nothing is copied from one step to the next: column B of row r - 1 is
     // computed right after column A of row r and takes the register of the old T[r - 1] (dead from there on), and the scores of a
-    // class are fetched for the NEXT step as soon as its three rows are done, into the registers they just left (the LDS latency
-    // hides behind the rest of the step).
-    template <bool PRED, bool HOIST = false>
+    // class are fetched for the NEXT step as soon as its rows are done, into the registers they just left (the LDS latency hides
+    // behind the rest of the step).  99 VALU instructions per step at RPC = 3 (30 cells), of which 47 issue at the half rate
+    // (31 v_max3_f32, 10 v_med3_i32, 3 DPP moves, 2 selects, 1 v_readlane): 4.7 cycles each + 2.4 for the others is the step's
+    // 357 SIMD cycles (tools/runs_r05: hoisting the additions out of the chain or other waves-per-SIMD settings move it by < 1 %).
+    template <bool PRED>
     __device__ __forceinline__ void step(int t, int qsrc, int snext)
     {
-        if constexpr (HOIST && !PRED) { step_hoisted(qsrc, snext); return; }
         const int qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
         const int qa = qn & 0xffff, qb = (int)((unsigned)qn >> 16);
         const int potA = potB + hh, potBn = potA + hh;
@@ -334,12 +327,12 @@ struct Screen2 {
         for (int c = 0; c < CPL; ++c) {
             if (act) {
 #pragma unroll
-                for (int r = 3 * c; r < 3 * c + 3; ++r) {
+                for (int r = RPC * c; r < RPC * c + RPC; ++r) {
                     const int diagA = r == 0 ? upS : T[r - 1];
                     const int ta = max3i(diagA + scA[c], T[r], ta_prev);
                     if (r > 0) {
                         // column B of row r - 1: diag = column A of row r - 2, left = column A of row r - 1, up = column B of row r - 2
-                        const int tb = max3i(ta_prev2 + scB[(r - 1) / 3], ta_prev, tb_prev2);
+                        const int tb = max3i(ta_prev2 + scB[(r - 1) / RPC], ta_prev, tb_prev2);
                         T[r - 1] = tb; tb_prev2 = tb;
                     }
                     ta_prev2 = ta_prev; ta_prev = ta;
@@ -353,48 +346,11 @@ struct Screen2 {
                     cmax = max3i(cmax, cA, cB);
                 }
             }
-            // the class's scores for the next step (scB[c] of the last row of class c is used one row later: fetch B one class behind)
-            scA[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(qa, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
-            if (c > 0) scB[c - 1] = *reinterpret_cast<const uint16_t*>(lds + med3i(qb, lc.lo2[c - 1], lc.hi2[c - 1]) + lc.off[c - 1]);
-            if (c == CPL - 1) scB[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(qb, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
+            // the class's scores for the next step (scB[c] serves the last row of class c one row later: fetch B one class behind)
+            scA[c] = score(qa, c);
+            if (c > 0) scB[c - 1] = score(qb, c - 1);
+            if (c == CPL - 1) scB[c] = score(qb, c);
         }
-        potB = potBn;
-        qq = qn;
-    }
-
-    // The same step with the additions of column A taken out of the chain: `diag + score` of a cell of column A depends on the
-    // PREVIOUS step's values only, so all fifteen are issued first (independent, full rate) and the max3 chain of the step never
-    // waits for an addition it has just issued (A/B on the device: tools/runs_r05).  Fifteen more live registers.
-    __device__ __forceinline__ void step_hoisted(int qsrc, int snext)
-    {
-        const int qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
-        const int qa = qn & 0xffff, qb = (int)((unsigned)qn >> 16);
-        const int potA = potB + hh, potBn = potA + hh;
-        const int upA = sel_mask(dpp_shr1(SbotA, potA), potA, top_mask);
-        const int upB = sel_mask(dpp_shr1(T[R2 - 1], potBn), potBn, top_mask);
-        int dA[R2];
-#pragma unroll
-        for (int r = 0; r < R2; ++r) dA[r] = (r == 0 ? upS : T[r - 1]) + scA[r / 3];
-        // the class scores of column A are dead: next step's
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) scA[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(qa, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
-        int ta_prev = upA, ta_prev2 = upS, tb_prev2 = upB;
-#pragma unroll
-        for (int r = 0; r < R2; ++r) {
-            const int ta = max3i(dA[r], T[r], ta_prev);
-            if (r > 0) {
-                const int tb = max3i(ta_prev2 + scB[(r - 1) / 3], ta_prev, tb_prev2);
-                T[r - 1] = tb; tb_prev2 = tb;
-            }
-            ta_prev2 = ta_prev; ta_prev = ta;
-        }
-        const int tb = max3i(ta_prev2 + scB[CPL - 1], ta_prev, tb_prev2);
-        T[R2 - 1] = tb;
-        SbotA = ta_prev;
-        upS = upB;
-        cmax = max3i(cmax, ta_prev - potA + STRQ_SCREEN_BIAS, tb - potBn + STRQ_SCREEN_BIAS);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) scB[c] = *reinterpret_cast<const uint16_t*>(lds + med3i(qb, lc.lo2[c], lc.hi2[c]) + lc.off[c]);
         potB = potBn;
         qq = qn;
     }
@@ -409,21 +365,10 @@ __device__ __forceinline__ int load_chunk2(const Screen2Task& tk, int chunk, int
     return (a * 2) | ((b * 2) << 16);
 }
 
-}  // namespace
-
-#ifndef STRQ_SCREEN2_WPE
-#define STRQ_SCREEN2_WPE 5
-#endif
-
-size_t screen2_lds_bytes(int tsize_a, int tsize_b)
-{
-    // both tables as 16-bit entries, each padded to a dword and followed by a zero pair (the rows below a flank)
-    return (size_t)(((tsize_a + 1) & ~1) + 2 + ((tsize_b + 1) & ~1) + 2) * 2;
-}
-
-template <bool HOIST>
+template <int RPC>
 __device__ __forceinline__ void screen2_body(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, const ScreenParams& sp)
 {
+    constexpr int R2 = RPC * CPL, MERGE = S / RPC;
     extern __shared__ uint32_t lds_all[];
     __shared__ int next_group;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -439,12 +384,12 @@ __device__ __forceinline__ void screen2_body(const Screen2Task* __restrict__ tas
         base[0] = 0; zero_idx[0] = (t0.tsize[0] + 1) & ~1;
         base[1] = zero_idx[0] + 2; zero_idx[1] = base[1] + ((t0.tsize[1] + 1) & ~1);
         {
-            // 2 (ceil(s * sc) + hh + v): what the merged row gains on a diagonal step (both rows' scores, both rows' potentials)
+            // MERGE (ceil(s * sc) + hh + v): what the merged row gains on a diagonal step (all its rows' scores and potentials)
             uint16_t* dst = reinterpret_cast<uint16_t*>(lds_all);
             const float scf = (float)sp.sc;
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                for (int i = threadIdx.x; i < t0.tsize[f]; i += 64 * SEG) dst[base[f] + i] = (uint16_t)(2 * ((int)ceilf(t0.table[f][i] * scf) + sp.cadd));
+                for (int i = threadIdx.x; i < t0.tsize[f]; i += 64 * SEG) dst[base[f] + i] = (uint16_t)(MERGE * ((int)ceilf(t0.table[f][i] * scf) + sp.cadd));
                 if (threadIdx.x == 0) { dst[zero_idx[f]] = 0; dst[zero_idx[f] + 1] = 0; }
             }
         }
@@ -470,8 +415,8 @@ __device__ __forceinline__ void screen2_body(const Screen2Task* __restrict__ tas
         }
         const uint64_t top_mask = 1ull | (1ull << LB);
         // lanes whose last register holds a flank's last row (rows below a flank score 0 and copy it)
-        const int lMa = (3 * tk.k[0] - 1) / R2, lMb = LB + (3 * tk.k[1] - 1) / R2;
-        Screen2 s2{ldsb, lc, top_mask, lane, tk.n, sp.hh};
+        const int lMa = (tk.k[0] - 1) / CPL, lMb = LB + (tk.k[1] - 1) / CPL;
+        Screen2<RPC> s2{ldsb, lc, top_mask, lane, tk.n, sp.hh};
         {
 #pragma unroll
             for (int r = 0; r < R2; ++r) s2.T[r] = STRQ_SCREEN_BIAS;
@@ -487,8 +432,8 @@ __device__ __forceinline__ void screen2_body(const Screen2Task* __restrict__ tas
             const bool full = (t0s >= 63) && (2 * (t0s + 64) <= tk.n);
             const int send = nsteps - t0s < 64 ? nsteps - t0s : 64;
             if (full) {
-                for (int s = 0; s < 63; ++s) s2.template step<false, HOIST>(t0s + s + 1, qcur, s + 1);
-                s2.template step<false, HOIST>(t0s + 64, qnext, 0);
+                for (int s = 0; s < 63; ++s) s2.template step<false>(t0s + s + 1, qcur, s + 1);
+                s2.template step<false>(t0s + 64, qnext, 0);
             } else {
                 for (int s = 0; s < send; ++s) {
                     const int qsrc = s == 63 ? qnext : qcur, snext = (s + 1) & 63;
@@ -504,16 +449,19 @@ __device__ __forceinline__ void screen2_body(const Screen2Task* __restrict__ tas
     }
 }
 
-// the committed instance and its A/B variants (STRQ_SCREEN2_VARIANT: 1 = additions hoisted, 4 waves per SIMD; 2 = the default body compiled for
-// 4 waves per SIMD; 3 = additions hoisted, 5 waves per SIMD)
-__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(STRQ_SCREEN2_WPE, STRQ_SCREEN2_WPE)))
-align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<false>(tasks, n_groups, queue, sp); }
-__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(4, 4)))
-align_screen2_kernel_v1(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<true>(tasks, n_groups, queue, sp); }
-__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(4, 4)))
-align_screen2_kernel_v2(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<false>(tasks, n_groups, queue, sp); }
-__global__ void __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(5, 5)))
-align_screen2_kernel_v3(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<true>(tasks, n_groups, queue, sp); }
+}  // namespace
+
+size_t screen2_lds_bytes(int tsize_a, int tsize_b)
+{
+    // both tables as 16-bit entries, each padded to a dword and followed by a zero pair (the rows below a flank)
+    return (size_t)(((tsize_a + 1) & ~1) + 2 + ((tsize_b + 1) & ~1) + 2) * 2;
+}
+
+// one kernel per merge factor: 2 (three DP rows per class, 15 per lane), 3 (two per class), 6 (one per class)
+#define STRQ_SCREEN2_ATTR(WPE_) __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(WPE_, WPE_)))
+__global__ void STRQ_SCREEN2_ATTR(5) align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<3>(tasks, n_groups, queue, sp); }
+__global__ void STRQ_SCREEN2_ATTR(6) align_screen3_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<2>(tasks, n_groups, queue, sp); }
+__global__ void STRQ_SCREEN2_ATTR(6) align_screen6_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<1>(tasks, n_groups, queue, sp); }
 
 // Candidate windows of every alignment.
 // A chunk's value v bounds the float32 last-row values S of its columns: S * sc <= max(v', bound) + slack, v' = v - m * v_gap
@@ -688,13 +636,14 @@ int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
     return 0;
 }
 
-int screen2_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
+int screen2_plan(const AlignParams& p, int samples, int max_n, int merge, ScreenParams* sp)
 {
-    // the fine frame at half the scale: a table entry is 2 (ceil(s sc) + hh + v) and has to fit 16 bits
+    // the fine frame at a smaller scale: a table entry is merge (ceil(s sc) + hh + v) and has to fit 16 bits
+    if (merge != 2 && merge != 3 && merge != 6) return 0;
     if (!screen_plan(p, samples, max_n, sp)) return 0;
     while (sp->sc >= 16) {
         const double smax = std::ceil((double)p.dist_offset * sp->sc);
-        if (2.0 * (smax + sp->cadd) <= 65000.0) return 1;
+        if ((double)merge * (smax + sp->cadd) <= 65000.0) return 1;
         if ((sp->hh & 1) || (sp->v & 1)) return 0;
         sp->slack = (sp->slack / sp->sc) * (sp->sc / 2);
         sp->sc /= 2; sp->hh /= 2; sp->v /= 2; sp->cadd = sp->hh + sp->v;
@@ -703,13 +652,12 @@ int screen2_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
 }
 
 int launch_screen2(hipStream_t stream, const Screen2Task* tasks, int n_groups, int* queue, const ScreenParams& sp,
-                   size_t lds_bytes, int groups_per_cu, int n_cu)
+                   size_t lds_bytes, int groups_per_cu, int n_cu, int merge)
 {
     if (n_groups <= 0) return 0;
-    int variant = 0;
-    if (const char* e = strq::opt("STRQ_SCREEN2_VARIANT")) variant = atoi(e);
-    auto kern = variant == 1 ? align_screen2_kernel_v1 : variant == 2 ? align_screen2_kernel_v2 : variant == 3 ? align_screen2_kernel_v3 : align_screen2_kernel;
-    if (variant == 1 || variant == 2) groups_per_cu = groups_per_cu < 4 ? groups_per_cu : 4;          // compiled for four waves per SIMD
+    auto kern = merge == 6 ? align_screen6_kernel : merge == 3 ? align_screen3_kernel : align_screen2_kernel;
+    if (merge == 2 && groups_per_cu > 5) groups_per_cu = 5;          // compiled for five waves per SIMD
+    if (groups_per_cu > 6) groups_per_cu = 6;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3(groups_per_cu * n_cu), dim3(64 * SEG), lds_bytes, stream, tasks, n_groups, queue, sp);
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -298,13 +298,18 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     const bool mode_fine = mode_opt && std::strcmp(mode_opt, "fine") == 0, mode_coarse = mode_opt && std::strcmp(mode_opt, "coarse") == 0;
     c->screen_mode_last = 0;
     bool did_coarse = false;
+    // flank rows per DP row of the coarse screen (2, 3 or 6: STRQ_SCREEN2_MERGE).  Measured on configs[2] (gpurun_out/r5j): screen 114.4 / 94.7 /
+    // 96.6 ms per 4096 reads, forward stage 131.6 / 115.8 / 130.9 ms -- with six rows per DP row the 10 table reads of a step bind, and
+    // the looser bound sends 14 % of the alignments into the second look (2.4 % at two, 6 % at three)
+    int coarse_merge = 3;
+    if (const char* e = strq::opt("STRQ_SCREEN2_MERGE")) { const int v = atoi(e); if (v == 2 || v == 3 || v == 6) coarse_merge = v; }
     std::vector<int> g2_of(nb, -1);                 // alignment -> its index in the coarse screen's task views
     ScreenTask* d_st2 = nullptr; int32_t* d_bound2 = nullptr; ScreenParams sp2; std::memset(&sp2, 0, sizeof(sp2));
     double coarse_cols = 0, coarse_all = 0;
     if (collapsed && !mode_fine && !strq::opt("STRQ_NO_SCREEN") && c->coarse_pause > 0 && !mode_coarse && !scr_forced) --c->coarse_pause;
-    else if (collapsed && !mode_fine && screen2_plan(c->ap, S, scr_max_n, &sp)) {
+    else if (collapsed && !mode_fine && screen2_plan(c->ap, S, scr_max_n, coarse_merge, &sp)) {
         // ---- coarse screen (align_screen2_kernel): reads whose two flank alignments are both in this sub-batch
-        int min_n = 65536, scr_groups = 5;
+        int min_n = 65536, scr_groups = 6;
         if (const char* e = strq::opt("STRQ_SCREEN_MIN_N")) min_n = atoi(e);
         if (const char* e = strq::opt("STRQ_SCREEN2_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 8) scr_groups = v; }
         std::map<int, std::vector<int>> by_read;
@@ -316,7 +321,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         const int ngr = (int)pairs.size();
         if (ngr > 0 && 2 * ngr >= (nb * 9) / 10) {
             constexpr int SSEG = STRQ_SCREEN_SEG;
-            sp.margin = (int32_t)std::lround((double)c->coarse_margin * sp.sc);
+            sp.margin = (int32_t)std::lround((double)c->coarse_margin * (coarse_merge == 6 ? 1.75 : coarse_merge == 3 ? 1.3 : 1.0) * sp.sc);
             if (const char* e = strq::opt("STRQ_SCREEN2_MARGIN")) sp.margin = (int32_t)std::lround(atof(e) * sp.sc);
             sp.max_cand = 16;
             if (const char* e = strq::opt("STRQ_SCREEN2_MAX_CAND")) sp.max_cand = atoi(e);
@@ -344,7 +349,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                         t.table[f] = jobs[J0[a[f]]].table; t.band_lo[f] = jobs[J0[a[f]]].band_lo; t.tsize[f] = info[J0[a[f]]].total; t.k[f] = in.k[a[f]];
                         ScreenTask v; std::memset(&v, 0, sizeof(v));
                         v.n = pc[w].n; v.m = in.m[a[f]]; v.k = in.k[a[f]]; v.col_off = pc[w].col_off; v.n_chunks = t.n_chunks;
-                        v.lane_last = f * STRQ_SCREEN2_LANE_B + (3 * in.k[a[f]] - 1) / STRQ_SCREEN2_R;
+                        v.lane_last = f * STRQ_SCREEN2_LANE_B + (in.k[a[f]] - 1) / STRQ_SCREEN2_CPL;
                         out_off[((size_t)2 * g + f) * SSEG + w] = out_words; out_words += (size_t)t.n_chunks;
                         stasks[((size_t)2 * g + f) * SSEG + w] = v;
                     }
@@ -371,20 +376,20 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             STRQ_HIP(c, hipMemcpyAsync(d_st, stasks.data(), stasks.size() * sizeof(ScreenTask), hipMemcpyHostToDevice, st));
             STRQ_HIP(c, hipMemcpyAsync(d_bound, bound.data(), bound.size() * 4, hipMemcpyHostToDevice, st));
             STRQ_HIP(c, hipEventRecord(c->ev[5], st));
-            if (launch_screen2(st, d_t2, ngr, c->queue.as<int>() + STRQ_QUEUE_FIRST - 1, sp, lds_bytes, scr_groups, c->n_cu)) { c->err = "coarse screen launch failed"; return STRQ_ERR_DEVICE; }
+            if (launch_screen2(st, d_t2, ngr, c->queue.as<int>() + STRQ_QUEUE_FIRST - 1, sp, lds_bytes, scr_groups, c->n_cu, coarse_merge)) { c->err = "coarse screen launch failed"; return STRQ_ERR_DEVICE; }
             STRQ_HIP(c, hipEventRecord(c->ev[6], st));
             if (launch_screen_windows(st, d_st, 2 * ngr, sp, d_bound, d_win)) { c->err = "screen windows launch failed"; return STRQ_ERR_DEVICE; }
             std::vector<ScreenWindows> hw((size_t)2 * ngr);
             STRQ_HIP(c, hipMemcpyAsync(hw.data(), d_win, hw.size() * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
             STRQ_HIP(c, hipStreamSynchronize(st));
-            c->screen_ran = true; did_coarse = true; c->screen_mode_last = 2;
+            c->screen_ran = true; did_coarse = true; c->screen_mode_last = 2; c->coarse_merge_last = coarse_merge;
             d_st2 = d_st; d_bound2 = d_bound; sp2 = sp;
             for (int g2 = 0; g2 < 2 * ngr; ++g2) g2_of[g2 & 1 ? pairs[(size_t)g2 / 2].second : pairs[(size_t)g2 / 2].first] = g2;
             if (const char* path = strq::opt("STRQ_SCREEN_DUMP")) {
                 std::vector<int32_t> ho(out_words);
                 STRQ_HIP(c, hipMemcpy(ho.data(), d_out, out_words * 4, hipMemcpyDeviceToHost));
                 if (FILE* fp = fopen(path, "wb")) {
-                    const int32_t hdr[8] = {2 * ngr, sp.sc, sp.hh, sp.v, 2, SSEG, sp.slack, sp.margin};
+                    const int32_t hdr[8] = {2 * ngr, sp.sc, sp.hh, sp.v, 2, SSEG, sp.slack, coarse_merge};
                     fwrite(hdr, 4, 8, fp);
                     for (int g2 = 0; g2 < 2 * ngr; ++g2) {
                         const int al = g2 & 1 ? pairs[(size_t)g2 / 2].second : pairs[(size_t)g2 / 2].first;
@@ -1020,13 +1025,22 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                                  (int)safe0 + L.first_task, redo, cnt, nullptr, nullptr, nullptr)) { c->err = "combine launch failed"; return STRQ_ERR_DEVICE; }
     }
     STRQ_HIP(c, hipEventRecord(c->ev[3], st));
-    for (auto& L : launches) {
+    for (size_t li = 0; li < launches.size();) {
         // the trace pass keeps one table per wave (it re-runs a few blocks of one piece per alignment); pick holds
-        // absolute task indices (a fast or a safe piece)
-        const int wpb = std::min(trace_wpb, (160 * 1024) / (std::max(L.lds_floats, 1) * 4));
-        if (launch_align(st, L.R, S, d_tasks, d_res + L.first, L.count, c->queue.as<int>() + qi, c->ap, L.lds_floats, wpb, c->n_cu,
+        // absolute task indices (a fast or a safe piece).  Launches that differ in their forward geometry only (waves per
+        // alignment behind a screen: one, two and four windows) are neighbours in result order and share one trace launch
+        const Launch& L = launches[li];
+        int count = L.count, lds_floats = L.lds_floats;
+        size_t lj = li + 1;
+        for (; lj < launches.size(); ++lj) {
+            const Launch& M = launches[lj];
+            if (M.R != L.R || M.NS != L.NS || M.packed != L.packed || L.NS != 1 || M.first != L.first + count) break;
+            count += M.count; lds_floats = std::max(lds_floats, M.lds_floats);
+        }
+        const int wpb = std::min(trace_wpb, (160 * 1024) / (std::max(lds_floats, 1) * 4));
+        if (launch_align(st, L.R, S, d_tasks, d_res + L.first, count, c->queue.as<int>() + qi, c->ap, lds_floats, wpb, c->n_cu,
                          c->scratch.as<uint64_t>(), 1, 0, L.packed, d_pick + L.first)) { c->err = "trace launch failed"; return STRQ_ERR_DEVICE; }
-        ++qi;
+        ++qi; li = lj;
     }
     STRQ_HIP(c, hipEventRecord(c->ev[4], st));
     out.d_tasks = d_heads; out.d_results = d_res; out.d_rec = c->rec.as<int32_t>();

@@ -104,6 +104,7 @@ struct strq_ctx {
     int coarse_fail = 0, screen_fail = 0;     // consecutive sub-batches on which the coarse / the fine screen did not pay: the pause doubles (8, 16, ... 256)
     float coarse_margin = 384.0f;
     int screen_mode_last = 0;                 // screen of the last align_core call: 0 none, 1 fine, 2 coarse
+    int coarse_merge_last = 0;                // ... and the flank rows per DP row of the coarse one
     int64_t redo_prev = 0;                    // second-round alignments of the batched call up to the previous sub-batch
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,

@@ -317,8 +317,8 @@ def _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
             assert np.array_equal(o[3], got[3][foff[a]:foff[a + 1]]), (i, f)
 
 
-@pytest.mark.parametrize("ka,kb", [(145, 145), (100, 140)])
-def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp_path, ka, kb):
+@pytest.mark.parametrize("ka,kb,merge", [(145, 145, 2), (100, 140, 2), (145, 145, 3), (145, 120, 6)])
+def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp_path, ka, kb, merge):
     """What the coarse screen claims: every chunk value is an upper bound of the exact last row of its columns, for both flanks of a
     read (lanes 0 .. 28 / 32 .. 60 of the wave), flanks shorter than 145 classes included; and what it is used for: the alignments
     return the oracle's bits through its windows."""
@@ -327,21 +327,23 @@ def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp
     ctx.set_align_params(*[float(v) for v in params])
     monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
     monkeypatch.setenv("STRQ_SCREEN_MODE", "coarse")
+    monkeypatch.setenv("STRQ_SCREEN2_MERGE", str(merge))
+    scale = {2: 512, 3: 512, 6: 256}[merge]
     dump = str(tmp_path / "screen2.bin")
     monkeypatch.setenv("STRQ_SCREEN_DUMP", dump)
     n = 60000
     reads, lval, fa, fb = _pair_reads(rng, n, ka, kb, [[20000], [41000, 5000], []], [[30000], [12000], [50000]])
     got, foff = _align_pairs(ctx, reads, lval, fa, fb)
     s = ctx.last_screen()
-    assert s["mode"] == "coarse" and s["scale"] == 512 and s["screened"] == 6, s
+    assert s["mode"] == "coarse" and s["scale"] == scale and s["screened"] == 6, s
     d = _read_dump(dump)
-    assert d["sc"] == 512 and d["mode"] == 2 and len(d["groups"]) == 6
+    assert d["sc"] == scale and d["mode"] == 2 and len(d["groups"]) == 6
     checked = 0
     for g in d["groups"]:
         lv = reads[g["a"] // 2]; flank = (fa, fb)[g["a"] % 2]
         m = len(flank)
         lM = g["lane_last"]
-        assert lM == (g["a"] % 2) * 32 + (m // 2 - 1) // 15
+        assert lM == (g["a"] % 2) * 32 + (m // 6 - 1) // 5
         shift = -m * d["v"]
         exact = _exact_last_row(lval[lv], flank, params)
         for pc in g["pieces"]:
@@ -362,7 +364,8 @@ def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp
     _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
 
 
-def test_coarse_windowed_alignments_equal_the_oracle(ctx, orc, monkeypatch):
+@pytest.mark.parametrize("merge", [2, 3, 6])
+def test_coarse_windowed_alignments_equal_the_oracle(ctx, orc, monkeypatch, merge):
     """Planted flanks at the seams of the coarse screen's pieces, in their overlap zones, at the ends of the read, twice, five times
     (more candidates than pieces) and not at all: score bits, end / start column and whole path equal the oracle's for both
     alignments of every read; without the screen the same bytes."""
@@ -371,6 +374,7 @@ def test_coarse_windowed_alignments_equal_the_oracle(ctx, orc, monkeypatch):
     ctx.set_align_params(*[float(v) for v in params])
     monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
     monkeypatch.setenv("STRQ_SCREEN_MODE", "coarse")
+    monkeypatch.setenv("STRQ_SCREEN2_MERGE", str(merge))
     n, k = 90000, 145
     seams = [n // 4, n // 2, 3 * n // 4, 8192, n - 8192]
     pa = [[p + d] for p in seams for d in (-700, -1, 0, 1, 130)] + [[3000, n - 4000], [100, 9000, 20000, 30000, n - 2000], [], [0], [n]]
