@@ -345,7 +345,7 @@ class Leg(object):
         self.fwd_ms = 0.0; self.fwd_launches = 0; self.stage_ms = np.zeros(8); self.counters = np.zeros(8)
         self.geoms = []; self.last = {}; self.mine = []; self.elapsed = 0.0; self.steps = 0
         self.screen = {"ms": 0.0, "wave_steps": 0.0, "screened": 0.0, "windowed": 0.0, "whole_read": 0.0, "window_columns": 0.0, "scale": 0.0, "candidate_chunks": 0.0}
-        self.second_round = [0, 0]; self.screen_mode = None
+        self.second_round = [0, 0]; self.screen_mode = None; self.screen_merge = 0
 
     def after_step(self, ctx, k, bi, res):
         self.last[bi] = res.copy()
@@ -358,7 +358,7 @@ class Leg(object):
         for key in ("ms", "wave_steps", "screened", "windowed", "whole_read", "window_columns", "candidate_chunks"):
             self.screen[key] += scr[key]
         self.screen["scale"] = scr["scale"]
-        self.screen_mode = scr.get("mode", self.screen_mode)
+        self.screen_mode = scr.get("mode", self.screen_mode); self.screen_merge = scr.get("merge", 0) or self.screen_merge
         sr = ctx.last_second_round()
         self.second_round[0] += sr[0]; self.second_round[1] += sr[1]
         self.steps += 1
@@ -383,8 +383,12 @@ def run_leg(ctx, reads, n_batches, steps, warmup, k0=0):
     return leg
 
 
-SCREEN_KERNELS = {"fine": ("align_screen_kernel", 111.0, 28.0, FLANK_ROWS / float(64 * 14)),
-                  "coarse": ("align_screen2_kernel", 120.0, 60.0, 2.0 * 435.0 / float(64 * 15))}
+# kernel, VALU instructions per wave-step of its steady-state loop (ISA; the committed SQ_INSTS_VALU profile takes precedence), DP cells per lane and step
+# (a merged cell of the coarse screens covers 2 / 3 / 6 cells of the reference's matrix), cells of the reference's matrix per lane and step, busy lanes
+SCREEN_KERNELS = {("fine", 0): ("align_screen_kernel", 111.0, 28.0, 28.0, FLANK_ROWS / float(64 * 14)),
+                  ("coarse", 2): ("align_screen2_kernel", 101.0, 30.0, 60.0, 58.0 / 64.0),
+                  ("coarse", 3): ("align_screen3_kernel", 81.0, 20.0, 60.0, 58.0 / 64.0),
+                  ("coarse", 6): ("align_screen6_kernel", 61.0, 10.0, 60.0, 58.0 / 64.0)}
 
 
 def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
@@ -465,7 +469,7 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
         exact["ms_per_step"] = (fwd_ms - screen["ms"]) / steps
         exact["note"] = "float32 DP over the screen's windows only (plus the host planning between the two passes, which the forward stage time includes)"
         mode = leg.screen_mode or "fine"
-        sk_name, sk_isa, sk_cells, sk_util = SCREEN_KERNELS.get(mode, SCREEN_KERNELS["fine"])
+        sk_name, sk_isa, sk_cells, sk_ref_cells, sk_util = SCREEN_KERNELS.get((mode, leg.screen_merge if mode == "coarse" else 0), SCREEN_KERNELS[("fine", 0)])
         scr_ip = by_kernel.get(sk_name)
         scr_note = None
         if scr_ip is None:
@@ -474,11 +478,12 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
         scr_steps_per_launch = screen["wave_steps"] / max(1, fwd_launches)
         achieved = scr_ip * scr_steps_per_launch / scr_launch_s / 1e9 if scr_launch_s > 0 else None
         roof = {"bound": "valu", "unit": "G wave-instructions/s", "peak": valu_peak, "kernel": sk_name, "screen_mode": mode,
+                "flank_rows_per_dp_row": leg.screen_merge if mode == "coarse" else 1,
                 "avg_launch_ms": scr_launch_s * 1e3, "launches_per_step": launches_per_step,
                 "wave_steps_per_launch": scr_steps_per_launch, "valu_insts_per_wave_step": scr_ip,
                 "valu_insts_source": prof.get("screen_valu_source") if scr_note is None else scr_note,
                 "achieved": achieved, "frac": achieved / valu_peak if achieved else None,
-                "instr_per_cell": scr_ip / sk_cells, "instr_per_cell_floor": 2.0,
+                "instr_per_cell": scr_ip / sk_cells, "instr_per_cell_floor": 2.0, "instr_per_cell_of_the_reference_matrix": scr_ip / sk_ref_cells,
                 "lane_utilisation": sk_util,
                 "gcups": gcups, "gcups_note": "cells of the reference's matrices (2 x 871 x (N + 1) per read) per second of the forward stage: the screen "
                                               "covers every one of them with an integer bound, the float32 DP recomputes the windows",

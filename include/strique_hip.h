@@ -321,10 +321,11 @@ int strq_last_second_round(const strq_ctx* ctx, int64_t out[2]);
  * every flank row)   [6] scale (scores are rounded up to multiples of 1 / scale)   [7] candidate chunks of 128 columns. */
 int strq_last_screen(const strq_ctx* ctx, double out[8]);
 /* Which screen the last sub-batch of the last batched call ran: [0] 0 none, 1 the fine screen (align_screen_kernel: one DP row per flank
- * row, bound within m / scale of the exact last row), 2 the coarse one (align_screen2_kernel: two flank rows per DP row, both flanks
+ * row, bound within m / scale of the exact last row), 2 the coarse one (align_screen3_kernel by default: three flank rows per DP row, both flanks
  * of a read per wave, candidates taken with a margin)   [1] / [2] sub-batches for which the coarse / the fine screen stays paused
- * (it did not pay on the last one it ran on)   [3] the coarse screen's candidate margin in score units. */
-int strq_last_screen_mode(const strq_ctx* ctx, int32_t out[4]);
+ * (it did not pay on the last one it ran on)   [3] the coarse screen's candidate margin in score units (x 1.3 / 1.75 at three / six
+ * rows per DP row)   [4] flank rows per DP row of the coarse screen that ran (2, 3 or 6; kernel align_screen<that>_kernel)   [5..7] 0. */
+int strq_last_screen_mode(const strq_ctx* ctx, int32_t out[8]);
 
 #ifdef __cplusplus
 }

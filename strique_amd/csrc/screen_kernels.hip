@@ -115,48 +115,47 @@ struct Screen {
         }
     }
 
+    // One step = the lane's two columns.  Nothing is copied from one step to the next (round 5, as in the coarse screen below): column B
+    // of row r - 1 is computed right after column A of row r and takes the register of the old T[r - 1], and the class scores of the
+    // NEXT step are fetched into the registers of this step's as soon as the rows' scores have been expanded from them.
     template <bool PRED>
     __device__ __forceinline__ void step(int t, int qsrc, int snext)
     {
-        int qn, nA[C], nB[C];
-        advance(qsrc, snext, qn, nA, nB);
+        const int qn = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qsrc, snext), qq, 0x138, 0xF, 0xF, false);
         // potentials j |e_h| of this step's two columns: what the free top row holds there
         const int potA = potB + hh, potBn = potA + hh;
         // the row above the lane: lane - 1's bottom cells (lane 0: the top row)
         const int upA = dpp_shr1(SbotA, potA);
         const int upB = dpp_shr1(T[R - 1], potBn);
+        int rsA[R], rsB[R];
+        expand(scA, rsA);
+        expand(scB, rsB);
+        fetch(qn & 0xffff, scA);
+        fetch((int)((unsigned)qn >> 16), scB);
         bool act = true, okB = true;
         if constexpr (PRED) { const int jB = 2 * (t - lane), jA = jB - 1; act = (jA >= 1) && (jA <= n); okB = jB <= n; }
         if (act) {
-            int rsA[R], rsB[R];
-            expand(scA, rsA);
-            expand(scB, rsB);
-            int TA[R], TB[R];
+            int ta_prev = upA, ta_prev2 = upS, tb_prev2 = upB;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                {
-                    const int diag = r == 0 ? upS : T[r - 1];
-                    const int up = r == 0 ? upA : TA[r > 0 ? r - 1 : 0];
-                    TA[r] = max3i(diag + rsA[r], T[r], up);
+                const int diagA = r == 0 ? upS : T[r - 1];
+                const int ta = max3i(diagA + rsA[r], T[r], ta_prev);
+                if (r > 0) {
+                    const int tb = max3i(ta_prev2 + rsB[r - 1], ta_prev, tb_prev2);
+                    T[r - 1] = tb; tb_prev2 = tb;
                 }
-                {
-                    const int diag = r == 0 ? upA : TA[r > 0 ? r - 1 : 0];
-                    const int up = r == 0 ? upB : TB[r > 0 ? r - 1 : 0];
-                    TB[r] = max3i(diag + rsB[r], TA[r], up);
-                }
+                ta_prev2 = ta_prev; ta_prev = ta;
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r) T[r] = TB[r];
-            SbotA = TA[R - 1];
+            const int tb = max3i(ta_prev2 + rsB[R - 1], ta_prev, tb_prev2);
+            T[R - 1] = tb;
+            SbotA = ta_prev;
             upS = upB;
             // last row (this lane's last register, see the header) minus the column potential: S[m][j] * sc + m |e_v| (+ bias)
-            const int cA = TA[R - 1] - potA + STRQ_SCREEN_BIAS, cB = okB ? TB[R - 1] - potBn + STRQ_SCREEN_BIAS : cA;
+            const int cA = ta_prev - potA + STRQ_SCREEN_BIAS, cB = okB ? tb - potBn + STRQ_SCREEN_BIAS : cA;
             cmax = max3i(cmax, cA, cB);
         }
         potB = potBn;
         qq = qn;
-#pragma unroll
-        for (int c = 0; c < C; ++c) { scA[c] = nA[c]; scB[c] = nB[c]; }
     }
 };
 

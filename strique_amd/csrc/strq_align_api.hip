@@ -323,7 +323,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             constexpr int SSEG = STRQ_SCREEN_SEG;
             sp.margin = (int32_t)std::lround((double)c->coarse_margin * (coarse_merge == 6 ? 1.75 : coarse_merge == 3 ? 1.3 : 1.0) * sp.sc);
             if (const char* e = strq::opt("STRQ_SCREEN2_MARGIN")) sp.margin = (int32_t)std::lround(atof(e) * sp.sc);
-            sp.max_cand = 16;
+            sp.max_cand = 8;          // (8, 16, 32 candidates and margins of 300 ... 700 score units measure within 1.5 % of each other: gpurun_out/r5n)
             if (const char* e = strq::opt("STRQ_SCREEN2_MAX_CAND")) sp.max_cand = atoi(e);
             std::vector<Screen2Task> t2((size_t)ngr * SSEG);
             std::vector<ScreenTask> stasks((size_t)2 * ngr * SSEG);
@@ -822,20 +822,34 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     // Behind the screen a sub-batch is thousands of windows (one launch, one wave per alignment) and a handful of alignments that
     // run large parts of their reads (launches of two / four waves per alignment): a ~20 ms tail if the launches follow each other.
     // The launch with the most alignments runs on a second stream, next to the others (gpurun_out/r4aa: degraded reads).
-    int side = -1;
+    // Round 5: every launch but the first on a stream of its own (up to three side streams): behind the coarse screen there are three
+    // launches of comparable length (alignments with one, two and three or four windows).
+    bool side = false; int n_side = 0;
+    std::vector<hipStream_t> lstream(launches.size(), st);
     if (c->screen_ran && launches.size() > 1 && max_ns == 1 && collapsed && !strq::opt("STRQ_ONE_STREAM")) {
-        side = 0;
-        for (size_t li = 1; li < launches.size(); ++li) if (launches[li].count > launches[side].count) side = (int)li;
-        if (!c->stream2) STRQ_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        side = true;
         if (!c->ev_fork) STRQ_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        if (!c->ev_join) STRQ_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         STRQ_HIP(c, hipEventRecord(c->ev_fork, st));
-        STRQ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        // STRQ_SIDE_STREAMS=3: every launch but the first on a side stream; default: only the launch with the most alignments
+        // (A/B on one box, gpurun_out/r5n)
+        const char* so = strq::opt("STRQ_SIDE_STREAMS");
+        const bool all_side = so && atoi(so) >= 3;
+        size_t biggest = 0;
+        for (size_t li = 1; li < launches.size(); ++li) if (launches[li].count > launches[biggest].count) biggest = li;
+        int used = 0;
+        for (size_t li = 0; li < launches.size(); ++li) {
+            if (all_side ? li == 0 : li != biggest) continue;
+            const int k = used % 3;
+            if (!c->side_stream[k]) { STRQ_HIP(c, hipStreamCreateWithFlags(&c->side_stream[k], hipStreamNonBlocking)); STRQ_HIP(c, hipEventCreateWithFlags(&c->side_join[k], hipEventDisableTiming)); }
+            if (used < 3) STRQ_HIP(c, hipStreamWaitEvent(c->side_stream[k], c->ev_fork, 0));
+            lstream[li] = c->side_stream[k]; ++used;
+        }
+        n_side = std::min(used, 3);
     }
     for (int level = 0; level < max_ns; ++level) {          // top strips first, then the strips below them
         for (size_t lidx = 0; lidx < launches.size(); ++lidx) {
             auto& L = launches[lidx];
-            hipStream_t lst = (int)lidx == side ? c->stream2 : st;
+            hipStream_t lst = lstream[lidx];
             if (level >= L.NS) continue;
             STRQ_DBG("forward launch R=%d strips=%d slice dwords=%d packed=%d level=%d count=%d tables/CU=%d segments=%d", L.R, L.NS, L.lds_floats, L.packed, level, L.count, L.tables, L.segs);
             int rc;
@@ -853,9 +867,11 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             ++qi; ++out.n_launches;
         }
     }
-    if (side >= 0) {
-        STRQ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
-        STRQ_HIP(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    if (side) {
+        for (int k = 0; k < n_side; ++k) {
+            STRQ_HIP(c, hipEventRecord(c->side_join[k], c->side_stream[k]));
+            STRQ_HIP(c, hipStreamWaitEvent(st, c->side_join[k], 0));
+        }
     }
     for (size_t li = 0; li < launches.size(); ++li) {
         auto& L = launches[li];
@@ -1210,8 +1226,7 @@ void strq_ctx_destroy(strq_ctx* c)
     for (HostModel* m : c->models) if (m) { m->blob.release(); delete m; }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (int k = 0; k < 3; ++k) { if (c->side_join[k]) (void)hipEventDestroy(c->side_join[k]); if (c->side_stream[k]) (void)hipStreamDestroy(c->side_stream[k]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1271,10 +1286,12 @@ int strq_last_screen(const strq_ctx* c, double out[8])
     return STRQ_OK;
 }
 
-int strq_last_screen_mode(const strq_ctx* c, int32_t out[4])
+int strq_last_screen_mode(const strq_ctx* c, int32_t out[8])
 {
     if (!c || !out) return STRQ_ERR_ARG;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
     out[0] = c->screen_mode_last; out[1] = c->coarse_pause; out[2] = c->screen_pause; out[3] = (int32_t)c->coarse_margin;
+    out[4] = c->screen_mode_last == 2 ? c->coarse_merge_last : 0;
     return STRQ_OK;
 }
 

@@ -80,8 +80,8 @@ struct strq_ctx {
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // second forward launch of a screened sub-batch (align_core), created on first use
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side_stream[3] = {};          // forward launches of a screened sub-batch beside the first one (align_core), created on first use
+    hipEvent_t ev_fork = nullptr, side_join[3] = {};
     hipEvent_t ev[8] = {};
     strq::AlignParams ap{-2.0f, -8.0f, -2.0f, -8.0f, 8.0f, -16.0f};   // src/align_raw.h:51-60
     std::string err;

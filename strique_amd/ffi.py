@@ -215,10 +215,10 @@ class Context(object):
         self._check(self._lib.strq_last_screen(self._h, _ptr(g)))
         keys = ("ms", "screened", "windowed", "whole_read", "window_columns", "wave_steps", "scale", "candidate_chunks")
         out = dict(zip(keys, (float(v) for v in g)))
-        m = np.zeros(4, np.int32)
+        m = np.zeros(8, np.int32)
         self._check(self._lib.strq_last_screen_mode(self._h, _ptr(m)))
         out["mode"] = {0: None, 1: "fine", 2: "coarse"}.get(int(m[0]))
-        out["coarse_pause"], out["fine_pause"], out["coarse_margin"] = int(m[1]), int(m[2]), int(m[3])
+        out["coarse_pause"], out["fine_pause"], out["coarse_margin"], out["merge"] = int(m[1]), int(m[2]), int(m[3]), int(m[4])
         return out
 
     def last_geometry(self):

@@ -42,7 +42,7 @@ def test_benchmarked_reads_through_the_screen_all_fields(pm, cfg, targets, mode)
     scr = rc.ctx.last_screen(); geo = rc.ctx.last_geometry(); redo = rc.ctx.last_second_round()
     rc.ctx.close()
     assert scr["mode"] == mode and scr["screened"] == 80 and scr["windowed"] == 80 and scr["scale"] == (512 if mode == "coarse" else 1024), scr
-    assert scr["window_columns"] < 0.02 * sum(2 * len(s) for s in sigs), scr
+    assert scr["window_columns"] < (0.05 if mode == "coarse" else 0.02) * sum(2 * len(s) for s in sigs), scr          # (coarse: both looks)
     # (coarse: alignments whose first look missed its certificate take the second look -- a handful; fine: none)
     assert redo[0] <= (8 if mode == "coarse" else 0), (geo, redo)
     target = targets["c9orf72"]
@@ -176,7 +176,7 @@ def test_bench_line_single_gpu_small(screen, monkeypatch):
         assert r["roofline_viterbi"]["kernel"].startswith("viterbi_g2_kernel") and 0 < r["roofline_viterbi"]["frac"] < 1
         assert r["host"]["peak_host_rss_gb_per_rank"] > 0
     if screen:
-        assert roof["kernel"] == "align_screen2_kernel" and roof["screen_mode"] == "coarse" and roof["with_windows"] == roof["alignments_screened_per_step"] == 1024
+        assert roof["kernel"] == "align_screen3_kernel" and roof["screen_mode"] == "coarse" and roof["flank_rows_per_dp_row"] == 3 and roof["with_windows"] == roof["alignments_screened_per_step"] == 1024
         assert re.match(r"align_forward_seg_kernel<14, 6, false, 1, 2, false, true>", roof["exact_pass"]["kernel"])
         assert roof["window_columns_over_columns_of_the_reads"] < 0.02
     else:
