@@ -474,12 +474,14 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
         scr_note = None
         if scr_ip is None:
             scr_ip = sk_isa; scr_note = "no committed SQ_INSTS_VALU profile of this kernel: instruction count of the steady-state loop (ISA)"
-        scr_launch_s = screen["ms"] / 1e3 / max(1, fwd_launches)
-        scr_steps_per_launch = screen["wave_steps"] / max(1, fwd_launches)
+        # one screen launch per sub-batch of (at most) 4096 reads
+        scr_launches = steps * max(1, -(-len(lens_one_batch) // 4096))
+        scr_launch_s = screen["ms"] / 1e3 / scr_launches
+        scr_steps_per_launch = screen["wave_steps"] / scr_launches
         achieved = scr_ip * scr_steps_per_launch / scr_launch_s / 1e9 if scr_launch_s > 0 else None
         roof = {"bound": "valu", "unit": "G wave-instructions/s", "peak": valu_peak, "kernel": sk_name, "screen_mode": mode,
                 "flank_rows_per_dp_row": leg.screen_merge if mode == "coarse" else 1,
-                "avg_launch_ms": scr_launch_s * 1e3, "launches_per_step": launches_per_step,
+                "avg_launch_ms": scr_launch_s * 1e3, "launches_per_step": scr_launches // steps,
                 "wave_steps_per_launch": scr_steps_per_launch, "valu_insts_per_wave_step": scr_ip,
                 "valu_insts_source": prof.get("screen_valu_source") if scr_note is None else scr_note,
                 "achieved": achieved, "frac": achieved / valu_peak if achieved else None,
@@ -487,9 +489,10 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
                 "lane_utilisation": sk_util,
                 "gcups": gcups, "gcups_note": "cells of the reference's matrices (2 x 871 x (N + 1) per read) per second of the forward stage: the screen "
                                               "covers every one of them with an integer bound, the float32 DP recomputes the windows",
-                "traffic": (prof.get("screen_hbm_bytes_per_read_column", 0.0) * 2.0 * n_samples / launches_per_step) or None,
+                "traffic": (prof.get("screen_hbm_bytes_per_read_column", 0.0) * 2.0 * n_samples / max(1, scr_launches // steps)) or None,
                 "traffic_source": prof.get("screen_traffic_source"),
-                "traffic_note": "the uint8 levels once per piece (1 B per column, overlaps included), the float32 score table of every alignment, 4 B written per 128 columns",
+                "traffic_note": "the uint8 levels once per piece (1 B per column, overlaps included; the coarse screen reads them once for both alignments of a read), the float32 score "
+                                "table of every alignment, 4 B written per 128 columns and alignment; measured with the kernel named in traffic_source",
                 "scale": screen["scale"],
                 "alignments_screened_per_step": screen["screened"] / steps, "with_windows": screen["windowed"] / steps,
                 "whole_read": screen["whole_read"] / steps,
@@ -535,7 +538,7 @@ def leg_summary(leg, reads, lens_one_batch, prof, nreps=None, n_batches=1):
            "roofline_viterbi": viterbi_roofline(leg, prof),
            "screen": {"mode": leg.screen_mode, "ms_per_step": leg.screen["ms"] / steps,
                       "share_of_alignments_with_windows": leg.screen["windowed"] / max(1.0, leg.screen["screened"]) if leg.screen["screened"] else 0.0,
-                      "alignments_screened_per_step": leg.screen["screened"] / steps,
+                      "alignments_screened_per_step": leg.screen["screened"] / steps, "wave_steps_per_step": leg.screen["wave_steps"] / steps,
                       "window_columns_over_columns_of_the_reads": leg.screen["window_columns"] / max(1.0, 2.0 * float(lens_one_batch.sum()) * steps),
                       "candidate_chunks_per_alignment": leg.screen["candidate_chunks"] / max(1.0, leg.screen["screened"])},
            "second_round_share": leg.second_round[0] / max(1, leg.second_round[1])}

@@ -673,26 +673,11 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
         else { v3u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = (unsigned)c; *reinterpret_cast<v3u*>(xst + kind * (G2_LDS_CELLS * 16)) = q; }
     };
     auto xload = [&](int kind, double& v, Pay& c) {         // ds_read_b128
-#ifdef STRQ_G2_LOAD96
-        // experiment: ds_read_b96 where the payload is one word -- no dead fourth register for the allocator to reuse under the load
-        if constexpr (!MARK) {
-            const v3u q = *reinterpret_cast<const v3u*>(xld + kind * (G2_LDS_CELLS * 16));
-            v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x); c = (int)q.z;
-            return;
-        }
-#endif
         const v4u q = *reinterpret_cast<const v4u*>(xld + kind * (G2_LDS_CELLS * 16));
         v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
         if constexpr (MARK) c = ((uint64_t)q.w << 32) | q.z; else c = (int)q.z;
     };
     auto xload_at = [&](int kind, int src_lane, double& v, Pay& c) {      // the cell of one lane, read by all (same address: one LDS cycle)
-#ifdef STRQ_G2_LOAD96
-        if constexpr (!MARK) {
-            const v3u q = *reinterpret_cast<const v3u*>(xbase + kind * (G2_LDS_CELLS * 16) + 16 * (src_lane + 1));
-            v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x); c = (int)q.z;
-            return;
-        }
-#endif
         const v4u q = *reinterpret_cast<const v4u*>(xbase + kind * (G2_LDS_CELLS * 16) + 16 * (src_lane + 1));
         v = __builtin_bit_cast(double, ((uint64_t)q.y << 32) | q.x);
         if constexpr (MARK) c = ((uint64_t)q.w << 32) | q.z; else c = (int)q.z;
@@ -753,8 +738,6 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
 #ifndef STRQ_G2_PRESWEEPS
 #define STRQ_G2_PRESWEEPS 2
 #endif
-            bool pre_win = true;
-            (void)pre_win;
 #pragma unroll
             for (int pre = 0; pre < STRQ_G2_PRESWEEPS; ++pre) {
                 double tin = dpp_shr1_f64(y[1]) + clp[0];
@@ -764,28 +747,7 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 const bool win = tin > y[1];
                 y[1] = max_f64_raw(y[1], tin);
                 yc[1] = win ? yc[0] : yc[1];
-                pre_win = win;
             }
-#ifdef STRQ_G2_WHILE
-            // experiment: the last unconditional sweep already says whether anything is left to do
-            if (STRQ_G2_PRESWEEPS > 0 && !__any(pre_win)) return;
-#endif
-#ifdef STRQ_G2_TESTFIRST
-            // experiment: test the cross-lane hop first (2 DPP moves + add + compare) and run the rest of a sweep only when some lane takes
-            // its left neighbour's value: the last, fruitless pass then costs 4 instead of 10 instructions.  Valid behind >= 1 full sweep
-            // (the in-lane hop has been applied to the current slot-0 values, so slot 1 can only change after slot 0 did).
-            static_assert(STRQ_G2_PRESWEEPS >= 1, "the test-first loop needs one full sweep in front of it");
-            for (;;) {
-                double tin = dpp_shr1_f64(y[1]) + clp[0];
-                if (!__any(tin > y[0])) break;
-                if constexpr (MARK) yc[0] = sel_shr1_u64(tin, y[0], yc[1], yc[0]); else yc[0] = sel_shr1_i32(tin, y[0], yc[1], yc[0]);
-                y[0] = max_f64_raw(y[0], tin);
-                tin = y[0] + clp[1];
-                const bool win = tin > y[1];
-                y[1] = max_f64_raw(y[1], tin);
-                yc[1] = win ? yc[0] : yc[1];
-            }
-#else
             for (;;) {
                 double tin = dpp_shr1_f64(y[1]) + clp[0];
                 if constexpr (MARK) yc[0] = sel_shr1_u64(tin, y[0], yc[1], yc[0]); else yc[0] = sel_shr1_i32(tin, y[0], yc[1], yc[0]);
@@ -796,7 +758,6 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 yc[1] = win ? yc[0] : yc[1];
                 if (!__any(win)) break;
             }
-#endif
         };
 
         double pv[4]; Pay pc[4]; double dv[2]; Pay dc[2];      // Me, Mo, Ie, Io of the previous time step; De, Do
@@ -815,13 +776,8 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             if (lane < 5) { const uint64_t u = __builtin_bit_cast(uint64_t, NEGINF); v4u q; q.x = (unsigned)u; q.y = (unsigned)(u >> 32); q.z = 0; q.w = 0; *reinterpret_cast<v4u*>(xbase + lane * (G2_LDS_CELLS * 16)) = q; }
             VIT_FENCE();
             xstore(2, dv[1], dc[1]);
-#ifdef STRQ_G2_EARLY2
-            if constexpr (LX2) { xstore(0, NEGINF, 0); xstore(1, NEGINF, 0); xstore(3, NEGINF, 0); xstore(4, NEGINF, 0); }
-#endif
             VIT_FENCE();
-#ifndef STRQ_G2_LATE_DO
             xload(2, rDo, qDo);
-#endif
         }
 
         auto step = [&](auto fast_c, auto odd_c, double x, int64_t t) {
@@ -831,17 +787,6 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             constexpr bool ODD = decltype(odd_c)::value;
             constexpr int B0 = ODD ? 1 : 0, B1 = ODD ? 3 : 2;
             (void)t;
-#ifdef STRQ_G2_LATE_DO
-            // experiment: lane - 1's odd delete slot is fetched at the head of the step that uses it, not behind the store of the step before
-            if constexpr (LX) xload(2, rDo, qDo);
-#endif
-#ifdef STRQ_G2_EARLY2
-            // experiment: everything lane - 1 / the broadcast lane hands to the even match slot is fetched here and used last
-            if constexpr (LX2) { xload(3, rMe, qMe); xload_at(ODD ? 0 : 3, bc0_lane, rB0, qB0); }
-#ifdef STRQ_G2_EARLY2_BARRIER
-            if constexpr (LX2) __builtin_amdgcn_sched_barrier(0);          // the scheduler otherwise sinks the three loads to their first use
-#endif
-#endif
             // previous values of lane - 1 (lane 0 receives 0.0: every column that uses them is -inf there)
             double sMe; Pay cMe;
             if constexpr (LX2) { sMe = rMe; cMe = qMe; } else { sMe = dpp_shr1_f64(pv[0]); cMe = shr1_pay(pc[0]); }
@@ -915,44 +860,16 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
             {
                 double nI, nM, nB; Pay cI, cM, cB;      // lane - 1's new Io, Mo; the new value of B1
                 if constexpr (LX) {
-#ifdef STRQ_G2_EARLY2
-                  if constexpr (LX2) {
-                    tour_mo(); tour_io(); tour_ie(); finish(K1{}); finish(K3{}); finish(K2{});
-                    xstore(0, nv[1], nc[1]); xstore(1, nv[3], nc[3]); if constexpr (!ODD) xstore(4, nv[2], nc[2]);
-                    VIT_FENCE();
-                    xload(0, nM, cM); xload(1, nI, cI); xload_at(ODD ? 1 : 4, bc1_lane, nB, cB);
-#ifdef STRQ_G2_EARLY2_BARRIER
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-                    tour_me(); finish(K0{});
-                    xstore(3, nv[0], nc[0]);
-                    VIT_FENCE();
-                    rMo = nM; rIo = nI; qMo = cM; qIo = cI;
-                  } else
-#endif
                   {
-#ifdef STRQ_G2_EARLY
-                    // experiment: the odd slots first -- their cells are on their way through LDS while the even slots (the larger tournaments) are evaluated
-                    tour_mo(); tour_io(); finish(K1{}); finish(K3{});
-                    xstore(0, nv[1], nc[1]); xstore(1, nv[3], nc[3]);
-                    VIT_FENCE();
-                    xload(0, nM, cM); xload(1, nI, cI);
-                    __builtin_amdgcn_sched_barrier(0);
-                    tour_me(); tour_ie(); finish(K0{}); finish(K2{});
-                    if constexpr (LX2) { xstore(3, nv[0], nc[0]); if constexpr (!ODD) xstore(4, nv[2], nc[2]); VIT_FENCE(); }
-#else
                     tour_me(); tour_mo(); tour_ie(); tour_io(); finish(K0{}); finish(K1{}); finish(K2{}); finish(K3{});
                     xstore(0, nv[1], nc[1]); xstore(1, nv[3], nc[3]);
                     if constexpr (LX2) { xstore(3, nv[0], nc[0]); if constexpr (!ODD) xstore(4, nv[2], nc[2]); }
                     VIT_FENCE();
                     xload(0, nM, cM); xload(1, nI, cI);
-#endif
                     rMo = nM; rIo = nI; qMo = cM; qIo = cI;          // ... which are next step's shifted previous values
                     if constexpr (LX2) {
                         xload_at(ODD ? 1 : 4, bc1_lane, nB, cB);
-#ifndef STRQ_G2_EARLY2
                         xload(3, rMe, qMe); xload_at(ODD ? 0 : 3, bc0_lane, rB0, qB0);      // for the next time step
-#endif
                     } else { nB = readlane_f64(nv[B1], bc1_lane); cB = readlane_pay(nc[B1], bc1_lane); }
                   }
                 } else {
@@ -979,9 +896,7 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
                 VIT_FENCE();
                 xstore(2, y[1], yc[1]);
                 VIT_FENCE();
-#ifndef STRQ_G2_LATE_DO
                 xload(2, rDo, qDo);
-#endif
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) { pv[k] = nv[k]; pc[k] = nc[k]; }
