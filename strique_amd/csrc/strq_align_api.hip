@@ -417,15 +417,22 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 if (w.n_win > 0 && !no_prune) {
                     wins[al] = w; c->screen_stats[2] += 1; ++windowed; mine = 0;
                     for (int k = 0; k < w.n_win; ++k) { c->screen_stats[4] += w.hi[k] - w.lo[k] + 1; mine += w.hi[k] - w.lo[k] + 1 + 4096; }
-                } else { c->screen_stats[3] += 1; below_bound += w.n_cand == 0; }
+                } else {
+                    c->screen_stats[3] += 1;
+                    // best bound below the score the pieces' cold start was planned for (the previous sub-batch scored higher): a planning
+                    // transient, not something the screen is to blame for -- its whole read does not count against the screen
+                    if (w.n_cand == 0 && !ov_fixed) { ++below_bound; mine = 0; }
+                }
                 all += in.n[al]; cols += mine; heavy += mine > 4 * 32768.0;          // more than four pieces of 32 k columns (the cut below)
             }
             coarse_cols = cols; coarse_all = all;
             c->screen_stats[3] += nb - 2 * ngr;          // alignments of the sub-batch the coarse screen does not take: their whole reads run
             c->screen_stats[5] += steps; c->screen_stats[6] = sp.sc;
-            // does it pay?  The coarse pass costs about half the float32 pass; its windows are wider than the fine screen's.  Reads on
-            // which it leaves large parts of the columns -- real reads often do: its bound is ~5 - 10 % above the exact scores where
-            // events are short, and the background of such reads is that close to the flank -- go to the fine screen for a while
+            // does it pay?  The coarse pass costs ~0.36 of the float32 pass over whole reads, the fine screen ~0.85.  Reads on which its two
+            // looks leave more than a tenth of the columns -- its bound is 5 - 10 % above the exact scores where events are short, and the
+            // background of such reads is that close to the flank: the chunks that reach the score found then cover most of the read
+            // (gpurun_out/r5r: 96 % of the alignments of the empirical-noise reads miss the first look's certificate) -- go to the fine
+            // screen for a while
             // (heavy alignments are cut into four pieces below and run next to the small windows on the second stream: a few per
             // cent of them cost their own work, not a tail)
             if (2 * ngr >= 64 && !no_prune && !mode_coarse && !scr_forced) {
@@ -1016,7 +1023,10 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             }
             // does the coarse screen still pay with what the second look had to run?
             const bool forced = scr_forced || mode_coarse;
-            if (coarse_all > 0 && coarse_cols + cols2 > 0.10 * coarse_all && nb >= 64 && !forced && c->coarse_pause == 0) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
+            // (also when more than a third of the alignments needed it: on such reads -- short events, a background as high as the flank --
+            // the chunks whose bound reaches the score found cover most of the read, and what does not fit the second look's task
+            // room runs its whole read in the second round)
+            if (coarse_all > 0 && (coarse_cols + cols2 > 0.10 * coarse_all || 3 * n2 > nb) && nb >= 64 && !forced && c->coarse_pause == 0) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
             STRQ_DBG("coarse screen, second look: %d alignments, %.2f %% of the columns (first look %.2f %%) -> pause %d", slot, 100.0 * cols2 / std::max(1.0, coarse_all), 100.0 * coarse_cols / std::max(1.0, coarse_all), c->coarse_pause);
         }
         if (any_redo) {
