@@ -358,7 +358,7 @@ class Leg(object):
         for key in ("ms", "wave_steps", "screened", "windowed", "whole_read", "window_columns", "candidate_chunks"):
             self.screen[key] += scr[key]
         self.screen["scale"] = scr["scale"]
-        self.screen_mode = scr.get("mode", self.screen_mode); self.screen_merge = scr.get("merge", 0) or self.screen_merge
+        self.screen_mode = scr.get("mode", self.screen_mode); self.screen_merge = scr.get("merge", 0)
         sr = ctx.last_second_round()
         self.second_round[0] += sr[0]; self.second_round[1] += sr[1]
         self.steps += 1
@@ -385,7 +385,8 @@ def run_leg(ctx, reads, n_batches, steps, warmup, k0=0):
 
 # kernel, VALU instructions per wave-step of its steady-state loop (ISA; the committed SQ_INSTS_VALU profile takes precedence), DP cells per lane and step
 # (a merged cell of the coarse screens covers 2 / 3 / 6 cells of the reference's matrix), cells of the reference's matrix per lane and step, busy lanes
-SCREEN_KERNELS = {("fine", 0): ("align_screen_kernel", 111.0, 28.0, 28.0, FLANK_ROWS / float(64 * 14)),
+SCREEN_KERNELS = {("fine", 0): ("align_screen_kernel", 98.0, 28.0, 28.0, FLANK_ROWS / float(64 * 14)),
+                  ("fine", 1): ("align_screen1_kernel", 161.0, 60.0, 60.0, 58.0 / 64.0),
                   ("coarse", 2): ("align_screen2_kernel", 101.0, 30.0, 60.0, 58.0 / 64.0),
                   ("coarse", 3): ("align_screen3_kernel", 81.0, 20.0, 60.0, 58.0 / 64.0),
                   ("coarse", 6): ("align_screen6_kernel", 61.0, 10.0, 60.0, 58.0 / 64.0)}
@@ -469,7 +470,7 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
         exact["ms_per_step"] = (fwd_ms - screen["ms"]) / steps
         exact["note"] = "float32 DP over the screen's windows only (plus the host planning between the two passes, which the forward stage time includes)"
         mode = leg.screen_mode or "fine"
-        sk_name, sk_isa, sk_cells, sk_ref_cells, sk_util = SCREEN_KERNELS.get((mode, leg.screen_merge if mode == "coarse" else 0), SCREEN_KERNELS[("fine", 0)])
+        sk_name, sk_isa, sk_cells, sk_ref_cells, sk_util = SCREEN_KERNELS.get((mode, leg.screen_merge), SCREEN_KERNELS[("fine", 0)])
         scr_ip = by_kernel.get(sk_name)
         scr_note = None
         if scr_ip is None:
@@ -480,7 +481,7 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
         scr_steps_per_launch = screen["wave_steps"] / scr_launches
         achieved = scr_ip * scr_steps_per_launch / scr_launch_s / 1e9 if scr_launch_s > 0 else None
         roof = {"bound": "valu", "unit": "G wave-instructions/s", "peak": valu_peak, "kernel": sk_name, "screen_mode": mode,
-                "flank_rows_per_dp_row": leg.screen_merge if mode == "coarse" else 1,
+                "flank_rows_per_dp_row": max(1, leg.screen_merge), "alignments_per_wave": 2 if leg.screen_merge else 1,
                 "avg_launch_ms": scr_launch_s * 1e3, "launches_per_step": scr_launches // steps,
                 "wave_steps_per_launch": scr_steps_per_launch, "valu_insts_per_wave_step": scr_ip,
                 "valu_insts_source": prof.get("screen_valu_source") if scr_note is None else scr_note,

@@ -306,9 +306,22 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     std::vector<int> g2_of(nb, -1);                 // alignment -> its index in the coarse screen's task views
     ScreenTask* d_st2 = nullptr; int32_t* d_bound2 = nullptr; ScreenParams sp2; std::memset(&sp2, 0, sizeof(sp2));
     double coarse_cols = 0, coarse_all = 0;
-    if (collapsed && !mode_fine && !strq::opt("STRQ_NO_SCREEN") && c->coarse_pause > 0 && !mode_coarse && !scr_forced) --c->coarse_pause;
-    else if (collapsed && !mode_fine && screen2_plan(c->ap, S, scr_max_n, coarse_merge, &sp)) {
-        // ---- coarse screen (align_screen2_kernel): reads whose two flank alignments are both in this sub-batch
+    // Two attempts at a screen that takes both flank alignments of a read per wave (screen_kernels.hip: screen2_body): the coarse one
+    // (merged rows, its own candidate rules and second look) unless it is paused or switched off, then -- if that did not run and the
+    // fine screen is not paused -- the same kernel without merging: the fine screen's bound and rules (merge_now = 1).  A sub-batch
+    // that does not hold both alignments of its reads (strq_align_batch with single alignments) falls through to the one-flank kernel.
+    for (int attempt = 0; attempt < 2 && !did_coarse; ++attempt) {
+    int merge_now = coarse_merge;
+    if (attempt == 0) {
+        if (!collapsed || mode_fine || strq::opt("STRQ_NO_SCREEN")) continue;
+        if (c->coarse_pause > 0 && !mode_coarse && !scr_forced) { --c->coarse_pause; continue; }
+    } else {
+        if (!collapsed || strq::opt("STRQ_NO_SCREEN") || strq::opt("STRQ_SCREEN_FINE_SINGLE") || (c->screen_pause > 0 && !scr_forced)) continue;
+        merge_now = 1;
+    }
+    const bool fine_rules = merge_now == 1;
+    if (screen2_plan(c->ap, S, scr_max_n, merge_now, &sp)) {
+        // ---- reads whose two flank alignments are both in this sub-batch
         int min_n = 65536, scr_groups = 6;
         if (const char* e = strq::opt("STRQ_SCREEN_MIN_N")) min_n = atoi(e);
         if (const char* e = strq::opt("STRQ_SCREEN2_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 8) scr_groups = v; }
@@ -321,10 +334,11 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
         const int ngr = (int)pairs.size();
         if (ngr > 0 && 2 * ngr >= (nb * 9) / 10) {
             constexpr int SSEG = STRQ_SCREEN_SEG;
-            sp.margin = (int32_t)std::lround((double)c->coarse_margin * (coarse_merge == 6 ? 1.75 : coarse_merge == 3 ? 1.3 : 1.0) * sp.sc);
+            sp.margin = (int32_t)std::lround((double)c->coarse_margin * (merge_now == 6 ? 1.75 : merge_now == 3 ? 1.3 : 1.0) * sp.sc);
             if (const char* e = strq::opt("STRQ_SCREEN2_MARGIN")) sp.margin = (int32_t)std::lround(atof(e) * sp.sc);
             sp.max_cand = 8;          // (8, 16, 32 candidates and margins of 300 ... 700 score units measure within 1.5 % of each other: gpurun_out/r5n)
             if (const char* e = strq::opt("STRQ_SCREEN2_MAX_CAND")) sp.max_cand = atoi(e);
+            if (fine_rules) { sp.margin = 0; sp.max_cand = 0; }          // the fine screen's rule: everything within m + 2 slack of the best chunk
             std::vector<Screen2Task> t2((size_t)ngr * SSEG);
             std::vector<ScreenTask> stasks((size_t)2 * ngr * SSEG);
             std::vector<int32_t> bound((size_t)2 * ngr);
@@ -376,20 +390,20 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             STRQ_HIP(c, hipMemcpyAsync(d_st, stasks.data(), stasks.size() * sizeof(ScreenTask), hipMemcpyHostToDevice, st));
             STRQ_HIP(c, hipMemcpyAsync(d_bound, bound.data(), bound.size() * 4, hipMemcpyHostToDevice, st));
             STRQ_HIP(c, hipEventRecord(c->ev[5], st));
-            if (launch_screen2(st, d_t2, ngr, c->queue.as<int>() + STRQ_QUEUE_FIRST - 1, sp, lds_bytes, scr_groups, c->n_cu, coarse_merge)) { c->err = "coarse screen launch failed"; return STRQ_ERR_DEVICE; }
+            if (launch_screen2(st, d_t2, ngr, c->queue.as<int>() + STRQ_QUEUE_FIRST - 1, sp, lds_bytes, scr_groups, c->n_cu, merge_now)) { c->err = "coarse screen launch failed"; return STRQ_ERR_DEVICE; }
             STRQ_HIP(c, hipEventRecord(c->ev[6], st));
             if (launch_screen_windows(st, d_st, 2 * ngr, sp, d_bound, d_win)) { c->err = "screen windows launch failed"; return STRQ_ERR_DEVICE; }
             std::vector<ScreenWindows> hw((size_t)2 * ngr);
             STRQ_HIP(c, hipMemcpyAsync(hw.data(), d_win, hw.size() * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
             STRQ_HIP(c, hipStreamSynchronize(st));
-            c->screen_ran = true; did_coarse = true; c->screen_mode_last = 2; c->coarse_merge_last = coarse_merge;
+            c->screen_ran = true; did_coarse = true; c->screen_mode_last = fine_rules ? 1 : 2; c->coarse_merge_last = merge_now;
             d_st2 = d_st; d_bound2 = d_bound; sp2 = sp;
             for (int g2 = 0; g2 < 2 * ngr; ++g2) g2_of[g2 & 1 ? pairs[(size_t)g2 / 2].second : pairs[(size_t)g2 / 2].first] = g2;
             if (const char* path = strq::opt("STRQ_SCREEN_DUMP")) {
                 std::vector<int32_t> ho(out_words);
                 STRQ_HIP(c, hipMemcpy(ho.data(), d_out, out_words * 4, hipMemcpyDeviceToHost));
                 if (FILE* fp = fopen(path, "wb")) {
-                    const int32_t hdr[8] = {2 * ngr, sp.sc, sp.hh, sp.v, 2, SSEG, sp.slack, coarse_merge};
+                    const int32_t hdr[8] = {2 * ngr, sp.sc, sp.hh, sp.v, 2, SSEG, sp.slack, merge_now};
                     fwrite(hdr, 4, 8, fp);
                     for (int g2 = 0; g2 < 2 * ngr; ++g2) {
                         const int al = g2 & 1 ? pairs[(size_t)g2 / 2].second : pairs[(size_t)g2 / 2].first;
@@ -435,16 +449,24 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             // screen for a while
             // (heavy alignments are cut into four pieces below and run next to the small windows on the second stream: a few per
             // cent of them cost their own work, not a tail)
-            if (2 * ngr >= 64 && !no_prune && !mode_coarse && !scr_forced) {
+            if (fine_rules) {
+                // the fine screen's own verdict (below, for the one-flank kernel): nearly every alignment windows, a few per cent of the columns
+                if (2 * ngr >= 64 && !no_prune && !scr_forced) {
+                    if (below_bound * 10 > 2 * ngr && !ov_fixed) c->score_fracs.clear();
+                    else if (windowed < 0.9 * (2 * ngr - (ov_fixed ? 0 : below_bound)) || cols > 0.06 * all || (long)heavy * 100 > 2L * 2 * ngr) { c->screen_pause = std::min(256, 8 << std::min(c->screen_fail, 5)); ++c->screen_fail; }
+                    else c->screen_fail = 0;
+                }
+            } else if (2 * ngr >= 64 && !no_prune && !mode_coarse && !scr_forced) {
                 // (alignments whose best bound lies below the score the pieces' cold start was sized for get no windows: the overlap
                 // was planned on the previous sub-batch's scores and this one scores lower -- no reason to pause, the plan follows)
                 if (below_bound * 10 > 2 * ngr && !ov_fixed) c->score_fracs.clear();
                 else if (windowed < 0.9 * (2 * ngr - (ov_fixed ? 0 : below_bound)) || cols > 0.10 * all || (long)heavy * 100 > 2L * 2 * ngr) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
                 else c->coarse_fail = 0;
             }
-            STRQ_DBG("coarse screen: %d reads, scale %d, margin %.0f, %d groups per CU, LDS %zu bytes: %d of %d alignments with windows (%d below the cold-start bound), %.2f %% of the columns, %d heavy -> pause %d",
-                     ngr, sp.sc, (double)sp.margin / sp.sc, scr_groups, lds_bytes, windowed, 2 * ngr, below_bound, 100.0 * cols / std::max(1.0, all), heavy, c->coarse_pause);
+            STRQ_DBG("%s screen (both flanks per wave): %d reads, scale %d, margin %.0f, %d groups per CU, LDS %zu bytes: %d of %d alignments with windows (%d below the cold-start bound), %.2f %% of the columns, %d heavy -> pause %d",
+                     fine_rules ? "fine" : "coarse", ngr, sp.sc, (double)sp.margin / sp.sc, scr_groups, lds_bytes, windowed, 2 * ngr, below_bound, 100.0 * cols / std::max(1.0, all), heavy, fine_rules ? c->screen_pause : c->coarse_pause);
         }
+    }
     }
     if (did_coarse) {
     } else if (collapsed && c->screen_pause > 0 && !scr_forced) {
@@ -505,7 +527,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             std::vector<ScreenWindows> hw((size_t)ng);
             STRQ_HIP(c, hipMemcpyAsync(hw.data(), d_win, hw.size() * sizeof(ScreenWindows), hipMemcpyDeviceToHost, st));
             STRQ_HIP(c, hipStreamSynchronize(st));
-            c->screen_ran = true; c->screen_mode_last = 1;
+            c->screen_ran = true; c->screen_mode_last = 1; c->coarse_merge_last = 0;
             if (const char* path = strq::opt("STRQ_SCREEN_DUMP")) {
                 // tests: the chunk maxima as the kernel wrote them (tests/test_gpu_screen.py checks them against the exact last row)
                 std::vector<int32_t> ho(out_words);
@@ -1022,7 +1044,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 if (launch_align_scatter(st, d_res2, d_pick2, reinterpret_cast<const int32_t*>(rb + p_first), reinterpret_cast<const int32_t*>(rb + p_pos), slot, d_res, d_pick)) { c->err = "scatter launch failed"; return STRQ_ERR_DEVICE; }
             }
             // does the coarse screen still pay with what the second look had to run?
-            const bool forced = scr_forced || mode_coarse;
+            const bool forced = scr_forced || mode_coarse || c->screen_mode_last == 1;
             // (also when more than a third of the alignments needed it: on such reads -- short events, a background as high as the flank --
             // the chunks whose bound reaches the score found cover most of the read, and what does not fit the second look's task
             // room runs its whole read in the second round)
@@ -1301,7 +1323,7 @@ int strq_last_screen_mode(const strq_ctx* c, int32_t out[8])
     if (!c || !out) return STRQ_ERR_ARG;
     for (int i = 0; i < 8; ++i) out[i] = 0;
     out[0] = c->screen_mode_last; out[1] = c->coarse_pause; out[2] = c->screen_pause; out[3] = (int32_t)c->coarse_margin;
-    out[4] = c->screen_mode_last == 2 ? c->coarse_merge_last : 0;
+    out[4] = c->screen_mode_last ? c->coarse_merge_last : 0;
     return STRQ_OK;
 }
 

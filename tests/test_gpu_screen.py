@@ -437,3 +437,51 @@ def test_options_per_context_override_the_environment(orc, monkeypatch):
     c.align_batch(lv, [0, len(lv)], lval[None, :], [0], flank, [0, len(flank)])
     assert c.last_screen()["screened"] == 0
     c.close()
+
+
+def test_fine_screen_with_both_flanks_per_wave_is_tight(ctx, orc, monkeypatch, tmp_path):
+    """The fine screen on a sub-batch that holds both alignments of its reads (every detect call): the two-flanks-per-wave kernel without
+    row merging (align_screen1_kernel) -- the same bound as align_screen_kernel: never below the exact last row, less than m / 1024
+    above it -- and the fine screen's rules (no margin, no candidate cap).  Results: the oracle's bits."""
+    rng = np.random.default_rng(4711)
+    params = orc.align_params(None)
+    ctx.set_align_params(*[float(v) for v in params])
+    monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
+    monkeypatch.setenv("STRQ_SCREEN_MODE", "fine")
+    dump = str(tmp_path / "screen1.bin")
+    monkeypatch.setenv("STRQ_SCREEN_DUMP", dump)
+    n = 60000
+    reads, lval, fa, fb = _pair_reads(rng, n, 145, 130, [[20000], [41000, 5000], []], [[30000], [12000], [50000]])
+    got, foff = _align_pairs(ctx, reads, lval, fa, fb)
+    s = ctx.last_screen()
+    assert s["mode"] == "fine" and s["merge"] == 1 and s["scale"] == 1024 and s["screened"] == 6, s
+    d = _read_dump(dump)
+    assert d["sc"] == 1024 and len(d["groups"]) == 6
+    checked = 0
+    for g in d["groups"]:
+        lv = reads[g["a"] // 2]; flank = (fa, fb)[g["a"] % 2]
+        m = len(flank); lM = g["lane_last"]; shift = -m * d["v"]
+        exact = _exact_last_row(lval[lv], flank, params)
+        for pc in g["pieces"]:
+            if pc["n"] <= 0:
+                continue
+            for c, x in enumerate(pc["vals"]):
+                lo, hi = max(128 * c - 2 * lM + 1, 1), min(128 * c - 2 * lM + 128, pc["n"])
+                if hi < lo:
+                    continue
+                ub = (int(x) + shift) / d["sc"]
+                ex = exact[pc["col_off"] + lo:pc["col_off"] + hi + 1].max()
+                if ex * d["sc"] >= g["bound"] and (pc["col_off"] == 0 or lo > 8192):
+                    assert ub >= ex - 1e-3, (g["a"], pc["col_off"], c, ub, ex)
+                    checked += 1
+                    if pc["col_off"] == 0:
+                        assert ub <= ex + m / d["sc"] + 0.05, (g["a"], c, ub, ex)
+        assert g["win"]["lower"] <= exact.max() + 1e-3 <= g["win"]["upper"] + 1e-3
+    assert checked > 1000
+    _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
+    # the one-flank kernel on the same sub-batch (STRQ_SCREEN_FINE_SINGLE): the same bytes
+    monkeypatch.setenv("STRQ_SCREEN_FINE_SINGLE", "1")
+    ref, _ = _align_pairs(ctx, reads, lval, fa, fb)
+    assert ctx.last_screen()["merge"] == 0 and ctx.last_screen()["mode"] == "fine"
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
