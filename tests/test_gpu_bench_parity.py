@@ -215,3 +215,15 @@ def test_bench_launches_its_own_ranks_from_a_clean_environment(tmp_path):
                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode != 0 and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     assert "HIP device" in p.stderr.decode()
+
+
+def test_bench_gather_falls_back_to_gloo_when_rccl_refuses():
+    """Two ranks on ONE device with `--backend nccl`: RCCL refuses ("Duplicate GPU detected") -- the job agrees on that over its gloo
+    control plane, gathers over gloo, and says so in the line (`collective.backend`, `collective.nccl_error`) instead of dying."""
+    lines, recs = _run_bench(["--gpus", "2", "--backend", "nccl", "--share-device", "--reads", "64", "--steps", "2", "--warmup", "1",
+                              "--no-cpu-baseline", "--check", "1", "--synth-workers", "2"], world=2, port="29547")
+    assert len(lines[0]) == 1 and len(lines[1]) == 0
+    r = recs[0]; coll = r["collective"]
+    assert r["n_gpus"] == 2 and r["world_size_seen_by_the_collective"] == 2 and r["check_ok"]
+    assert coll["backend"] == "gloo" and coll["backend_requested"] == "nccl" and coll["nccl_error"]
+    assert coll["ranks"]["rows_equal_every_ranks_digest"] is True and coll["rows_on_rank_0"] == 2 * 2 * 64
