@@ -322,7 +322,9 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     const bool fine_rules = merge_now == 1;
     if (screen2_plan(c->ap, S, scr_max_n, merge_now, &sp)) {
         // ---- reads whose two flank alignments are both in this sub-batch
-        int min_n = 65536, scr_groups = 6;
+        // reads from which the pass pays (gpurun_out/r5z: the coarse screen wins from ~30 k samples on -- 5000-nt reads 79.8 k against 70.7 k
+        // reads/s, 3000-nt reads 110.6 k against 114.7 k; the fine bound costs twice as much and keeps round 4's 64 k)
+        int min_n = fine_rules ? 65536 : 28672, scr_groups = 6;
         if (const char* e = strq::opt("STRQ_SCREEN_MIN_N")) min_n = atoi(e);
         if (const char* e = strq::opt("STRQ_SCREEN2_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 8) scr_groups = v; }
         std::map<int, std::vector<int>> by_read;
@@ -442,8 +444,10 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             coarse_cols = cols; coarse_all = all;
             c->screen_stats[3] += nb - 2 * ngr;          // alignments of the sub-batch the coarse screen does not take: their whole reads run
             c->screen_stats[5] += steps; c->screen_stats[6] = sp.sc;
-            // does it pay?  The coarse pass costs ~0.36 of the float32 pass over whole reads, the fine screen ~0.85.  Reads on which its two
-            // looks leave more than a tenth of the columns -- its bound is 5 - 10 % above the exact scores where events are short, and the
+            // does it pay?  The coarse pass costs ~0.36 of the float32 pass over whole reads, the fine bound ~0.72 (0.85 on the one-flank kernel), the
+            // exact pass over a share x of the columns (windows + their cold-start overlaps: what `cols` counts) ~1.3 x: the coarse path beats the
+            // fine one while x < ~0.3 (short reads sit at 0.15 - 0.25 from the overlaps alone), the fine bound beats no screen while x < ~0.2.
+            // Reads on which the coarse screen's two looks leave more than that, or whose first look certifies less than two thirds -- its bound is 5 - 10 % above the exact scores where events are short, and the
             // background of such reads is that close to the flank: the chunks that reach the score found then cover most of the read
             // (gpurun_out/r5r: 96 % of the alignments of the empirical-noise reads miss the first look's certificate) -- go to the fine
             // screen for a while
@@ -453,14 +457,14 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 // the fine screen's own verdict (below, for the one-flank kernel): nearly every alignment windows, a few per cent of the columns
                 if (2 * ngr >= 64 && !no_prune && !scr_forced) {
                     if (below_bound * 10 > 2 * ngr && !ov_fixed) c->score_fracs.clear();
-                    else if (windowed < 0.9 * (2 * ngr - (ov_fixed ? 0 : below_bound)) || cols > 0.06 * all || (long)heavy * 100 > 2L * 2 * ngr) { c->screen_pause = std::min(256, 8 << std::min(c->screen_fail, 5)); ++c->screen_fail; }
+                    else if (windowed < 0.9 * (2 * ngr - (ov_fixed ? 0 : below_bound)) || cols > 0.15 * all || (long)heavy * 100 > 2L * 2 * ngr) { c->screen_pause = std::min(256, 8 << std::min(c->screen_fail, 5)); ++c->screen_fail; }
                     else c->screen_fail = 0;
                 }
             } else if (2 * ngr >= 64 && !no_prune && !mode_coarse && !scr_forced) {
                 // (alignments whose best bound lies below the score the pieces' cold start was sized for get no windows: the overlap
                 // was planned on the previous sub-batch's scores and this one scores lower -- no reason to pause, the plan follows)
                 if (below_bound * 10 > 2 * ngr && !ov_fixed) c->score_fracs.clear();
-                else if (windowed < 0.9 * (2 * ngr - (ov_fixed ? 0 : below_bound)) || cols > 0.10 * all || (long)heavy * 100 > 2L * 2 * ngr) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
+                else if (windowed < 0.9 * (2 * ngr - (ov_fixed ? 0 : below_bound)) || cols > 0.30 * all || (long)heavy * 100 > 2L * 2 * ngr) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
                 else c->coarse_fail = 0;
             }
             STRQ_DBG("%s screen (both flanks per wave): %d reads, scale %d, margin %.0f, %d groups per CU, LDS %zu bytes: %d of %d alignments with windows (%d below the cold-start bound), %.2f %% of the columns, %d heavy -> pause %d",
@@ -585,7 +589,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                     // (no windows because the best bound lies below the score the pieces' cold start was sized for: the overlap was
                     // planned on the previous sub-batch's scores and this one scores lower -- the plan follows, no pause)
                     if (below_bound * 10 > ng && !ov_fixed) c->score_fracs.clear();
-                    else if (windowed < 0.9 * (ng - (ov_fixed ? 0 : below_bound)) || cols > 0.06 * all || (long)heavy * 100 > 2L * ng) { c->screen_pause = std::min(256, 8 << std::min(c->screen_fail, 5)); ++c->screen_fail; }
+                    else if (windowed < 0.9 * (ng - (ov_fixed ? 0 : below_bound)) || cols > 0.10 * all || (long)heavy * 100 > 2L * ng) { c->screen_pause = std::min(256, 8 << std::min(c->screen_fail, 5)); ++c->screen_fail; }
                     else c->screen_fail = 0;
                 }
                 STRQ_DBG("screen verdict: %d of %d with windows (%d below the cold-start bound), %.2f %% of the columns inside them, %d heavy alignments -> pause %d", windowed, ng, below_bound, 100.0 * cols / std::max(1.0, all), heavy, c->screen_pause);
@@ -1048,7 +1052,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
             // (also when more than a third of the alignments needed it: on such reads -- short events, a background as high as the flank --
             // the chunks whose bound reaches the score found cover most of the read, and what does not fit the second look's task
             // room runs its whole read in the second round)
-            if (coarse_all > 0 && (coarse_cols + cols2 > 0.10 * coarse_all || 3 * n2 > nb) && nb >= 64 && !forced && c->coarse_pause == 0) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
+            if (coarse_all > 0 && (coarse_cols + cols2 > 0.30 * coarse_all || 3 * n2 > nb) && nb >= 64 && !forced && c->coarse_pause == 0) { c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail; }
             STRQ_DBG("coarse screen, second look: %d alignments, %.2f %% of the columns (first look %.2f %%) -> pause %d", slot, 100.0 * cols2 / std::max(1.0, coarse_all), 100.0 * coarse_cols / std::max(1.0, coarse_all), c->coarse_pause);
         }
         if (any_redo) {
