@@ -16,7 +16,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCREENS = ("align_screen2_kernel", "align_screen3_kernel", "align_screen6_kernel", "align_screen_kernel")
+SCREENS = ("align_screen1_kernel", "align_screen2_kernel", "align_screen3_kernel", "align_screen6_kernel", "align_screen_kernel")
 
 
 def short(name):
@@ -127,6 +127,25 @@ def main():
             consts["viterbi_valu_source"] = "profiles/%s_sq.md (rocprofv3 --pmc SQ_INSTS_VALU of %s over bench.py --reads %d: %.4g) / the Viterbi time steps of the same run (strq_last_counters: %.0f)" % (
                 tag, k.split("::")[-1], pmc_reads, sq[k]["SQ_INSTS_VALU"], ts)
             f.write("\n`%s`: %.4g VALU instructions over %.4g time steps = **%.2f VALU instructions per time step** of a window.\n" % (k.split("::")[-1], sq[k]["SQ_INSTS_VALU"], ts, ipt))
+    # the fine screen's pass (STRQ_SCREEN_MODE=fine: the fine bound on the two-flank body, align_screen1_kernel)
+    fine_dir = os.path.join(src, "pmc_sq_fine")
+    if os.path.isdir(fine_dir):
+        sqf, _ = per_kernel(one(os.path.join(fine_dir, "**", "*counter_collection.csv")))
+        fbj = bench_json(os.path.join(src, "bench_sq_fine.log"))
+        with open(os.path.join(out, tag + "_sq.md"), "a") as f:
+            for k, v in sqf.items():
+                if not any(k.endswith(x) for x in SCREENS):
+                    continue
+                name = k.split("::")[-1]
+                steps = fbj["screen"]["wave_steps_per_step"] * fbj["steps"]
+                ip = v["SQ_INSTS_VALU"] / steps
+                wc = v.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+                consts.setdefault("valu_insts_per_wave_step_by_kernel", {})[name] = ip
+                f.write("\n`%s` (the fine screen, `STRQ_SCREEN_MODE=fine`, a pass of its own over the same 1024 reads): %.4g VALU instructions over %.4g wave-steps = **%.2f VALU "
+                        "instructions per wave-step** (one wave-step = 2 DP columns of both flank alignments of a read, 30 rows per lane); issuing %.0f %%, VALU %.0f %%, issue stall %.0f %%, "
+                        "waitcnt %.0f %%, LDS bank conflicts %.0f %% of the wave cycles; %.2f ms per launch.\n"
+                        % (name, v["SQ_INSTS_VALU"], steps, ip, 100 * v.get("SQ_ACTIVE_INST_ANY", 0) / wc, 100 * v.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+                           100 * v.get("SQ_WAIT_INST_ANY", 0) / wc, 100 * v.get("SQ_WAIT_ANY", 0) / wc, 100 * v.get("SQ_LDS_BANK_CONFLICT", 0) / wc, fbj["screen"]["ms_per_step"]))
     json.dump(consts, open(consts_path, "w"), indent=1)
     print(json.dumps({k: consts[k] for k in consts if "screen" in k or "viterbi" in k or k == "valu_insts_per_wave_step_by_kernel"}, indent=1))
 
