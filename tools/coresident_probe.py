@@ -8,7 +8,10 @@ other way round.  Register budget per SIMD: one Viterbi wave of <= 192 VGPRs + t
 Prints reads/s of (a) one context over the whole batch, default geometry, (b) one context with the co-residency geometry,
 (c) the two threads together.
 
-    python tools/coresident_probe.py [reads_per_half=2048] [steps=6]
+    python tools/coresident_probe.py [reads_per_half=2048] [steps=6] [clean|empirical] [default|coresident geometry for (c)]
+
+With "empirical" reads (noise resampled from the bundled real read) the Viterbi launch lasts as long as its longest, mislocated window
+(profiles/r05_viterbi_tail.txt) while most of the GPU idles: the second context's forward stage can run under that tail.
 """
 import os
 import sys
@@ -48,13 +51,16 @@ def loop(rc, steps, out, delay=0.0):
 def main():
     half = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    workload = sys.argv[3] if len(sys.argv) > 3 else "clean"
+    geo_c = sys.argv[4] if len(sys.argv) > 4 else "coresident"
     pm, cfg = bench.load_inputs()
-    sigs, strands, _ = bench.make_batches_parallel(2 * half, 50000, 0, 16)
+    sigs, strands, _ = bench.make_batches_parallel(2 * half, 50000, 0, 16, workload)
     geo = {"STRQ_SCREEN2_GROUPS": "3", "STRQ_VIT_G2_WAVES": "4"}
+    print("workload %s, %d reads, mean %d samples" % (workload, 2 * half, int(np.mean([len(s) for s in sigs]))))
     # (a) one context, default geometry, the whole batch
     rc = make_ctx(pm, cfg, {})
     upload(rc, sigs, strands)
-    for _ in range(2):
+    for _ in range(4):
         rc.ctx.batch_run()
     t0 = time.time()
     for _ in range(steps):
@@ -75,16 +81,17 @@ def main():
     step_s = dt / steps
     rc.ctx.close()
     # (c) two contexts, half a batch each, half a step apart
-    a = make_ctx(pm, cfg, geo); b = make_ctx(pm, cfg, geo)
+    gc = geo if geo_c == "coresident" else {}
+    a = make_ctx(pm, cfg, gc); b = make_ctx(pm, cfg, gc)
     upload(a, sigs[:half], strands[:half]); upload(b, sigs[half:], strands[half:])
     for rc2 in (a, b):
-        for _ in range(2):
+        for _ in range(4):
             rc2.ctx.batch_run()
     oa, ob = [], []
     ta = threading.Thread(target=loop, args=(a, 2 * steps, oa)); tb = threading.Thread(target=loop, args=(b, 2 * steps, ob, step_s / 4))
     ta.start(); tb.start(); ta.join(); tb.join()
     span = max(oa[0][1], ob[0][1]) - min(oa[0][0], ob[0][0])
-    print("(c) two contexts of %d reads, co-resident kernels: %.0f reads/s (%.1f ms per %d reads)" % (half, 2 * half * 2 * steps / span, span / (2 * steps) * 1e3, 2 * half))
+    print("(c) two contexts of %d reads (%s geometry), co-resident kernels: %.0f reads/s (%.1f ms per %d reads)" % (half, geo_c, 2 * half * 2 * steps / span, span / (2 * steps) * 1e3, 2 * half))
     ra = a.ctx.batch_fetch(); rb = b.ctx.batch_fetch()
     print("rows:", len(ra), len(rb))
 

@@ -110,7 +110,7 @@ def main():
         sk = [k for k in sq if any(k.endswith(s) for s in SCREENS)]
         if sk and sb:
             k = sk[0]; name = k.split("::")[-1]
-            steps = sb["roofline"]["wave_steps_per_launch"] * sb["roofline"]["launches_per_step"]
+            steps = sb["screen"]["wave_steps_per_step"] * sb["steps"]
             ip = sq[k]["SQ_INSTS_VALU"] / steps
             consts.setdefault("valu_insts_per_wave_step_by_kernel", {})[name] = ip
             consts["screen_valu_source"] = "profiles/%s_sq.md (rocprofv3 --pmc SQ_INSTS_VALU over bench.py --reads %d; wave-steps from strq_last_screen of the same run)" % (tag, pmc_reads)
