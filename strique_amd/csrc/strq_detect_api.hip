@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <time.h>
@@ -382,8 +383,23 @@ static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
     return STRQ_OK;
 }
 
+// STRQ_FORWARD_TOKEN=1: contexts of one process that work on different batches at the same time (one host thread each: `count --contexts 2`)
+// take turns in the forward stage.  The stage fills the GPU with one long-lived wave per read, so two of them side by side only delay each
+// other; the Viterbi launch that follows lasts as long as its longest window while most of the GPU idles (reads whose flanks were
+// mislocated decode windows of 10^5 steps and more).  A context that has queued its Viterbi launches hands the token on, and the other
+// context's conditioning and flank alignments run under that tail.
+static std::mutex g_forward_token;
+struct ForwardToken {
+    bool held = false;
+    void take() { g_forward_token.lock(); held = true; }
+    void pass() { if (held) { g_forward_token.unlock(); held = false; } }
+    ~ForwardToken() { pass(); }
+};
+
 static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, int64_t next_r1)
 {
+    ForwardToken token;
+    { const char* e = strq::opt("STRQ_FORWARD_TOKEN"); if (e && atoi(e) > 0) token.take(); }
     Batch& B = d->batch;
     hipStream_t st = c->stream;
     const int nr = (int)(r1 - r0);
@@ -556,6 +572,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         ++qi;
       } }
     STRQ_HIP(c, hipEventRecord(d->ev[3], st));
+    token.pass();
     // ---- results.  Everything of this sub-batch is queued: fetch the next sub-batch's samples while it runs
     // (before the read-backs below -- a device-to-host copy into pageable memory blocks the host until the stream
     // has drained, which would leave the upload exposed).

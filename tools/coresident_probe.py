@@ -8,7 +8,7 @@ other way round.  Register budget per SIMD: one Viterbi wave of <= 192 VGPRs + t
 Prints reads/s of (a) one context over the whole batch, default geometry, (b) one context with the co-residency geometry,
 (c) the two threads together.
 
-    python tools/coresident_probe.py [reads_per_half=2048] [steps=6] [clean|empirical] [default|coresident geometry for (c)]
+    python tools/coresident_probe.py [reads_per_half=2048] [steps=6] [clean|empirical] [default|coresident|token geometry for (c); token = default geometry + STRQ_FORWARD_TOKEN=1: the contexts take turns in the forward stage]
 
 With "empirical" reads (noise resampled from the bundled real read) the Viterbi launch lasts as long as its longest, mislocated window
 (profiles/r05_viterbi_tail.txt) while most of the GPU idles: the second context's forward stage can run under that tail.
@@ -81,7 +81,7 @@ def main():
     step_s = dt / steps
     rc.ctx.close()
     # (c) two contexts, half a batch each, half a step apart
-    gc = geo if geo_c == "coresident" else {}
+    gc = geo if geo_c == "coresident" else ({"STRQ_FORWARD_TOKEN": "1"} if geo_c == "token" else {})
     a = make_ctx(pm, cfg, gc); b = make_ctx(pm, cfg, gc)
     upload(a, sigs[:half], strands[:half]); upload(b, sigs[half:], strands[half:])
     for rc2 in (a, b):
