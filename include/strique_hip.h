@@ -167,9 +167,10 @@ int strq_viterbi_batch(strq_ctx* ctx, int32_t model_id, int64_t n_seq, const dou
  *                       comes from exact histograms on the GPU and host_stats is ignored.  float64
  *                       reads have no histogram: their six scalars per read -- median and MAD of the
  *                       median-filtered signal, (c1, h1) of its minmax map and of the raw signal's
- *                       (STRique.py:142-143,152-160,590-592) -- are taken on the host with numpy's
- *                       arithmetic, by the library itself when host_stats is NULL (strq_host_stats,
- *                       one thread per core) or by the caller (six doubles per read).
+ *                       (STRique.py:142-143,152-160,590-592) -- come from a radix selection over the
+ *                       samples and numpy's own summation tree on the GPU when host_stats is NULL
+ *                       (cond_kernels.hip: f64_stats_kernel; bit-equal to np.median / np.mean /
+ *                       np.percentile), or from the caller (six doubles per read, e.g. strq_host_stats).
  * A read whose normalisation is undefined (constant signal, empty percentile tails: numpy hands the
  * reference NaN medians there) gets status 1 and the n = 0 row the reference writes for it -- its
  * offset / ticks come from aligning an all-NaN signal, every cell scoring dist_min, which is what
@@ -218,7 +219,8 @@ int strq_batch_run(strq_ctx* ctx);
  * times a different one every step); strq_batch_fetch still returns the rows of the whole upload. */
 int strq_batch_run_range(strq_ctx* ctx, int64_t first, int64_t last);
 int strq_batch_fetch(strq_ctx* ctx, strq_result* out);
-/* The host-side statistics of float64 reads (no context, no device): out[6 * i ..] = median, MAD, c1, h1 of
+/* A host-side helper, not on the path of strq_detect_batch (which takes these on the GPU): the statistics of float64 reads
+ * with numpy's arithmetic (no context, no device): out[6 * i ..] = median, MAD, c1, h1 of
  * medfilt(read i, 3) and c1, h1 of read i itself (0, 1 unless want_raw) -- what numpy's median / mean / percentile
  * give repeatCounter.detect (STRique.py:590-597). */
 int strq_host_stats(const double* signals, const int64_t* offsets, int64_t n_reads, int32_t want_raw, double* out);

@@ -96,8 +96,8 @@ class repeatCounter(object):
             return []
         tcs = [self._classifier_for(t, s) for t, _, s in items]
         sigs = [np.asarray(r) for _, r, _ in items]
-        # DAC samples that fit int16 take the all-GPU path (exact histograms); everything else is float64
-        # (the library takes its order statistics on the host, strq_host_stats).  A mixed batch runs as two device batches.
+        # DAC samples that fit int16 take their order statistics from exact histograms; everything else is float64
+        # (radix selection on the GPU, cond_kernels.hip: f64_stats_kernel).  A mixed batch runs as two device batches.
         def fits_int16(s):
             if s.dtype.kind not in 'iu':
                 return False

@@ -28,6 +28,9 @@ struct ReadCond {
 int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, const ReadCond* rc, int n_reads,
                             int max_n, uint32_t* hist_flt, uint32_t* hist_raw, uint32_t* range4);      // range4: 4 zeroed words per read (occupied bins of flt / raw)
 int launch_medfilt_f64(hipStream_t s, const double* raw, double* flt, const ReadCond* rc, int n_reads, int max_n);
+// float64 reads: median, MAD, f_c1, f_h1 and the status of every read from its filtered samples, r_c1, r_h1 from the raw ones when `raw` is
+// given; chunk_sums: one double per 8192 samples of a read, read i's at chunk_first[i]
+int launch_f64_stats(hipStream_t s, const double* flt, const double* raw, ReadCond* rc, int n_reads, double* chunk_sums, const int64_t* chunk_first);
 // which: 0 = filtered int16 histogram (fills med, mad, f_*), 1 = 8-bit histogram (fills m_* and level_val),
 //        2 = raw int16 histogram (fills r_*)
 int launch_hist_stats(hipStream_t s, const uint32_t* hist, int nbins, int bias, ReadCond* rc, int n_reads,

@@ -550,6 +550,202 @@ quant_morph_kernel(const T* __restrict__ flt_all, uint8_t* __restrict__ levels_a
     if (h8[threadIdx.x]) atomicAdd(&hist8[(size_t)blockIdx.y * 256 + threadIdx.x], h8[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// float64 reads (what the reference's unit tests feed, scripts/STRique_test.py): no histogram is exact for them, so the
+// order statistics come from a radix selection over the samples themselves and the MAD from numpy's own summation tree.
+//   np.median / np.percentile(x, [1, 99]) ('linear', numpy's _lerp) / the medians of the two tails (STRique.py:152-160):
+//     ten order statistics in two rounds (the tails' sizes are known after the first), each round eight passes of a
+//     most-significant-byte-first radix selection over order-preserving 64-bit keys, all ranks of a round in the same pass;
+//   np.mean(|x - median|) (STRique.py:142-143): numpy reduces a contiguous float64 array in chunks of 8192 elements (the
+//     ufunc buffer), each chunk by pairwise summation -- blocks of at most 128 elements with eight running sums, blocks
+//     combined by recursive halving (numpy/_core/src/umath/loops_utils.h.src) -- and adds the chunk sums in order.  A full
+//     chunk is 64 blocks of 128: one block per lane, combined by a butterfly (a + b is commutative, the tree is the same);
+//     the last, partial chunk follows the recursion's uneven cuts.
+// One workgroup per (read, signal): signal 0 = the median-filtered samples (median, MAD, c1, h1), 1 = the raw samples
+// (c1, h1; modification pass only).  -0.0 is taken as +0.0 (equal under every comparison numpy makes).
+#define F64S_THREADS 1024
+#define F64S_MAX_RANKS 6
+#define F64S_MAX_LEAVES 192
+
+static __device__ __forceinline__ uint64_t f64_key(double x)
+{
+    if (x == 0.0) x = 0.0;
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static __device__ __forceinline__ double f64_from_key(uint64_t k)
+{
+    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// numpy's pairwise sum of |x[i] - med| over one block (len <= 128)
+static __device__ double abs_dev_block(const double* __restrict__ x, double med, int len)
+{
+    if (len < 8) {
+        double r = 0.0;
+        for (int i = 0; i < len; ++i) r += fabs(x[i] - med);
+        return r;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = fabs(x[j] - med);
+    int i = 8;
+    for (; i < len - (len % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += fabs(x[i + j] - med);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < len; ++i) res += fabs(x[i] - med);
+    return res;
+}
+
+__global__ void __launch_bounds__(F64S_THREADS)
+f64_stats_kernel(const double* __restrict__ flt_all, const double* __restrict__ raw_all, ReadCond* __restrict__ rc_all,
+                 double* __restrict__ chunk_sums_all, const int64_t* __restrict__ chunk_first)
+{
+    __shared__ uint32_t hist[F64S_MAX_RANKS][256];
+    __shared__ uint64_t s_prefix[F64S_MAX_RANKS];
+    __shared__ long long s_rem[F64S_MAX_RANKS];
+    __shared__ int s_src[F64S_MAX_RANKS];
+    __shared__ unsigned long long s_cnt[2];
+    __shared__ int s_flag;
+    __shared__ int leaf_a[F64S_MAX_LEAVES], leaf_len[F64S_MAX_LEAVES], s_leaves;
+    __shared__ double leaf_sum[F64S_MAX_LEAVES];
+    const int t = threadIdx.x, which = blockIdx.y;
+    ReadCond& rc = rc_all[blockIdx.x];
+    const int n = rc.n;
+    const double* x = (which == 0 ? flt_all : raw_all) + rc.off;
+    const double nan = __builtin_nan("");
+    auto finish = [&](double med, double mad, double c1, double h1) {
+        if (t != 0) return;
+        if (which == 0) {
+            rc.med = med; rc.mad = mad; rc.f_c1 = c1; rc.f_h1 = h1;
+            const bool ok = isfinite(med) && mad > 0.0 && isfinite(c1) && h1 > 0.0 && isfinite(h1);
+            rc.status = ok ? COND_OK : COND_DEGENERATE;
+        } else { rc.r_c1 = c1; rc.r_h1 = h1; }
+    };
+    if (n <= 0) { finish(nan, nan, nan, nan); return; }
+    // NaN in, NaN out (np.median / np.percentile)
+    if (t == 0) s_flag = 0;
+    __syncthreads();
+    { int bad = 0;
+      for (int i = t; i < n; i += F64S_THREADS) { const double v = x[i]; bad |= !(v == v); }
+      if (bad) s_flag = 1; }
+    __syncthreads();
+    if (s_flag) { finish(nan, nan, nan, nan); return; }
+
+    // ranks[0..k) -> s_prefix[0..k): keys of the order statistics
+    auto select = [&](int k) {
+        if (t < k) { s_prefix[t] = 0; s_src[t] = 0; }
+        __syncthreads();
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            for (int b = t; b < k * 256; b += F64S_THREADS) hist[b >> 8][b & 255] = 0;
+            __syncthreads();
+            uint64_t pre[F64S_MAX_RANKS]; bool own[F64S_MAX_RANKS];
+            for (int j = 0; j < k; ++j) { pre[j] = pass == 0 ? 0 : (s_prefix[j] >> (shift + 8)); own[j] = s_src[j] == j; }
+            for (int i = t; i < n; i += F64S_THREADS) {
+                const uint64_t key = f64_key(x[i]);
+                const uint64_t hi = pass == 0 ? 0 : (key >> (shift + 8));
+                const int byte = (int)((key >> shift) & 255);
+                for (int j = 0; j < k; ++j) if (own[j] && hi == pre[j]) atomicAdd(&hist[j][byte], 1u);
+            }
+            __syncthreads();
+            if (t < k) {
+                const uint32_t* h = hist[s_src[t]];
+                long long rem = s_rem[t];
+                int b = 0;
+                for (; b < 255; ++b) { const long long c = h[b]; if (rem < c) break; rem -= c; }
+                s_rem[t] = rem; s_prefix[t] |= (uint64_t)b << shift;
+            }
+            __syncthreads();
+            if (t == 0) for (int j = 0; j < k; ++j) { int src = j; for (int q = 0; q < j; ++q) if ((s_prefix[q] >> shift) == (s_prefix[j] >> shift)) { src = s_src[q]; break; } s_src[j] = src; }
+            __syncthreads();
+        }
+    };
+    const double last = (double)(n - 1);
+    const double vi_lo = last * 0.01, vi_hi = last * 0.99;
+    long long p_lo = (long long)floor(vi_lo), p_hi = (long long)floor(vi_hi);
+    long long x_lo = p_lo + 1, x_hi = p_hi + 1;
+    double g_lo, g_hi;
+    if (vi_lo >= last) { g_lo = vi_lo + 1.0; p_lo = x_lo = (long long)n - 1; } else g_lo = vi_lo - (double)p_lo;
+    if (vi_hi >= last) { g_hi = vi_hi + 1.0; p_hi = x_hi = (long long)n - 1; } else g_hi = vi_hi - (double)p_hi;
+    if (t == 0) { s_rem[0] = p_lo; s_rem[1] = x_lo; s_rem[2] = p_hi; s_rem[3] = x_hi; s_rem[4] = (n - 1) / 2; s_rem[5] = n / 2; }
+    select(which == 0 ? 6 : 4);
+    const double q_lo = np_lerp(f64_from_key(s_prefix[0]), f64_from_key(s_prefix[1]), g_lo);
+    const double q_hi = np_lerp(f64_from_key(s_prefix[2]), f64_from_key(s_prefix[3]), g_hi);
+    const double med = which == 0 ? (f64_from_key(s_prefix[4]) + f64_from_key(s_prefix[5])) / 2 : nan;
+    __syncthreads();
+    // sizes of the two tails (strict comparisons, STRique.py:155-156)
+    if (t == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
+    { unsigned long long cl = 0, ch = 0;
+      for (int i = t; i < n; i += F64S_THREADS) { const double v = x[i]; cl += v < q_lo; ch += v > q_hi; }
+      for (int o = 32; o > 0; o >>= 1) { cl += __shfl_xor(cl, o, 64); ch += __shfl_xor(ch, o, 64); }
+      if ((t & 63) == 0) { if (cl) atomicAdd(&s_cnt[0], cl); if (ch) atomicAdd(&s_cnt[1], ch); } }
+    __syncthreads();
+    const long long c_lo = (long long)s_cnt[0], c_hi = (long long)s_cnt[1];
+    double c1 = nan, h1 = nan;
+    if (c_lo > 0 && c_hi > 0) {
+        if (t == 0) { s_rem[0] = (c_lo - 1) / 2; s_rem[1] = c_lo / 2; s_rem[2] = n - c_hi + (c_hi - 1) / 2; s_rem[3] = n - c_hi + c_hi / 2; }
+        select(4);
+        const double m_lo = (f64_from_key(s_prefix[0]) + f64_from_key(s_prefix[1])) / 2;
+        const double m_hi = (f64_from_key(s_prefix[2]) + f64_from_key(s_prefix[3])) / 2;
+        c1 = m_lo + (m_hi - m_lo) / 2;
+        h1 = (m_hi - m_lo) / 2;
+    }
+    if (which != 0) { finish(nan, nan, c1, h1); return; }
+    // ---- MAD = np.mean(|x - med|)
+    double* chunk_sums = chunk_sums_all + chunk_first[blockIdx.x];
+    const int n_chunks = (n + 8191) / 8192, full = n / 8192;
+    const int wave = t >> 6, lane = t & 63;
+    for (int ch = wave; ch < full; ch += F64S_THREADS / 64) {
+        double r = abs_dev_block(x + (size_t)ch * 8192 + lane * 128, med, 128);
+        for (int o = 1; o < 64; o <<= 1) r += __shfl_xor(r, o, 64);
+        if (lane == 0) chunk_sums[ch] = r;
+    }
+    if (n_chunks > full) {
+        // the partial chunk: the recursion's cuts (n2 = len / 2 rounded down to a multiple of 8), blocks left to right
+        const int base = full * 8192, len = n - base;
+        if (t == 0) {
+            int sa[16], sl[16], sp = 0, nl = 0;
+            sa[0] = 0; sl[0] = len; sp = 1;
+            while (sp > 0) {
+                const int a = sa[sp - 1], l = sl[sp - 1]; --sp;
+                if (l <= 128) { leaf_a[nl] = a; leaf_len[nl] = l; ++nl; continue; }
+                int n2 = l / 2; n2 -= n2 % 8;
+                sa[sp] = a + n2; sl[sp] = l - n2; ++sp;      // right half, taken after ...
+                sa[sp] = a; sl[sp] = n2; ++sp;               // ... the left one
+            }
+            s_leaves = nl;
+        }
+        __syncthreads();
+        if (t < s_leaves) leaf_sum[t] = abs_dev_block(x + base + leaf_a[t], med, leaf_len[t]);
+        __syncthreads();
+        if (t == 0) {
+            int sl[16], stage[16], sp = 0, li = 0; double left[16], ret = 0.0;
+            sl[0] = len; stage[0] = 0; sp = 1;
+            while (sp > 0) {
+                const int l = sl[sp - 1];
+                if (l <= 128) { ret = leaf_sum[li++]; --sp; continue; }
+                int n2 = l / 2; n2 -= n2 % 8;
+                if (stage[sp - 1] == 0) { stage[sp - 1] = 1; sl[sp] = n2; stage[sp] = 0; ++sp; }
+                else if (stage[sp - 1] == 1) { left[sp - 1] = ret; stage[sp - 1] = 2; sl[sp] = l - n2; stage[sp] = 0; ++sp; }
+                else { ret = left[sp - 1] + ret; --sp; }
+            }
+            chunk_sums[full] = ret;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) {
+        double res = 0.0;
+        for (int ch = 0; ch < n_chunks; ++ch) res += chunk_sums[ch];
+        finish(med, res / (double)n, c1, h1);
+    }
+}
+
 static inline dim3 tile_grid(int max_n, int n_reads) { return dim3((max_n + 7 + COND_TILE - 1) / COND_TILE, n_reads); }      // + 7: tiles may start up to seven samples in front of a read
 
 int launch_medfilt_hist_i16(hipStream_t s, const int16_t* raw, int16_t* flt, const ReadCond* rc, int n_reads, int max_n,
@@ -571,6 +767,12 @@ int launch_medfilt_f64(hipStream_t s, const double* raw, double* flt, const Read
 {
     if (n_reads <= 0 || max_n <= 0) return 0;
     hipLaunchKernelGGL((medfilt_kernel<double>), tile_grid(max_n, n_reads), dim3(256), 0, s, raw, flt, rc, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int launch_f64_stats(hipStream_t s, const double* flt, const double* raw, ReadCond* rc, int n_reads, double* chunk_sums, const int64_t* chunk_first)
+{
+    if (n_reads <= 0) return 0;
+    hipLaunchKernelGGL(f64_stats_kernel, dim3(n_reads, raw ? 2 : 1), dim3(F64S_THREADS), 0, s, flt, raw, rc, chunk_sums, chunk_first);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int launch_hist_stats(hipStream_t s, const uint32_t* hist, int nbins, int bias, ReadCond* rc, int n_reads, PoreStats ps,

@@ -1,4 +1,6 @@
-// Order statistics of float64 reads, on the host (no device code in this file).
+// Order statistics of float64 reads, on the host (no device code in this file).  A helper behind strq_host_stats for callers
+// that want the six scalars without a device (and the numpy-pinned twin the GPU path is tested against): strq_detect_batch
+// itself takes them on the GPU (cond_kernels.hip: f64_stats_kernel) since round 5.
 //
 // int16 reads -- what a fast5 file holds -- get every statistic of the conditioning from exact histograms on the
 // GPU (cond_kernels.hip).  float64 reads (what the reference's own unit tests feed, scripts/STRique_test.py) have no

@@ -138,7 +138,7 @@ struct DetectState {
     bool have_ps = false;
     std::vector<Target> targets;
     Batch batch;
-    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange, modpool;
+    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange, modpool, f64s;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
     int64_t part_reads = 0, part_samples = 0;      // strq_batch_upload_part: reads uploaded so far / samples announced
@@ -159,7 +159,7 @@ void detect_state_free(strq_ctx* c)
     if (!c->detect) return;
     DetectState* d = static_cast<DetectState*>(c->detect);
     for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx, &d->order,
-                      &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern, &d->hrange, &d->modpool}) b->release();
+                      &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern, &d->hrange, &d->modpool, &d->f64s}) b->release();
     if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     for (int i = 0; i < DetectState::N_STAGE; ++i) { if (d->stage[i]) (void)hipHostFree(d->stage[i]); if (d->stage_ev[i]) (void)hipEventDestroy(d->stage_ev[i]); }
@@ -414,9 +414,11 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         loff[i] = rc[i].off;
         max_n = std::max(max_n, rc[i].n);
         if (B.dtype == 1) {
+            rc[i].h2 = (d->ps.M_hi - d->ps.M_lo) / 2; rc[i].c2 = d->ps.M_lo + (d->ps.M_hi - d->ps.M_lo) / 2;
+        }
+        if (B.dtype == 1 && !B.host_stats.empty()) {
             const double* hs = &B.host_stats[(size_t)(r0 + i) * 6];
             rc[i].med = hs[0]; rc[i].mad = hs[1]; rc[i].f_c1 = hs[2]; rc[i].f_h1 = hs[3]; rc[i].r_c1 = hs[4]; rc[i].r_h1 = hs[5];
-            rc[i].h2 = (d->ps.M_hi - d->ps.M_lo) / 2; rc[i].c2 = d->ps.M_lo + (d->ps.M_hi - d->ps.M_lo) / 2;
             const bool okv = std::isfinite(hs[0]) && hs[1] > 0.0 && std::isfinite(hs[2]) && hs[3] > 0.0 && std::isfinite(hs[3]);
             rc[i].status = okv ? COND_OK : COND_DEGENERATE;
         }
@@ -511,6 +513,16 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
             bad |= launch_quant_morph_i16(st, reinterpret_cast<const int16_t*>(flt_base), levels, d_rc + i0, np_, max_n, hist8);
         } else {
             bad |= launch_medfilt_f64(st, reinterpret_cast<const double*>(raw), reinterpret_cast<double*>(flt_base), d_rc + i0, np_, max_n);
+            if (B.host_stats.empty()) {
+                // median, MAD and the two 'minmax' maps of every read: one double of scratch per 8192 samples (numpy's mean)
+                std::vector<int64_t> first((size_t)np_ + 1, 0);
+                for (int i = 0; i < np_; ++i) first[(size_t)i + 1] = first[(size_t)i] + (rc[i0 + i].n + 8191) / 8192;
+                const size_t first_bytes = (((size_t)np_ + 1) * 8 + 255) & ~(size_t)255;
+                STRQ_HIP(c, d->f64s.reserve(first_bytes + (size_t)first[(size_t)np_] * 8 + 256));
+                STRQ_HIP(c, hipMemcpyAsync(d->f64s.p, first.data(), ((size_t)np_ + 1) * 8, hipMemcpyHostToDevice, st));
+                bad |= launch_f64_stats(st, reinterpret_cast<const double*>(flt_base), any_mod ? reinterpret_cast<const double*>(raw) : nullptr, d_rc + i0, np_,
+                                        reinterpret_cast<double*>(d->f64s.as<char>() + first_bytes), d->f64s.as<int64_t>());
+            }
             bad |= launch_quant_morph_f64(st, reinterpret_cast<const double*>(flt_base), levels, d_rc + i0, np_, max_n, hist8);
         }
         bad |= launch_hist_stats(st, hist8, 256, 0, d_rc + i0, np_, d->ps, 1, level_val, nullptr, 0);
@@ -699,15 +711,9 @@ static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int3
         if (B.off[i + 1] < B.off[i] || B.off[i + 1] - B.off[i] > ((int64_t)1 << 30)) { c->err = "bad offsets"; return STRQ_ERR_ARG; }
     }
     B.host_stats.clear();
+    // float64 reads have no exact histogram: their order statistics come from a radix selection on the GPU (cond_kernels.hip:
+    // f64_stats_kernel) unless the caller hands over its own (numpy's) six scalars per read
     if (dtype == 1 && host_stats) B.host_stats.assign(host_stats, host_stats + n_reads * 6);
-    else if (dtype == 1) {
-        // float64 reads have no exact histogram: their order statistics are taken on the host (host_stats.hip)
-        bool want_raw = false;
-        for (int64_t i = 0; i < n_reads; ++i) want_raw |= d->targets[B.target[i]].mod_model_id >= 0;
-        B.host_stats.resize((size_t)n_reads * 6);
-        host_stats_batch(static_cast<const double*>(signals), offsets, n_reads, want_raw, B.host_stats.data(),
-                         reinterpret_cast<const double* const*>(reads));
-    }
     const size_t bytes = (size_t)(n_reads ? B.off[n_reads] : 0) * (dtype == 0 ? 2 : 8);
     STRQ_HIP(c, B.raw.reserve(bytes + 64));
     B.forget_host();

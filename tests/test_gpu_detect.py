@@ -175,6 +175,58 @@ def test_empty_batch_and_tiny_reads(gpu_counter, want, pm, targets):
     assert [g[0] for g in got] == [0, 0]
 
 
+def test_float64_order_statistics_equal_numpy(pm, pm_mod, cfg, targets):
+    """float64 reads have no exact histogram: their median, MAD and the two 'minmax' maps (STRique.py:142-143, 152-160, 590-592)
+    come from a radix selection and from numpy's own summation tree on the GPU (cond_kernels.hip: f64_stats_kernel).  Bit for bit
+    against scipy medfilt(3), np.median, np.mean(|x - median|), np.percentile([1, 99]) and the medians of the tails, at sizes
+    around every blocking boundary of numpy's pairwise summation (8, 128, 8192) and with ties, zeros of both signs, two-valued
+    and constant reads."""
+    import warnings
+    import scipy.signal
+    from strique_amd.counter import repeatCounter
+    rc = repeatCounter(pm, mod_model_file=pm_mod, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    for name, (repeat, prefix, suffix) in targets.items():
+        rc.add_target(name, repeat, prefix, suffix)
+    rng = np.random.default_rng(99)
+    sizes = [1, 2, 3, 7, 8, 9, 100, 127, 128, 129, 1000, 8191, 8192, 8193, 8200, 16384, 16385, 24000, 40000, 100003, 284184]
+    sigs = []
+    for k, n in enumerate(sizes):
+        if k % 3 == 0:
+            s = rng.normal(90, 12, n)
+        elif k % 3 == 1:
+            s = np.round(rng.normal(90, 12, n) * 4) / 4            # many ties
+        else:
+            s = rng.normal(90, 12, n); s[rng.integers(0, n, max(1, n // 50))] = 300.0
+        sigs.append(s)
+    sigs.append(np.full(500, 42.0))                                 # constant: empty tails
+    sigs.append(np.where(np.arange(9000) % 2, 1.0, 2.0))            # two values
+    z = rng.normal(0, 1, 20000); z[rng.integers(0, 20000, 3000)] = 0.0; z[rng.integers(0, 20000, 3000)] = -0.0
+    sigs.append(z)                                                  # negative values, zeros of both signs
+    sigs.append(-np.abs(rng.normal(500, 100, 12345)))               # all negative
+
+    def tails(x):
+        q_lo, q_hi = np.percentile(x, [1, 99])
+        m_lo = np.median(x[x < q_lo]); m_hi = np.median(x[x > q_hi])
+        return m_lo + (m_hi - m_lo) / 2, (m_hi - m_lo) / 2
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for s in sigs:
+            rc.detect_batch([("c9orf72", s, "+")])
+            sc = rc.ctx.debug_conditioning(0, 1)[2]
+            flt = scipy.signal.medfilt(s, 3)
+            med = np.median(flt)
+            want = [med, np.mean(np.absolute(np.subtract(flt, med)))] + list(tails(flt)) + list(tails(s))
+            got = [sc[0], sc[1], sc[2], sc[3], sc[6], sc[7]]
+            assert np.array_equal(np.asarray(want), np.asarray(got), equal_nan=True), (len(s), want, got)
+    # several reads in one batch: every read its own workgroups and its own scratch
+    batch = [("c9orf72", s, "+") for s in sigs[8:16]]
+    rc.detect_batch(batch)
+    for i, (_, s, _) in enumerate(batch):
+        flt = scipy.signal.medfilt(s, 3); med = np.median(flt)
+        sc = rc.ctx.debug_conditioning(i, 1)[2]
+        assert sc[0] == med and sc[1] == np.mean(np.absolute(np.subtract(flt, med))), (i, len(s))
+
+
 def test_sub_batches_give_the_same_results(gpu_counter, pm, targets, monkeypatch):
     """A batch larger than one sub-batch is processed in pieces (strq_batch_run); the pieces must not
     see each other: results equal those of the one-piece run, in input order."""
