@@ -649,7 +649,19 @@ f64_stats_kernel(const double* __restrict__ flt_all, const double* __restrict__ 
                 const uint64_t key = f64_key(x[i]);
                 const uint64_t hi = pass == 0 ? 0 : (key >> (shift + 8));
                 const int byte = (int)((key >> shift) & 255);
-                for (int j = 0; j < k; ++j) if (own[j] && hi == pre[j]) atomicAdd(&hist[j][byte], 1u);
+                // the high bytes of a read's samples are all but constant: the lanes that share the first matching lane's byte
+                // add their count with one atomic instead of queueing on one LDS address, the others add for themselves
+                for (int j = 0; j < k; ++j) {
+                    if (!own[j]) continue;
+                    const bool m = hi == pre[j];
+                    const unsigned long long act = __ballot(m);
+                    if (!act) continue;
+                    const int leader = __ffsll((long long)act) - 1;
+                    const int lb = __shfl(byte, leader, 64);
+                    const unsigned long long same = __ballot(m && byte == lb);
+                    if ((t & 63) == leader) atomicAdd(&hist[j][lb], (uint32_t)__popcll(same));
+                    else if (m && byte != lb) atomicAdd(&hist[j][byte], 1u);
+                }
             }
             __syncthreads();
             if (t < k) {
