@@ -227,6 +227,24 @@ def test_float64_order_statistics_equal_numpy(pm, pm_mod, cfg, targets):
         assert sc[0] == med and sc[1] == np.mean(np.absolute(np.subtract(flt, med))), (i, len(s))
 
 
+def test_float64_reads_with_the_callers_own_statistics(gpu_counter, pm, targets):
+    """strq_detect_batch(..., host_stats): a caller may hand over numpy's six scalars per float64 read (here: strq_host_stats, the
+    host-side helper pinned against numpy on CPU); the rows equal those of the library's own statistics from the GPU."""
+    from strique_amd import ffi
+    rng = np.random.default_rng(5)
+    sigs, tids = [], []
+    for k in range(6):
+        name = ["c9orf72", "fmr1"][k % 2]; strand = "+-"[(k // 2) % 2]
+        sigs.append(_read(pm, targets, name, strand, int(rng.integers(3000, 9000)), int(rng.integers(5, 70)), 700 + k, as_int16=False))
+        tids.append(gpu_counter._classifier_for(name, strand).target_id)
+    off = np.zeros(len(sigs) + 1, np.int64); off[1:] = np.cumsum([len(s) for s in sigs])
+    flat = np.concatenate(sigs)
+    own = gpu_counter.ctx.detect_batch(flat, off, tids)
+    given = gpu_counter.ctx.detect_batch(flat, off, tids, host_stats=ffi.host_stats(flat, off))
+    assert own.tobytes() == given.tobytes()
+    assert (own["count"] > 0).sum() >= 5
+
+
 def test_sub_batches_give_the_same_results(gpu_counter, pm, targets, monkeypatch):
     """A batch larger than one sub-batch is processed in pieces (strq_batch_run); the pieces must not
     see each other: results equal those of the one-piece run, in input order."""
