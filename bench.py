@@ -432,7 +432,7 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
             "gcups": gcups, "gcups_note": "cells of the reference's matrices (2 x 871 x (N + 1) per read) per second of the forward stage",
             "traffic": (prof.get("hbm_bytes_per_column", 0.0) * counters[1] / max(1, fwd_launches)) or None,
             "traffic_source": prof.get("traffic_source"),
-            "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBS,
+            "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "work_rate_over_hbm_peak": hbm_alg / HBM_PEAK_GBS,
                                 "bytes_per_launch": bytes_per_step / launches_per_step,
                                 "note": "SURVEY.md 8d algorithmic bytes (int16 signal once + the reference's 1 B/cell trace) over the measured "
                                         "launch time.  These bytes never move here (checkpoint + recompute instead of a per-cell trace), "
@@ -500,7 +500,7 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
                 "window_columns_over_columns_of_the_reads": screen["window_columns"] / max(1.0, 2.0 * n_samples * steps),
                 "hbm_algorithmic": exact.get("hbm_algorithmic"),
                 "exact_pass": {k: exact.get(k) for k in ("kernel", "ms_per_step", "note", "waves_per_alignment", "score_tables_per_cu", "wave_steps_per_launch",
-                                                          "columns_computed_over_columns_of_the_reads", "valu_insts_per_wave_step", "overlap_worst_case", "frac", "useful_frac")}}
+                                                          "columns_computed_over_columns_of_the_reads", "valu_insts_per_wave_step", "overlap_worst_case", "frac")}}
         if achieved:
             roof["useful_achieved"] = achieved * (2.0 * sk_cells / scr_ip) * roof["lane_utilisation"]
             roof["useful_frac"] = roof["useful_achieved"] / valu_peak
@@ -574,6 +574,7 @@ def main():
     ap.add_argument("--workload", default="clean", choices=["clean", "empirical"], help="reads of the headline measurement (clean = BASELINE configs[2])")
     ap.add_argument("--check", type=int, default=2, help="reads verified against the CPU oracle, all six fields (LUT variant: same bits)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the result gather for N > 1 (nccl = RCCL)")
+    ap.add_argument("--detail", default=None, help="where rank 0 writes the full record (default: gpurun_out/bench_detail.json); the line on stdout is the compact one")
     ap.add_argument("--share-device", action="store_true", help="testing only: all ranks use HIP device 0 (needs --backend gloo)")
     args = ap.parse_args()
 
@@ -871,7 +872,8 @@ def main():
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
             out["vs_cpu_baseline_note"] = "GPU / the CPU port on the %s CPUs the job may use; against the extrapolated whole machine: %.0f x" % (
                 out["cpu_baseline"]["cores"], value / out["cpu_baseline"]["extrapolated_physical_cores"]["reads_per_s"])
-        print(json.dumps(out))
+        detail_path = write_detail(out, args.detail)
+        print(json.dumps(compact_line(out, detail_path), separators=(",", ":")))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()
@@ -879,6 +881,95 @@ def main():
     if rank == 0 and not check_ok:
         sys.stderr.write("bench.py: GPU rows differ from the CPU oracle -- see \"check\" in the JSON line\n")
         raise SystemExit(1)
+
+
+def _r(v, sig=6):
+    """Floats of the compact line: six significant digits."""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v))
+    return v
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+COMPACT_LIMIT = 4096
+
+
+def write_detail(out, path):
+    """The full record (every leg, every roofline block, the CPU sweep, notes) goes to a FILE: the driver keeps an 8 KB tail of
+    stdout, and round 5's 25 KB line could not be parsed from it.  Returns the path written (None when nothing could be)."""
+    cands = [path] if path else [os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                                 os.path.join(os.environ.get("TMPDIR", "/tmp"), "strique_bench_detail.json")]
+    for p in cands:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(p)), exist_ok=True)
+            with open(p, "w") as f:
+                json.dump(out, f)
+            return p
+        except OSError:
+            continue
+    return None
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line rank 0 prints: the benchmark contract's keys, `roofline` of the dominant kernel, `roofline_viterbi`,
+    `cpu_baseline`, the A/B values, the collective's state -- under COMPACT_LIMIT bytes whatever the run was (a CPU test holds
+    it to that with round 5's 25 KB record).  Only rates that are fractions of a peak (<= 1 by construction) are called `frac`."""
+    roof = out.get("roofline") or {}
+    line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "boundary", "reads_per_gpu_per_step", "total_reads", "read_nt", "distinct_batches_per_gpu", "sharding"))
+    line["roofline"] = _pick(roof, ("bound", "kernel", "unit", "achieved", "peak", "frac", "traffic", "avg_launch_ms", "launches_per_step",
+                                    "wave_steps_per_launch", "valu_insts_per_wave_step", "valu_insts_source", "lane_utilisation", "gcups"))
+    line["roofline"].setdefault("traffic", None)
+    ex = roof.get("exact_pass")
+    if isinstance(ex, dict):
+        line["roofline"]["exact_pass"] = _pick(ex, ("kernel", "ms_per_step", "frac", "columns_computed_over_columns_of_the_reads"))
+    if out.get("roofline_viterbi"):
+        line["roofline_viterbi"] = _pick(out["roofline_viterbi"], ("kernel", "ms_per_step", "achieved", "peak", "frac", "frac_of_float64_issue", "valu_insts_per_time_step"))
+    if out.get("stage_ms_per_step"):
+        line["stage_ms_per_step"] = {k: _r(v, 4) for k, v in out["stage_ms_per_step"].items()}
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "cpu_model", "per_core_reads_per_s", "workers_of_value", "physical_cores"))
+        c["sample"] = str(cb.get("sample", ""))[:220]
+        if cb.get("lut_variant"):
+            c["lut_variant_value"] = _r(cb["lut_variant"].get("value"))
+        if cb.get("extrapolated_physical_cores"):
+            c["extrapolated"] = {"cores": cb["extrapolated_physical_cores"].get("cores"), "reads_per_s": _r(cb["extrapolated_physical_cores"].get("reads_per_s")), "measured": False}
+        line["cpu_baseline"] = c
+        line["vs_cpu_baseline"] = _r(out.get("vs_cpu_baseline"))
+    for k in ("value_no_screen", "value_fine_screen", "value_degraded", "value_degraded_serial", "host_inclusive_reads_per_s", "resident_reads_per_s"):
+        if out.get(k) is not None:
+            line[k] = _r(out[k])
+    hb = out.get("host_buffers")
+    if hb:
+        line["host_buffers"] = _pick(hb, ("reads", "sub_batches", "seconds", "same_rows_as_resident_run"))
+    coll = out.get("collective")
+    if coll:
+        line["collective"] = _pick(coll, ("backend", "backend_requested", "rows_on_rank_0"))
+        line["collective"]["nccl_error"] = (coll.get("nccl_error") or None) and str(coll["nccl_error"])[:160]
+        ranks = coll.get("ranks") or {}
+        if ranks:
+            line["collective"]["rows_equal_every_ranks_digest"] = ranks.get("rows_equal_every_ranks_digest")
+            if ranks.get("ms_per_step_per_rank"):
+                line["collective"]["ms_per_step_per_rank"] = [_r(v, 5) for v in ranks["ms_per_step_per_rank"]]
+    line["world_size_seen_by_the_collective"] = out.get("world_size_seen_by_the_collective")
+    if out.get("host"):
+        line["host"] = _pick(out["host"], ("synth_s", "upload_s", "cpu_quota_cores"))
+    line["check_ok"] = out.get("check_ok"); line["checked_reads"] = len(out.get("check") or [])
+    line["detail"] = detail_path
+    s = json.dumps(line, separators=(",", ":"))
+    # whatever a future field adds: drop the optional blocks, least important first, until the line fits
+    for k in ("host", "stage_ms_per_step", "host_buffers", "resident_reads_per_s", "data"):
+        if len(s) < COMPACT_LIMIT:
+            break
+        line.pop(k, None); s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < COMPACT_LIMIT, len(s)
+    return line
 
 
 def _cpu_check(sig, strand):

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 import warnings
 
 import numpy as np
@@ -255,3 +256,39 @@ def test_empirical_noise_fixture_and_generator(pm, cfg):
     b2, sb = synth.make_read(t, 7, 3, 8000, (repeat, prefix, suffix), 40, noise=noise)
     assert sa == sb and np.array_equal(a, b2) and a.dtype == np.int16
     assert 7.5 * 8000 < len(a) < 11.0 * 8000
+
+
+def test_bench_prints_a_compact_last_line(tmp_path):
+    """The driver keeps an 8 KB tail of bench.py's stdout and parses its LAST line: round 5's record had grown to 25 KB and could not
+    be read.  bench.compact_line() of that very record (profiles/r05_bench_default.json) is under 4 KB, is valid JSON, carries
+    `roofline` (bound / achieved / peak / frac / traffic) and `cpu_baseline` (value / cores / kind / sample), and no key called
+    `frac` in it exceeds 1; the full record goes to a file (bench.write_detail)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    assert len(json.dumps(full)) > 20000
+    path = bench.write_detail(full, str(tmp_path / "d" / "detail.json"))
+    assert json.load(open(path)) == full
+    line = bench.compact_line(full, path)
+    s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < 4096 and "\n" not in s
+    back = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in back, k
+    assert back["config"]["workload"].startswith("BASELINE configs[2]")
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"} <= set(back["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(back["cpu_baseline"])
+    assert back["roofline_viterbi"]["kernel"].startswith("viterbi_g2_kernel")
+
+    def fracs(d):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                for f in fracs(v):
+                    yield f
+            elif k == "frac" or k.endswith("_frac"):
+                yield v
+    assert all(0 <= f <= 1 for f in fracs(back)), list(fracs(back))
+    # a record bloated by future fields still fits: the optional blocks go first
+    full["data"] = "x" * 3000
+    assert len(json.dumps(bench.compact_line(full, path), separators=(",", ":"))) < 4096

@@ -87,9 +87,13 @@ def test_benchmarked_kernel_instance_all_fields(pm, cfg, targets, monkeypatch):
 
 
 def _run_bench(extra, world=1, port="29541", timeout=900):
+    """Runs bench.py; returns the JSON lines per rank and the FULL records (bench.py --detail) -- after holding the printed line
+    to the compact contract: one line, under 4 KB, carrying the keys the driver parses."""
     import json
     import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="strq_bench_"), "detail.json")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra + ["--detail", detail]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if world > 1:
         env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(world))
@@ -98,7 +102,14 @@ def _run_bench(extra, world=1, port="29541", timeout=900):
     outs = [p.communicate(timeout=timeout) for p in procs]
     assert all(p.returncode == 0 for p in procs), [(o[0].decode()[-2000:], o[1].decode()[-2000:]) for o in outs]
     lines = [[ln for ln in o[0].decode().splitlines() if ln.startswith("{")] for o in outs]
-    return lines, [json.loads(l[0]) for l in lines if l]
+    for l in lines:
+        if l:
+            assert len(l[0]) < 4096, len(l[0])
+            c = json.loads(l[0])
+            assert {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "config", "check_ok", "detail"} <= set(c), sorted(c)
+            full = json.load(open(c["detail"]))
+            assert c["value"] == pytest.approx(full["value"], rel=1e-5) and c["n_gpus"] == full["n_gpus"]
+    return lines, [json.load(open(json.loads(l[0])["detail"])) for l in lines if l]
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -202,8 +213,10 @@ def test_bench_launches_its_own_ranks_from_a_clean_environment(tmp_path):
     p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    r = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 4096 and p.stdout.decode().rstrip().splitlines()[-1] == lines[0]
+    c = json.loads(lines[0])
+    assert c["collective"]["backend"] == "gloo" and c["collective"]["rows_equal_every_ranks_digest"] is True
+    r = json.load(open(c["detail"]))
     assert r["n_gpus"] == 4 == r["world_size_seen_by_the_collective"] and r["check_ok"]
     coll = r["collective"]
     assert coll["backend"] == "gloo" and "bench.py itself" in coll["launched_by"] and coll["rows_on_rank_0"] == 2 * 4 * 64
