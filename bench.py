@@ -347,9 +347,17 @@ class Leg(object):
         self.screen = {"ms": 0.0, "wave_steps": 0.0, "screened": 0.0, "windowed": 0.0, "whole_read": 0.0, "window_columns": 0.0, "scale": 0.0, "candidate_chunks": 0.0}
         self.second_round = [0, 0]; self.screen_mode = None; self.screen_merge = 0
 
-    def after_step(self, ctx, k, bi, res):
+    def rows(self, k, bi, res):
         self.last[bi] = res.copy()
         self.mine.append((k, self.last[bi]))
+
+    def late_viterbi(self, ms, time_steps):
+        """The Viterbi launches of the LAST step, which the final fetch waited for (strq_batch_fetch_range)."""
+        self.stage_ms[6] += ms; self.counters[7] += time_steps
+
+    def stats(self, ctx):
+        """After a run call: its conditioning / alignment figures, and the Viterbi figures of the sub-batch it took the rows of
+        (the one before: the library keeps two sub-batches in flight)."""
         tm = ctx.last_timing(); cn = ctx.last_counters()
         self.fwd_ms += float(tm[1]); self.fwd_launches += int(tm[7]); self.stage_ms += tm
         self.counters[:3] += cn[:3]; self.counters[3:7] = cn[3:7]; self.counters[7] += cn[7]
@@ -364,20 +372,42 @@ class Leg(object):
         self.steps += 1
 
 
+def run_steps(ctx, leg, reads, n_batches, steps, k0, each=None):
+    """`steps` steps over the resident batches in rotation.  A step = strq_batch_run_range over one batch; its rows are fetched
+    (strq_batch_fetch_range) after the NEXT step has been queued -- the library runs a step's HMM Viterbi launches under the next
+    step's conditioning and flank alignments -- and the last step's rows before this returns: every kernel and every row of the
+    `steps` steps lies between the caller's two clock readings.  `each(k, rows)`: called with every step's rows (the gather
+    after every step).  Returns k0 + steps."""
+    prev = None
+    if n_batches < 2 and each is None:
+        each = lambda k, rows: None          # one resident batch: a step's rows would be overwritten by the next step's -- fetched right away
+    for i in range(steps):
+        k = k0 + i; bi = k % n_batches
+        ctx.batch_run_range(bi * reads, (bi + 1) * reads)
+        leg.stats(ctx)
+        if each is not None:          # rows wanted right away: no second step in flight
+            v0 = float(ctx.last_timing()[6]); c0 = float(ctx.last_counters()[7])
+            rows = ctx.batch_fetch_range(bi * reads, (bi + 1) * reads)
+            leg.late_viterbi(float(ctx.last_timing()[6]) - v0, float(ctx.last_counters()[7]) - c0)
+            leg.rows(k, bi, rows); each(k, rows)
+            continue
+        if prev is not None:
+            leg.rows(prev[0], prev[1], ctx.batch_fetch_range(prev[1] * reads, (prev[1] + 1) * reads))
+        prev = (k, bi)
+    if prev is not None:
+        v0 = float(ctx.last_timing()[6]); c0 = float(ctx.last_counters()[7])
+        leg.rows(prev[0], prev[1], ctx.batch_fetch_range(prev[1] * reads, (prev[1] + 1) * reads))
+        leg.late_viterbi(float(ctx.last_timing()[6]) - v0, float(ctx.last_counters()[7]) - c0)
+    return k0 + steps
+
+
 def run_leg(ctx, reads, n_batches, steps, warmup, k0=0):
     """`warmup` untimed + `steps` timed steps over the resident batches in rotation, on one process (the extra legs at N = 1)."""
+    k = run_steps(ctx, Leg(), reads, n_batches, warmup, k0)
+    ctx.batch_fetch(); ctx.device_synchronize()
     leg = Leg()
-    k = k0
-    for _ in range(warmup):
-        bi = k % n_batches
-        ctx.batch_run_range(bi * reads, (bi + 1) * reads); ctx.batch_fetch(); k += 1
-    ctx.device_synchronize()
     t0 = time.time()
-    for _ in range(steps):
-        bi = k % n_batches
-        ctx.batch_run_range(bi * reads, (bi + 1) * reads)
-        res = ctx.batch_fetch()[bi * reads:(bi + 1) * reads]
-        leg.after_step(ctx, k, bi, res); k += 1
+    run_steps(ctx, leg, reads, n_batches, steps, k)
     ctx.device_synchronize()
     leg.elapsed = time.time() - t0
     return leg
@@ -661,27 +691,17 @@ def main():
         pos = np.concatenate([((k - k0) * world + rank) * args.reads + np.arange(len(r)) for k, r in parts])
         return sdist.gather_records(recs, pos, len(parts) * world * args.reads, device=coll_dev, group=coll_group)
 
-    def step(k):
-        bi = k % n_batches                      # a different resident batch every step
-        lo, hi = bi * args.reads, (bi + 1) * args.reads
-        ctx.batch_run_range(lo, hi)
-        res = ctx.batch_fetch()[lo:hi]
-        if dist is not None and args.gather_every_step:
-            gather([(k, res)])
-        return bi, res
-
-    k_step = 0
-    for _ in range(args.warmup):
-        bi, res = step(k_step); k_step += 1
+    each = (lambda k, rows: gather([(k, rows)])) if (dist is not None and args.gather_every_step) else None
+    warm_leg = Leg()
+    k_step = run_steps(ctx, warm_leg, args.reads, n_batches, args.warmup, 0, each)          # a different resident batch every step
+    ctx.batch_fetch()
     if dist is not None and args.warmup and not args.gather_every_step:
-        gather([(k_step - 1, res)])             # warm the collective up as well (communicator set-up is not part of a step)
+        gather([warm_leg.mine[-1]])             # warm the collective up as well (communicator set-up is not part of a step)
     barrier()
     t0 = time.time()
     main_leg = Leg()
     gathered_rows = None
-    for _ in range(args.steps):
-        bi, res = step(k_step); k_step += 1
-        main_leg.after_step(ctx, k_step - 1, bi, res)
+    k_step = run_steps(ctx, main_leg, args.reads, n_batches, args.steps, k_step, each)
     mine = main_leg.mine; last = main_leg.last
     table = None
     if dist is not None and not args.gather_every_step:
@@ -696,11 +716,12 @@ def main():
         import hashlib
         import torch
         digest = hashlib.sha256(np.concatenate([r for _, r in mine]).tobytes()).digest()[:8]
-        mine_info = np.zeros(4, np.int64)
+        mine_info = np.zeros(5, np.int64)
         mine_info[0] = int.from_bytes(digest, "little", signed=True)
         mine_info[1] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss          # KiB
         mine_info[2] = len(pinned) if pinned else 0
         mine_info[3] = device
+        mine_info[4] = int(elapsed * 1e6)          # this rank's own time over the steps (the line's ms_per_step is the maximum)
         t = torch.from_numpy(mine_info)
         infos = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(infos, t)
@@ -720,7 +741,8 @@ def main():
                 if args.dump_rows:
                     np.save(args.dump_rows, table)
             rank_report = {"rows_equal_every_ranks_digest": rows_ok, "peak_host_rss_gb_per_rank": [round(float(i[1]) / 1048576.0, 3) for i in infos],
-                           "cpus_pinned_per_rank": [int(i[2]) for i in infos], "hip_device_per_rank": [int(i[3]) for i in infos]}
+                           "cpus_pinned_per_rank": [int(i[2]) for i in infos], "hip_device_per_rank": [int(i[3]) for i in infos],
+                           "ms_per_step_per_rank": [float(i[4]) / 1e3 / max(1, args.steps) for i in infos]}
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -845,13 +867,20 @@ def main():
             # degraded reads: their own resident batch (the clean ones are dropped)
             kept_clean = kept; kept = None
             dargs = argparse.Namespace(**vars(args)); dargs.reads = args.degraded_reads or args.reads
-            dl, dstr, dn, dkept, dgen, dup = stage_resident(ctx, counter, dargs, 0, 1, synth_workers, "empirical", keep_first=1, keep_all=False)
-            dleg = run_leg(ctx, dargs.reads, 1, 2 * args.leg_steps, 3, 0)      # three untimed steps: the screens' own adaptation (overlap plan, pauses, margin) settles
-            legs["degraded"] = leg_summary(dleg, dargs.reads, dl, prof, dn, 1)
+            dnb = 2                                                             # two batches in rotation: two steps in flight, as in the headline
+            dl, dstr, dn, dkept, dgen, dup = stage_resident(ctx, counter, dargs, 0, dnb, synth_workers, "empirical", keep_first=1, keep_all=False)
+            dleg = run_leg(ctx, dargs.reads, dnb, 2 * args.leg_steps, 4, 0)      # four untimed steps: the screens' own adaptation (overlap plan, pauses, margin) settles
+            legs["degraded"] = leg_summary(dleg, dargs.reads, dl[:dargs.reads], prof, dn, dnb)
             legs["degraded"]["workload"] = "%d reads, %d nt, noise resampled from the bundled real read (strique_amd.synth.EmpiricalNoise: N~%d samples)" % (dargs.reads, args.read_nt, int(dl.mean()))
             ctx.set_option("STRQ_NO_SCREEN", "1")
-            dleg2 = run_leg(ctx, dargs.reads, 1, args.leg_steps, 1, 0)
+            dleg2 = run_leg(ctx, dargs.reads, dnb, args.leg_steps, 1, 0)
             ctx.set_option("STRQ_NO_SCREEN", None)
+            ctx.set_option("STRQ_SERIAL", "1")
+            dleg3 = run_leg(ctx, dargs.reads, dnb, args.leg_steps, 2, 0)
+            ctx.set_option("STRQ_SERIAL", None)
+            legs["degraded"]["value_serial"] = dargs.reads * dleg3.steps / dleg3.elapsed
+            legs["degraded"]["viterbi_ms_serial"] = float(dleg3.stage_ms[6]) / max(1, dleg3.steps)
+            out["value_degraded_serial"] = legs["degraded"]["value_serial"]
             legs["degraded"]["value_no_screen"] = dargs.reads * dleg2.steps / dleg2.elapsed
             legs["degraded"]["forward_dp_ms_no_screen"] = float(dleg2.stage_ms[1]) / max(1, dleg2.steps)
             if args.check > 0:

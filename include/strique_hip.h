@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 11 (11: strq_set_option, strq_get_option, strq_batch_upload_part, strq_last_screen_mode; 10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 12 (12: strq_batch_fetch_range, two sub-batches in flight; 11: strq_set_option, strq_get_option, strq_batch_upload_part, strq_last_screen_mode; 10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -216,9 +216,18 @@ int strq_batch_upload_part(strq_ctx* ctx, int64_t total_reads, int64_t total_sam
                            const void* signals, int32_t dtype, const int64_t* offsets, const int32_t* target_id);
 int strq_batch_run(strq_ctx* ctx);
 /* Only reads [first, last) of the uploaded batch (several batches kept resident side by side: a benchmark that
- * times a different one every step); strq_batch_fetch still returns the rows of the whole upload. */
+ * times a different one every step); strq_batch_fetch still returns the rows of the whole upload.
+ * The run calls work in sub-batches (16 reads per CU) and keep TWO of them in flight: the HMM Viterbi launches of a sub-batch
+ * run on a second stream under the conditioning and flank alignments of the next (the reference's workers are independent in the
+ * same way, scripts/STRique.py:743-746), and its rows are taken one sub-batch late.  A run call therefore returns with the
+ * Viterbi launches of its LAST sub-batch still queued; every call that hands out rows waits for what it needs:
+ * strq_batch_fetch / strq_batch_fetch_mod / strq_detect_batch* for everything, strq_batch_fetch_range for the sub-batches that
+ * hold reads of [first, last) only -- so `run(k + 1); fetch_range(k)` never waits for k + 1.  The rows are the same whatever
+ * the order (STRQ_SERIAL=1: everything on one stream, rows before the run call returns, as up to ABI 11).  Sub-batches with a
+ * modification model run serially (their second pass needs the decoded repeat stretch on the host). */
 int strq_batch_run_range(strq_ctx* ctx, int64_t first, int64_t last);
 int strq_batch_fetch(strq_ctx* ctx, strq_result* out);
+int strq_batch_fetch_range(strq_ctx* ctx, int64_t first, int64_t last, strq_result* out);
 /* A host-side helper, not on the path of strq_detect_batch (which takes these on the GPU): the statistics of float64 reads
  * with numpy's arithmetic (no context, no device): out[6 * i ..] = median, MAD, c1, h1 of
  * medfilt(read i, 3) and c1, h1 of read i itself (0, 1 unless want_raw) -- what numpy's median / mean / percentile

@@ -163,6 +163,7 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
     STRQ_HIP(c, hipEventRecord(c->ev[0], st));
     if (launch_lut_build(st, d_jobs, d_info, nj, max_k, d_hard, d_hard_count, hard_cap, c->ap)) { c->err = "lut launch failed"; return STRQ_ERR_DEVICE; }
     STRQ_HIP(c, hipEventRecord(c->ev[1], st));
+    if (in.after_tables) { const int arc = in.after_tables(); if (arc) return arc; }
     std::vector<LutInfo> info(nj);
     int hard_count = 0;
     STRQ_HIP(c, hipMemcpyAsync(info.data(), d_info, (size_t)nj * sizeof(LutInfo), hipMemcpyDeviceToHost, st));
@@ -1209,7 +1210,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
 
 extern "C" {
 
-int strq_abi_version(void) { return 11; }
+int strq_abi_version(void) { return 12; }
 
 int strq_set_option(strq_ctx* c, const char* key, const char* value)
 {

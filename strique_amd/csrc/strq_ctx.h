@@ -6,6 +6,7 @@
 #include <vector>
 #include <map>
 #include <cstdio>
+#include <functional>
 #include "align_kernels.h"
 #include "viterbi_kernels.h"
 #include "screen_kernels.h"
@@ -46,6 +47,9 @@ struct AlignCoreIn {
     const int* n = nullptr; const int* m = nullptr; const int* k = nullptr; const int* R = nullptr;
     const int* NS = nullptr;               // strips per alignment (1 or 2)
     const float* const* flank = nullptr;   // host: flank template of each alignment
+    // called once the score-table kernel of the sub-batch is queued (its workgroups take most of a CU's LDS: whatever is to share the
+    // GPU with the alignment kernels that follow is launched behind it -- strq_detect_api.hip); a non-zero return aborts the call
+    std::function<int()> after_tables;
 };
 struct AlignCoreOut {
     std::vector<int> order;                // task position -> alignment index
@@ -105,7 +109,7 @@ struct strq_ctx {
     float coarse_margin = 384.0f;
     int screen_mode_last = 0;                 // screen of the last align_core call: 0 none, 1 fine, 2 coarse
     int coarse_merge_last = 0;                // ... and the flank rows per DP row of the coarse one
-    int64_t redo_prev = 0;                    // second-round alignments of the batched call up to the previous sub-batch
+    
     // workspace
     strq::DevBuf levels, level_val, flank_cls, tables, tables3, band_lo, col0, ckpt, rec, tasks, results,
         queue, scratch, lutinfo, hard, misc, vit_x, vit_tasks, vit_bp, vit_path, bnd,

@@ -138,10 +138,29 @@ struct DetectState {
     bool have_ps = false;
     std::vector<Target> targets;
     Batch batch;
-    DevBuf flt, rc, hist16, hist8, geom, vit, vres, idx, order, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange, modpool, f64s;
+    DevBuf rc, hist16, hist8, geom, idx, hist_raw, bp, path, modtask, modsig, modlen, pattern, hrange, modpool, f64s;
     hipEvent_t ev[4] = {};
     bool ev_ok = false;
-    int64_t part_reads = 0, part_samples = 0;      // strq_batch_upload_part: reads uploaded so far / samples announced
+    int64_t part_reads = 0;              // strq_batch_upload_part: reads uploaded so far
+    // Two sub-batches are in flight at a time: the Viterbi launches of sub-batch k run on `vit_stream` while the conditioning and the
+    // flank alignments of sub-batch k + 1 are queued on the context's stream (the Viterbi launch lasts as long as its longest window --
+    // reads whose flanks were mislocated decode 10^5 steps and more -- and most of the GPU idles under that tail).  What a Viterbi launch
+    // reads or writes exists twice (filtered signal, tasks, results, order, queue heads); results come back one sub-batch late.
+    struct Slot {
+        DevBuf flt, vit, vres, order, vq;
+        bool active = false;             // forward stage done, results not yet in Batch::results
+        bool launch_pending = false;     // ... and its Viterbi launches not yet queued (they go behind the conditioning of the next sub-batch)
+        struct VL { int shape, first, count, max_states; };
+        std::vector<VL> vls;             // the Viterbi launches of the sub-batch: kernel shape, task range
+        int vit_mode = 0;                // 0 count, 2 MARK (modification pass follows)
+        int64_t r0 = 0; int nr = 0;
+        std::vector<int32_t> vit_slot;
+        void* pinned = nullptr; size_t pinned_cap = 0;      // ReadGeom[nr], VitResult[nr], ReadCond[nr], unsigned redo
+        hipEvent_t fwd_done = nullptr, v0 = nullptr, v1 = nullptr;
+    };
+    Slot slot[2];
+    int next_slot = 0;
+    hipStream_t vit_stream = nullptr;
     int levels_shift = 0;                // bytes the level stream of the current sub-batch starts behind the buffer's base (alignment phase)
     hipStream_t copy_stream = nullptr;   // host -> HBM uploads that overlap the kernels of the previous sub-batch
     static constexpr int N_STAGE = 4;    // pinned staging ring of upload_reads
@@ -158,8 +177,15 @@ void detect_state_free(strq_ctx* c)
 {
     if (!c->detect) return;
     DetectState* d = static_cast<DetectState*>(c->detect);
-    for (DevBuf* b : {&d->batch.raw, &d->flt, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->vit, &d->vres, &d->idx, &d->order,
+    if (d->vit_stream) (void)hipStreamSynchronize(d->vit_stream);
+    for (DevBuf* b : {&d->batch.raw, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->idx,
                       &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern, &d->hrange, &d->modpool, &d->f64s}) b->release();
+    for (auto& sl : d->slot) {
+        for (DevBuf* b : {&sl.flt, &sl.vit, &sl.vres, &sl.order, &sl.vq}) b->release();
+        if (sl.pinned) (void)hipHostFree(sl.pinned);
+        for (hipEvent_t e : {sl.fwd_done, sl.v0, sl.v1}) if (e) (void)hipEventDestroy(e);
+    }
+    if (d->vit_stream) (void)hipStreamDestroy(d->vit_stream);
     if (d->ev_ok) for (auto& e : d->ev) (void)hipEventDestroy(e);
     if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     for (int i = 0; i < DetectState::N_STAGE; ++i) { if (d->stage[i]) (void)hipHostFree(d->stage[i]); if (d->stage_ev[i]) (void)hipEventDestroy(d->stage_ev[i]); }
@@ -170,8 +196,8 @@ void detect_state_free(strq_ctx* c)
 // Modification pass for the reads of one sub-batch whose target has a modification model.
 // The flanked-model Viterbi ran in MARK mode (viterbi_kernels.hip): its result carries the first and
 // last sample decoded into the repeat section, which is all detect step 13 (STRique.py:608) needs.
-static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const std::vector<ReadCond>& rc,
-                        const std::vector<ReadGeom>& geom, const std::vector<VitResult>& vres,
+static int run_mod_pass(strq_ctx* c, DetectState* d, DetectState::Slot& sl, int64_t r0, int nr, const ReadCond* rc,
+                        const ReadGeom* geom, const VitResult* vres,
                         const std::vector<int32_t>& vit_slot)
 {
     Batch& B = d->batch;
@@ -257,7 +283,7 @@ static int run_mod_pass(strq_ctx* c, DetectState* d, int64_t r0, int nr, const s
         STRQ_HIP(c, hipMemcpyAsync(d_tb + first, vt2.data() + first, (size_t)(sidx - first) * sizeof(VitTask), hipMemcpyHostToDevice, st));
         int* d_order = nullptr;
         if (sidx - first <= 8192) {
-            d_order = d->order.as<int>() + first;
+            d_order = sl.order.as<int>() + first;
             if (launch_vit_sort(st, d_tb + first, sidx - first, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
         }
         if (const int vrc = launch_viterbi(st, g.first, mx, d_tb + first, d_tr + first, sidx - first, c->queue.as<int>() + qi, c->n_cu, use_hub ? 3 : 1, d_order)) {
@@ -396,6 +422,89 @@ struct ForwardToken {
     ~ForwardToken() { pass(); }
 };
 
+static void publish_timing(strq_ctx* c, const Batch& B)
+{
+    std::fill(c->timing, c->timing + 8, 0.0f);
+    c->timing[0] = B.t_lut; c->timing[1] = B.t_fwd; c->timing[2] = B.t_trace; c->timing[5] = B.t_cond; c->timing[6] = B.t_vit;
+    c->timing[3] = B.t_lut + B.t_fwd + B.t_trace + B.t_cond + B.t_vit; c->timing[4] = (float)B.n_hard; c->timing[7] = (float)B.n_fwd_launches;
+}
+
+// Queues the Viterbi launches of a sub-batch whose forward stage is complete (sort by window length, one persistent launch per kernel
+// shape, results to pinned host memory) on `vs`, behind `after` when given.
+static int launch_viterbi_of(strq_ctx* c, DetectState* d, DetectState::Slot& sl, hipStream_t vs, hipEvent_t after)
+{
+    if (!sl.launch_pending) return STRQ_OK;
+    sl.launch_pending = false;
+    const int nr = sl.nr;
+    VitResult* h_vres = reinterpret_cast<VitResult*>(static_cast<ReadGeom*>(sl.pinned) + nr);
+    if (after) STRQ_HIP(c, hipStreamWaitEvent(vs, after, 0));
+    STRQ_HIP(c, hipMemsetAsync(sl.vq.p, 0, 1024, vs));
+    for (auto& v : sl.vls)
+        if (v.count <= 8192 && launch_vit_sort(vs, sl.vit.as<VitTask>() + v.first, v.count, sl.order.as<int>() + v.first)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
+    STRQ_HIP(c, hipEventRecord(sl.v0, vs));
+    int qi = 0;
+    std::memset(c->vit_launches, 0, sizeof(c->vit_launches));
+    for (auto& v : sl.vls) {
+        ++c->vit_launches[0];
+        ++c->vit_launches[(v.shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 ? 1 : ((v.shape & ~VIT_SHAPE_SS) == VIT_SHAPE_CSR ? 3 : 2)];
+        int* d_order = v.count <= 8192 ? sl.order.as<int>() + v.first : nullptr;
+        const int rc2 = launch_viterbi(vs, v.shape, v.max_states, sl.vit.as<VitTask>() + v.first, sl.vres.as<VitResult>() + v.first, v.count,
+                                       sl.vq.as<int>() + qi, c->n_cu, sl.vit_mode, d_order, (after && vs != c->stream) ? 4 : 0);
+        if (rc2) {
+            c->err = (rc2 == 2 || rc2 == 3) ? "viterbi: decode mode not available for this model's kernel shape" : "viterbi launch failed";
+            return (rc2 == 2 || rc2 == 3) ? STRQ_ERR_UNSUPPORTED : STRQ_ERR_DEVICE;
+        }
+        ++qi;
+    }
+    STRQ_HIP(c, hipMemcpyAsync(h_vres, sl.vres.p, (size_t)nr * sizeof(VitResult), hipMemcpyDeviceToHost, vs));
+    STRQ_HIP(c, hipEventRecord(sl.v1, vs));
+    return STRQ_OK;
+}
+
+// Results of a sub-batch whose Viterbi launches were queued earlier: waits for them, fills Batch::results (and runs the
+// modification pass of the sub-batch, which needs the decoded repeat stretch on the host).
+static int harvest(strq_ctx* c, DetectState* d, DetectState::Slot& sl)
+{
+    if (!sl.active) return STRQ_OK;
+    sl.active = false;
+    Batch& B = d->batch;
+    { const int lrc = launch_viterbi_of(c, d, sl, d->vit_stream, nullptr); if (lrc) return lrc; }      // nobody came after this sub-batch
+    STRQ_HIP(c, hipEventSynchronize(sl.v1));
+    const int nr = sl.nr; const int64_t r0 = sl.r0;
+    const ReadGeom* geom = static_cast<const ReadGeom*>(sl.pinned);
+    const VitResult* vres = reinterpret_cast<const VitResult*>(geom + nr);
+    const ReadCond* rc_out = reinterpret_cast<const ReadCond*>(vres + nr);
+    bool any_mod = false;
+    for (int i = 0; i < nr; ++i) {
+        strq_result& o = B.results[r0 + i];
+        std::memset(&o, 0, sizeof(o));
+        const ReadGeom& g = geom[i];
+        const VitResult& v = vres[sl.vit_slot[i]];
+        o.status = rc_out[i].status == COND_OK ? 0 : 1;
+        o.score_prefix = g.score_prefix; o.score_suffix = g.score_suffix;
+        o.prefix_begin = g.prefix_begin; o.prefix_end = g.prefix_end; o.suffix_begin = g.suffix_begin; o.suffix_end = g.suffix_end;
+        o.offset = g.prefix_end; o.ticks = std::max<int64_t>(g.suffix_begin - g.prefix_end, 0);
+        if (g.gate) c->counters[7] += (double)(g.suffix_end - g.prefix_begin);
+        if (g.gate && v.status == 0) {
+            o.count = (int32_t)v.counted + d->targets[B.target[r0 + i]].count_bias;
+            o.log_p = v.logp;
+        }
+        any_mod |= d->targets[B.target[r0 + i]].mod_model_id >= 0;
+    }
+    float ms;
+    STRQ_HIP(c, hipEventElapsedTime(&ms, sl.v0, sl.v1)); B.t_vit += ms;
+    publish_timing(c, B);
+    if (any_mod) return run_mod_pass(c, d, sl, r0, nr, rc_out, geom, vres, sl.vit_slot);
+    return STRQ_OK;
+}
+
+// every sub-batch still in flight, oldest first
+static int drain(strq_ctx* c, DetectState* d)
+{
+    for (int k = 0; k < 2; ++k) { const int rc = harvest(c, d, d->slot[(d->next_slot + k) & 1]); if (rc) return rc; }
+    return STRQ_OK;
+}
+
 static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, int64_t next_r1)
 {
     ForwardToken token;
@@ -405,6 +514,11 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     const int nr = (int)(r1 - r0);
     const int esz = B.dtype == 0 ? 2 : 8;
     const int64_t s0 = B.off[r0], tot = B.off[r1] - s0;
+    // the slot of this sub-batch (its previous user's results are taken first: normally done a sub-batch ago)
+    DetectState::Slot& sl = d->slot[d->next_slot];
+    DetectState::Slot& other = d->slot[d->next_slot ^ 1];
+    { const int hrc = harvest(c, d, sl); if (hrc) return hrc; }
+    d->next_slot ^= 1;
     int max_n = 0;
     std::vector<ReadCond> rc(nr);
     std::vector<int64_t> loff(nr + 1);
@@ -424,7 +538,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         }
     }
     loff[nr] = tot;
-    STRQ_HIP(c, d->flt.reserve((size_t)tot * esz + 64 + 16));
+    STRQ_HIP(c, sl.flt.reserve((size_t)tot * esz + 64 + 16));
     STRQ_HIP(c, c->levels.reserve((size_t)tot + 64 + 8));
     STRQ_HIP(c, c->level_val.reserve((size_t)nr * 256 * 4));
     STRQ_HIP(c, d->rc.reserve((size_t)nr * sizeof(ReadCond)));
@@ -436,9 +550,12 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     const char* raw = d->batch.raw.as<char>() + (size_t)s0 * esz;
     // the filtered signal of the sub-batch starts at the same offset inside a 16-byte line as its raw signal, so that the
     // conditioning kernels can move both with aligned 16-byte accesses
-    char* const flt_base = d->flt.as<char>() + (reinterpret_cast<uintptr_t>(raw) & 15);
+    char* const flt_base = sl.flt.as<char>() + (reinterpret_cast<uintptr_t>(raw) & 15);
     bool any_mod = false;
     for (int i = 0; i < nr; ++i) any_mod |= d->targets[B.target[r0 + i]].mod_model_id >= 0;
+    // STRQ_SERIAL=1: the Viterbi launches on the context's own stream and their results before the call returns, as up to round 5.
+    // (A sub-batch with a modification model runs that way too: its second pass needs the decoded repeat stretch on the host.)
+    const bool serial = any_mod || strq::opt("STRQ_SERIAL") != nullptr;
     uint32_t* d_hist_raw = nullptr; uint32_t* d_range = nullptr;
     if (B.dtype == 0) {
         STRQ_HIP(c, hipMemsetAsync(d->hist16.p, 0, (size_t)nr * 65536 * 4, st));
@@ -462,15 +579,16 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         if (shape < 0) { c->err = "model does not fit a compiled Viterbi kernel"; return STRQ_ERR_UNSUPPORTED; }
         by_shape[shape].push_back(i);
     }
-    std::vector<int32_t> vit_slot(nr);
-    struct VL { int shape, first, count, max_states; };
-    std::vector<VL> vls;
-    { int sl = 0;
+    std::vector<int32_t>& vit_slot = sl.vit_slot;
+    vit_slot.assign(nr, 0);
+    std::vector<DetectState::Slot::VL>& vls = sl.vls;
+    vls.clear();
+    { int k = 0;
       for (auto& g : by_shape) {
         int mx = 0;
         for (int i : g.second) mx = std::max(mx, c->models[d->targets[B.target[r0 + i]].model_id]->h.n_cells);
-        vls.push_back({g.first, sl, (int)g.second.size(), mx});
-        for (int i : g.second) vit_slot[i] = sl++;
+        vls.push_back({g.first, k, (int)g.second.size(), mx});
+        for (int i : g.second) vit_slot[i] = k++;
       } }
     const size_t idx_ints = (size_t)nr * 5;        // task_of (2 per read), trim (2 per read), vit_slot
     STRQ_HIP(c, d->idx.reserve(idx_ints * 4 + (size_t)nr * 8 + 64));
@@ -479,9 +597,33 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     STRQ_HIP(c, hipMemcpyAsync(d_model_of, model_of.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(d_slot, vit_slot.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, d->geom.reserve((size_t)nr * sizeof(ReadGeom)));
-    STRQ_HIP(c, d->vit.reserve((size_t)nr * sizeof(VitTask)));
-    STRQ_HIP(c, d->vres.reserve((size_t)nr * sizeof(VitResult)));
-    STRQ_HIP(c, d->order.reserve((size_t)nr * 4 + 64));
+    STRQ_HIP(c, sl.vit.reserve((size_t)nr * sizeof(VitTask)));
+    STRQ_HIP(c, sl.vres.reserve((size_t)nr * sizeof(VitResult)));
+    STRQ_HIP(c, sl.order.reserve((size_t)nr * 4 + 64));
+    STRQ_HIP(c, sl.vq.reserve(1024));
+    {
+        const size_t need = (size_t)nr * (sizeof(ReadGeom) + sizeof(VitResult) + sizeof(ReadCond)) + 64;
+        if (need > sl.pinned_cap) {
+            if (sl.pinned) { STRQ_HIP(c, hipHostFree(sl.pinned)); sl.pinned = nullptr; sl.pinned_cap = 0; }
+            STRQ_HIP(c, hipHostMalloc(&sl.pinned, need + need / 8, hipHostMallocDefault));
+            sl.pinned_cap = need + need / 8;
+        }
+        if (!sl.fwd_done) {
+            STRQ_HIP(c, hipEventCreateWithFlags(&sl.fwd_done, hipEventDisableTiming));
+            STRQ_HIP(c, hipEventCreate(&sl.v0)); STRQ_HIP(c, hipEventCreate(&sl.v1));
+        }
+        if (!d->vit_stream) {
+            // the older sub-batch's Viterbi launches go first where both streams have workgroups to place
+            int lo = 0, hi = 0;
+            STRQ_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const char* e = strq::opt("STRQ_VIT_PRIORITY");
+            STRQ_HIP(c, hipStreamCreateWithPriority(&d->vit_stream, hipStreamNonBlocking, (e && atoi(e) == 0) ? lo : hi));
+        }
+    }
+    ReadGeom* h_geom = static_cast<ReadGeom*>(sl.pinned);
+    VitResult* h_vres = reinterpret_cast<VitResult*>(h_geom + nr);
+    ReadCond* h_rc = reinterpret_cast<ReadCond*>(h_vres + nr);
+    unsigned int* h_redo = reinterpret_cast<unsigned int*>(h_rc + nr);
 
     // Conditioning, the two flank alignments and the positions / gate of the reads, in `parts` pieces: a
     // sub-batch whose samples are still in the caller's buffer is uploaded piece by piece, each piece's
@@ -545,6 +687,20 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         AlignCoreIn ci; AlignCoreOut co;
         ci.nb = na; ci.samples = S; ci.d_levels = levels; ci.read_off = loff.data() + i0; ci.d_level_val = level_val;
         ci.read = a_read.data(); ci.n = n.data(); ci.m = m.data(); ci.k = k.data(); ci.R = R.data(); ci.NS = NS.data(); ci.flank = fl.data();
+        if (part == 0) ci.after_tables = [&]() -> int {
+            // The sub-batch before this one: its Viterbi launches start when this sub-batch's conditioning and score tables are through
+            // -- a few ms of HBM-bound streaming kernels that crawl next to a GPU full of Viterbi waves (gpurun_out/r6d: 66 ms instead
+            // of 5.7 ms), and a table kernel whose workgroups want most of a CU's LDS and cannot be placed next to them at all
+            // (gpurun_out/r6h: the whole forward stage waited for the Viterbi launch to end).  The alignment kernels that follow
+            // share the SIMDs with the Viterbi waves at little cost.
+            const bool queued_now = other.launch_pending;
+            const int lrc = launch_viterbi_of(c, d, other, d->vit_stream, c->ev[1]); if (lrc) return lrc;
+            // ... and they are dispatched after them: persistent workgroups that fill every CU for the length of the screen would
+            // otherwise win the race now and then, and the Viterbi workgroups (eight waves of 192 VGPRs each: a whole CU's worth at
+            // once) could not be placed before the screen has ended -- the serial order again
+            if (queued_now) STRQ_HIP(c, hipStreamWaitEvent(st, other.v0, 0));
+            return STRQ_OK;
+        };
         const int rcode = align_core(c, ci, co);
         if (rcode) return rcode;
         B.n_hard += co.n_hard; B.n_fwd_launches += co.n_launches;
@@ -559,83 +715,57 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         FinalizeArgs fa;
         fa.tasks = co.d_tasks; fa.results = co.d_results; fa.task_of = d_task_of + 2 * (size_t)i0; fa.trim = d_trim + 2 * (size_t)i0; fa.vit_slot = d_slot + i0;
         fa.rc = d_rc + i0; fa.model_of = d_model_of + i0; fa.flt = flt_base; fa.is_f64 = B.dtype; fa.ps = d->ps;
-        fa.geom = d->geom.as<ReadGeom>() + i0; fa.vit = d->vit.as<VitTask>(); fa.n_reads = np_;
+        fa.geom = d->geom.as<ReadGeom>() + i0; fa.vit = sl.vit.as<VitTask>(); fa.n_reads = np_;
         hipLaunchKernelGGL(finalize_kernel, dim3((np_ + 127) / 128), dim3(128), 0, st, fa);
         STRQ_HIP(c, hipGetLastError());
     }
-    STRQ_HIP(c, hipMemsetAsync(c->queue.p, 0, 1024, st));
-    STRQ_HIP(c, hipEventRecord(d->ev[2], st));
-    { int qi = 0;
-      std::memset(c->vit_launches, 0, sizeof(c->vit_launches));
-      for (auto& v : vls) {
-        ++c->vit_launches[0];
-        ++c->vit_launches[(v.shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2 ? 1 : ((v.shape & ~VIT_SHAPE_SS) == VIT_SHAPE_CSR ? 3 : 2)];
-        int* d_order = nullptr;
-        if (v.count <= 8192) {
-            d_order = d->order.as<int>() + v.first;
-            if (launch_vit_sort(st, d->vit.as<VitTask>() + v.first, v.count, d_order)) { c->err = "sort launch failed"; return STRQ_ERR_DEVICE; }
-        }
-        const int rc2 = launch_viterbi(st, v.shape, v.max_states, d->vit.as<VitTask>() + v.first, d->vres.as<VitResult>() + v.first, v.count,
-                                       c->queue.as<int>() + qi, c->n_cu, any_mod ? 2 : 0, d_order);
-        if (rc2) {
-            c->err = (rc2 == 2 || rc2 == 3) ? "viterbi: decode mode not available for this model's kernel shape" : "viterbi launch failed";
-            return (rc2 == 2 || rc2 == 3) ? STRQ_ERR_UNSUPPORTED : STRQ_ERR_DEVICE;
-        }
-        ++qi;
-      } }
-    STRQ_HIP(c, hipEventRecord(d->ev[3], st));
+    // positions and conditioning status of the sub-batch to the host (pinned: the copies do not block), then the fork: everything the
+    // Viterbi launches read is final behind `fwd_done`
+    STRQ_HIP(c, hipMemcpyAsync(h_geom, d->geom.p, (size_t)nr * sizeof(ReadGeom), hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipMemcpyAsync(h_rc, d_rc, (size_t)nr * sizeof(ReadCond), hipMemcpyDeviceToHost, st));
+    *h_redo = 0;
+    if (c->redo_total.p) STRQ_HIP(c, hipMemcpyAsync(h_redo, c->redo_total.p, 4, hipMemcpyDeviceToHost, st));
+    STRQ_HIP(c, hipEventRecord(sl.fwd_done, st));
+    sl.vit_mode = any_mod ? 2 : 0;
+    sl.active = true; sl.launch_pending = true; sl.r0 = r0; sl.nr = nr;
+    // The Viterbi launches of this sub-batch: now on the context's stream (serial order), or -- two sub-batches in flight -- behind the
+    // conditioning of the NEXT sub-batch (launch_viterbi_of from there), at the latest when somebody asks for the rows.  Conditioning is a
+    // few ms of HBM-bound streaming kernels that crawl next to a GPU full of Viterbi waves (gpurun_out/r6d: 66 ms instead of 5.7 ms); the
+    // flank-alignment kernels that follow share the SIMDs with them at little cost.
+    if (serial) { const int lrc = launch_viterbi_of(c, d, sl, st, nullptr); if (lrc) return lrc; }
+    else if (token.held) { const int lrc = launch_viterbi_of(c, d, sl, d->vit_stream, sl.fwd_done); if (lrc) return lrc; }      // contexts taking turns: the other one's forward stage comes next
     token.pass();
-    // ---- results.  Everything of this sub-batch is queued: fetch the next sub-batch's samples while it runs
-    // (before the read-backs below -- a device-to-host copy into pageable memory blocks the host until the stream
-    // has drained, which would leave the upload exposed).
+    // Everything of this sub-batch is queued: fetch the next sub-batch's samples while it runs.
     { const double tu = now_s(); const int urc = upload_reads(c, d, next_r1); if (urc) return urc;
       STRQ_DBG("  prefetch of the next sub-batch %.1f ms", (now_s() - tu) * 1e3); }
-    std::vector<ReadGeom> geom(nr); std::vector<VitResult> vres(nr); std::vector<ReadCond> rc_out(nr);
-    STRQ_HIP(c, hipMemcpyAsync(geom.data(), d->geom.p, (size_t)nr * sizeof(ReadGeom), hipMemcpyDeviceToHost, st));
-    STRQ_HIP(c, hipMemcpyAsync(vres.data(), d->vres.p, (size_t)nr * sizeof(VitResult), hipMemcpyDeviceToHost, st));
-    STRQ_HIP(c, hipMemcpyAsync(rc_out.data(), d_rc, (size_t)nr * sizeof(ReadCond), hipMemcpyDeviceToHost, st));
-    unsigned int redo_so_far = 0;
-    if (c->redo_total.p) STRQ_HIP(c, hipMemcpyAsync(&redo_so_far, c->redo_total.p, 4, hipMemcpyDeviceToHost, st));
-    STRQ_HIP(c, hipStreamSynchronize(st));
-    c->second_round[0] = redo_so_far; c->second_round[1] += 2 * (int64_t)nr;
-    c->redo_prev = redo_so_far;
-    for (int i = 0; i < nr; ++i) {
-        strq_result& o = B.results[r0 + i];
-        std::memset(&o, 0, sizeof(o));
-        const ReadGeom& g = geom[i];
-        const VitResult& v = vres[vit_slot[i]];
-        o.status = rc_out[i].status == COND_OK ? 0 : 1;
-        o.score_prefix = g.score_prefix; o.score_suffix = g.score_suffix;
-        o.prefix_begin = g.prefix_begin; o.prefix_end = g.prefix_end; o.suffix_begin = g.suffix_begin; o.suffix_end = g.suffix_end;
-        o.offset = g.prefix_end; o.ticks = std::max<int64_t>(g.suffix_begin - g.prefix_end, 0);
-        if (g.gate) c->counters[7] += (double)(g.suffix_end - g.prefix_begin);
-        if (g.gate && v.status == 0) {
-            o.count = (int32_t)v.counted + d->targets[B.target[r0 + i]].count_bias;
-            o.log_p = v.logp;
-        }
-    }
+    // the forward stage of this sub-batch is complete here (its Viterbi launches need not be)
+    STRQ_HIP(c, hipEventSynchronize(sl.fwd_done));
+    c->second_round[0] = *h_redo; c->second_round[1] += 2 * (int64_t)nr;
     // score distribution of this sub-batch for the overlap planning of the next one (align_core)
     if (c->ap.dist_offset > 0.0f) {
         c->score_fracs.clear(); double sum_n = 0;
         for (int i = 0; i < nr; ++i) {
-            if (rc_out[i].n <= 0) continue;
+            if (rc[i].n <= 0) continue;
             const Target& t = d->targets[B.target[r0 + i]];
-            c->score_fracs.push_back(geom[i].best_prefix / ((float)t.prefix_ext.size() * c->ap.dist_offset));
-            c->score_fracs.push_back(geom[i].best_suffix / ((float)t.suffix_ext.size() * c->ap.dist_offset));
-            sum_n += rc_out[i].n;
+            c->score_fracs.push_back(h_geom[i].best_prefix / ((float)t.prefix_ext.size() * c->ap.dist_offset));
+            c->score_fracs.push_back(h_geom[i].best_suffix / ((float)t.suffix_ext.size() * c->ap.dist_offset));
+            sum_n += rc[i].n;
         }
         std::sort(c->score_fracs.begin(), c->score_fracs.end());
         c->mean_n = c->score_fracs.empty() ? 0.0 : sum_n / (double)(c->score_fracs.size() / 2);
     }
-    if (any_mod) {
-        const int rcm = run_mod_pass(c, d, r0, nr, rc_out, geom, vres, vit_slot);
-        if (rcm) return rcm;
-    }
     float ms;
     STRQ_HIP(c, hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); B.t_cond += ms;
-    STRQ_HIP(c, hipEventElapsedTime(&ms, d->ev[2], d->ev[3])); B.t_vit += ms;
     const int rcode = align_core_times(c, &B.t_lut, &B.t_fwd, &B.t_trace);      // of the last piece when the sub-batch ran in pieces
-    return rcode;
+    if (rcode) return rcode;
+    // results: of the sub-batch before this one (its Viterbi launches ran under this sub-batch's forward stage) -- or, serially, of this one
+    if (strq::opt("STRQ_DEBUG") && !serial && other.active && !other.launch_pending && c->screen_ran) {
+        float a = 0, b = 0, e = 0;
+        (void)hipEventSynchronize(other.v1);
+        (void)hipEventElapsedTime(&a, other.v0, c->ev[5]); (void)hipEventElapsedTime(&e, other.v0, c->ev[6]); (void)hipEventElapsedTime(&b, other.v0, other.v1);
+        STRQ_DBG("overlap: Viterbi launches of the previous sub-batch start at 0, end at %.1f ms; this sub-batch's screen runs from %.1f to %.1f ms", b, a, e);
+    }
+    return harvest(c, d, serial ? sl : other);
 }
 
 }  // namespace strq
@@ -683,6 +813,7 @@ int strq_batch_fetch_mod(strq_ctx* c, char* pool, int64_t pool_cap, int64_t* off
 {
     if (!c || !off) return STRQ_ERR_ARG;
     DetectState* d = dstate(c);
+    { const int rc = drain(c, d); if (rc) return rc; }
     int64_t pos = 0;
     for (size_t i = 0; i < d->batch.mod.size(); ++i) {
         off[i] = pos;
@@ -702,6 +833,7 @@ static int batch_prepare(strq_ctx* c, int64_t n_reads, const void* signals, int3
     if (n_reads < 0 || (n_reads > 0 && ((!signals && !reads) || !offsets || !target_id)) || (dtype != 0 && dtype != 1)) { c->err = "bad argument"; return STRQ_ERR_ARG; }
     if (!d->have_ps) { c->err = "strq_set_pore_stats has not been called"; return STRQ_ERR_ARG; }
     STRQ_HIP(c, hipSetDevice(c->device));
+    { const int rc = drain(c, d); if (rc) return rc; }          // sub-batches of the previous batch still in flight
     Batch& B = d->batch;
     B.n_reads = n_reads; B.dtype = dtype;
     B.off.assign(offsets, offsets + n_reads + 1);
@@ -750,6 +882,7 @@ int strq_batch_upload_part(strq_ctx* c, int64_t total_reads, int64_t total_sampl
     Batch& B = d->batch;
     if (first_read == 0) {
         // a new resident batch: device memory for all of it now, the parts follow in order
+        { const int rc = drain(c, d); if (rc) return rc; }
         B.forget_host();
         B.n_reads = total_reads; B.dtype = dtype;
         B.off.assign((size_t)total_reads + 1, 0); B.target.assign((size_t)total_reads, 0);
@@ -758,10 +891,11 @@ int strq_batch_upload_part(strq_ctx* c, int64_t total_reads, int64_t total_sampl
         B.results.assign((size_t)total_reads, strq_result());
         B.mod.assign((size_t)total_reads, std::string("-"));
         B.uploaded = 0; B.on_host = false;
-        d->part_reads = 0; d->part_samples = total_samples;
+        d->part_reads = 0;
         if (!d->ev_ok) { for (auto& e : d->ev) STRQ_HIP(c, hipEventCreate(&e)); d->ev_ok = true; }
     }
     if (B.n_reads != total_reads || d->part_reads != first_read) { c->err = "parts of a resident batch must follow each other, first_read = reads uploaded so far"; return STRQ_ERR_ARG; }
+    if (n_reads == 0) return STRQ_OK;
     const int64_t base = B.off[(size_t)first_read];
     for (int64_t i = 0; i < n_reads; ++i) {
         const int64_t len = offsets[i + 1] - offsets[i];
@@ -775,7 +909,10 @@ int strq_batch_upload_part(strq_ctx* c, int64_t total_reads, int64_t total_sampl
         if (need > B.raw.cap) {          // more samples than announced: a larger buffer, the parts uploaded so far move over
             DevBuf bigger;
             STRQ_HIP(c, bigger.reserve(need + need / 2));
-            if (base > 0) STRQ_HIP(c, hipMemcpy(bigger.p, B.raw.p, (size_t)base * 2, hipMemcpyDeviceToDevice));
+            if (base > 0) {
+                const hipError_t e = hipMemcpy(bigger.p, B.raw.p, (size_t)base * 2, hipMemcpyDeviceToDevice);
+                if (e != hipSuccess) { bigger.release(); c->err = std::string("hipMemcpy (growing the resident batch): ") + hipGetErrorString(e); return STRQ_ERR_DEVICE; }
+            }
             B.raw.release();
             B.raw = bigger;
         }
@@ -807,7 +944,7 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
     STRQ_HIP(c, hipSetDevice(c->device));
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
     std::fill(c->counters, c->counters + 8, 0.0);
-    c->second_round[0] = c->second_round[1] = 0; c->redo_prev = 0;
+    c->second_round[0] = c->second_round[1] = 0;
     for (double& v : c->screen_stats) v = 0;
     STRQ_HIP(c, c->redo_total.reserve(64));
     STRQ_HIP(c, hipMemsetAsync(c->redo_total.p, 0, 64, c->stream));
@@ -847,17 +984,35 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
         STRQ_DBG("sub-batch %zu: reads %ld..%ld  %.1f ms", k, (long)cuts[k], (long)cuts[k + 1], (now_s() - t1) * 1e3);
     }
     B.forget_host();      // the caller's buffers are not referenced after the call
-    std::fill(c->timing, c->timing + 8, 0.0f);
-    c->timing[0] = B.t_lut; c->timing[1] = B.t_fwd; c->timing[2] = B.t_trace; c->timing[5] = B.t_cond; c->timing[6] = B.t_vit;
-    c->timing[3] = B.t_lut + B.t_fwd + B.t_trace + B.t_cond + B.t_vit; c->timing[4] = (float)B.n_hard; c->timing[7] = (float)B.n_fwd_launches;
+    publish_timing(c, B);
     return STRQ_OK;
 }
 
 int strq_batch_fetch(strq_ctx* c, strq_result* out)
 {
     if (!c || !out) return STRQ_ERR_ARG;
+    strq::CtxScope scope_(c);
     DetectState* d = dstate(c);
+    STRQ_HIP(c, hipSetDevice(c->device));
+    { const int rc = drain(c, d); if (rc) return rc; }
     std::memcpy(out, d->batch.results.data(), d->batch.results.size() * sizeof(strq_result));
+    return STRQ_OK;
+}
+
+int strq_batch_fetch_range(strq_ctx* c, int64_t first, int64_t last, strq_result* out)
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    strq::CtxScope scope_(c);
+    DetectState* d = dstate(c);
+    if (first < 0 || last < first || last > d->batch.n_reads) { c->err = "read range outside the uploaded batch"; return STRQ_ERR_ARG; }
+    STRQ_HIP(c, hipSetDevice(c->device));
+    // only the sub-batches in flight that hold reads of the range are waited for (oldest first): a caller that runs range k + 1
+    // before it fetches range k never waits for the Viterbi launches of k + 1
+    for (int k = 0; k < 2; ++k) {
+        DetectState::Slot& sl = d->slot[(d->next_slot + k) & 1];
+        if (sl.active && sl.r0 < last && sl.r0 + sl.nr > first) { const int rc = harvest(c, d, sl); if (rc) return rc; }
+    }
+    std::memcpy(out, d->batch.results.data() + first, (size_t)(last - first) * sizeof(strq_result));
     return STRQ_OK;
 }
 
@@ -901,6 +1056,7 @@ int strq_debug_conditioning(strq_ctx* c, int64_t read, uint8_t* levels, int64_t 
 {
     if (!c) return STRQ_ERR_ARG;
     DetectState* d = dstate(c);
+    { const int drc = drain(c, d); if (drc) return drc; }
     ReadCond rc;
     STRQ_HIP(c, hipMemcpy(&rc, d->rc.as<ReadCond>() + read, sizeof(rc), hipMemcpyDeviceToHost));
     if (levels) STRQ_HIP(c, hipMemcpy(levels, c->levels.as<uint8_t>() + d->levels_shift + rc.off, (size_t)std::min<int64_t>(n, rc.n), hipMemcpyDeviceToHost));

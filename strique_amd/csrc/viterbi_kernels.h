@@ -122,7 +122,8 @@ int vit_shape_of(const VitModel& model_host);      // -1 if no compiled shape fi
 int vit_shape_for(const VitModel& model_host, int want_bp);      // the same, or VIT_SHAPE_G2 when the model has a register-resident image and the mode allows it
 int vit_shape_silent_slots(int shape);             // silent slots per lane of that kernel shape
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
-                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr);
+                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order = nullptr, int waves_hint = 0);
+// waves_hint 4: the launch shares the GPU with other kernels (register-resident shape: four waves per workgroup instead of eight)
 // want_bp: 0 = count only, 1 = back-pointers, 2 = repeat-section marks (flanked model), 3 = hub records (modification model)
 int launch_vit_sort(hipStream_t stream, const VitTask* tasks, int n, int* order);   // order by descending T (n <= 8192)
 int launch_vit_traceback(hipStream_t stream, const VitTask* tasks, const VitResult* results,

@@ -952,10 +952,13 @@ viterbi_g2_kernel(const VitTask* __restrict__ tasks, VitResult* __restrict__ res
     }
 }
 
-static int launch_viterbi_g2(hipStream_t stream, const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
+static int launch_viterbi_g2(hipStream_t stream, const VitTask* tasks, VitResult* results, int n_tasks, int* queue, int n_cu, int want_bp, const int* order, int waves_hint)
 {
     if (want_bp != 0 && want_bp != 2) return 2;
-    int nw = 8, lx = 2;
+    // one workgroup per CU: eight waves (two per SIMD, 2 x 192 VGPRs) when the launch has the GPU to itself; four (one per SIMD) when it
+    // shares the CUs with the next sub-batch's flank-alignment kernels, whose waves then find 320 VGPRs per SIMD instead of 128
+    // (gpurun_out/r6i: 175 against 180 ms per step of 4096 reads; alone, four waves take 83 ms against 64)
+    int nw = waves_hint == 4 ? 4 : 8, lx = 2;
     if (const char* e = strq::opt("STRQ_VIT_G2_WAVES")) { const int v = atoi(e); if (v == 12 || v == 8 || v == 4) nw = v; }      // experiments
     if (const char* e = strq::opt("STRQ_VIT_G2_LDS")) { const int v = atoi(e); if (v >= 0 && v <= 2) lx = v; }
     const dim3 grid(n_cu), block(64 * nw);
@@ -1265,12 +1268,12 @@ static int vit_launch_shape(hipStream_t stream, int max_cells, const VitTask* ta
 
 // `shape` as returned by vit_shape_of: kernel shape | VIT_SHAPE_SS for single-stage models
 int launch_viterbi(hipStream_t stream, int shape, int max_cells, const VitTask* tasks, VitResult* results,
-                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order)
+                   int n_tasks, int* queue, int n_cu, int want_bp, const int* order, int waves_hint)
 {
     const int ss = (shape & VIT_SHAPE_SS) ? 1 : 0;
     if ((shape & ~VIT_SHAPE_SS) == VIT_SHAPE_CSR) return launch_viterbi_csr(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, order);
     if ((shape & ~VIT_SHAPE_SS) == VIT_SHAPE_G2)
-        return launch_viterbi_g2(stream, tasks, results, n_tasks, queue, n_cu, want_bp, order);
+        return launch_viterbi_g2(stream, tasks, results, n_tasks, queue, n_cu, want_bp, order, waves_hint);
     switch (shape & ~VIT_SHAPE_SS) {
         case 0: return vit_launch_shape<4, 2, 6, 3, 3>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);
         case 1: return vit_launch_shape<1, 1, 8, 8, 4>(stream, max_cells, tasks, results, n_tasks, queue, n_cu, want_bp, ss, order);

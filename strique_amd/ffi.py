@@ -330,6 +330,12 @@ class Context(object):
         self._check(self._lib.strq_batch_fetch(self._h, _ptr(out)))
         return out
 
+    def batch_fetch_range(self, first, last):
+        """Rows of reads [first, last) (strq_batch_fetch_range): waits only for the sub-batches in flight that hold them."""
+        out = np.zeros(max(0, int(last) - int(first)), dtype=RESULT_DTYPE)
+        self._check(self._lib.strq_batch_fetch_range(self._h, ctypes.c_int64(first), ctypes.c_int64(last), _ptr(out)))
+        return out
+
     def detect_batch(self, signals, offsets, target_ids, host_stats=None):
         """strq_detect_batch: signals stay in this (host) buffer and are uploaded one sub-batch ahead of
         the kernels.  Use batch_upload / batch_run / batch_fetch to keep a batch resident in HBM."""

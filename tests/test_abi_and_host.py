@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.strq_abi_version() == 11
+    assert lib.strq_abi_version() == 12
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -183,7 +183,7 @@ def test_bench_line_single_gpu_small(screen, monkeypatch):
         assert legs["no_screen"]["screen"]["alignments_screened_per_step"] == 0 and re.match(r"align_forward_seg_kernel<14, 6, false, 4", legs["no_screen"]["roofline"]["kernel"])
         assert legs["fine_screen"]["roofline"]["kernel"] == "align_screen1_kernel" and legs["fine_screen"]["screen"]["mode"] == "fine"
         assert r["value_no_screen"] == legs["no_screen"]["value"] > 0 and r["value_degraded"] == legs["degraded"]["value"] > 0
-        assert legs["degraded"]["check"]["all_fields_equal"] and legs["degraded"]["planted_count_recovered"]["of"] == 512
+        assert legs["degraded"]["check"]["all_fields_equal"] and legs["degraded"]["planted_count_recovered"]["of"] == 1024
         assert r["roofline_viterbi"]["kernel"].startswith("viterbi_g2_kernel") and 0 < r["roofline_viterbi"]["frac"] < 1
         assert r["host"]["peak_host_rss_gb_per_rank"] > 0
     if screen:

@@ -245,7 +245,7 @@ def test_float64_reads_with_the_callers_own_statistics(gpu_counter, pm, targets)
     assert (own["count"] > 0).sum() >= 5
 
 
-def test_sub_batches_give_the_same_results(gpu_counter, pm, targets, monkeypatch):
+def test_sub_batches_give_the_same_results(gpu_counter, want, pm, targets, monkeypatch):
     """A batch larger than one sub-batch is processed in pieces (strq_batch_run); the pieces must not
     see each other: results equal those of the one-piece run, in input order."""
     rng = np.random.default_rng(21)
@@ -257,6 +257,53 @@ def test_sub_batches_give_the_same_results(gpu_counter, pm, targets, monkeypatch
     monkeypatch.setenv("STRQ_SUBBATCH_READS", "3")
     pieces = gpu_counter.detect_batch(items)
     assert pieces == whole
+    # two sub-batches in flight (the default: a sub-batch's Viterbi launches run under the next one's flank alignments, rows are
+    # taken one sub-batch late) against everything on one stream (STRQ_SERIAL, the order of rounds 1-5): the same rows
+    monkeypatch.setenv("STRQ_SERIAL", "1")
+    serial = gpu_counter.detect_batch(items)
+    assert serial == whole
+    monkeypatch.delenv("STRQ_SERIAL")
+    # an oracle row at either end of the batch (the last sub-batch is the one still in flight when the run call returns)
+    for i in (0, len(items) - 1):
+        name, sig, strand = items[i]
+        w = want(name, sig, strand)
+        assert tuple(pieces[i][:6]) == tuple(w[:6]), (i, pieces[i], w)
+
+
+def test_rows_of_a_range_while_the_next_is_in_flight(gpu_counter, pm, targets, monkeypatch):
+    """strq_batch_run_range returns with the Viterbi launches of its last sub-batch queued; strq_batch_fetch_range waits only for
+    the sub-batches that hold the rows asked for.  A resident batch of 12 reads run as four ranges, each fetched after the next has
+    been queued (bench.py's step loop), then again in one call and serially: the same rows every way -- and fetching a range that
+    was never run gives empty rows, not someone else's."""
+    rng = np.random.default_rng(5)
+    items = []
+    for k in range(12):
+        name = ["c9orf72", "fmr1"][k % 2]; strand = "+-"[(k // 2) % 2]
+        items.append((name, _read(pm, targets, name, strand, int(rng.integers(2500, 7000)), int(rng.integers(4, 60)), 4400 + k), strand))
+    ctx = gpu_counter.ctx
+    sigs = [np.ascontiguousarray(it[1]) for it in items]
+    off = np.zeros(len(sigs) + 1, np.int64); off[1:] = np.cumsum([len(x) for x in sigs])
+    tids = [gpu_counter._classifier_for(it[0], it[2]).target_id for it in items]
+    monkeypatch.setenv("STRQ_SUBBATCH_READS", "2")
+    ctx.batch_upload(np.concatenate(sigs), off, tids)
+    ctx.batch_run(); one_call = ctx.batch_fetch().copy()
+    ctx.batch_upload(np.concatenate(sigs), off, tids)
+    assert not ctx.batch_fetch_range(0, 12)["count"].any()          # nothing has run on this upload
+    got = np.zeros_like(one_call); prev = None
+    for lo in (0, 3, 6, 9):
+        ctx.batch_run_range(lo, lo + 3)
+        if prev is not None:
+            got[prev:prev + 3] = ctx.batch_fetch_range(prev, prev + 3)
+        prev = lo
+    got[prev:prev + 3] = ctx.batch_fetch_range(prev, prev + 3)
+    assert got.tobytes() == one_call.tobytes()
+    monkeypatch.setenv("STRQ_SERIAL", "1")
+    ctx.batch_upload(np.concatenate(sigs), off, tids)
+    ctx.batch_run()
+    assert ctx.batch_fetch().tobytes() == one_call.tobytes()
+    assert (one_call["count"] > 0).sum() >= 10
+    with pytest.raises(Exception):
+        ctx.batch_fetch_range(5, 13)
 
 
 def test_two_contexts_taking_turns_give_the_rows_of_one(gpu_counter, pm, cfg, targets):
