@@ -346,6 +346,7 @@ class Leg(object):
         self.geoms = []; self.last = {}; self.mine = []; self.elapsed = 0.0; self.steps = 0
         self.screen = {"ms": 0.0, "wave_steps": 0.0, "screened": 0.0, "windowed": 0.0, "whole_read": 0.0, "window_columns": 0.0, "scale": 0.0, "candidate_chunks": 0.0}
         self.second_round = [0, 0]; self.screen_mode = None; self.screen_merge = 0
+        self.overlap = {"viterbi_ms": 0.0, "under_screen_ms": 0.0, "under_alignment_stage_ms": 0.0, "sub_batches": 0.0}
 
     def rows(self, k, bi, res):
         self.last[bi] = res.copy()
@@ -369,6 +370,9 @@ class Leg(object):
         self.screen_mode = scr.get("mode", self.screen_mode); self.screen_merge = scr.get("merge", 0)
         sr = ctx.last_second_round()
         self.second_round[0] += sr[0]; self.second_round[1] += sr[1]
+        ov = ctx.last_overlap()
+        for key in self.overlap:
+            self.overlap[key] += ov[key]
         self.steps += 1
 
 
@@ -534,6 +538,22 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
         if achieved:
             roof["useful_achieved"] = achieved * (2.0 * sk_cells / scr_ip) * roof["lane_utilisation"]
             roof["useful_frac"] = roof["useful_achieved"] / valu_peak
+        ov = leg.overlap
+        vit_ip = prof.get("viterbi_valu_insts_per_time_step")
+        if achieved and vit_ip and ov["under_screen_ms"] > 0 and ov["viterbi_ms"] > 0 and scr_launch_s > 0:
+            # Two sub-batches in flight: the previous step's Viterbi launch (one wave per SIMD) runs on the same SIMDs while this launch
+            # lasts.  The issue rate of the launch window is the sum of both kernels' instructions over it; the screen's own rate is kept
+            # beside it, and the rate of the screen ALONE on the GPU comes from the serial leg (`kernel_alone`, filled in by main()).
+            vit_instr_per_step = vit_ip * leg.counters[7] / steps
+            in_window = vit_instr_per_step * ov["under_screen_ms"] / ov["viterbi_ms"]
+            co = in_window / max(1, scr_launches // steps) / scr_launch_s / 1e9
+            roof["achieved_own"] = achieved; roof["frac_own"] = achieved / valu_peak
+            roof["co_running"] = {"kernel": (prof.get("viterbi_kernel", "viterbi_g2_kernel<false, 8, 2>")).replace("<false, 8,", "<false, 4,") + " of the previous step, second stream",
+                                  "ms_under_this_launch_per_step": ov["under_screen_ms"] / steps, "viterbi_ms_per_step": ov["viterbi_ms"] / steps,
+                                  "achieved": co, "valu_insts_per_time_step": vit_ip}
+            roof["achieved"] = achieved + co; roof["frac"] = (achieved + co) / valu_peak
+            roof["kernel"] = sk_name + " + co-running " + roof["co_running"]["kernel"].split(" of ")[0]
+            roof["achieved_definition"] = "VALU instructions of BOTH kernels issued inside this launch's window (HIP events) / its duration"
     return roof
 
 
@@ -550,6 +570,10 @@ def viterbi_roofline(leg, prof):
            "ms_per_step": vit_ms, "time_steps_per_step": tsteps,
            "us_per_time_step_per_wave_slot": (vit_ms * 1e3) / max(1.0, tsteps / (8 * N_SIMD / 4)),
            "valu_insts_per_time_step": ip, "valu_insts_source": prof.get("viterbi_valu_source")}
+    if leg.overlap["under_alignment_stage_ms"] > 0:
+        out["kernel"] = out["kernel"].replace("<false, 8,", "<false, 4,")
+        out["co_running_share"] = leg.overlap["under_alignment_stage_ms"] / max(1e-9, leg.overlap["viterbi_ms"])
+        out["note"] = "the launch runs on a second stream under the next step's flank-alignment kernels (one wave per SIMD, sharing them): ms_per_step is its duration there, not GPU time it has to itself"
     if ip and vit_ms > 0:
         out["achieved"] = ip * tsteps / (vit_ms * 1e-3) / 1e9
         out["frac"] = out["achieved"] / valu_peak
@@ -563,6 +587,7 @@ def viterbi_roofline(leg, prof):
 def leg_summary(leg, reads, lens_one_batch, prof, nreps=None, n_batches=1):
     steps = max(1, leg.steps)
     out = {"value": reads * steps / leg.elapsed if leg.elapsed > 0 else None, "unit": "reads/s", "steps": leg.steps, "ms_per_step": leg.elapsed / steps * 1e3,
+           "overlap_ms_per_step": {k: v / steps for k, v in leg.overlap.items() if k != "sub_batches"},
            "stage_ms_per_step": {"conditioning": float(leg.stage_ms[5]) / steps, "score_tables": float(leg.stage_ms[0]) / steps,
                                  "forward_dp": float(leg.stage_ms[1]) / steps, "trace": float(leg.stage_ms[2]) / steps, "viterbi": float(leg.stage_ms[6]) / steps},
            "roofline": roofline_blocks(leg, lens_one_batch, prof),
@@ -861,6 +886,14 @@ def main():
             ctx.set_option("STRQ_SCREEN_MODE", "fine")
             legs["fine_screen"] = leg_summary(run_leg(ctx, args.reads, n_batches, args.leg_steps, 1, k_step), args.reads, one, prof, nreps, n_batches)
             ctx.set_option("STRQ_SCREEN_MODE", None)
+            ctx.set_option("STRQ_SERIAL", "1")          # one sub-batch at a time, every kernel alone on the GPU (the order of rounds 1-5)
+            legs["serial"] = leg_summary(run_leg(ctx, args.reads, n_batches, args.leg_steps, 1, k_step), args.reads, one, prof, nreps, n_batches)
+            ctx.set_option("STRQ_SERIAL", None)
+            out["value_serial"] = legs["serial"]["value"]
+            sr_, sv_ = legs["serial"]["roofline"], legs["serial"]["roofline_viterbi"]
+            out["roofline"]["kernel_alone"] = {"kernel": sr_.get("kernel"), "avg_launch_ms": sr_.get("avg_launch_ms"), "achieved": sr_.get("achieved"), "frac": sr_.get("frac"),
+                                               "source": "legs.serial of this run (STRQ_SERIAL=1: the launch has the GPU to itself)"}
+            out["roofline_viterbi"]["kernel_alone"] = {"kernel": sv_.get("kernel"), "ms_per_step": sv_.get("ms_per_step"), "frac": sv_.get("frac"), "frac_of_float64_issue": sv_.get("frac_of_float64_issue")}
             out["value_no_screen"] = legs["no_screen"]["value"]
             out["value_fine_screen"] = legs["fine_screen"]["value"]
             out["roofline_no_screen"] = legs["no_screen"]["roofline"]
@@ -954,11 +987,20 @@ def compact_line(out, detail_path=None):
     line["roofline"] = _pick(roof, ("bound", "kernel", "unit", "achieved", "peak", "frac", "traffic", "avg_launch_ms", "launches_per_step",
                                     "wave_steps_per_launch", "valu_insts_per_wave_step", "valu_insts_source", "lane_utilisation", "gcups"))
     line["roofline"].setdefault("traffic", None)
+    for k in ("achieved_own", "frac_own"):
+        if roof.get(k) is not None:
+            line["roofline"][k] = _r(roof[k])
+    if isinstance(roof.get("co_running"), dict):
+        line["roofline"]["co_running"] = _pick(roof["co_running"], ("kernel", "ms_under_this_launch_per_step", "achieved"))
+    if isinstance(roof.get("kernel_alone"), dict):
+        line["roofline"]["kernel_alone"] = _pick(roof["kernel_alone"], ("avg_launch_ms", "frac"))
     ex = roof.get("exact_pass")
     if isinstance(ex, dict):
         line["roofline"]["exact_pass"] = _pick(ex, ("kernel", "ms_per_step", "frac", "columns_computed_over_columns_of_the_reads"))
     if out.get("roofline_viterbi"):
-        line["roofline_viterbi"] = _pick(out["roofline_viterbi"], ("kernel", "ms_per_step", "achieved", "peak", "frac", "frac_of_float64_issue", "valu_insts_per_time_step"))
+        line["roofline_viterbi"] = _pick(out["roofline_viterbi"], ("kernel", "ms_per_step", "achieved", "peak", "frac", "frac_of_float64_issue", "valu_insts_per_time_step", "co_running_share"))
+        if isinstance(out["roofline_viterbi"].get("kernel_alone"), dict):
+            line["roofline_viterbi"]["kernel_alone"] = _pick(out["roofline_viterbi"]["kernel_alone"], ("ms_per_step", "frac", "frac_of_float64_issue"))
     if out.get("stage_ms_per_step"):
         line["stage_ms_per_step"] = {k: _r(v, 4) for k, v in out["stage_ms_per_step"].items()}
     cb = out.get("cpu_baseline")
@@ -971,7 +1013,7 @@ def compact_line(out, detail_path=None):
             c["extrapolated"] = {"cores": cb["extrapolated_physical_cores"].get("cores"), "reads_per_s": _r(cb["extrapolated_physical_cores"].get("reads_per_s")), "measured": False}
         line["cpu_baseline"] = c
         line["vs_cpu_baseline"] = _r(out.get("vs_cpu_baseline"))
-    for k in ("value_no_screen", "value_fine_screen", "value_degraded", "value_degraded_serial", "host_inclusive_reads_per_s", "resident_reads_per_s"):
+    for k in ("value_serial", "value_no_screen", "value_fine_screen", "value_degraded", "value_degraded_serial", "host_inclusive_reads_per_s", "resident_reads_per_s"):
         if out.get(k) is not None:
             line[k] = _r(out[k])
     hb = out.get("host_buffers")

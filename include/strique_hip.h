@@ -35,7 +35,7 @@ extern "C" {
 typedef struct strq_ctx strq_ctx;
 
 /* Version of this ABI (bumped on any signature change). */
-int strq_abi_version(void);   /* currently 12 (12: strq_batch_fetch_range, two sub-batches in flight; 11: strq_set_option, strq_get_option, strq_batch_upload_part, strq_last_screen_mode; 10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
+int strq_abi_version(void);   /* currently 12 (12: strq_batch_fetch_range, strq_last_overlap, two sub-batches in flight; 11: strq_set_option, strq_get_option, strq_batch_upload_part, strq_last_screen_mode; 10: strq_last_screen, strq_debug_screen_plan; 9: strq_last_viterbi_launches, strq_last_second_round, strq_inflate_backend, strq_inflate_many, strq_inflate_stats, strq_h5_locate, strq_vbz_chunks; 8: strq_model_set_positions; 5: strq_host_stats, host_stats of strq_detect_batch / strq_batch_upload optional; 6: strq_detect_batch_reads; 7: strq_last_geometry, strq_batch_run_range, strq_inflate_chunks) */
 
 /* Create a context on HIP device `device_id`.  Fails (STRQ_ERR_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -337,6 +337,11 @@ int strq_last_screen(const strq_ctx* ctx, double out[8]);
  * (it did not pay on the last one it ran on)   [3] the coarse screen's candidate margin in score units (x 1.3 / 1.75 at three / six
  * rows per DP row)   [4] flank rows per DP row of the coarse screen that ran (2, 3 or 6; kernel align_screen<that>_kernel)   [5..7] 0. */
 int strq_last_screen_mode(const strq_ctx* ctx, int32_t out[8]);
+/* The two sub-batches in flight, since the start of the last run call: [0] ms of HMM Viterbi launches whose rows were taken
+ * [1] of them, ms that lay under the screen kernel of the sub-batch that followed   [2] ... under its whole alignment stage
+ * (screen, exact pass, trace)   [3] sub-batches counted in [1], [2] (those whose rows were taken by the following sub-batch's run
+ * call; a sub-batch nobody followed runs its Viterbi launches alone). */
+int strq_last_overlap(const strq_ctx* ctx, double out[4]);
 
 #ifdef __cplusplus
 }

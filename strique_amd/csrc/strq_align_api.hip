@@ -78,7 +78,24 @@ struct BatchOut { float* score; int64_t* j_end; int64_t* j0; int32_t* rec; };
 // One sub-batch of alignments whose reads (levels, level values) are already in HBM.
 // Leaves AlignTask / AlignResult / rec on the device in task order (`out.order[pos]` = index of
 // the alignment handled by task `pos`).
+static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out, bool allow_bail, bool* bailed);
+
+// One attempt -- or two: a sub-batch on which the coarse screen's first look certifies less than two thirds of the alignments is not
+// worth its second look (on such reads the chunks that reach the score found cover most of the read: gpurun_out/r5r, r6d -- 650 ms for a
+// forward stage the fine screen does in 253).  The attempt stops there, the coarse screen pauses, and the sub-batch starts over with the
+// fine screen: ~150 ms lost to the retry instead of ~390.
 int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
+{
+    double saved[8];
+    std::memcpy(saved, c->screen_stats, sizeof(saved));
+    bool bailed = false;
+    const int rc = align_core_once(c, in, out, true, &bailed);
+    if (rc || !bailed) return rc;
+    std::memcpy(c->screen_stats, saved, sizeof(saved));
+    return align_core_once(c, in, out, false, &bailed);
+}
+
+static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out, bool allow_bail, bool* bailed)
 {
     const int nb = in.nb, S = in.samples;
     hipStream_t st = c->stream;
@@ -942,6 +959,23 @@ int align_core(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out)
                 else redo_keep[li].push_back(a);
             }
         }
+        {
+            // more than a third of the alignments missed the first look's certificate: stop here (align_core starts the sub-batch over)
+            size_t n_redo = l2.size();
+            for (auto& v : redo_keep) n_redo += v.size();
+            const bool forced = scr_forced || mode_coarse || c->screen_mode_last == 1;
+            if (allow_bail && !forced && nb >= 64 && 3 * n_redo > (size_t)nb && !strq::opt("STRQ_SCREEN2_NO_BAIL")) {
+                c->coarse_pause = std::min(256, 8 << std::min(c->coarse_fail, 5)); ++c->coarse_fail;
+                float ms = 0;
+                STRQ_HIP(c, hipEventRecord(c->ev[3], st));
+                STRQ_HIP(c, hipStreamSynchronize(st));
+                STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->aborted_fwd_ms += ms;
+                STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[5], c->ev[6])); c->aborted_screen_ms += ms;
+                STRQ_DBG("coarse screen: %zu of %d alignments missed the first look's certificate -> the sub-batch starts over with the fine screen, pause %d", n_redo, nb, c->coarse_pause);
+                *bailed = true;
+                return STRQ_OK;
+            }
+        }
         if (!l2.empty()) {
             const int n2 = (int)l2.size();
             // device scratch: list, thresholds, windows, positions, piece results, alignment results, picks
@@ -1104,7 +1138,9 @@ int align_core_times(strq_ctx* c, float* t_lut, float* t_fwd, float* t_tr)
 {
     float ms;
     STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); *t_lut += ms;
-    STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); *t_fwd += ms;
+    STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); *t_fwd += ms + c->aborted_fwd_ms;
+    c->screen_stats[0] += c->aborted_screen_ms;          // an attempt that was stopped after the coarse screen's first look (align_core)
+    c->aborted_fwd_ms = c->aborted_screen_ms = 0;
     STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); *t_tr += ms;
     if (c->screen_ran) { STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[5], c->ev[6])); c->screen_stats[0] += ms; }
     return STRQ_OK;
@@ -1316,6 +1352,12 @@ int strq_debug_screen_plan(const float params[6], int32_t samples, int32_t max_n
     return 1;
 }
 
+int strq_last_overlap(const strq_ctx* c, double out[4])
+{
+    if (!c || !out) return STRQ_ERR_ARG;
+    for (int i = 0; i < 4; ++i) out[i] = c->overlap[i];
+    return STRQ_OK;
+}
 int strq_last_screen(const strq_ctx* c, double out[8])
 {
     if (!c || !out) return STRQ_ERR_ARG;

@@ -96,6 +96,7 @@ struct strq_ctx {
     int64_t second_round[2] = {};             // strq_last_second_round: alignments that ran the second forward round / alignments, last batched call
     strq::DevBuf redo_total;                  // device counter behind second_round[0]
     double screen_stats[8] = {};              // strq_last_screen
+    double overlap[4] = {};                   // strq_last_overlap
     bool screen_ran = false;                  // the last align_core call ran the screen (events 5, 6 bracket it)
     // The screen pays when nearly every alignment gets windows (a read that holds its flank clearly) and costs a pass when not:
     // a sub-batch in which fewer than 90 % did, whose windows hold more than 6 % of the columns, or in which more than one alignment
@@ -107,6 +108,7 @@ struct strq_ctx {
     int coarse_pause = 0;
     int coarse_fail = 0, screen_fail = 0;     // consecutive sub-batches on which the coarse / the fine screen did not pay: the pause doubles (8, 16, ... 256)
     float coarse_margin = 384.0f;
+    float aborted_fwd_ms = 0, aborted_screen_ms = 0;      // forward / screen time of an attempt align_core stopped and started over (added to the call's times)
     int screen_mode_last = 0;                 // screen of the last align_core call: 0 none, 1 fine, 2 coarse
     int coarse_merge_last = 0;                // ... and the flank rows per DP row of the coarse one
     

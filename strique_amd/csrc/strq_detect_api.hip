@@ -463,7 +463,7 @@ static int launch_viterbi_of(strq_ctx* c, DetectState* d, DetectState::Slot& sl,
 
 // Results of a sub-batch whose Viterbi launches were queued earlier: waits for them, fills Batch::results (and runs the
 // modification pass of the sub-batch, which needs the decoded repeat stretch on the host).
-static int harvest(strq_ctx* c, DetectState* d, DetectState::Slot& sl)
+static int harvest(strq_ctx* c, DetectState* d, DetectState::Slot& sl, bool under_current = false)
 {
     if (!sl.active) return STRQ_OK;
     sl.active = false;
@@ -493,6 +493,19 @@ static int harvest(strq_ctx* c, DetectState* d, DetectState::Slot& sl)
     }
     float ms;
     STRQ_HIP(c, hipEventElapsedTime(&ms, sl.v0, sl.v1)); B.t_vit += ms;
+    c->overlap[0] += ms;
+    if (under_current) {
+        // how much of these launches lay under the alignment kernels of the sub-batch that followed (whose events are the context's
+        // current ones): [forward stage start, trace end], and the screen kernel alone
+        auto under = [&](hipEvent_t a, hipEvent_t b) -> double {
+            float ta = 0, tb = 0;
+            if (hipEventElapsedTime(&ta, sl.v0, a) != hipSuccess || hipEventElapsedTime(&tb, sl.v0, b) != hipSuccess) return 0.0;
+            return std::max(0.0, std::min((double)ms, (double)tb) - std::max(0.0, (double)ta));
+        };
+        if (c->screen_ran) c->overlap[1] += under(c->ev[5], c->ev[6]);
+        c->overlap[2] += under(c->ev[2], c->ev[4]);
+        c->overlap[3] += 1;
+    }
     publish_timing(c, B);
     if (any_mod) return run_mod_pass(c, d, sl, r0, nr, rc_out, geom, vres, sl.vit_slot);
     return STRQ_OK;
@@ -538,7 +551,8 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         }
     }
     loff[nr] = tot;
-    STRQ_HIP(c, sl.flt.reserve((size_t)tot * esz + 64 + 16));
+    // both slots are sized together: the first sub-batch on the second slot would otherwise pay a 3 GB hipMalloc in the middle of a run
+    for (DetectState::Slot* q : {&sl, &other}) if (q == &sl || !q->active) STRQ_HIP(c, q->flt.reserve((size_t)tot * esz + 64 + 16));
     STRQ_HIP(c, c->levels.reserve((size_t)tot + 64 + 8));
     STRQ_HIP(c, c->level_val.reserve((size_t)nr * 256 * 4));
     STRQ_HIP(c, d->rc.reserve((size_t)nr * sizeof(ReadCond)));
@@ -597,21 +611,24 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     STRQ_HIP(c, hipMemcpyAsync(d_model_of, model_of.data(), (size_t)nr * 8, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, hipMemcpyAsync(d_slot, vit_slot.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
     STRQ_HIP(c, d->geom.reserve((size_t)nr * sizeof(ReadGeom)));
-    STRQ_HIP(c, sl.vit.reserve((size_t)nr * sizeof(VitTask)));
-    STRQ_HIP(c, sl.vres.reserve((size_t)nr * sizeof(VitResult)));
-    STRQ_HIP(c, sl.order.reserve((size_t)nr * 4 + 64));
-    STRQ_HIP(c, sl.vq.reserve(1024));
-    {
+    for (DetectState::Slot* q : {&sl, &other}) {
+        if (q != &sl && q->active) continue;          // (in flight: its buffers are in use and large enough for what it holds)
+        STRQ_HIP(c, q->vit.reserve((size_t)nr * sizeof(VitTask)));
+        STRQ_HIP(c, q->vres.reserve((size_t)nr * sizeof(VitResult)));
+        STRQ_HIP(c, q->order.reserve((size_t)nr * 4 + 64));
+        STRQ_HIP(c, q->vq.reserve(1024));
         const size_t need = (size_t)nr * (sizeof(ReadGeom) + sizeof(VitResult) + sizeof(ReadCond)) + 64;
-        if (need > sl.pinned_cap) {
-            if (sl.pinned) { STRQ_HIP(c, hipHostFree(sl.pinned)); sl.pinned = nullptr; sl.pinned_cap = 0; }
-            STRQ_HIP(c, hipHostMalloc(&sl.pinned, need + need / 8, hipHostMallocDefault));
-            sl.pinned_cap = need + need / 8;
+        if (need > q->pinned_cap) {
+            if (q->pinned) { STRQ_HIP(c, hipHostFree(q->pinned)); q->pinned = nullptr; q->pinned_cap = 0; }
+            STRQ_HIP(c, hipHostMalloc(&q->pinned, need + need / 8, hipHostMallocDefault));
+            q->pinned_cap = need + need / 8;
         }
-        if (!sl.fwd_done) {
-            STRQ_HIP(c, hipEventCreateWithFlags(&sl.fwd_done, hipEventDisableTiming));
-            STRQ_HIP(c, hipEventCreate(&sl.v0)); STRQ_HIP(c, hipEventCreate(&sl.v1));
+        if (!q->fwd_done) {
+            STRQ_HIP(c, hipEventCreateWithFlags(&q->fwd_done, hipEventDisableTiming));
+            STRQ_HIP(c, hipEventCreate(&q->v0)); STRQ_HIP(c, hipEventCreate(&q->v1));
         }
+    }
+    {
         if (!d->vit_stream) {
             // the older sub-batch's Viterbi launches go first where both streams have workgroups to place
             int lo = 0, hi = 0;
@@ -765,7 +782,8 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         (void)hipEventElapsedTime(&a, other.v0, c->ev[5]); (void)hipEventElapsedTime(&e, other.v0, c->ev[6]); (void)hipEventElapsedTime(&b, other.v0, other.v1);
         STRQ_DBG("overlap: Viterbi launches of the previous sub-batch start at 0, end at %.1f ms; this sub-batch's screen runs from %.1f to %.1f ms", b, a, e);
     }
-    return harvest(c, d, serial ? sl : other);
+    if (serial) return harvest(c, d, sl);
+    return harvest(c, d, other, /*under_current=*/true);
 }
 
 }  // namespace strq
@@ -944,6 +962,7 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
     STRQ_HIP(c, hipSetDevice(c->device));
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
     std::fill(c->counters, c->counters + 8, 0.0);
+    std::fill(c->overlap, c->overlap + 4, 0.0);
     c->second_round[0] = c->second_round[1] = 0;
     for (double& v : c->screen_stats) v = 0;
     STRQ_HIP(c, c->redo_total.reserve(64));

@@ -221,6 +221,13 @@ class Context(object):
         out["coarse_pause"], out["fine_pause"], out["coarse_margin"], out["merge"] = int(m[1]), int(m[2]), int(m[3]), int(m[4])
         return out
 
+    def last_overlap(self):
+        """strq_last_overlap as a dict: Viterbi ms harvested since the last run call started, and how much of it lay under the
+        following sub-batch's screen kernel / whole alignment stage."""
+        g = np.zeros(4, np.float64)
+        self._check(self._lib.strq_last_overlap(self._h, _ptr(g)))
+        return dict(zip(("viterbi_ms", "under_screen_ms", "under_alignment_stage_ms", "sub_batches"), (float(v) for v in g)))
+
     def last_geometry(self):
         """strq_last_geometry as a dict: which forward-DP kernel instance the last batched call ran."""
         g = np.zeros(8, np.int32)

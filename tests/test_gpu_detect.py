@@ -574,6 +574,40 @@ def test_empirical_noise_reads_equal_the_oracle(pm, cfg, targets):
             assert tuple(a[:6]) == tuple(w[:6]), (key, strand, w, a)
 
 
+def test_a_hopeless_coarse_attempt_starts_over_with_the_fine_screen(pm, cfg, targets):
+    """Forty empirical-noise reads (80 alignments: the pause rules apply from 64 on).  The coarse screen's first look certifies hardly
+    any of them; instead of a second look over most of their columns the sub-batch starts over with the fine screen (align_core) and
+    the coarse screen pauses.  The rows are those of the fine screen alone and of a run with that rule switched off
+    (STRQ_SCREEN2_NO_BAIL), byte for byte, and the oracle's on six of them."""
+    import oracle_pool
+    from strique_amd import synth
+    from strique_amd.counter import repeatCounter
+    table = synth.KmerTable(pm)
+    noise = synth.EmpiricalNoise()
+    items = []
+    for i in range(40):
+        strand = "+-"[i % 2]
+        sig = synth.make_read(table, 7, 9100 + i, 50000, targets["c9orf72"], (200, 500, 1000, 1500)[i % 4], strand=strand, noise=noise)[0]
+        items.append(("c9orf72", sig, strand))
+    rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    rc.add_target("c9orf72", *targets["c9orf72"])
+    got = rc.detect_batch(items); scr = rc.ctx.last_screen()
+    assert scr["mode"] == "fine" and scr["coarse_pause"] >= 7 and scr["screened"] == 80, scr          # started over: the fine screen's figures only
+    rc.ctx.set_option("STRQ_SCREEN_MODE", "fine")
+    fine = rc.detect_batch(items)
+    rc.ctx.close()
+    rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
+    rc.add_target("c9orf72", *targets["c9orf72"])
+    rc.ctx.set_option("STRQ_SCREEN2_NO_BAIL", "1")
+    through = rc.detect_batch(items); scr2 = rc.ctx.last_screen()
+    rc.ctx.close()
+    assert scr2["mode"] == "coarse" and scr2["coarse_pause"] >= 7, scr2
+    assert got == fine == through
+    want = oracle_pool.detect_many([(sig, strand, targets[name]) for name, sig, strand in items[:6]])
+    for (name, sig, strand), w, a in zip(items[:6], want, got[:6]):
+        assert tuple(a[:6]) == tuple(w[:6]), (strand, w, a)
+
+
 def test_every_flank_length_of_the_fourteen_row_shape(pm, cfg, orc, opm, monkeypatch):
     """Flanks of 134 ... 154 nt (129 ... 149 k-mer classes, 774 ... 894 flank rows) all run at 14 rows per lane, and the last
     flank row sits in register (m - 1) % 14 of its lane -- 1, 3, ..., 13 over this range.  Round 3 knew that register at
