@@ -338,6 +338,72 @@ def stage_resident(ctx, counter, args, first_read, n_batches, workers, workload,
     return np.array(lens, np.int64), strands_all, nreps_all, kept, t_gen, t_up
 
 
+def stage_resident_shared(ctx, counter, args, n_batches, workers, workload, rank, world, dist, keep_first):
+    """N > 1: the job's reads are synthesised ONCE -- every rank makes 1 / N of a pool of `n_batches` batches (14 ms of numpy per 50 kb
+    read: 3 x 4096 reads per rank on 16 / N CPUs each would be minutes of set-up at N = 8) and writes its share to /dev/shm; after a
+    barrier every rank uploads the whole pool from there in its own order: rank r starts with pool batch r mod n_batches and rotates
+    the reads inside a batch by r x reads / N, so no two ranks run the same launch at the same time.  Returns what stage_resident
+    returns (lengths, strands, planted counts in THIS rank's order)."""
+    import shutil
+    total = n_batches * args.reads
+    tag = [None]
+    if rank == 0:
+        tag[0] = "strq_bench_%d_%d" % (os.getpid(), int(time.time()))
+    dist.broadcast_object_list(tag, src=0)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else os.environ.get("TMPDIR", "/tmp")
+    pool_dir = os.path.join(base, tag[0])
+    os.makedirs(pool_dir, exist_ok=True)
+    t0 = time.time()
+    lo, hi = total * rank // world, total * (rank + 1) // world
+    for p0 in range(lo, hi, 512):
+        cnt = min(512, hi - p0)
+        sigs, strands, nreps = make_batches_parallel(cnt, args.read_nt, p0, workers, workload)
+        off = np.zeros(cnt + 1, np.int64); off[1:] = np.cumsum([len(x) for x in sigs])
+        np.save(os.path.join(pool_dir, "sig_%08d.npy" % p0), np.concatenate(sigs))
+        np.savez(os.path.join(pool_dir, "meta_%08d.npz" % p0), off=off, strands=np.array([st == "+" for st in strands]), nreps=np.array(nreps, np.int64))
+        del sigs
+    t_gen = time.time() - t0
+    dist.barrier()
+    # the pool's parts, in pool order
+    parts = sorted(int(f[4:12]) for f in os.listdir(pool_dir) if f.startswith("sig_"))
+    meta = {}
+    for p0 in parts:
+        m = np.load(os.path.join(pool_dir, "meta_%08d.npz" % p0))
+        meta[p0] = (m["off"], m["strands"], m["nreps"])
+    pool_len = np.concatenate([np.diff(meta[p0][0]) for p0 in parts]); pool_plus = np.concatenate([meta[p0][1] for p0 in parts]); pool_nrep = np.concatenate([meta[p0][2] for p0 in parts])
+    part_of = np.concatenate([np.full(len(meta[p0][2]), p0) for p0 in parts]); idx_in = np.concatenate([np.arange(len(meta[p0][2])) for p0 in parts])
+    order = np.concatenate([((b + rank) % n_batches) * args.reads + (np.arange(args.reads) + rank * args.reads // world) % args.reads for b in range(n_batches)])
+    est = int(pool_len.sum())
+    t0 = time.time()
+    lens, strands_all, nreps_all, kept = [], [], [], {}
+    cache = {}
+    for q0 in range(0, total, 512):
+        ids = order[q0:q0 + 512]
+        part = []
+        for g in ids:
+            p0 = int(part_of[g])
+            if p0 not in cache:
+                if len(cache) > 3:
+                    cache.pop(next(iter(cache)))
+                cache[p0] = np.load(os.path.join(pool_dir, "sig_%08d.npy" % p0), mmap_mode="r")
+            o = meta[p0][0]; j = int(idx_in[g])
+            part.append(np.asarray(cache[p0][o[j]:o[j + 1]]))
+        st = ["+" if pool_plus[g] else "-" for g in ids]
+        tids = [counter._classifier_for("c9orf72", x).target_id for x in st]
+        off = np.zeros(len(part) + 1, np.int64); off[1:] = np.cumsum([len(x) for x in part])
+        ctx.batch_upload_part(total, est, q0, np.concatenate(part), off, tids)
+        lens += [len(x) for x in part]; strands_all += st; nreps_all += [int(pool_nrep[g]) for g in ids]
+        for k, x in enumerate(part):
+            if (q0 + k) % args.reads < keep_first:
+                kept[q0 + k] = x.copy()
+    t_up = time.time() - t0
+    cache.clear()
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(pool_dir, ignore_errors=True)
+    return np.array(lens, np.int64), strands_all, nreps_all, kept, t_gen, t_up
+
+
 class Leg(object):
     """Measurements of a run of steps on one context (what the roofline blocks are priced with)."""
 
@@ -622,13 +688,16 @@ def main():
     ap.add_argument("--gather-every-step", action="store_true", help="N > 1: run the result gather after every step instead of once after the last one")
     ap.add_argument("--dump-rows", default=None, help="testing: rank 0 saves the gathered table of the timed steps (numpy .npy) here")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive strq_detect_batch measurement")
-    ap.add_argument("--host-leg-batches", type=int, default=3, help="sub-batches of the PCIe-inclusive leg")
+    ap.add_argument("--host-leg-batches", type=int, default=8, help="sub-batches of the PCIe-inclusive leg (the resident batches in rotation: only the first one's upload is exposed)")
     ap.add_argument("--no-legs", action="store_true", help="skip the A/B legs (no screen, fine screen, degraded reads) that follow the headline measurement at N = 1")
     ap.add_argument("--leg-steps", type=int, default=3, help="timed steps of every A/B leg (after one untimed step)")
     ap.add_argument("--degraded-reads", type=int, default=0, help="reads of the degraded-read leg (0: --reads)")
     ap.add_argument("--workload", default="clean", choices=["clean", "empirical"], help="reads of the headline measurement (clean = BASELINE configs[2])")
     ap.add_argument("--check", type=int, default=2, help="reads verified against the CPU oracle, all six fields (LUT variant: same bits)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the result gather for N > 1 (nccl = RCCL)")
+    ap.add_argument("--private-reads", action="store_true", help="N > 1: every rank synthesises its own batches (default: one pool for the job, made once, 1 / N per rank, read by all in different orders)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --reads per GPU per step whatever N (the default); strong: --total-reads per step for the whole job, 1 / N of them per GPU")
+    ap.add_argument("--total-reads", type=int, default=0, help="--scaling strong: reads of one step over all GPUs (BASELINE configs[3]: 100000)")
     ap.add_argument("--detail", default=None, help="where rank 0 writes the full record (default: gpurun_out/bench_detail.json); the line on stdout is the compact one")
     ap.add_argument("--share-device", action="store_true", help="testing only: all ranks use HIP device 0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -639,6 +708,13 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus, or plainly (bench.py starts its own rank processes)" % (args.gpus, world))
     n_batches = max(1, args.batches)
+    if args.scaling == "strong":
+        # a fixed job: --total-reads per step, rank r takes its 1 / N (rounded up: the last ranks' rows of padding are real reads too, so the
+        # job never does less than it says); two resident batches per GPU so that the footprint stays that of the weak mode
+        if args.total_reads <= 0:
+            raise SystemExit("bench.py: --scaling strong needs --total-reads")
+        args.reads = -(-args.total_reads // world)
+        n_batches = max(1, min(n_batches, 2))
     device = 0 if args.share_device else local
     if world > 1 and not args.share_device:
         have = visible_devices()
@@ -693,8 +769,11 @@ def main():
     first_read = rank * n_batches * args.reads
     want_host_leg = (not args.no_host_leg) and world == 1
     keep_first = max(args.check, 0)
-    lens, strands, nreps, kept, t_gen, t_up = stage_resident(ctx, counter, args, first_read, n_batches, synth_workers, args.workload,
-                                                              keep_first=max(keep_first, 256 if (world == 1 and not args.no_cpu_baseline) else 0), keep_all=want_host_leg)
+    if world > 1 and not args.private_reads:
+        lens, strands, nreps, kept, t_gen, t_up = stage_resident_shared(ctx, counter, args, n_batches, synth_workers, args.workload, rank, world, dist, keep_first)
+    else:
+        lens, strands, nreps, kept, t_gen, t_up = stage_resident(ctx, counter, args, first_read, n_batches, synth_workers, args.workload,
+                                                                  keep_first=max(keep_first, 256 if (world == 1 and not args.no_cpu_baseline) else 0), keep_all=want_host_leg)
     tids = [counter._classifier_for("c9orf72", st).target_id for st in strands]
 
     def barrier():
@@ -803,7 +882,7 @@ def main():
         out = {
             "metric": "reads/s for STRique 'count' on 50 kb r9.4 signals", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "value_definition": "whole-job reads/s with the int16 signals resident in HBM when the timed region starts (the benchmark "
                                 "contract); `host_inclusive_reads_per_s` is the same pipeline with the signals starting in pageable host "
                                 "RAM (SURVEY.md 8d's wording), uploads overlapped with the kernels",
@@ -813,7 +892,9 @@ def main():
                     % ("SURVEY.md 8d recipe" if args.workload == "clean" else "noise resampled from the bundled real read: strique_amd.synth.EmpiricalNoise", n_batches),
             "config": {"workload": "BASELINE configs[2]: %d reads/GPU/step, %d nt (N~%d samples), C9orf72 GGGGCC x {200,500,1000,1500,2000}%s"
                                    % (args.reads, args.read_nt, n_samples // max(1, args.reads), "" if args.workload == "clean" else " -- EMPIRICAL noise, not the BASELINE recipe"),
-                       "reads_per_gpu_per_step": args.reads, "read_nt": args.read_nt, "distinct_batches_per_gpu": n_batches,
+                       "reads_per_gpu_per_step": args.reads, "total_reads": (args.total_reads if args.scaling == "strong" else None), "read_nt": args.read_nt, "distinct_batches_per_gpu": n_batches,
+                       "reads_pool": None if world == 1 else ("one pool per rank" if args.private_reads else "one pool for the job (every rank makes 1/N of it, all ranks run all of it in rotated orders)"),
+                       "boundary": "int16 signals resident in HBM when the clock starts (benchmark contract); host_inclusive_reads_per_s = the same from pageable host RAM (SURVEY.md 8d)",
                        "sharding": "reads over ranks, no data-path collective"},
             "world_size_seen_by_the_collective": world_seen[0],
             "collective": None if world == 1 else {"what": "all_gather of the result records to rank 0 (%s)" % ("RCCL" if coll_backend == "nccl" else coll_backend),

@@ -499,9 +499,7 @@ def run_count(stream, loci, get_raw, counter, log, batch_size, rank=0, world=1, 
     batch = []
 
     def fetch_many(qnames):
-        from .fast5 import SlabAllocator
-        # STRQ_READ_SLABS=1: the reads of a task share huge-page slabs instead of one numpy array each (tools/reader_probe.py)
-        alloc = SlabAllocator() if takes_alloc and os.environ.get("STRQ_READ_SLABS") else None
+        alloc = None          # (huge-page slabs shared by the reads of a task measured no gain over one inflate call per task: profiles/r04_reader.md -- removed)
         if not takes_alloc or os.environ.get("STRQ_READ_ONE_BY_ONE"):
             return [fetch(q, alloc) for q in qnames]
         # compressed datasets: located first (Python, under the interpreter lock), then inflated together in one native call

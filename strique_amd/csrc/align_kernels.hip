@@ -1103,7 +1103,6 @@ int launch_align_segments(hipStream_t stream, int R, int S, const AlignTask* tas
                           int tables_per_cu, int n_cu, int packed, const int* group_list, const int* n_list, bool known_last_row)
 {
     if (!(p.open_h == p.ext_h && p.open_v == p.ext_v)) return 2;
-    if (strq::opt("STRQ_DP_SWITCHED")) known_last_row = false;          // A/B: the switched loop for STRique's own flanks too
     AlignParams ps = p;
     if (packed) { ps.open_h *= STRQ_PK_SCALE; ps.ext_h *= STRQ_PK_SCALE; ps.open_v *= STRQ_PK_SCALE; ps.ext_v *= STRQ_PK_SCALE; }
     const int wpe = align_segments_wpe(segs, tables_per_cu);

@@ -456,11 +456,10 @@ size_t screen2_lds_bytes(int tsize_a, int tsize_b)
     return (size_t)(((tsize_a + 1) & ~1) + 2 + ((tsize_b + 1) & ~1) + 2) * 2;
 }
 
-// one kernel per merge factor: 2 (three DP rows per class, 15 per lane), 3 (two per class), 6 (one per class)
+// MERGE = 3: two DP rows per class, ten per lane.  (Rounds 5 measured MERGE 2 and 6 as well -- 114.4 and 96.6 ms per 4096 reads against
+// 94.7, with 2.4 % / 14 % of the alignments in the second look against 6 %: DESIGN.md 4.2e -- those instances are gone.)
 #define STRQ_SCREEN2_ATTR(WPE_) __attribute__((amdgpu_flat_work_group_size(64 * STRQ_SCREEN_SEG, 64 * STRQ_SCREEN_SEG), amdgpu_waves_per_eu(WPE_, WPE_)))
-__global__ void STRQ_SCREEN2_ATTR(5) align_screen2_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<3>(tasks, n_groups, queue, sp); }
 __global__ void STRQ_SCREEN2_ATTR(6) align_screen3_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<2>(tasks, n_groups, queue, sp); }
-__global__ void STRQ_SCREEN2_ATTR(6) align_screen6_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<1>(tasks, n_groups, queue, sp); }
 // ... and no merging at all: the fine screen's bound (one DP row per flank row, 30 per lane) for both flanks of a read in one wave, without the class
 // selects of align_screen_kernel -- what the fine screen runs on whenever a sub-batch holds both alignments of its reads (every detect call)
 __global__ void STRQ_SCREEN2_ATTR(4) align_screen1_kernel(const Screen2Task* __restrict__ tasks, int n_groups, int* __restrict__ queue, ScreenParams sp) { screen2_body<6>(tasks, n_groups, queue, sp); }
@@ -641,7 +640,7 @@ int screen_plan(const AlignParams& p, int samples, int max_n, ScreenParams* sp)
 int screen2_plan(const AlignParams& p, int samples, int max_n, int merge, ScreenParams* sp)
 {
     // the fine frame at a smaller scale: a table entry is merge (ceil(s sc) + hh + v) and has to fit 16 bits
-    if (merge != 1 && merge != 2 && merge != 3 && merge != 6) return 0;
+    if (merge != 1 && merge != 3) return 0;
     if (!screen_plan(p, samples, max_n, sp)) return 0;
     while (sp->sc >= 16) {
         const double smax = std::ceil((double)p.dist_offset * sp->sc);
@@ -657,8 +656,8 @@ int launch_screen2(hipStream_t stream, const Screen2Task* tasks, int n_groups, i
                    size_t lds_bytes, int groups_per_cu, int n_cu, int merge)
 {
     if (n_groups <= 0) return 0;
-    auto kern = merge == 6 ? align_screen6_kernel : merge == 3 ? align_screen3_kernel : merge == 1 ? align_screen1_kernel : align_screen2_kernel;
-    if (merge == 2 && groups_per_cu > 5) groups_per_cu = 5;          // compiled for five waves per SIMD
+    if (merge != 3 && merge != 1) return 2;
+    auto kern = merge == 3 ? align_screen3_kernel : align_screen1_kernel;
     if (merge == 1 && groups_per_cu > 4) groups_per_cu = 4;          // ... for four
     if (groups_per_cu > 6) groups_per_cu = 6;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -319,8 +319,7 @@ static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out
     // flank rows per DP row of the coarse screen (2, 3 or 6: STRQ_SCREEN2_MERGE).  Measured on configs[2] (gpurun_out/r5j): screen 114.4 / 94.7 /
     // 96.6 ms per 4096 reads, forward stage 131.6 / 115.8 / 130.9 ms -- with six rows per DP row the 10 table reads of a step bind, and
     // the looser bound sends 14 % of the alignments into the second look (2.4 % at two, 6 % at three)
-    int coarse_merge = 3;
-    if (const char* e = strq::opt("STRQ_SCREEN2_MERGE")) { const int v = atoi(e); if (v == 2 || v == 3 || v == 6) coarse_merge = v; }
+    const int coarse_merge = 3;
     std::vector<int> g2_of(nb, -1);                 // alignment -> its index in the coarse screen's task views
     ScreenTask* d_st2 = nullptr; int32_t* d_bound2 = nullptr; ScreenParams sp2; std::memset(&sp2, 0, sizeof(sp2));
     double coarse_cols = 0, coarse_all = 0;
@@ -334,7 +333,7 @@ static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out
         if (!collapsed || mode_fine || strq::opt("STRQ_NO_SCREEN")) continue;
         if (c->coarse_pause > 0 && !mode_coarse && !scr_forced) { --c->coarse_pause; continue; }
     } else {
-        if (!collapsed || strq::opt("STRQ_NO_SCREEN") || strq::opt("STRQ_SCREEN_FINE_SINGLE") || (c->screen_pause > 0 && !scr_forced)) continue;
+        if (!collapsed || strq::opt("STRQ_NO_SCREEN") || (c->screen_pause > 0 && !scr_forced)) continue;
         merge_now = 1;
     }
     const bool fine_rules = merge_now == 1;
@@ -354,7 +353,7 @@ static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out
         const int ngr = (int)pairs.size();
         if (ngr > 0 && 2 * ngr >= (nb * 9) / 10) {
             constexpr int SSEG = STRQ_SCREEN_SEG;
-            sp.margin = (int32_t)std::lround((double)c->coarse_margin * (merge_now == 6 ? 1.75 : merge_now == 3 ? 1.3 : 1.0) * sp.sc);
+            sp.margin = (int32_t)std::lround((double)c->coarse_margin * (merge_now == 3 ? 1.3 : 1.0) * sp.sc);
             if (const char* e = strq::opt("STRQ_SCREEN2_MARGIN")) sp.margin = (int32_t)std::lround(atof(e) * sp.sc);
             sp.max_cand = 8;          // (8, 16, 32 candidates and margins of 300 ... 700 score units measure within 1.5 % of each other: gpurun_out/r5n)
             if (const char* e = strq::opt("STRQ_SCREEN2_MAX_CAND")) sp.max_cand = atoi(e);
@@ -881,19 +880,16 @@ static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out
         side = true;
         if (!c->ev_fork) STRQ_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         STRQ_HIP(c, hipEventRecord(c->ev_fork, st));
-        // STRQ_SIDE_STREAMS=3: every launch but the first on a side stream; default: only the launch with the most alignments
-        // (A/B on one box, gpurun_out/r5n)
-        const char* so = strq::opt("STRQ_SIDE_STREAMS");
-        const bool all_side = so && atoi(so) >= 3;
+        // the launch with the most alignments goes to the side stream (every launch but the first on a stream of its own measured the
+        // same: gpurun_out/r5n)
         size_t biggest = 0;
         for (size_t li = 1; li < launches.size(); ++li) if (launches[li].count > launches[biggest].count) biggest = li;
         int used = 0;
-        for (size_t li = 0; li < launches.size(); ++li) {
-            if (all_side ? li == 0 : li != biggest) continue;
-            const int k = used % 3;
+        {
+            const int k = 0;
             if (!c->side_stream[k]) { STRQ_HIP(c, hipStreamCreateWithFlags(&c->side_stream[k], hipStreamNonBlocking)); STRQ_HIP(c, hipEventCreateWithFlags(&c->side_join[k], hipEventDisableTiming)); }
-            if (used < 3) STRQ_HIP(c, hipStreamWaitEvent(c->side_stream[k], c->ev_fork, 0));
-            lstream[li] = c->side_stream[k]; ++used;
+            STRQ_HIP(c, hipStreamWaitEvent(c->side_stream[k], c->ev_fork, 0));
+            lstream[biggest] = c->side_stream[k]; ++used;
         }
         n_side = std::min(used, 3);
     }

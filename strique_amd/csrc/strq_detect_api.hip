@@ -409,19 +409,6 @@ static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto)
     return STRQ_OK;
 }
 
-// STRQ_FORWARD_TOKEN=1: contexts of one process that work on different batches at the same time (one host thread each: `count --contexts 2`)
-// take turns in the forward stage.  The stage fills the GPU with one long-lived wave per read, so two of them side by side only delay each
-// other; the Viterbi launch that follows lasts as long as its longest window while most of the GPU idles (reads whose flanks were
-// mislocated decode windows of 10^5 steps and more).  A context that has queued its Viterbi launches hands the token on, and the other
-// context's conditioning and flank alignments run under that tail.
-static std::mutex g_forward_token;
-struct ForwardToken {
-    bool held = false;
-    void take() { g_forward_token.lock(); held = true; }
-    void pass() { if (held) { g_forward_token.unlock(); held = false; } }
-    ~ForwardToken() { pass(); }
-};
-
 static void publish_timing(strq_ctx* c, const Batch& B)
 {
     std::fill(c->timing, c->timing + 8, 0.0f);
@@ -520,8 +507,6 @@ static int drain(strq_ctx* c, DetectState* d)
 
 static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, int64_t next_r1)
 {
-    ForwardToken token;
-    { const char* e = strq::opt("STRQ_FORWARD_TOKEN"); if (e && atoi(e) > 0) token.take(); }
     Batch& B = d->batch;
     hipStream_t st = c->stream;
     const int nr = (int)(r1 - r0);
@@ -750,8 +735,6 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     // few ms of HBM-bound streaming kernels that crawl next to a GPU full of Viterbi waves (gpurun_out/r6d: 66 ms instead of 5.7 ms); the
     // flank-alignment kernels that follow share the SIMDs with them at little cost.
     if (serial) { const int lrc = launch_viterbi_of(c, d, sl, st, nullptr); if (lrc) return lrc; }
-    else if (token.held) { const int lrc = launch_viterbi_of(c, d, sl, d->vit_stream, sl.fwd_done); if (lrc) return lrc; }      // contexts taking turns: the other one's forward stage comes next
-    token.pass();
     // Everything of this sub-batch is queued: fetch the next sub-batch's samples while it runs.
     { const double tu = now_s(); const int urc = upload_reads(c, d, next_r1); if (urc) return urc;
       STRQ_DBG("  prefetch of the next sub-batch %.1f ms", (now_s() - tu) * 1e3); }

@@ -225,7 +225,7 @@ class H5File(object):
 
     def dataset(self, path, alloc=None, defer=False):
         """The values of a dataset.  `alloc(n, dtype)` (optional) supplies the ZERO-FILLED output array of a chunked dataset
-        instead of numpy (SlabAllocator).  `defer`: a deflate-compressed dataset comes back as an InflatePlan -- its output
+        instead of numpy.  `defer`: a deflate-compressed dataset comes back as an InflatePlan -- its output
         array allocated, its chunks located, nothing inflated yet -- for inflate_plans() to fill together with others."""
         fast = self._fast_dataset(path, alloc, defer)          # the common layout, resolved by the library in one call
         if fast is not None:
@@ -489,41 +489,6 @@ def inflate_plans(plans):
     if rc < 0:
         raise ValueError("strq_inflate_many: bad argument")
     return [None if s == 0 else ("chunk %d of a deflate-compressed dataset is damaged" % (-s - 2) if s < -1 else "bad chunk table") for s in status]
-
-
-class SlabAllocator(object):
-    """Zero-filled output arrays carved out of large anonymous mappings advised to use huge pages.
-
-    A chunked dataset is inflated into a fresh array, and a fresh array is page faults: 183 of them per 375 k-sample read, all
-    taking the process's memory-map lock.  With a dozen reader threads inflating 4 ... 5 k reads/s that lock, not the
-    inflate, bounded the `count` command on compressed fast5 files (more threads, or a faster inflate, changed nothing:
-    gpurun_out/r4c).  One 32 MB mapping per reader task, MADV_HUGEPAGE, serves ~40 reads with 16 faults of 2 MB.  The
-    arrays keep their mapping alive (buffer protocol); it goes when the last of them does.  Not thread-safe: one per task."""
-
-    def __init__(self, slab_bytes=32 << 20):
-        self.slab_bytes = slab_bytes
-        self._buf = None
-        self._off = 0
-
-    def _new_slab(self, nbytes):
-        import mmap
-        size = max(self.slab_bytes, (nbytes + 4095) & ~4095)
-        mm = mmap.mmap(-1, size)
-        try:
-            mm.madvise(mmap.MADV_HUGEPAGE)
-        except (AttributeError, OSError, ValueError):
-            pass                                        # no transparent huge pages: small pages, still one mmap call per slab
-        self._buf = np.frombuffer(mm, np.uint8)
-        self._off = 0
-
-    def __call__(self, n, dtype):
-        dtype = np.dtype(dtype)
-        nbytes = int(n) * dtype.itemsize
-        if self._buf is None or self._off + nbytes > self._buf.size:
-            self._new_slab(nbytes)
-        out = self._buf[self._off:self._off + nbytes].view(dtype)
-        self._off = (self._off + nbytes + 63) & ~63
-        return out
 
 
 _CHUNK_ENTRY = {}          # rank -> numpy dtype of a chunk B-tree leaf entry

@@ -180,7 +180,7 @@ def test_reader_tasks_inflate_their_reads_in_one_call(tmp_path, cfg, monkeypatch
             return [(int(raw[:50].sum()) % 997, 1.0, 2.0, -1.0, len(raw), int(raw[-1]), "-") for t, raw, s in items]
 
     outs = {}
-    for mode, env in (("batched", {}), ("one_by_one", {"STRQ_READ_ONE_BY_ONE": "1"}), ("slabs", {"STRQ_READ_SLABS": "1"})):
+    for mode, env in (("batched", {}), ("one_by_one", {"STRQ_READ_ONE_BY_ONE": "1"})):
         with monkeypatch.context() as mp:
             for k, v in env.items():
                 mp.setenv(k, v)
@@ -190,7 +190,7 @@ def test_reader_tasks_inflate_their_reads_in_one_call(tmp_path, cfg, monkeypatch
             cli.run_count(iter(lines), loci, idx.get_raw, FakeCounter(), log, 16, 0, 1, out, readers=3)
             outs[mode] = out.getvalue()
             assert any(reads[11][0] in m for _, m in err), (mode, err)
-    assert outs["batched"] == outs["one_by_one"] == outs["slabs"]
+    assert outs["batched"] == outs["one_by_one"]
     rows = outs["batched"].splitlines()[1:]
     assert len(rows) == 69 and all(reads[11][0] not in r for r in rows)
     by_id = {r.split("\t")[0]: r.split("\t") for r in rows}

@@ -135,12 +135,18 @@ def test_bench_four_and_eight_ranks_on_one_gpu(world, tmp_path, pm, cfg):
     import bench
     dump = str(tmp_path / "rows.npy")
     reads, steps, warmup, read_nt = 64, 2, 1, 50000
-    lines, recs = _run_bench(["--gpus", str(world), "--backend", "gloo", "--share-device", "--reads", str(reads), "--steps", str(steps), "--warmup", str(warmup),
-                              "--read-nt", str(read_nt), "--no-cpu-baseline", "--check", "1", "--synth-workers", "1", "--dump-rows", dump],
+    # N = 4: weak scaling, the job's reads made once (every rank 1 / N of the pool, all ranks run all of it in rotated orders);
+    # N = 8: strong scaling (--total-reads 506 -> 64 per GPU and step), every rank its own reads
+    shared = world == 4
+    mode = ["--reads", str(reads)] if shared else ["--scaling", "strong", "--total-reads", str(8 * reads - 6), "--private-reads"]
+    lines, recs = _run_bench(["--gpus", str(world), "--backend", "gloo", "--share-device", "--steps", str(steps), "--warmup", str(warmup),
+                              "--read-nt", str(read_nt), "--no-cpu-baseline", "--check", "1", "--synth-workers", "1", "--dump-rows", dump] + mode,
                              world=world, port=str(29560 + world), timeout=1500)
     assert [len(l) for l in lines] == [1] + [0] * (world - 1)
     r = recs[0]
-    assert r["n_gpus"] == world and r["world_size_seen_by_the_collective"] == world and r["scaling"] == "weak" and r["check_ok"]
+    assert r["n_gpus"] == world and r["world_size_seen_by_the_collective"] == world and r["scaling"] == ("weak" if shared else "strong") and r["check_ok"]
+    assert r["config"]["reads_per_gpu_per_step"] == reads and r["config"]["total_reads"] == (None if shared else 8 * reads - 6)
+    assert len(coll_ms := r["collective"]["ranks"]["ms_per_step_per_rank"]) == world and max(coll_ms) <= r["ms_per_step"] * 1.001
     coll = r["collective"]
     assert coll["rows_on_rank_0"] == steps * world * reads and "once" in coll["when"]
     ranks = coll["ranks"]
@@ -150,13 +156,21 @@ def test_bench_four_and_eight_ranks_on_one_gpu(world, tmp_path, pm, cfg):
     if ncpu >= world:
         assert sum(ranks["cpus_pinned_per_rank"]) == ncpu and min(ranks["cpus_pinned_per_rank"]) >= ncpu // world - 1, ranks
     assert abs(r["value"] - world * reads * steps / (r["ms_per_step"] * steps / 1e3)) < 1e-6 * r["value"]
-    # the same reads through one process: rank k's batches are reads [k * 3 * reads, (k + 1) * 3 * reads) of the recipe
+    # the same reads through one process.  Private reads: rank k's batches are reads [k * nb * reads, (k + 1) * nb * reads) of the recipe;
+    # one pool: its batches are the pool's, starting with batch k mod nb, the reads of a batch rotated by k * reads / N
     table = np.load(dump)
     counter = _fresh_counter(pm, cfg, {"c9orf72": tuple(cfg["repeat"]["c9orf72"][3:6])})
+    nb = r["config"]["distinct_batches_per_gpu"]
+    assert nb == (3 if shared else 2)
+    pool = bench.make_batch(pm, cfg, nb * reads, read_nt, 0) if shared else None
     for rank in range(world):
-        sigs, strands, _ = bench.make_batch(pm, cfg, 3 * reads, read_nt, rank * 3 * reads)
+        if shared:
+            order = np.concatenate([((b + rank) % nb) * reads + (np.arange(reads) + rank * reads // world) % reads for b in range(nb)])
+            sigs = [pool[0][g] for g in order]; strands = [pool[1][g] for g in order]
+        else:
+            sigs, strands, _ = bench.make_batch(pm, cfg, nb * reads, read_nt, rank * nb * reads)
         for j, k in enumerate(range(warmup, warmup + steps)):
-            bi = k % 3
+            bi = k % nb
             got = counter.detect_batch([("c9orf72", s, st) for s, st in zip(sigs[bi * reads:(bi + 1) * reads], strands[bi * reads:(bi + 1) * reads])])
             part = table[(j * world + rank) * reads:(j * world + rank + 1) * reads]
             for g, t in zip(got, part):

@@ -306,49 +306,6 @@ def test_rows_of_a_range_while_the_next_is_in_flight(gpu_counter, pm, targets, m
         ctx.batch_fetch_range(5, 13)
 
 
-def test_two_contexts_taking_turns_give_the_rows_of_one(gpu_counter, pm, cfg, targets):
-    """STRQ_FORWARD_TOKEN=1: two contexts of one process, one host thread each, take turns in the forward stage (the second one's
-    conditioning and flank alignments run under the first one's Viterbi launch).  Each gets half of the reads, several passes
-    in a row; the rows are those of one context over all reads."""
-    import threading
-    from strique_amd.counter import repeatCounter
-    rng = np.random.default_rng(77)
-    items = []
-    for k in range(12):
-        name = ["c9orf72", "fmr1"][k % 2]; strand = "+-"[(k // 2) % 2]
-        items.append((name, _read(pm, targets, name, strand, int(rng.integers(2500, 9000)), int(rng.integers(4, 80)), 900 + k), strand))
-    whole = gpu_counter.detect_batch(items)
-    halves = [items[0::2], items[1::2]]
-    ctxs = []
-    for _ in halves:
-        rc = repeatCounter(pm, align_config=cfg["align"], HMM_config=cfg["HMM"], device=0)
-        for name, (repeat, prefix, suffix) in targets.items():
-            rc.add_target(name, repeat, prefix, suffix)
-        rc.ctx.set_option("STRQ_FORWARD_TOKEN", "1")
-        rc.ctx.set_option("STRQ_SUBBATCH_READS", "2")       # several turns per call
-        ctxs.append(rc)
-    got = [None, None]; errs = []
-
-    def work(i):
-        try:
-            for _ in range(3):
-                got[i] = ctxs[i].detect_batch(halves[i])
-        except Exception as e:       # noqa: BLE001 -- reported below, in the main thread
-            errs.append(e)
-
-    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(120)
-    assert not errs, errs
-    assert all(not t.is_alive() for t in threads), "a context kept the forward token"
-    assert got[0] == whole[0::2] and got[1] == whole[1::2]
-
-
-# ---------------------------------------------------------------------------------------------
-# BASELINE.json configs, each met by the oracle at least once at its own size
-# ---------------------------------------------------------------------------------------------
 def test_config1_ten_kb_thirty_repeats(gpu_counter, want, pm, targets):
     """configs[1]: 10 kb reads, 30 x GGGGCC (C9orf72), both strands."""
     items = [("c9orf72", _read(pm, targets, "c9orf72", st, 10000, 30, 500 + i), st) for i, st in enumerate("+-")]

@@ -317,8 +317,8 @@ def _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
             assert np.array_equal(o[3], got[3][foff[a]:foff[a + 1]]), (i, f)
 
 
-@pytest.mark.parametrize("ka,kb,merge", [(145, 145, 2), (100, 140, 2), (145, 145, 3), (145, 120, 6)])
-def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp_path, ka, kb, merge):
+@pytest.mark.parametrize("ka,kb", [(145, 145), (100, 140)])
+def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp_path, ka, kb):
     """What the coarse screen claims: every chunk value is an upper bound of the exact last row of its columns, for both flanks of a
     read (lanes 0 .. 28 / 32 .. 60 of the wave), flanks shorter than 145 classes included; and what it is used for: the alignments
     return the oracle's bits through its windows."""
@@ -327,8 +327,7 @@ def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp
     ctx.set_align_params(*[float(v) for v in params])
     monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
     monkeypatch.setenv("STRQ_SCREEN_MODE", "coarse")
-    monkeypatch.setenv("STRQ_SCREEN2_MERGE", str(merge))
-    scale = {2: 512, 3: 512, 6: 256}[merge]
+    scale = 512          # three flank rows per DP row (the one merge factor left: DESIGN.md 4.2e)
     dump = str(tmp_path / "screen2.bin")
     monkeypatch.setenv("STRQ_SCREEN_DUMP", dump)
     n = 60000
@@ -364,8 +363,7 @@ def test_coarse_chunk_values_bound_the_exact_last_row(ctx, orc, monkeypatch, tmp
     _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
 
 
-@pytest.mark.parametrize("merge", [2, 3, 6])
-def test_coarse_windowed_alignments_equal_the_oracle(ctx, orc, monkeypatch, merge):
+def test_coarse_windowed_alignments_equal_the_oracle(ctx, orc, monkeypatch):
     """Planted flanks at the seams of the coarse screen's pieces, in their overlap zones, at the ends of the read, twice, five times
     (more candidates than pieces) and not at all: score bits, end / start column and whole path equal the oracle's for both
     alignments of every read; without the screen the same bytes."""
@@ -374,7 +372,6 @@ def test_coarse_windowed_alignments_equal_the_oracle(ctx, orc, monkeypatch, merg
     ctx.set_align_params(*[float(v) for v in params])
     monkeypatch.setenv("STRQ_SCREEN_MIN_N", "0")
     monkeypatch.setenv("STRQ_SCREEN_MODE", "coarse")
-    monkeypatch.setenv("STRQ_SCREEN2_MERGE", str(merge))
     n, k = 90000, 145
     seams = [n // 4, n // 2, 3 * n // 4, 8192, n - 8192]
     pa = [[p + d] for p in seams for d in (-700, -1, 0, 1, 130)] + [[3000, n - 4000], [100, 9000, 20000, 30000, n - 2000], [], [0], [n]]
@@ -479,9 +476,3 @@ def test_fine_screen_with_both_flanks_per_wave_is_tight(ctx, orc, monkeypatch, t
         assert g["win"]["lower"] <= exact.max() + 1e-3 <= g["win"]["upper"] + 1e-3
     assert checked > 1000
     _check_pairs_against_the_oracle(orc, params, reads, lval, fa, fb, got, foff)
-    # the one-flank kernel on the same sub-batch (STRQ_SCREEN_FINE_SINGLE): the same bytes
-    monkeypatch.setenv("STRQ_SCREEN_FINE_SINGLE", "1")
-    ref, _ = _align_pairs(ctx, reads, lval, fa, fb)
-    assert ctx.last_screen()["merge"] == 0 and ctx.last_screen()["mode"] == "fine"
-    for a, b in zip(got, ref):
-        assert np.array_equal(a, b)

@@ -46,12 +46,12 @@ for trial in range(trials):
             rc.ctx.set_option("STRQ_SCREEN_MIN_N", "0")
             pick = trial % 6
             if pick < 3:
-                rc.ctx.set_option("STRQ_SCREEN_MODE", "coarse"); rc.ctx.set_option("STRQ_SCREEN2_MERGE", (2, 3, 6)[pick])
+                rc.ctx.set_option("STRQ_SCREEN_MODE", "coarse")
                 rc.ctx.set_option("STRQ_SCREEN2_MARGIN", int(rng.choice([1, 50, 400]))); rc.ctx.set_option("STRQ_SCREEN2_MAX_CAND", int(rng.choice([1, 4, 16])))
             elif pick == 3:
                 rc.ctx.set_option("STRQ_SCREEN_MODE", "fine")
             elif pick == 4:
-                rc.ctx.set_option("STRQ_SCREEN_MODE", "fine"); rc.ctx.set_option("STRQ_SCREEN_FINE_SINGLE", "1")
+                rc.ctx.set_option("STRQ_NO_SCREEN", "1")
     except Exception as e:
         print("trial", trial, "setup:", str(e)[:80]); continue
     table = synth.KmerTable(pm_mod if with_mod and rng.random() < 0.5 else pm)
