@@ -1007,7 +1007,7 @@ static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out
                     for (size_t li = 0; li < launches.size(); ++li) { const Launch& L = launches[li]; if (l2[(size_t)k2].pos >= L.first && l2[(size_t)k2].pos < L.first + L.count) redo_keep[li].push_back(l2[(size_t)k2].pos - L.first); }
                 }
             }
-            const int piece_cols = 8192;
+            const int piece_cols = 8192;          // (4096 / 2048 own columns per piece: forward stage 118.3 / 119.7 ms against 114.9 -- every piece pays its cold start: gpurun_out/r6n)
             std::vector<AlignTask> t2; t2.reserve((size_t)n2 * 4);
             std::vector<int32_t> pos_sorted, grp_first;          // per alignment: its slot, its first group
             size_t ck2 = 0; int slot = 0, n_grp = 0; double cols2 = 0;

@@ -160,12 +160,19 @@ struct DetectState {
     };
     Slot slot[2];
     int next_slot = 0;
+    // samples of the NEXT sub-batch travel host -> HBM on a thread of their own while this thread sequences the kernels of the current one
+    // (align_core blocks it in three host round trips per sub-batch: an upload from the same thread only started when those were through,
+    // and the GPU idled under it -- 250 ms per 4096 reads instead of 175: gpurun_out/r6n)
+    std::thread up_thread;
+    int up_rc = 0;
     hipStream_t vit_stream = nullptr;
     int levels_shift = 0;                // bytes the level stream of the current sub-batch starts behind the buffer's base (alignment phase)
     hipStream_t copy_stream = nullptr;   // host -> HBM uploads that overlap the kernels of the previous sub-batch
     static constexpr int N_STAGE = 4;    // pinned staging ring of upload_reads
     void* stage[N_STAGE] = {}; hipEvent_t stage_ev[N_STAGE] = {}; bool stage_busy[N_STAGE] = {};
 };
+
+static int upload_join(DetectState* d);
 
 static DetectState* dstate(strq_ctx* c)
 {
@@ -177,6 +184,7 @@ void detect_state_free(strq_ctx* c)
 {
     if (!c->detect) return;
     DetectState* d = static_cast<DetectState*>(c->detect);
+    (void)upload_join(d);
     if (d->vit_stream) (void)hipStreamSynchronize(d->vit_stream);
     for (DevBuf* b : {&d->batch.raw, &d->rc, &d->hist16, &d->hist8, &d->geom, &d->idx,
                       &d->hist_raw, &d->bp, &d->path, &d->modtask, &d->modsig, &d->modlen, &d->pattern, &d->hrange, &d->modpool, &d->f64s}) b->release();
@@ -354,6 +362,27 @@ static void host_bytes(const Batch& B, size_t esz, char* dst, size_t pos, size_t
     }
 }
 
+static int upload_reads(strq_ctx* c, DetectState* d, int64_t upto);
+
+// waits for the prefetch thread (if any); returns what its upload returned
+static int upload_join(DetectState* d)
+{
+    if (d->up_thread.joinable()) d->up_thread.join();
+    const int rc = d->up_rc; d->up_rc = 0;
+    return rc;
+}
+
+static void upload_prefetch(strq_ctx* c, DetectState* d, int64_t upto)
+{
+    Batch& B = d->batch;
+    if (!B.on_host || upto <= B.uploaded) return;
+    d->up_thread = std::thread([c, d, upto] {
+        strq::CtxScope scope_(c);
+        if (hipSetDevice(c->device) != hipSuccess) { d->up_rc = STRQ_ERR_DEVICE; return; }
+        d->up_rc = upload_reads(c, d, upto);
+    });
+}
+
 // Samples of reads [B.uploaded, upto) from the caller's (pageable) buffer into `raw`.  The runtime's own
 // pageable path measures 8.3 GB/s; here the bytes go through a ring of pinned staging buffers: a few host
 // threads copy the next piece into a free slot while the DMA engine drains the previous ones on the copy
@@ -515,6 +544,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     // the slot of this sub-batch (its previous user's results are taken first: normally done a sub-batch ago)
     DetectState::Slot& sl = d->slot[d->next_slot];
     DetectState::Slot& other = d->slot[d->next_slot ^ 1];
+    { const int urc = upload_join(d); if (urc) { c->err = "upload of the sub-batch's samples failed (prefetch thread)"; return urc; } }
     { const int hrc = harvest(c, d, sl); if (hrc) return hrc; }
     d->next_slot ^= 1;
     int max_n = 0;
@@ -637,6 +667,8 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         const int i0 = (int)((int64_t)nr * part / parts), i1 = (int)((int64_t)nr * (part + 1) / parts), np_ = i1 - i0;
         if (np_ <= 0) continue;
         { const int urc = upload_reads(c, d, r0 + i1); if (urc) return urc; }
+        // this sub-batch's samples are in HBM (or queued): the next sub-batch's follow on their own thread from here on
+        if (part == parts - 1) upload_prefetch(c, d, next_r1);
         int max_n = 0;
         for (int i = i0; i < i1; ++i) max_n = std::max(max_n, rc[i].n);
         if (part == 0) STRQ_HIP(c, hipEventRecord(d->ev[0], st));
@@ -735,9 +767,6 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     // few ms of HBM-bound streaming kernels that crawl next to a GPU full of Viterbi waves (gpurun_out/r6d: 66 ms instead of 5.7 ms); the
     // flank-alignment kernels that follow share the SIMDs with them at little cost.
     if (serial) { const int lrc = launch_viterbi_of(c, d, sl, st, nullptr); if (lrc) return lrc; }
-    // Everything of this sub-batch is queued: fetch the next sub-batch's samples while it runs.
-    { const double tu = now_s(); const int urc = upload_reads(c, d, next_r1); if (urc) return urc;
-      STRQ_DBG("  prefetch of the next sub-batch %.1f ms", (now_s() - tu) * 1e3); }
     // the forward stage of this sub-batch is complete here (its Viterbi launches need not be)
     STRQ_HIP(c, hipEventSynchronize(sl.fwd_done));
     c->second_round[0] = *h_redo; c->second_round[1] += 2 * (int64_t)nr;
@@ -982,9 +1011,10 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
         const double t1 = now_s();
         // samples not yet in HBM (first sub-batch of strq_detect_batch) are uploaded piece by piece inside
         const int rc = run_sub_batch(c, d, cuts[k], cuts[k + 1], k + 2 < cuts.size() ? cuts[k + 2] : cuts[k + 1]);
-        if (rc) return rc;
+        if (rc) { (void)upload_join(d); return rc; }          // (the prefetch thread reads the caller's buffers: never left running)
         STRQ_DBG("sub-batch %zu: reads %ld..%ld  %.1f ms", k, (long)cuts[k], (long)cuts[k + 1], (now_s() - t1) * 1e3);
     }
+    { const int urc = upload_join(d); if (urc) { c->err = "upload of the batch's samples failed (prefetch thread)"; return urc; } }
     B.forget_host();      // the caller's buffers are not referenced after the call
     publish_timing(c, B);
     return STRQ_OK;
