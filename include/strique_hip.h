@@ -322,8 +322,9 @@ int strq_last_geometry(const strq_ctx* ctx, int32_t out[8]);
  * either parity)   [2] on the lane-layout kernels   [3] on the general kernel (viterbi_csr_kernel). */
 int strq_last_viterbi_launches(const strq_ctx* ctx, int32_t out[4]);
 /* Flank alignments of the last batched call whose first forward round -- column segments cut with the short, adaptive
- * overlap -- did not reach the score that certifies it, and which therefore ran the second round with the worst-case
- * overlap: [0] such alignments, [1] all alignments (two per read).  What a read that does not contain its flank costs. */
+ * overlap, or the screen's windows -- did not reach the score that certifies it, and which therefore ran the second round over their
+ * whole read with the worst-case overlap: [0] such alignments, [1] all alignments (two per read).  What a read that does not contain
+ * its flank costs.  (Alignments the coarse screen's second look resolved with more windows are not in [0]: strq_last_screen_mode [5].) */
 int strq_last_second_round(const strq_ctx* ctx, int64_t out[2]);
 /* The upper-bound screen of the last batched call (csrc/screen_kernels.hip: an integer DP over the whole read whose last-row
  * values bound the float32 ones of src/align_raw.h:106-158 from above, so that the exact DP only runs over the column windows
@@ -335,7 +336,9 @@ int strq_last_screen(const strq_ctx* ctx, double out[8]);
  * row, bound within m / scale of the exact last row), 2 the coarse one (align_screen3_kernel by default: three flank rows per DP row, both flanks
  * of a read per wave, candidates taken with a margin)   [1] / [2] sub-batches for which the coarse / the fine screen stays paused
  * (it did not pay on the last one it ran on)   [3] the coarse screen's candidate margin in score units (x 1.3 / 1.75 at three / six
- * rows per DP row)   [4] flank rows per DP row of the coarse screen that ran (2, 3 or 6; kernel align_screen<that>_kernel)   [5..7] 0. */
+ * rows per DP row)   [4] flank rows per DP row of the screen that ran (3: align_screen3_kernel, 1: align_screen1_kernel, 0: the one-flank
+ * kernel)   [5] alignments of the last batched call that missed the first look's certificate and were resolved by the coarse screen's second look
+ * (or belonged to an attempt that started over with the fine screen)   [6..7] 0. */
 int strq_last_screen_mode(const strq_ctx* ctx, int32_t out[8]);
 /* The two sub-batches in flight, since the start of the last run call: [0] ms of HMM Viterbi launches whose rows were taken
  * [1] of them, ms that lay under the screen kernel of the sub-batch that followed   [2] ... under its whole alignment stage

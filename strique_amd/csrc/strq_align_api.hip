@@ -32,16 +32,28 @@ static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
 CtxScope::CtxScope(const strq_ctx* c) : prev(t_cur_ctx) { t_cur_ctx = c; }
 CtxScope::~CtxScope() { t_cur_ctx = prev; }
+// The value is COPIED under the lock into one of a few thread-local strings (a strq_set_option on another thread may rehash or free
+// the entry the moment the lock is released; several contexts with a host thread each is a supported way to use the library): the
+// pointer returned stays valid until the calling thread has asked for eight more switches.
 const char* opt(const char* key)
 {
+    static thread_local std::string ring[8];
+    static thread_local unsigned ring_pos = 0;
+    auto keep = [&](const std::string& v) -> const char* {
+        if (v.empty()) return nullptr;
+        std::string& slot = ring[ring_pos++ & 7u];
+        slot = v;
+        return slot.c_str();
+    };
     if (t_cur_ctx) {
+        std::lock_guard<std::mutex> lk(t_cur_ctx->options_mu);
         auto it = t_cur_ctx->options.find(key);
-        if (it != t_cur_ctx->options.end()) return it->second.empty() ? nullptr : it->second.c_str();
+        if (it != t_cur_ctx->options.end()) return keep(it->second);
     }
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         auto it = g_opts.find(key);
-        if (it != g_opts.end()) return it->second.empty() ? nullptr : it->second.c_str();
+        if (it != g_opts.end()) return keep(it->second);
     }
     return getenv(key);
 }
@@ -967,6 +979,7 @@ static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out
                 STRQ_HIP(c, hipStreamSynchronize(st));
                 STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->aborted_fwd_ms += ms;
                 STRQ_HIP(c, hipEventElapsedTime(&ms, c->ev[5], c->ev[6])); c->aborted_screen_ms += ms;
+                c->look2_served += (int64_t)n_redo;          // counted by the combine kernel, dropped with this attempt
                 STRQ_DBG("coarse screen: %zu of %d alignments missed the first look's certificate -> the sub-batch starts over with the fine screen, pause %d", n_redo, nb, c->coarse_pause);
                 *bailed = true;
                 return STRQ_OK;
@@ -1056,6 +1069,7 @@ static int align_core_once(strq_ctx* c, const AlignCoreIn& in, AlignCoreOut& out
                 groups2.push_back(g);
             }
             grp_first.push_back(n_grp);
+            c->look2_served += slot;
             if (slot > 0) {
                 // device scratch of the launch: piece results, group results, picks, group ranges, slots
                 const size_t p_seg = 0, p_res = p_seg + (size_t)n_grp * 4 * sizeof(AlignResult), p_pick = p_res + (size_t)n_grp * sizeof(AlignResult),
@@ -1183,7 +1197,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
         m[a] = (int)mm; n[a] = (int)nn;
     }
     hipStream_t st = c->stream;
-    c->second_round[0] = 0; c->second_round[1] = NA;          // strq_last_second_round of this call
+    c->second_round[0] = 0; c->second_round[1] = NA; c->look2_served = 0;          // strq_last_second_round of this call
     STRQ_HIP(c, c->redo_total.reserve(64));
     STRQ_HIP(c, hipMemsetAsync(c->redo_total.p, 0, 64, st));
     const int64_t tot_levels = in.read_off[in.n_reads];
@@ -1233,7 +1247,7 @@ static int run_align_batch(strq_ctx* c, const BatchIn& in, const BatchOut& out)
     {
         unsigned int redo = 0;
         STRQ_HIP(c, hipMemcpy(&redo, c->redo_total.p, 4, hipMemcpyDeviceToHost));
-        c->second_round[0] = redo;
+        c->second_round[0] = (int64_t)redo - c->look2_served;
     }
     return STRQ_OK;
 }
@@ -1247,7 +1261,7 @@ int strq_abi_version(void) { return 12; }
 int strq_set_option(strq_ctx* c, const char* key, const char* value)
 {
     if (!key || std::strncmp(key, "STRQ_", 5) != 0) { if (c) c->err = "option keys start with STRQ_"; return STRQ_ERR_ARG; }
-    if (c) { if (value) c->options[key] = value; else c->options.erase(key); return STRQ_OK; }
+    if (c) { std::lock_guard<std::mutex> lk(c->options_mu); if (value) c->options[key] = value; else c->options.erase(key); return STRQ_OK; }
     std::lock_guard<std::mutex> lk(g_opt_mu);
     if (value) g_opts[key] = value; else g_opts.erase(key);
     return STRQ_OK;
@@ -1366,6 +1380,7 @@ int strq_last_screen_mode(const strq_ctx* c, int32_t out[8])
     if (!c || !out) return STRQ_ERR_ARG;
     for (int i = 0; i < 8; ++i) out[i] = 0;
     out[0] = c->screen_mode_last; out[1] = c->coarse_pause; out[2] = c->screen_pause; out[3] = (int32_t)c->coarse_margin;
+    out[5] = (int32_t)std::min<int64_t>(c->look2_served, INT32_MAX);
     out[4] = c->screen_mode_last ? c->coarse_merge_last : 0;
     return STRQ_OK;
 }

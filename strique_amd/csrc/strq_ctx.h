@@ -7,6 +7,7 @@
 #include <map>
 #include <cstdio>
 #include <functional>
+#include <mutex>
 #include "align_kernels.h"
 #include "viterbi_kernels.h"
 #include "screen_kernels.h"
@@ -81,6 +82,7 @@ struct strq_ctx {
     // of the library is read through strq::opt(key): this map first, then the process-wide table (strq_set_option(NULL, ...)),
     // then the environment variable of the same name -- so that one process can run A/B legs on the same resident batches.
     std::map<std::string, std::string> options;
+    mutable std::mutex options_mu;            // strq_set_option on one thread, strq::opt on another (the upload thread of the context; a second context's host thread never sees this map)
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
@@ -94,7 +96,8 @@ struct strq_ctx {
     int32_t geometry[8] = {};                 // strq_last_geometry
     int32_t vit_launches[4] = {};             // strq_last_viterbi_launches
     int64_t second_round[2] = {};             // strq_last_second_round: alignments that ran the second forward round / alignments, last batched call
-    strq::DevBuf redo_total;                  // device counter behind second_round[0]
+    strq::DevBuf redo_total;                  // device counter: alignments whose first forward round missed its certificate (second look + whole-read second round)
+    int64_t look2_served = 0;                 // of them, resolved by the coarse screen's second look (or dropped with an attempt that started over): not whole-read reruns
     double screen_stats[8] = {};              // strq_last_screen
     double overlap[4] = {};                   // strq_last_overlap
     bool screen_ran = false;                  // the last align_core call ran the screen (events 5, 6 bracket it)
@@ -103,8 +106,8 @@ struct strq_ctx {
     // in 4096 is left with over 32 k columns to run (a tail behind thousands of small windows) pauses it for the next eight
     // sub-batches of this context, then it is tried again.
     int screen_pause = 0;
-    // the coarse screen in front of it (align_screen2_kernel): paused the same way when it leaves too many columns; its candidate
-    // margin (score units below the best chunk bound) grows when alignments miss the certificate (strq_detect_api.hip)
+    // the coarse screen in front of it (align_screen3_kernel): paused the same way when it leaves too many columns or certifies too
+    // few alignments in its first look; its candidate margin (score units below the best chunk bound) is a constant
     int coarse_pause = 0;
     int coarse_fail = 0, screen_fail = 0;     // consecutive sub-batches on which the coarse / the fine screen did not pay: the pause doubles (8, 16, ... 256)
     float coarse_margin = 384.0f;

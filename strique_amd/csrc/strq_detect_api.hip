@@ -769,7 +769,7 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     if (serial) { const int lrc = launch_viterbi_of(c, d, sl, st, nullptr); if (lrc) return lrc; }
     // the forward stage of this sub-batch is complete here (its Viterbi launches need not be)
     STRQ_HIP(c, hipEventSynchronize(sl.fwd_done));
-    c->second_round[0] = *h_redo; c->second_round[1] += 2 * (int64_t)nr;
+    c->second_round[0] = (int64_t)*h_redo - c->look2_served; c->second_round[1] += 2 * (int64_t)nr;
     // score distribution of this sub-batch for the overlap planning of the next one (align_core)
     if (c->ap.dist_offset > 0.0f) {
         c->score_fracs.clear(); double sum_n = 0;
@@ -975,7 +975,7 @@ int strq_batch_run_range(strq_ctx* c, int64_t first, int64_t last)
     B.t_cond = B.t_lut = B.t_fwd = B.t_trace = B.t_vit = 0; B.n_hard = 0; B.n_fwd_launches = 0;
     std::fill(c->counters, c->counters + 8, 0.0);
     std::fill(c->overlap, c->overlap + 4, 0.0);
-    c->second_round[0] = c->second_round[1] = 0;
+    c->second_round[0] = c->second_round[1] = 0; c->look2_served = 0;
     for (double& v : c->screen_stats) v = 0;
     STRQ_HIP(c, c->redo_total.reserve(64));
     STRQ_HIP(c, hipMemsetAsync(c->redo_total.p, 0, 64, c->stream));

@@ -219,6 +219,7 @@ class Context(object):
         self._check(self._lib.strq_last_screen_mode(self._h, _ptr(m)))
         out["mode"] = {0: None, 1: "fine", 2: "coarse"}.get(int(m[0]))
         out["coarse_pause"], out["fine_pause"], out["coarse_margin"], out["merge"] = int(m[1]), int(m[2]), int(m[3]), int(m[4])
+        out["second_look"] = int(m[5])          # alignments resolved by the coarse screen's second look (not in strq_last_second_round)
         return out
 
     def last_overlap(self):

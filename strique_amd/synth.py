@@ -55,7 +55,7 @@ def make_sequence(rng, total_nt, prefix, repeat, n_repeat, suffix, strand="+"):
 
 class EmpiricalNoise(object):
     """Dwell times, per-occurrence level offsets and per-sample residuals of the one real read the reference bundles
-    (tests/golden/empirical_noise.npz, made by tests/golden/make_empirical_noise.py from the oracle's decode of
+    (strique_amd/data/empirical_noise.npz, made by tests/golden/make_empirical_noise.py from the oracle's decode of
     data/c9orf72.fast5), resampled independently (bootstrap): a k-mer occurrence gets a dwell from the pool (0 = the k-mer
     is skipped), its level is the table mean plus an offset from the pool, every sample adds a residual from the pool scaled
     by the k-mer's table stdv.
@@ -69,7 +69,7 @@ class EmpiricalNoise(object):
     def __init__(self, path=None, offset_scale=0.8, resid_scale=1.0):
         import os
         if path is None:
-            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "empirical_noise.npz")
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "empirical_noise.npz")          # package data (written by tests/golden/make_empirical_noise.py)
         z = np.load(path)
         self.dwell = z["dwell"].astype(np.int64)
         self.level_offset = z["level_offset"].astype(np.float64) * offset_scale

@@ -87,3 +87,18 @@ def oracle_tc(orc, opm, targets, name, strand, hmm_cfg, opm_mod=None):
         repeat, prefix, suffix = targets[name]
         _TC_CACHE[key] = orc.classifier(repeat, prefix, suffix, strand, opm, opm_mod, hmm_cfg)
     return _TC_CACHE[key]
+
+
+def oracle_map(fn, jobs, workers=None):
+    """fn(job) for every job, on a few threads: the oracle's DP and Viterbi are ctypes calls into oracle/liboracle.so, which release
+    the interpreter lock -- the expected values of a test with dozens of 100 k-column alignments come in seconds instead of a
+    minute (the GPU suite has a time limit).  Results in job order; the first exception is re-raised."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = list(jobs)
+    if workers is None:
+        workers = max(1, min(8, len(jobs), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4))
+    if workers <= 1:
+        return [fn(j) for j in jobs]
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, jobs))

@@ -2,7 +2,7 @@
 documented row: docs/installation/test.md:15-16) -- replaces the normal / uniform generator of scripts/STRique.py:182-195 for the
 "degraded" workload of bench.py and tests.  Test infrastructure: run in the build container, the .npz is the committed fixture.
 
-    python tests/golden/make_empirical_noise.py          # writes tests/golden/empirical_noise.npz
+    python tests/golden/make_empirical_noise.py          # writes strique_amd/data/empirical_noise.npz (package data of strique_amd.synth)
 
 The read is decoded with the CPU oracle (conditioning, both flank alignments, flanked-repeat HMM Viterbi with the full path,
 oracle/strique_oracle.py).  Along the path every run of samples at one chain position (match or insert state of one k-mer; the two
@@ -87,7 +87,7 @@ def main():
     out = dict(dwell=np.array(dwell, np.int32), level_offset=np.array(offs, np.float32), resid_z=rz.astype(np.float32),
                source=np.array("data/c9orf72.fast5 read ce47b364-ed6e-4409-808a-1041c0b5aac2, window [%d, %d), %d events"
                                % (info["prefix_begin"], info["suffix_end"], len(events))))
-    np.savez_compressed(os.path.join(HERE, "empirical_noise.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "..", "..", "strique_amd", "data", "empirical_noise.npz"), **out)
     dw = out["dwell"]
     print("events %d (+%d skipped k-mers); dwell mean %.2f median %d p5 %d p95 %d max %d" % (len(events), int((dw == 0).sum()), dw.mean(), np.median(dw), np.percentile(dw, 5), np.percentile(dw, 95), dw.max()))
     print("level offsets as measured: sd %.2f pA, sampling noise of the medians %.2f pA -> shrunk by %.3f" % (offs_raw_sd, np.sqrt(v_noise), shrink))

@@ -245,7 +245,7 @@ def test_empirical_noise_fixture_and_generator(pm, cfg):
     """The degraded-read workload: dwell / level-offset / residual pools taken from the bundled real read (tests/golden/
     make_empirical_noise.py), resampled by strique_amd.synth.EmpiricalNoise -- seeded, and with the real read's statistics."""
     from strique_amd import synth
-    z = np.load(os.path.join(ROOT, "tests", "golden", "empirical_noise.npz"))
+    z = np.load(os.path.join(ROOT, "strique_amd", "data", "empirical_noise.npz"))
     dw = z["dwell"]
     assert 4000 < len(dw) < 5000 and 8.5 < dw.mean() < 10.0 and np.median(dw) == 7 and (dw == 0).sum() > 10
     assert 1.0 < z["level_offset"].std() < 2.0 and 1.8 < z["resid_z"].std() < 2.3

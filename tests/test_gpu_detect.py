@@ -458,8 +458,10 @@ def test_targets_with_other_flank_lengths(pm, cfg, orc, opm):
             sig = synth.make_read(table, 9, 7000 + 2 * k + (strand == "-"), total, custom[name], nrep, strand=strand)[0]
             items.append((name, sig, strand))
     got = rc.detect_batch(items)
-    for (name, sig, strand), g in zip(items, got):
-        w = orc.detect(sig, oracle_tc(orc, opm, custom, name, strand, cfg["HMM"]), opm, params)[0]
+    from conftest import oracle_map
+    tcs = {(name, strand): oracle_tc(orc, opm, custom, name, strand, cfg["HMM"]) for name, _, strand in items}
+    want = oracle_map(lambda it: orc.detect(it[1], tcs[(it[0], it[2])], opm, params)[0], items)
+    for (name, sig, strand), g, w in zip(items, got, want):
         assert tuple(g[:6]) == tuple(w[:6]), (name, strand, g, w)
         assert g[0] > 0, (name, strand, g)
     with pytest.raises(Exception, match="flank shape"):
@@ -518,7 +520,7 @@ def test_empirical_noise_reads_equal_the_oracle(pm, cfg, targets):
     runs = {}
     runs["default"] = rc.detect_batch(items); modes = [rc.ctx.last_screen()["mode"]]
     rc.ctx.set_option("STRQ_SCREEN_MODE", "coarse")
-    runs["coarse"] = rc.detect_batch(items); modes.append(rc.ctx.last_screen()["mode"]); redo = rc.ctx.last_second_round()
+    runs["coarse"] = rc.detect_batch(items); modes.append(rc.ctx.last_screen()["mode"]); redo = [rc.ctx.last_screen()["second_look"] + rc.ctx.last_second_round()[0]]
     rc.ctx.set_option("STRQ_SCREEN_MODE", "fine")
     runs["fine"] = rc.detect_batch(items); modes.append(rc.ctx.last_screen()["mode"])
     rc.ctx.set_option("STRQ_NO_SCREEN", "1")

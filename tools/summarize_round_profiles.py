@@ -2,7 +2,7 @@
 """profiles/<tag>_*.md from the raw rocprofv3 output of tools/runs_r05/gpu_r5_l.sh (gpurun_out/prof_<tag>/): the default bench line
 with the coarse screen (csrc/screen_kernels.hip: align_screen3_kernel, three flank rows per DP row, both flanks of a read per wave).
 
-    python tools/summarize_r05_profiles.py r05 [pmc_reads]
+    python tools/summarize_round_profiles.py r06 [pmc_reads]          # (r05: the same script, round 5)
 
 Writes <tag>_kernel_stats.{csv,md}, <tag>_pmc.md, <tag>_sq.md and the constants bench.py prices its rooflines with into
 profiles/dp_constants.json: VALU instructions per wave-step and HBM bytes per column of the screen kernel that ran, VALU instructions
@@ -40,6 +40,10 @@ def per_kernel(path):
 
 
 def bench_json(log):
+    # round 6: bench.py prints a compact line; the full record of a profiled pass is in <log minus .log>.json (--detail)
+    detail = os.path.splitext(log)[0] + ".json"
+    if os.path.exists(detail):
+        return json.load(open(detail))
     line = None
     if os.path.exists(log):
         for ln in open(log):
@@ -58,16 +62,25 @@ def main():
     rows = list(csv.DictReader(open(stats)))
     b = bench_json(os.path.join(src, "bench_kt.log"))
     with open(os.path.join(out, tag + "_kernel_stats.md"), "w") as f:
+        cmd_file = os.path.join(src, "cmd_kt.txt")
+        cmd = open(cmd_file).read().strip() if os.path.exists(cmd_file) else ("bench.py --steps 2 --warmup 1 --reads 4096 --batches 1 --synth-workers 8 --no-cpu-baseline --no-host-leg --no-legs --check 0")
         f.write("# rocprofv3 --kernel-trace --stats (%s: the default line, coarse screen on)\n\n" % tag)
-        f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s/kt -o %s -- python3 bench.py --steps 2 --warmup 1 "
-                "--reads 4096 --batches 1 --synth-workers 8 --no-cpu-baseline --no-host-leg --no-legs --check 0` (3 passes over 4096 reads of 50 kb: 1 warm-up + 2 timed).  "
-                "Raw table: `%s_kernel_stats.csv`.\n\n" % (tag, tag, tag))
+        f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s/kt -o %s -- python3 %s` (4096 reads of 50 kb per step).  "
+                "Raw table: `%s_kernel_stats.csv`.\n\n" % (tag, tag, cmd, tag))
         f.write("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n")
         for r in rows:
             f.write("| %s | %s | %.3f | %.1f | %s |\n" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
         if b:
-            f.write("\nbench.py line of the same (profiled) run: value %.1f %s, `roofline.kernel` %s, avg launch %.2f ms (HIP events inside bench.py), stages %s\n"
+            f.write("\nbench.py record of the same (profiled) run: value %.1f %s, `roofline.kernel` %s, screen launch %.2f ms on average (HIP events inside bench.py), stages %s\n"
                     % (b["value"], b["unit"], b["roofline"]["kernel"], b["screen"]["ms_per_step"], json.dumps(b.get("stage_ms_per_step"))))
+            if b["roofline"].get("co_running"):
+                f.write("\nTwo sub-batches in flight: `%s` runs on a second stream under the screen of the following step (%.1f ms of it per step inside the screen's "
+                        "launch window: `strq_last_overlap`), so both kernels' durations above are those of launches that SHARE the SIMDs -- except the first timed step's screen "
+                        "(nothing to run beside it after the warm-up's rows were taken) and the last step's Viterbi launch (eight waves per CU, alone).  `%s_overlap.txt` lists "
+                        "which launches overlapped in this trace.\n" % (b["roofline"]["co_running"]["kernel"], b["roofline"]["co_running"]["ms_under_this_launch_per_step"], tag))
+    ov = os.path.join(src, "overlap.txt")
+    if os.path.exists(ov):
+        shutil.copy(ov, os.path.join(out, tag + "_overlap.txt"))
 
     consts_path = os.path.join(out, "dp_constants.json")
     consts = json.load(open(consts_path)) if os.path.exists(consts_path) else {}
