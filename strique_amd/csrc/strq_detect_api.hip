@@ -721,6 +721,9 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         AlignCoreIn ci; AlignCoreOut co;
         ci.nb = na; ci.samples = S; ci.d_levels = levels; ci.read_off = loff.data() + i0; ci.d_level_val = level_val;
         ci.read = a_read.data(); ci.n = n.data(); ci.m = m.data(); ci.k = k.data(); ci.R = R.data(); ci.NS = NS.data(); ci.flank = fl.data();
+        // (Launched behind this sub-batch's SCREEN instead -- under the exact pass and the trace, whose launches leave most of the GPU idle --
+        // the eight Viterbi waves per CU take the LDS and registers those launches need: exact pass 69 instead of 19 ms, 180 against 175 ms per
+        // step on clean reads, 400 against 338 on empirical ones: gpurun_out/r6r.)
         if (part == 0) ci.after_tables = [&]() -> int {
             // The sub-batch before this one: its Viterbi launches start when this sub-batch's conditioning and score tables are through
             // -- a few ms of HBM-bound streaming kernels that crawl next to a GPU full of Viterbi waves (gpurun_out/r6d: 66 ms instead
