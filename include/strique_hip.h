@@ -223,8 +223,7 @@ int strq_batch_run(strq_ctx* ctx);
  * Viterbi launches of its LAST sub-batch still queued; every call that hands out rows waits for what it needs:
  * strq_batch_fetch / strq_batch_fetch_mod / strq_detect_batch* for everything, strq_batch_fetch_range for the sub-batches that
  * hold reads of [first, last) only -- so `run(k + 1); fetch_range(k)` never waits for k + 1.  The rows are the same whatever
- * the order (STRQ_SERIAL=1: everything on one stream, rows before the run call returns, as up to ABI 11).  Sub-batches with a
- * modification model run serially (their second pass needs the decoded repeat stretch on the host). */
+ * the order (STRQ_SERIAL=1: everything on one stream, rows before the run call returns, as up to ABI 11). */
 int strq_batch_run_range(strq_ctx* ctx, int64_t first, int64_t last);
 int strq_batch_fetch(strq_ctx* ctx, strq_result* out);
 int strq_batch_fetch_range(strq_ctx* ctx, int64_t first, int64_t last, strq_result* out);

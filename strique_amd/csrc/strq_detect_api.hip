@@ -583,8 +583,10 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
     bool any_mod = false;
     for (int i = 0; i < nr; ++i) any_mod |= d->targets[B.target[r0 + i]].mod_model_id >= 0;
     // STRQ_SERIAL=1: the Viterbi launches on the context's own stream and their results before the call returns, as up to round 5.
-    // (A sub-batch with a modification model runs that way too: its second pass needs the decoded repeat stretch on the host.)
-    const bool serial = any_mod || strq::opt("STRQ_SERIAL") != nullptr;
+    // (A sub-batch with a modification model is pipelined like any other: its MARK-mode Viterbi launches run under the next sub-batch's
+    // alignments; its second pass -- which needs the decoded repeat stretch on the host -- runs when its rows are taken, on the context's
+    // stream, which is idle then: the taking thread has just waited for the following sub-batch's forward stage, or is the caller's fetch.)
+    const bool serial = strq::opt("STRQ_SERIAL") != nullptr;
     uint32_t* d_hist_raw = nullptr; uint32_t* d_range = nullptr;
     if (B.dtype == 0) {
         STRQ_HIP(c, hipMemsetAsync(d->hist16.p, 0, (size_t)nr * 65536 * 4, st));

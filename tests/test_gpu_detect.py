@@ -152,6 +152,14 @@ def test_modification_pass(pm, pm_mod, cfg, orc, opm, opm_mod, targets):
             assert tuple(g) == tuple(want), (g, want)
             assert set(g[6]) <= set("01") and abs(len(g[6]) - g[0]) <= 3
             assert abs(g[0] - n_true) <= 1, (g[0], n_true)
+    # sub-batches of a modification target are in flight two at a time as well (their MARK-mode Viterbi launches under the next one's
+    # alignments, their second pass when the rows are taken): the same rows and patterns in pieces, and in the serial order
+    whole = rc.detect_batch(int_items + int_items[::-1])
+    rc.ctx.set_option("STRQ_SUBBATCH_READS", "3")
+    pieces = rc.detect_batch(int_items + int_items[::-1])
+    rc.ctx.set_option("STRQ_SERIAL", "1")
+    serial = rc.detect_batch(int_items + int_items[::-1])
+    assert whole == pieces == serial and all(set(g[6]) <= set("01") and g[0] > 0 for g in whole)
 
 
 def test_empty_batch_and_tiny_reads(gpu_counter, want, pm, targets):

@@ -38,13 +38,15 @@ def run(name, config_id, read_nt, picks):
     off = np.zeros(n + 1, np.int64); off[1:] = np.cumsum([len(s) for s in sigs])
     ctx = rc.ctx
     ctx.batch_upload(np.concatenate(sigs), off, tids)
-    ctx.batch_run()
+    ctx.batch_run(); ctx.batch_fetch()
+    ctx.device_synchronize()
     t0 = time.time()
     for _ in range(2):
-        ctx.batch_run()
+        ctx.batch_run()          # (two sub-batches in flight: the second pass's forward stage runs over the first one's Viterbi launches)
+    res = ctx.batch_fetch()      # ... and the last pass's Viterbi launches end inside the clock
     ctx.device_synchronize()
     dt = (time.time() - t0) / 2
-    res = ctx.batch_fetch(); tm = ctx.last_timing()
+    tm = ctx.last_timing()
     ok = int(sum(abs(int(r["count"]) - w) <= 2 for r, w in zip(res, want)))
     print("%s: %d reads, N~%d samples: %.1f ms per pass = %.0f reads/s   stages(ms) cond %.1f tables %.1f fwd %.1f trace %.1f viterbi %.1f   planted count recovered (+-2): %d/%d"
           % (name, n, off[-1] // n, dt * 1e3, n / dt, tm[5], tm[0], tm[1], tm[2], tm[6], ok, n), flush=True)
