@@ -48,8 +48,8 @@ struct AlignCoreIn {
     const int* n = nullptr; const int* m = nullptr; const int* k = nullptr; const int* R = nullptr;
     const int* NS = nullptr;               // strips per alignment (1 or 2)
     const float* const* flank = nullptr;   // host: flank template of each alignment
-    // called once the score-table kernel of the sub-batch is queued (its workgroups take most of a CU's LDS: whatever is to share the
-    // GPU with the alignment kernels that follow is launched behind it -- strq_detect_api.hip); a non-zero return aborts the call
+    // called once the score-table kernel of the sub-batch is queued (whatever is to share the GPU with the alignment kernels that
+    // follow is launched behind it -- strq_detect_api.hip); a non-zero return aborts the call
     std::function<int()> after_tables;
 };
 struct AlignCoreOut {

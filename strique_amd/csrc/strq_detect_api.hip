@@ -729,9 +729,9 @@ static int run_sub_batch(strq_ctx* c, DetectState* d, int64_t r0, int64_t r1, in
         if (part == 0) ci.after_tables = [&]() -> int {
             // The sub-batch before this one: its Viterbi launches start when this sub-batch's conditioning and score tables are through
             // -- a few ms of HBM-bound streaming kernels that crawl next to a GPU full of Viterbi waves (gpurun_out/r6d: 66 ms instead
-            // of 5.7 ms), and a table kernel whose workgroups want most of a CU's LDS and cannot be placed next to them at all
-            // (gpurun_out/r6h: the whole forward stage waited for the Viterbi launch to end).  The alignment kernels that follow
-            // share the SIMDs with the Viterbi waves at little cost.
+            // of 5.7 ms; hist_stats_kernel alone keeps 60 KB of LDS per workgroup), and queued before the table kernel the Viterbi
+            // launch kept the next screen from being dispatched until it had ended (gpurun_out/r6h against r6i, measured, both
+            // priorities).  The alignment kernels that follow share the SIMDs with the Viterbi waves.
             const bool queued_now = other.launch_pending;
             const int lrc = launch_viterbi_of(c, d, other, d->vit_stream, c->ev[1]); if (lrc) return lrc;
             // ... and they are dispatched after them: persistent workgroups that fill every CU for the length of the screen would
