@@ -760,3 +760,29 @@ def test_large_repeat_unit_with_the_modification_model(pm, pm_mod, cfg, orc, opm
         assert tuple(g) == tuple(w), (strand, g, w)
         assert g[0] > 0 and set(g[6]) <= set("01") and len(g[6]) > 0
     rc.ctx.close()
+
+
+def test_overlap_counters_say_what_ran_beside_what(gpu_counter, pm, targets, monkeypatch):
+    """strq_last_overlap: with two sub-batches in flight the Viterbi launches of a sub-batch lie under the alignment stage of the one that
+    follows (counted when the following run call takes the rows); serially nothing overlaps; either way the rows are the same."""
+    items = []
+    for k in range(8):
+        strand = "+-"[k % 2]
+        items.append(("c9orf72", _read(pm, targets, "c9orf72", strand, 30000, 150 + 40 * k, 5200 + k), strand))
+    ctx = gpu_counter.ctx
+    sigs = [np.ascontiguousarray(it[1]) for it in items]
+    off = np.zeros(len(sigs) + 1, np.int64); off[1:] = np.cumsum([len(x) for x in sigs])
+    tids = [gpu_counter._classifier_for(it[0], it[2]).target_id for it in items]
+    monkeypatch.setenv("STRQ_SUBBATCH_READS", "4")
+    ctx.batch_upload(np.concatenate(sigs), off, tids)
+    ctx.batch_run()
+    ov = ctx.last_overlap()          # the first sub-batch's rows were taken by the second one's run; the second one is still in flight
+    assert ov["sub_batches"] == 1 and ov["viterbi_ms"] > 0 and 0 < ov["under_alignment_stage_ms"] <= ov["viterbi_ms"] * 1.001, ov
+    rows = ctx.batch_fetch().copy()
+    assert ctx.last_overlap()["viterbi_ms"] > ov["viterbi_ms"]          # ... and taken by the fetch: alone, not counted as overlapped
+    assert ctx.last_overlap()["sub_batches"] == 1
+    monkeypatch.setenv("STRQ_SERIAL", "1")
+    ctx.batch_run()
+    ov = ctx.last_overlap()
+    assert ov["sub_batches"] == 0 and ov["under_alignment_stage_ms"] == 0 and ov["viterbi_ms"] > 0, ov
+    assert ctx.batch_fetch().tobytes() == rows.tobytes() and (rows["count"] > 100).all()
