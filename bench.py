@@ -618,6 +618,9 @@ def roofline_blocks(leg, lens_one_batch, prof, ctx_geo=None):
                                   "ms_under_this_launch_per_step": ov["under_screen_ms"] / steps, "viterbi_ms_per_step": ov["viterbi_ms"] / steps,
                                   "achieved": co, "valu_insts_per_time_step": vit_ip}
             roof["achieved"] = achieved + co; roof["frac"] = (achieved + co) / valu_peak
+            # float64 instructions hold the issue port for two slots (profiles/r02_valu_rates.md: every f64 VALU instruction at half rate): the share of
+            # the window's issue CYCLES the two kernels fill -- what is left is what neither of them could use
+            roof["issue_cycles_frac"] = min(1.0, (achieved + 2.0 * co) / valu_peak)
             roof["kernel"] = sk_name + " + co-running " + roof["co_running"]["kernel"].split(" of ")[0]
             roof["achieved_definition"] = "VALU instructions of BOTH kernels issued inside this launch's window (HIP events) / its duration"
     return roof
@@ -1068,7 +1071,7 @@ def compact_line(out, detail_path=None):
     line["roofline"] = _pick(roof, ("bound", "kernel", "unit", "achieved", "peak", "frac", "traffic", "avg_launch_ms", "launches_per_step",
                                     "wave_steps_per_launch", "valu_insts_per_wave_step", "valu_insts_source", "lane_utilisation", "gcups"))
     line["roofline"].setdefault("traffic", None)
-    for k in ("achieved_own", "frac_own"):
+    for k in ("achieved_own", "frac_own", "issue_cycles_frac"):
         if roof.get(k) is not None:
             line["roofline"][k] = _r(roof[k])
     if isinstance(roof.get("co_running"), dict):

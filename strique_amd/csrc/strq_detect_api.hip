@@ -149,7 +149,7 @@ struct DetectState {
     struct Slot {
         DevBuf flt, vit, vres, order, vq;
         bool active = false;             // forward stage done, results not yet in Batch::results
-        bool launch_pending = false;     // ... and its Viterbi launches not yet queued (they go behind the conditioning of the next sub-batch)
+        bool launch_pending = false;     // ... and its Viterbi launches not yet queued (they go behind the score-table kernel of the next sub-batch)
         struct VL { int shape, first, count, max_states; };
         std::vector<VL> vls;             // the Viterbi launches of the sub-batch: kernel shape, task range
         int vit_mode = 0;                // 0 count, 2 MARK (modification pass follows)
