@@ -217,7 +217,9 @@ def count(argv):
     parser.add_argument("--t", type=int, default=0, help="Reader threads that fetch and inflate raw signals ahead of the GPU batches (the reference's worker-process count); "
                                                           "0 (default): this rank's share of the CPUs the job may use (affinity mask, cgroup quota), at most 24")
     parser.add_argument("--log_level", default='warning', choices=LEVELS, help="Log level")
-    parser.add_argument("--batch", type=int, default=2048, help="Reads per GPU batch")
+    parser.add_argument("--batch", type=int, default=2048, help="Reads per GPU batch.  (The library works in sub-batches of 16 reads per CU, two of them in flight, so a batch of "
+                                                                "8192 and more keeps the HMM decode of one sub-batch under the alignments of the next -- but `count` is bound by reading "
+                                                                "the files, and smaller batches keep readers and GPU busy at the same time: profiles/r06_cli_probe.txt)")
     parser.add_argument("--device", type=int, default=0, help="HIP device")
     parser.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend when launched with torchrun (default: nccl = RCCL)")
     parser.add_argument("--share-device", action="store_true", help="testing: every rank uses --device instead of its LOCAL_RANK")

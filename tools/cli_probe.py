@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end throughput of the `count` command on files: synthetic 10 kb reads written into bulk fast5 files
 (strique_amd/h5write.py, contiguous int16), indexed, routed through a SAM file, counted and written as TSV.
-usage (GPU box): python tools/cli_probe.py [n_reads] [read_nt] [--t N]"""
+usage (GPU box): python tools/cli_probe.py [n_reads] [read_nt] [--t N] [--batch A,B,...]   (reads per GPU batch of `count`; default 4096,8192: one pass pair each)"""
 import io
 import os
 import sys
@@ -73,14 +73,17 @@ open(os.path.join(data, "reads.fofn"), "w").write(buf.getvalue())
 print("index: %.2f s" % (time.time() - t0), flush=True)
 argv = ["count", os.path.join(data, "reads.fofn"), os.path.join(tmp, "r9.model"), os.path.join(tmp, "repeat.tsv"), "--config", os.path.join(tmp, "cfg.json"),
         "--algn", os.path.join(tmp, "aln.sam"), "--out", os.path.join(tmp, "out.tsv"), "--t", str(threads), "--batch", "4096"]
+batch_sizes = [int(v) for v in sys.argv[sys.argv.index("--batch") + 1].split(",")] if "--batch" in sys.argv else [4096, 8192]
 if "--profile" in sys.argv:
     import cProfile, pstats
     cProfile.run("cli.main(argv)", os.path.join(tmp, "prof"))
     pstats.Stats(os.path.join(tmp, "prof")).sort_stats("cumtime").print_stats(22)
 import gc
-for rep in range(3):
+for bs in batch_sizes:
+  argv[-1] = str(bs)
+  for rep in range(2):
     gc.collect()                                         # the previous pass's context (tens of GB of device buffers) goes first
     t0 = time.time(); cli.main(argv); dt = time.time() - t0
     rows = [l.split("\t") for l in open(os.path.join(tmp, "out.tsv")).read().splitlines()[1:]]
     ok = sum(abs(int(r[3]) - planted[r[0]]) <= 2 for r in rows)
-    print("count pass %d: %d rows in %.2f s = %.0f reads/s end to end (files -> TSV), planted count recovered %d/%d" % (rep, len(rows), dt, len(rows) / dt, ok, len(rows)), flush=True)
+    print("count --batch %d pass %d: %d rows in %.2f s = %.0f reads/s end to end (files -> TSV), planted count recovered %d/%d" % (bs, rep, len(rows), dt, len(rows) / dt, ok, len(rows)), flush=True)
