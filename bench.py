@@ -349,9 +349,22 @@ def stage_resident_shared(ctx, counter, args, n_batches, workers, workload, rank
     tag = [None]
     if rank == 0:
         tag[0] = "strq_bench_%d_%d" % (os.getpid(), int(time.time()))
+        # where the pool goes: shared memory if it has the room (a container's /dev/shm can be 64 MB), else a temporary directory
+        need = int(total * args.read_nt * (9.6 if workload == "empirical" else 7.6) * 2 * 1.15)
+        tag.append(None)
+        for base in ("/dev/shm", os.environ.get("TMPDIR") or "/tmp", "/tmp"):
+            try:
+                st = os.statvfs(base)
+                if st.f_bavail * st.f_frsize > need:
+                    tag[1] = base; break
+            except OSError:
+                continue
+    else:
+        tag.append(None)
     dist.broadcast_object_list(tag, src=0)
-    base = "/dev/shm" if os.path.isdir("/dev/shm") else os.environ.get("TMPDIR", "/tmp")
-    pool_dir = os.path.join(base, tag[0])
+    if tag[1] is None:          # nowhere to put a shared pool: every rank makes its own reads after all
+        return None
+    pool_dir = os.path.join(tag[1], tag[0])
     os.makedirs(pool_dir, exist_ok=True)
     t0 = time.time()
     lo, hi = total * rank // world, total * (rank + 1) // world
@@ -772,8 +785,13 @@ def main():
     first_read = rank * n_batches * args.reads
     want_host_leg = (not args.no_host_leg) and world == 1
     keep_first = max(args.check, 0)
+    staged = None
     if world > 1 and not args.private_reads:
-        lens, strands, nreps, kept, t_gen, t_up = stage_resident_shared(ctx, counter, args, n_batches, synth_workers, args.workload, rank, world, dist, keep_first)
+        staged = stage_resident_shared(ctx, counter, args, n_batches, synth_workers, args.workload, rank, world, dist, keep_first)
+        if staged is None:
+            args.private_reads = True
+    if staged is not None:
+        lens, strands, nreps, kept, t_gen, t_up = staged
     else:
         lens, strands, nreps, kept, t_gen, t_up = stage_resident(ctx, counter, args, first_read, n_batches, synth_workers, args.workload,
                                                                   keep_first=max(keep_first, 256 if (world == 1 and not args.no_cpu_baseline) else 0), keep_all=want_host_leg)
