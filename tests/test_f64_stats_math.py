@@ -2,7 +2,10 @@
 order-preserving 64-bit keys, most-significant-byte-first selection of several ranks at once, and np.mean's summation tree
 (8192-element chunks, blocks of 128 with eight running sums, recursive halving) evaluated the way the kernel does it -- one block
 per lane and a butterfly for a full chunk, the recursion's uneven cuts for the partial one.  The GPU test
-(test_gpu_detect.py::test_float64_order_statistics_equal_numpy) compares the kernel itself with the same numpy calls."""
+(test_gpu_detect.py::test_float64_order_statistics_equal_numpy) compares the kernel itself with the same numpy calls.
+The summation tree is numpy's implementation detail (pairwise sum: 128-element blocks, eight accumulators, an 8192-element
+buffer of the reduction loop): it has been this way since numpy 1.9 and is what numpy 2.2.6 (this image) does; a numpy that
+changes it would fail THESE tests first, on CPU -- the bit-equality claim of the float64 path is a claim about that arithmetic."""
 import numpy as np
 import pytest
 
