@@ -68,8 +68,34 @@ class pore_model(object):
             mad = self.MAD(signal)
             nrm_signal = np.divide(np.subtract(signal, med), mad)
             nrm_signal = np.add(np.multiply(nrm_signal, self.model_MAD), self.model_median)
+        elif mode == "entropy":
+            # STRique.py:161-171 -- not on the count path (detect normalises with 'minmax'); kept for callers of the class.
+            # MAD of every 500-sample window (the tail mirrored), the 50 largest jumps of that profile, a mask 750 samples wide around
+            # them, then the median / MAD map over the masked samples.  One Python-level MAD per window like the reference's list
+            # comprehension: np.mean over a row of a 2-D view sums in another order.
+            n = 500
+            a = np.append(signal, signal[-1:-1 - (n - 1):-1])
+            windows = np.lib.stride_tricks.sliding_window_view(a, n)
+            sliding = [self.MAD(w) for w in windows]
+            sliding += [sliding[-1]]
+            diff_signal = np.abs(np.diff(sliding))
+            ind = np.argpartition(diff_signal, -50)[-50:]
+            diff_mask = np.zeros(len(diff_signal), dtype=np.uint8)
+            diff_mask[ind] = 1
+            # skimage.morphology.dilation(mask, rectangle(1, 750)) of scikit-image < 0.15 on a 1 x N image: an even footprint of width W
+            # covers in[i - (W/2 - 1) .. i + W/2], borders reflected (recalled, like the 1 x 8 windows of the hot path)
+            import scipy.ndimage
+            diff_mask = scipy.ndimage.maximum_filter1d(diff_mask, size=750, mode="reflect", origin=-1).astype(bool)
+            med = np.median(signal[diff_mask])
+            mad = self.MAD(signal[diff_mask])
+            nrm_signal = np.divide(np.subtract(signal, med), mad)
+            nrm_signal = np.add(np.multiply(nrm_signal, self.model_MAD), self.model_median)
         else:
-            raise ValueError("normalisation mode %r is not part of the count path" % (mode,))
+            # the reference's `else:` branch takes every other value as 'median' (STRique.py:172-176)
+            med = np.median(signal)
+            mad = self.MAD(signal)
+            nrm_signal = np.divide(np.subtract(signal, med), mad)
+            nrm_signal = np.add(np.multiply(nrm_signal, self.model_MAD), self.model_median)
         if clip:
             np.clip(nrm_signal, self.model_min + .5, self.model_max - .5, out=nrm_signal)
         return nrm_signal

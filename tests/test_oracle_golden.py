@@ -37,6 +37,17 @@ def test_normalize2model_bitwise(pm, pm_mod, orc, opm):
     assert np.array_equal(pm.generate_signal("".join(map(chr, [])) or _seq60(n), samples=8), n["generate_fixed"])
 
 
+def test_normalize2model_entropy_mode(pm):
+    """mode='entropy' (STRique.py:161-171; not on the count path): bit-equal to what the reference's own code computes on a seeded
+    signal (tests/golden/make_entropy_golden.py ran it with scikit-image's dilation stood in for by the recalled 1-D window:
+    pinned up to that window), with and without the clip; any other mode string is 'median', as in the reference."""
+    z = np.load(os.path.join(GOLDEN, "normalize_entropy.npz"))
+    assert np.array_equal(pm.normalize2model(z["signal"], mode="entropy"), z["entropy"])
+    assert np.array_equal(pm.normalize2model(z["signal"], clip=False, mode="entropy"), z["entropy_noclip"])
+    assert not np.array_equal(z["entropy"], pm.normalize2model(z["signal"], mode="median"))
+    assert np.array_equal(pm.normalize2model(z["signal"], mode="whatever"), pm.normalize2model(z["signal"], mode="median"))
+
+
 def _seq60(n):
     # the sequence is not stored; recover it from the fixture generator's seed
     rng = np.random.Generator(np.random.PCG64(20260001))
